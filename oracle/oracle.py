@@ -1,0 +1,145 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/lograst_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  Nothing under ``log_amd/`` imports it.  Parity status and the reference file:line each
+stage follows are documented in the header of ``lograst_oracle.c``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblograst_oracle.so")
+
+FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
+REC = 12
+TILE = 16
+
+
+class OraView(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float),
+        ("scale_modifier", ctypes.c_float),
+        ("filter_mode", ctypes.c_int32), ("ndc_cull", ctypes.c_int32),
+        ("view", ctypes.c_float * 16), ("proj", ctypes.c_float * 16), ("bg", ctypes.c_float * 3),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    src = os.path.join(_HERE, "lograst_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liblograst_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.ora_project.restype = ctypes.c_int64
+    return _lib
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def make_view(width, height, tanfovx, tanfovy, viewmatrix, projmatrix, bg, scale_modifier=1.0,
+              filter_mode=FILTER_CLAMP, ndc_cull=1):
+    v = OraView()
+    v.width, v.height = int(width), int(height)
+    v.tanfovx, v.tanfovy = float(tanfovx), float(tanfovy)
+    v.scale_modifier = float(scale_modifier)
+    v.filter_mode, v.ndc_cull = int(filter_mode), int(ndc_cull)
+    v.view[:] = _f32(viewmatrix).reshape(-1).tolist()
+    v.proj[:] = _f32(projmatrix).reshape(-1).tolist()
+    v.bg[:] = _f32(bg).reshape(-1).tolist()
+    return v
+
+
+def grid(view):
+    gx = (view.width + TILE - 1) // TILE
+    gy = (view.height + TILE - 1) // TILE
+    return gx, gy
+
+
+def compute_radius(means, scales, rots, proj, viewm, fx, fy, tanfovx, tanfovy):
+    """A0 -- LoG/cuda/compute_radius_kernel.cu:107-183."""
+    means, scales, rots = _f32(means), _f32(scales), _f32(rots)
+    proj, viewm = _f32(proj).reshape(-1), _f32(viewm).reshape(-1)
+    P = means.shape[0]
+    out = np.zeros(P, np.float32)
+    lib().ora_compute_radius(ctypes.c_int32(P), _p(means), _p(scales), _p(rots), _p(proj), _p(viewm),
+                             ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_float(tanfovx),
+                             ctypes.c_float(tanfovy), _p(out))
+    return out
+
+
+def forward(view, means, scales, rots, opac, colors, extras=True):
+    """Full forward.  Returns a dict with every intermediate the HIP path is compared against."""
+    means, scales, rots = _f32(means), _f32(scales), _f32(rots)
+    opac, colors = _f32(opac).reshape(-1), _f32(colors)
+    N = means.shape[0]
+    W, H = view.width, view.height
+    gx, gy = grid(view)
+    T = gx * gy
+    radii = np.zeros(N, np.int32)
+    rec = np.zeros((max(N, 1), REC), np.float32)
+    touched = np.zeros(max(N, 1), np.uint32)
+    L = lib()
+    I = L.ora_project(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots), _p(opac),
+                      _p(colors), _p(radii), _p(rec), _p(touched))
+    offsets = np.zeros(T + 1, np.uint32)
+    plist = np.zeros(max(int(I), 1), np.uint32)
+    rc = L.ora_bin(ctypes.byref(view), ctypes.c_int32(N), _p(radii), _p(rec), _p(offsets), _p(plist))
+    assert rc == 0
+    image = np.zeros((3, H, W), np.float32)
+    final_T = np.zeros((H, W), np.float32)
+    n_contrib = np.zeros((H, W), np.int32)
+    pid = np.full((H, W), -1, np.int32) if extras else None
+    pwp = np.zeros((H, W), np.float32) if extras else None
+    pw = np.zeros(max(N, 1), np.float32) if extras else None
+    L.ora_blend_fwd(ctypes.byref(view), ctypes.c_int32(N), _p(rec), _p(offsets), _p(plist), _p(image),
+                    _p(final_T), _p(n_contrib),
+                    _p(pid) if extras else None, _p(pwp) if extras else None, _p(pw) if extras else None)
+    return dict(N=N, I=int(I), radii=radii, rec=rec[:N], tiles_touched=touched[:N], tile_offsets=offsets,
+                point_list=plist[:int(I)], image=image, final_T=final_T, n_contrib=n_contrib,
+                point_id_pixel=pid, point_weight_pixel=pwp, point_weight=(pw[:N] if extras else None),
+                inputs=(means, scales, rots, opac, colors))
+
+
+def backward(view, fwd, dL_dimage):
+    """Full backward for a forward() result.  Returns grads dict."""
+    means, scales, rots, opac, colors = fwd["inputs"]
+    N = fwd["N"]
+    dL = _f32(dL_dimage)
+    n = max(N, 1)
+    g_mean2d = np.zeros((n, 3), np.float32)
+    g_conic = np.zeros((n, 4), np.float32)
+    g_opac = np.zeros(n, np.float32)
+    g_col = np.zeros((n, 3), np.float32)
+    g_means = np.zeros((n, 3), np.float32)
+    g_scales = np.zeros((n, 3), np.float32)
+    g_rots = np.zeros((n, 4), np.float32)
+    L = lib()
+    rec = np.ascontiguousarray(fwd["rec"]) if N else np.zeros((1, REC), np.float32)
+    plist = fwd["point_list"] if fwd["I"] else np.zeros(1, np.uint32)
+    L.ora_blend_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(rec), _p(fwd["tile_offsets"]), _p(plist),
+                    _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL), _p(g_mean2d), _p(g_conic), _p(g_opac),
+                    _p(g_col))
+    L.ora_project_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots),
+                      _p(fwd["radii"]), _p(g_mean2d), _p(g_conic), _p(g_means), _p(g_scales), _p(g_rots))
+    return dict(means3D=g_means[:N], means2D=g_mean2d[:N], scales=g_scales[:N], rotations=g_rots[:N],
+                opacities=g_opac[:N].reshape(-1, 1), colors=g_col[:N], conic=g_conic[:N])

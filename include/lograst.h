@@ -1,0 +1,138 @@
+/*
+ * lograst.h -- C ABI of liblograst.so: the MI355X (gfx950) differentiable Gaussian-splatting
+ * rasterizer behind LoG's operator surface.
+ *
+ * The reference (zju3dv/LoG) has no C ABI of its own: its boundary is two pybind11 torch extensions
+ * built from third-party repos plus one in-tree JIT extension.  Each entry point below
+ * names the reference interface it stands behind; the Python shims that reproduce those interfaces
+ * one-to-one live in log_amd/rasterizer.py and log_amd/compute_radius.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; all floats are fp32;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); nothing synchronises the
+ *     host except lograst_forward_project when `num_instances_host` != NULL, and lograst_profile_read;
+ *   - no allocation happens inside the library: the caller sizes scratch with the *_bytes helpers
+ *     (the Python shim uses torch's caching allocator);
+ *   - return value 0 = success, negative = error (lograst_last_error() gives the text);
+ *   - matrices use LoG's row-vector convention, flat row-major: t = p_row @ M
+ *     (/root/reference/LoG/dataset/base.py:40-46).
+ */
+#ifndef LOGRAST_H
+#define LOGRAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOGRAST_VERSION 1
+#define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
+#define LOGRAST_REC_FLOATS 12  /* floats per projected-Gaussian record (48 B) */
+
+/* 2-D low-pass flavours */
+#define LOGRAST_FILTER_NONE 0   /* use_filter=False of the fork (LoG/render/renderer.py:151-152) */
+#define LOGRAST_FILTER_DILATE 1 /* upstream package: cov.xx += 0.3 (LoG/model/geometry.py:87-88) */
+#define LOGRAST_FILTER_CLAMP 2  /* `wodilate` fork: cov.xx = max(cov.xx, 0.3) (LoG/cuda/compute_radius_kernel.cu:100-104) */
+
+/* error codes */
+#define LOGRAST_OK 0
+#define LOGRAST_ERR_ARG -1
+#define LOGRAST_ERR_HIP -2
+#define LOGRAST_ERR_CAPACITY -3
+
+/* Per-call view description.  Stands for GaussianRasterizationSettings
+ * (/root/reference/LoG/render/renderer.py:63-76): image_height/width, tanfovx/y, bg, scale_modifier,
+ * viewmatrix, projmatrix.  sh_degree/campos/prefiltered/debug have no effect on this path (LoG always
+ * passes colors_precomp, renderer.py:72-75,144-145). */
+typedef struct lograst_view {
+  int32_t width, height;
+  float tanfovx, tanfovy;
+  float scale_modifier;
+  int32_t filter_mode;     /* LOGRAST_FILTER_* */
+  int32_t ndc_cull;        /* 1: also cull |ndc.x|,|ndc.y| > 1.3 (compute_radius_kernel.cu:131-134) */
+  int32_t extras;          /* 1: produce the fork's point_id_pixel / point_weight_pixel / point_weight */
+  const float* viewmatrix; /* device, 16 floats */
+  const float* projmatrix; /* device, 16 floats */
+  const float* bg;         /* device, 3 floats */
+} lograst_view;
+
+int lograst_version(void);
+const char* lograst_last_error(void);
+
+/* ---- sizing helpers --------------------------------------------------------------------------- */
+/* bytes of the per-tile state block for a WxH image (counts, offsets, cursors, header) */
+size_t lograst_tile_state_bytes(int32_t width, int32_t height);
+/* bytes of the projected-record array for N Gaussians */
+size_t lograst_geom_bytes(int32_t n);
+/* bytes of the (depth,id) key buffer / the sorted id list for `capacity` tile instances */
+size_t lograst_keys_bytes(uint32_t capacity);
+size_t lograst_list_bytes(uint32_t capacity);
+
+/* ---- A0: LoG/cuda compute_radius --------------------------------------------------------------
+ * Replaces compute_radius_module.compute_radius (/root/reference/LoG/cuda/compute_radius_kernel.cu:158-187;
+ * caller LoG/model/level_of_gaussian.py:81-84): projected 3-sigma radius in pixels (float, no ceil),
+ * 0 where |ndc| > 1.3 or det == 0. */
+int lograst_compute_radius(int32_t p, const float* means3d, const float* scales, const float* rotations,
+                           const float* projmatrix, const float* viewmatrix, float focal_x, float focal_y,
+                           float tanfovx, float tanfovy, float* radii_out, void* stream);
+
+/* ---- forward, stage 1: projection + tile counting + scan (A1, A2) -----------------------------
+ * Stands for the first half of GaussianRasterizer.forward (called at LoG/render/renderer.py:153,190-198;
+ * LoG/model/level_of_gaussian.py:211-219).  Writes radii[n] (API output), geom (n records), and
+ * tile_state (per-tile counts/offsets).  The total number of tile instances is left in
+ * tile_state and, if num_instances_host != NULL (pinned or pageable host memory), also copied there
+ * after a stream synchronise so the caller can size the key/list buffers exactly. */
+int lograst_forward_project(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                            const float* rotations, const float* opacities, const float* colors,
+                            int32_t* radii, void* geom, void* tile_state, uint32_t* num_instances_host,
+                            void* stream);
+
+/* ---- forward, stage 2: per-tile bucketing + per-tile depth sort + compositing (A3, A4, A5, A7, A8)
+ * keys: scratch of lograst_keys_bytes(capacity) (dead after the call); point_list: lograst_list_bytes
+ * (capacity), kept for backward.  If the real instance count exceeds `capacity` nothing is rendered,
+ * LOGRAST_ERR_CAPACITY is NOT detectable without a sync, so: when the caller passed the exact count
+ * from stage 1 this cannot happen; when it passed a guess it must check lograst_read_overflow later.
+ * Outputs: image[3,H,W], final_T[H,W], n_contrib[H,W] (both kept for backward), and when
+ * view->extras: point_id_pixel[H,W] (i32, -1 = none), point_weight_pixel[H,W], point_weight[n]. */
+int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
+                           uint64_t* keys, uint32_t* point_list, uint32_t capacity, float* image,
+                           float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
+                           float* point_weight_pixel, float* point_weight, void* stream);
+
+/* Copies {num_instances, overflow_flag} of a tile_state to host (synchronises the stream). */
+int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uint32_t* overflow_host,
+                       void* stream);
+
+/* ---- backward (A6, A6b) ------------------------------------------------------------------------
+ * Stands for _RasterizeGaussians.backward of the third-party package, triggered by loss.backward()
+ * (LoG/utils/trainer.py:158).  dL_dimage[3,H,W] in; all gradient outputs are overwritten:
+ *   dL_dmeans2d[n,3]  (x,y = d/d ndc, z = 0; consumed at LoG/model/counter.py:40,46)
+ *   dL_dmeans3d[n,3], dL_dscales[n,3], dL_drotations[n,4], dL_dopacities[n], dL_dcolors[n,3]
+ * dL_dconic[n,4] is scratch. */
+int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                     const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
+                     const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
+                     const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
+                     float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
+                     void* stream);
+
+/* ---- debugging / test access to intermediates --------------------------------------------------
+ * Pointers into a tile_state block (device): offsets has tiles+1 entries. */
+const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height);
+
+/* ---- per-kernel timing with HIP events on the launch stream (used by bench.py) -----------------
+ * When enabled every kernel launch is bracketed by hipEventRecord on its stream.  read() synchronises
+ * the recorded events and returns, for kernel slot i < LOGRAST_NUM_KERNELS, accumulated milliseconds
+ * and launch counts since the last reset. */
+#define LOGRAST_NUM_KERNELS 12
+void lograst_profile_enable(int on);
+void lograst_profile_reset(void);
+int lograst_profile_read(double* ms_out, int64_t* count_out);
+const char* lograst_kernel_name(int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOGRAST_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of liblograst.so (C ABI: include/lograst.h).  Fails loudly when the library is
+missing -- there is no CPU or PyTorch fallback for the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblograst.so")
+
+FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
+REC_FLOATS = 12
+NUM_KERNELS = 12
+
+c_void_p, c_int32, c_uint32, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
+                                                  ctypes.c_float, ctypes.c_size_t)
+
+
+class LograstView(ctypes.Structure):
+    """struct lograst_view (include/lograst.h)."""
+    _fields_ = [
+        ("width", c_int32), ("height", c_int32),
+        ("tanfovx", c_float), ("tanfovy", c_float),
+        ("scale_modifier", c_float),
+        ("filter_mode", c_int32), ("ndc_cull", c_int32), ("extras", c_int32),
+        ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("bg", c_void_p),
+    ]
+
+
+class LograstError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGNATURES = {
+    "lograst_version": (ctypes.c_int, []),
+    "lograst_last_error": (ctypes.c_char_p, []),
+    "lograst_tile_state_bytes": (c_size_t, [c_int32, c_int32]),
+    "lograst_geom_bytes": (c_size_t, [c_int32]),
+    "lograst_keys_bytes": (c_size_t, [c_uint32]),
+    "lograst_list_bytes": (c_size_t, [c_uint32]),
+    "lograst_tile_offsets": (c_void_p, [c_void_p, c_int32, c_int32]),
+    "lograst_compute_radius": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                              c_float, c_float, c_float, c_void_p, c_void_p]),
+    "lograst_forward_project": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_forward_render": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
+    "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 18),
+    "lograst_profile_enable": (None, [ctypes.c_int]),
+    "lograst_profile_reset": (None, []),
+    "lograst_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "lograst_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Loads liblograst.so (after torch, so both share one HIP runtime).  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LograstError(
+                f"{LIB_PATH} is missing: build it with `python -m log_amd.build` (hipcc, gfx950). "
+                "log_amd has no CPU fallback.")
+        import torch  # noqa: F401  -- loads libamdhip64 first so the .so binds to torch's runtime
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.lograst_version() != 1:
+            raise LograstError("liblograst.so version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LograstError(f"liblograst error {rc}: {lib().lograst_last_error().decode()}")
+
+
+def profile_enable(on=True):
+    lib().lograst_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().lograst_profile_reset()
+
+
+def profile_read():
+    """-> {kernel_name: (total_ms, launches)} since the last reset (synchronises recorded events)."""
+    ms = (ctypes.c_double * NUM_KERNELS)()
+    cnt = (ctypes.c_int64 * NUM_KERNELS)()
+    check(lib().lograst_profile_read(ms, cnt))
+    return {lib().lograst_kernel_name(i).decode(): (ms[i], cnt[i]) for i in range(NUM_KERNELS) if cnt[i]}

@@ -1,0 +1,62 @@
+"""Builds log_amd/lib/liblograst.so from log_amd/csrc/*.hip with hipcc for gfx950 (in-tree, so the
+.so travels to the GPU box with the repo snapshot).  `python -m log_amd.build [--force]`."""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "liblograst.so")
+OBJDIR = os.path.join(LIBDIR, "obj")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+# -ffp-contract=off      : explicit fmaf only (bit-exact contract with the oracle; see csrc/common.hpp)
+# -munsafe-fp-atomics    : float atomicAdd -> global_atomic_add_f32 instead of a CAS loop
+# -mcode-object-version=5: loadable by both the ROCm 7.2 runtime and torch's bundled 7.0 runtime
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+         "-mcode-object-version=5", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(os.path.dirname(HERE), "include", "lograst.h"),
+                                                             os.path.abspath(__file__)]
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
+        if force or _newer(o, [s] + hdrs):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or jobs or _newer(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

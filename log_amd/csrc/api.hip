@@ -1,0 +1,270 @@
+// api.hip -- extern "C" entry points of liblograst.so (declared in include/lograst.h), launch
+// sequencing, error text and the HIP-event per-kernel timer.  No allocation, no host sync except where
+// the header says so.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+// launchers (defined next to their kernels)
+void lr_launch_radius(int P, const float* means, const float* scales, const float* rots, const float* proj,
+                      const float* view, float fx, float fy, float tanfovx, float tanfovy, float* radii,
+                      hipStream_t s);
+void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
+                       const float* opac, const float* colors, int* radii, void* geom, uint32_t* tile_counts,
+                       hipStream_t s);
+void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
+void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
+                    uint32_t capacity, hipStream_t s);
+void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
+                    hipStream_t s);
+void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
+                         const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
+                         int* pid, float* pwp, float* pw, hipStream_t s);
+void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
+                         const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
+                         const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
+                         hipStream_t s);
+void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
+                           const int* radii, const float* g_mean2d, const float* g_conic, float* g_means3d,
+                           float* g_scales, float* g_rots, hipStream_t s);
+
+static thread_local std::string g_err;
+static int lr_fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define LR_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return lr_fail(LOGRAST_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));              \
+  } while (0)
+
+int lr_env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return (e && *e) ? std::atoi(e) : dflt;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------
+static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
+    "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
+    "blend_fwd", "blend_bwd", "project_bwd", "misc", "reserved"};
+struct ProfRec { int slot; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_open;     // begin recorded, waiting for end
+static std::vector<ProfRec> g_prof_done;
+static std::vector<hipEvent_t> g_event_pool;
+static double g_prof_ms[LOGRAST_NUM_KERNELS];
+static int64_t g_prof_cnt[LOGRAST_NUM_KERNELS];
+static std::mutex g_prof_mu;
+
+static hipEvent_t lr_get_event() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void lr_prof_begin(int slot, hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{slot, lr_get_event(), lr_get_event()};
+  (void)hipEventRecord(r.a, s);
+  g_prof_open.push_back(r);
+}
+void lr_prof_end(int slot, hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (size_t i = g_prof_open.size(); i-- > 0;) {
+    if (g_prof_open[i].slot == slot) {
+      (void)hipEventRecord(g_prof_open[i].b, s);
+      g_prof_done.push_back(g_prof_open[i]);
+      g_prof_open.erase(g_prof_open.begin() + (long)i);
+      return;
+    }
+  }
+}
+static void lr_prof_drain_locked() {
+  for (auto& r : g_prof_done) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_prof_ms[r.slot] += ms;
+      g_prof_cnt[r.slot] += 1;
+    }
+    g_event_pool.push_back(r.a);
+    g_event_pool.push_back(r.b);
+  }
+  g_prof_done.clear();
+}
+
+static int lr_make_view(const lograst_view* in, LrView* out) {
+  if (!in) return lr_fail(LOGRAST_ERR_ARG, "view is NULL");
+  if (in->width <= 0 || in->height <= 0) return lr_fail(LOGRAST_ERR_ARG, "image size must be positive");
+  if (in->width > 65535 * 16 || in->height > 65535 * 16) return lr_fail(LOGRAST_ERR_ARG, "image too large");
+  if (!in->viewmatrix || !in->projmatrix || !in->bg) return lr_fail(LOGRAST_ERR_ARG, "viewmatrix/projmatrix/bg must be device pointers");
+  if (in->filter_mode < 0 || in->filter_mode > 2) return lr_fail(LOGRAST_ERR_ARG, "bad filter_mode");
+  out->W = in->width; out->H = in->height;
+  out->gx = (in->width + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  out->gy = (in->height + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  out->tanfovx = in->tanfovx; out->tanfovy = in->tanfovy;
+  out->fx = (float)in->width / (2.0f * in->tanfovx);
+  out->fy = (float)in->height / (2.0f * in->tanfovy);
+  out->scale_modifier = in->scale_modifier;
+  out->filter_mode = in->filter_mode; out->ndc_cull = in->ndc_cull; out->extras = in->extras;
+  out->view = in->viewmatrix; out->proj = in->projmatrix; out->bg = in->bg;
+  return LOGRAST_OK;
+}
+
+extern "C" {
+
+int lograst_version(void) { return LOGRAST_VERSION; }
+const char* lograst_last_error(void) { return g_err.c_str(); }
+
+size_t lograst_tile_state_bytes(int32_t width, int32_t height) {
+  uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  return sizeof(uint32_t) * (size_t)lr_state_words(gx * gy);
+}
+size_t lograst_geom_bytes(int32_t n) { return sizeof(float) * LOGRAST_REC_FLOATS * (size_t)(n > 0 ? n : 0); }
+size_t lograst_keys_bytes(uint32_t capacity) { return sizeof(uint64_t) * (size_t)capacity; }
+size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }
+
+const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height) {
+  uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  return reinterpret_cast<const uint32_t*>(tile_state) + lr_offsets_off(gx * gy);
+}
+
+int lograst_compute_radius(int32_t p, const float* means3d, const float* scales, const float* rotations,
+                           const float* projmatrix, const float* viewmatrix, float focal_x, float focal_y,
+                           float tanfovx, float tanfovy, float* radii_out, void* stream) {
+  if (p < 0) return lr_fail(LOGRAST_ERR_ARG, "negative point count");
+  if (p == 0) return LOGRAST_OK;
+  if (!means3d || !scales || !rotations || !projmatrix || !viewmatrix || !radii_out)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  lr_launch_radius(p, means3d, scales, rotations, projmatrix, viewmatrix, focal_x, focal_y, tanfovx, tanfovy,
+                   radii_out, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+int lograst_forward_project(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                            const float* rotations, const float* opacities, const float* colors,
+                            int32_t* radii, void* geom, void* tile_state, uint32_t* num_instances_host,
+                            void* stream) {
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
+  if (n > 0 && (!means3d || !scales || !rotations || !opacities || !colors || !radii || !geom))
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t tiles = (uint32_t)(v.gx * v.gy);
+  uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
+  // zero header + counts (offsets/cursors are fully rewritten by the scan)
+  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)lr_offsets_off(tiles), s));
+  lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_counts_off(), s);
+  lr_launch_scan(st, tiles, s);
+  LR_HIP(hipGetLastError());
+  if (num_instances_host) {
+    LR_HIP(hipMemcpyAsync(num_instances_host, st + LR_HDR_NUM, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LR_HIP(hipStreamSynchronize(s));
+  }
+  return LOGRAST_OK;
+}
+
+int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
+                           uint64_t* keys, uint32_t* point_list, uint32_t capacity, float* image,
+                           float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
+                           float* point_weight_pixel, float* point_weight, void* stream) {
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (!tile_state || !image || !final_t || !n_contrib) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (capacity > 0 && (!keys || !point_list)) return lr_fail(LOGRAST_ERR_ARG, "keys/point_list NULL with capacity > 0");
+  if (v.extras && (!point_id_pixel || !point_weight_pixel || (n > 0 && !point_weight)))
+    return lr_fail(LOGRAST_ERR_ARG, "extras requested but output pointers are NULL");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t tiles = (uint32_t)(v.gx * v.gy);
+  uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
+  if (v.extras && n > 0) LR_HIP(hipMemsetAsync(point_weight, 0, sizeof(float) * (size_t)n, s));
+  lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, s);
+  lr_launch_sort(st, tiles, keys, point_list, capacity, s);
+  lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
+                      point_weight_pixel, point_weight, s);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uint32_t* overflow_host,
+                       void* stream) {
+  if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
+  uint32_t hdr[2] = {0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  LR_HIP(hipMemcpyAsync(hdr, tile_state, sizeof(hdr), hipMemcpyDeviceToHost, s));
+  LR_HIP(hipStreamSynchronize(s));
+  if (num_instances_host) *num_instances_host = hdr[0];
+  if (overflow_host) *overflow_host = hdr[1];
+  return LOGRAST_OK;
+}
+
+int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                     const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
+                     const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
+                     const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
+                     float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
+                     void* stream) {
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (n == 0) return LOGRAST_OK;
+  if (!means3d || !scales || !rotations || !radii || !geom || !tile_state || !final_t || !n_contrib || !dl_dimage ||
+      !dl_dmeans2d || !dl_dconic || !dl_dopacities || !dl_dcolors || !dl_dmeans3d || !dl_dscales || !dl_drotations)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t tiles = (uint32_t)(v.gx * v.gy);
+  const uint32_t* st = reinterpret_cast<const uint32_t*>(tile_state);
+  LR_HIP(hipMemsetAsync(dl_dmeans2d, 0, sizeof(float) * 3 * (size_t)n, s));
+  LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * 4 * (size_t)n, s));
+  LR_HIP(hipMemsetAsync(dl_dopacities, 0, sizeof(float) * (size_t)n, s));
+  LR_HIP(hipMemsetAsync(dl_dcolors, 0, sizeof(float) * 3 * (size_t)n, s));
+  // capacity check is a forward concern: a list that rendered is by construction within capacity
+  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dmeans2d,
+                      dl_dconic, dl_dopacities, dl_dcolors, s);
+  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
+                        dl_drotations, s);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+void lograst_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+}
+void lograst_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  lr_prof_drain_locked();
+  std::memset(g_prof_ms, 0, sizeof(g_prof_ms));
+  std::memset(g_prof_cnt, 0, sizeof(g_prof_cnt));
+}
+int lograst_profile_read(double* ms_out, int64_t* count_out) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  lr_prof_drain_locked();
+  for (int i = 0; i < LOGRAST_NUM_KERNELS; i++) {
+    if (ms_out) ms_out[i] = g_prof_ms[i];
+    if (count_out) count_out[i] = g_prof_cnt[i];
+  }
+  return LOGRAST_OK;
+}
+const char* lograst_kernel_name(int slot) {
+  return (slot >= 0 && slot < LOGRAST_NUM_KERNELS) ? kKernelNames[slot] : "";
+}
+
+}  // extern "C"

@@ -1,0 +1,193 @@
+// common.hpp -- shared device helpers for liblograst (gfx950 / CDNA4 only; wave = 64).
+//
+// Numerics contract: compiled with -ffp-contract=off; every fused multiply-add is an explicit
+// __builtin_fmaf.  All operations feeding integer outputs (radii, tile rects, per-tile order,
+// n_contrib, point_id_pixel) follow one fixed fp32 op sequence so that the CPU oracle (test
+// infrastructure, never linked here) can reproduce them bit-for-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lograst.h"
+
+#define LR_WAVE 64
+
+// ---- tile_state layout (uint32 words) ------------------------------------------------------------
+// [0] num_instances  [1] overflow flag  [2..15] reserved
+// [16 .. 16+T)            per-tile counts
+// [16+Tp .. 16+Tp+T+1)    exclusive offsets (T+1 entries)
+// [16+2Tp .. 16+2Tp+T)    fill cursors
+#define LR_HDR_WORDS 16
+#define LR_HDR_NUM 0
+#define LR_HDR_OVERFLOW 1
+__host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
+__host__ __device__ inline uint32_t lr_counts_off() { return LR_HDR_WORDS; }
+__host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { return LR_HDR_WORDS + lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return LR_HDR_WORDS + 2 * lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return LR_HDR_WORDS + 3 * lr_tpad(tiles); }
+
+// Device-side view (kernel argument, by value).
+struct LrView {
+  int W, H, gx, gy;
+  float tanfovx, tanfovy, fx, fy, scale_modifier;
+  int filter_mode, ndc_cull, extras;
+  const float* view;
+  const float* proj;
+  const float* bg;
+};
+
+#define LR_DEV __device__ __forceinline__
+
+LR_DEV float lr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+LR_DEV float lr_dot3p(float a0, float a1, float a2, float b0, float b1, float b2, float c) {
+  return lr_fma(a0, b0, lr_fma(a1, b1, lr_fma(a2, b2, c)));
+}
+LR_DEV float lr_dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return lr_fma(a0, b0, lr_fma(a1, b1, a2 * b2));
+}
+
+// exp(x), x <= 0: 2^(x*log2e) with a degree-5 polynomial on [-0.5, 0.5] (max rel err 2.1e-7).  A fixed
+// op sequence instead of v_exp_f32 so that forward decisions (alpha floor, T stop, arg-max) are
+// reproducible on the host.
+LR_DEV float lr_exp(float x) {
+  float t = x * 1.44269504088896341f;
+  t = fmaxf(t, -125.0f);
+  float n = rintf(t);
+  float f = t - n;
+  float p = 0x1.5c08e4p-10f;
+  p = lr_fma(p, f, 0x1.3d0c52p-7f);
+  p = lr_fma(p, f, 0x1.c6b6e4p-5f);
+  p = lr_fma(p, f, 0x1.ebf918p-3f);
+  p = lr_fma(p, f, 0x1.62e428p-1f);
+  p = lr_fma(p, f, 0x1.000002p+0f);
+  int ni = (int)n;
+  return __uint_as_float(__float_as_uint(p) + ((uint32_t)ni << 23));
+}
+
+// power = -0.5 (A dx^2 + C dy^2) - B dx dy with hA = -0.5 A, hC = -0.5 C, nB = -B (exact scalings).
+LR_DEV float lr_power(float hA, float nB, float hC, float dx, float dy) {
+  return lr_fma(hA * dx, dx, lr_fma(hC * dy, dy, (nB * dx) * dy));
+}
+
+// cov3D = R diag(s^2) R^T; quaternion (r,x,y,z) is NOT normalised
+// (/root/reference/LoG/cuda/compute_radius_kernel.cu:28-58, :36).
+LR_DEV void lr_cov3d(const float s[3], const float q[4], float R[9], float Sg[6]) {
+  float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1.f - 2.f * lr_fma(y, y, z * z); R[1] = 2.f * lr_fma(x, y, -(r * z)); R[2] = 2.f * lr_fma(x, z, r * y);
+  R[3] = 2.f * lr_fma(x, y, r * z); R[4] = 1.f - 2.f * lr_fma(x, x, z * z); R[5] = 2.f * lr_fma(y, z, -(r * x));
+  R[6] = 2.f * lr_fma(x, z, -(r * y)); R[7] = 2.f * lr_fma(y, z, r * x); R[8] = 1.f - 2.f * lr_fma(x, x, y * y);
+  float M[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) M[3 * i + k] = R[3 * i + k] * s[k];
+  Sg[0] = lr_dot3(M[0], M[1], M[2], M[0], M[1], M[2]);
+  Sg[1] = lr_dot3(M[0], M[1], M[2], M[3], M[4], M[5]);
+  Sg[2] = lr_dot3(M[0], M[1], M[2], M[6], M[7], M[8]);
+  Sg[3] = lr_dot3(M[3], M[4], M[5], M[3], M[4], M[5]);
+  Sg[4] = lr_dot3(M[3], M[4], M[5], M[6], M[7], M[8]);
+  Sg[5] = lr_dot3(M[6], M[7], M[8], M[6], M[7], M[8]);
+}
+
+struct LrEwa {
+  float t[3];
+  float ux, uy;
+  int cx, cy;
+  float txc, tyc;
+  float j00, j02, j11, j12;
+  float T0[3], T1[3];
+  float a_raw, b, c_raw, a, c;
+};
+
+// EWA projection of the 3-D covariance (/root/reference/LoG/cuda/compute_radius_kernel.cu:63-105),
+// with the low-pass selectable: fork max(.,0.3) (:102-103) / upstream +0.3 (LoG/model/geometry.py:87-88) / none.
+LR_DEV void lr_ewa(const float p[3], const float Sg[6], const float* __restrict__ V, float fx, float fy,
+                   float tanfovx, float tanfovy, int filter_mode, LrEwa& e) {
+  e.t[0] = lr_dot3p(V[0], V[4], V[8], p[0], p[1], p[2], V[12]);
+  e.t[1] = lr_dot3p(V[1], V[5], V[9], p[0], p[1], p[2], V[13]);
+  e.t[2] = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
+  float tz = e.t[2];
+  float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+  float txtz = e.t[0] / tz, tytz = e.t[1] / tz;
+  e.cx = (txtz < -limx) || (txtz > limx);
+  e.cy = (tytz < -limy) || (tytz > limy);
+  e.ux = fminf(limx, fmaxf(-limx, txtz));
+  e.uy = fminf(limy, fmaxf(-limy, tytz));
+  e.txc = e.ux * tz;
+  e.tyc = e.uy * tz;
+  float tz2 = tz * tz;
+  e.j00 = fx / tz; e.j02 = -(fx * e.txc) / tz2;
+  e.j11 = fy / tz; e.j12 = -(fy * e.tyc) / tz2;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    e.T0[j] = lr_fma(e.j00, V[4 * j + 0], e.j02 * V[4 * j + 2]);
+    e.T1[j] = lr_fma(e.j11, V[4 * j + 1], e.j12 * V[4 * j + 2]);
+  }
+  float w0[3], w1[3];
+  w0[0] = lr_dot3(Sg[0], Sg[1], Sg[2], e.T0[0], e.T0[1], e.T0[2]);
+  w0[1] = lr_dot3(Sg[1], Sg[3], Sg[4], e.T0[0], e.T0[1], e.T0[2]);
+  w0[2] = lr_dot3(Sg[2], Sg[4], Sg[5], e.T0[0], e.T0[1], e.T0[2]);
+  w1[0] = lr_dot3(Sg[0], Sg[1], Sg[2], e.T1[0], e.T1[1], e.T1[2]);
+  w1[1] = lr_dot3(Sg[1], Sg[3], Sg[4], e.T1[0], e.T1[1], e.T1[2]);
+  w1[2] = lr_dot3(Sg[2], Sg[4], Sg[5], e.T1[0], e.T1[1], e.T1[2]);
+  e.a_raw = lr_dot3(e.T0[0], e.T0[1], e.T0[2], w0[0], w0[1], w0[2]);
+  e.b = lr_dot3(e.T0[0], e.T0[1], e.T0[2], w1[0], w1[1], w1[2]);
+  e.c_raw = lr_dot3(e.T1[0], e.T1[1], e.T1[2], w1[0], w1[1], w1[2]);
+  if (filter_mode == LOGRAST_FILTER_DILATE) { e.a = e.a_raw + 0.3f; e.c = e.c_raw + 0.3f; }
+  else if (filter_mode == LOGRAST_FILTER_CLAMP) { e.a = fmaxf(e.a_raw, 0.3f); e.c = fmaxf(e.c_raw, 0.3f); }
+  else { e.a = e.a_raw; e.c = e.c_raw; }
+}
+
+LR_DEV float lr_radius_from_cov(float a, float c, float det) {
+  float mid = 0.5f * (a + c);
+  float disc = fmaxf(0.1f, mid * mid - det);
+  float sq = sqrtf(disc);
+  float l1 = mid + sq, l2 = mid - sq;
+  return 3.f * sqrtf(fmaxf(l1, l2));
+}
+
+// ---- wave64 helpers ------------------------------------------------------------------------------
+LR_DEV float lr_readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+LR_DEV int lr_readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// DPP wave64 sum; the total ends up in lane 63 (row_shr within 16-lane rows, then row broadcasts).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+LR_DEV float lr_dpp_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
+  return v + __int_as_float(moved);
+}
+LR_DEV float lr_wave_sum_to63(float v) {
+  v = lr_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+  v = lr_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+  v = lr_dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4, banks 1-3
+  v = lr_dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
+  v = lr_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 -> rows 1,3
+  v = lr_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+LR_DEV float lr_dpp_max(float v) {
+  // old = v for lanes that receive nothing (bound_ctrl=false keeps `old`)
+  int moved = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return fmaxf(v, __int_as_float(moved));
+}
+LR_DEV float lr_wave_max_to63(float v) {
+  v = lr_dpp_max<0x111, 0xf, 0xf>(v);
+  v = lr_dpp_max<0x112, 0xf, 0xf>(v);
+  v = lr_dpp_max<0x114, 0xf, 0xe>(v);
+  v = lr_dpp_max<0x118, 0xf, 0xc>(v);
+  v = lr_dpp_max<0x142, 0xa, 0xf>(v);
+  v = lr_dpp_max<0x143, 0xc, 0xf>(v);
+  return v;
+}
+
+// ---- host-side launch bookkeeping (api.hip) ------------------------------------------------------
+enum LrKernelSlot {
+  LRK_RADIUS = 0, LRK_PROJECT, LRK_SCAN, LRK_FILL, LRK_SORT_SMALL, LRK_SORT_LARGE, LRK_SORT_HUGE,
+  LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_RESERVED
+};
+void lr_prof_begin(int slot, hipStream_t s);
+void lr_prof_end(int slot, hipStream_t s);
+int lr_env_int(const char* name, int dflt);

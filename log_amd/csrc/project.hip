@@ -1,0 +1,224 @@
+// project.hip -- per-Gaussian streaming kernels: A0 compute_radius, A1 projection (+ A2 tile counting),
+// tile scan, and A3 per-tile bucket fill.  HBM-bound: every Gaussian attribute is read exactly once,
+// coalesced; the 48-byte projected record is written once.
+#include "common.hpp"
+
+// ---- A0 -------------------------------------------------------------------------------------------
+// Stands for compute_radius_cuda (/root/reference/LoG/cuda/compute_radius_kernel.cu:107-156):
+// float radius (no ceil), |ndc|>1.3 cull only, fork low-pass max(.,0.3), det==0 -> 0.
+__global__ void __launch_bounds__(256)
+lr_radius_kernel(int P, const float* __restrict__ means, const float* __restrict__ scales,
+                 const float* __restrict__ rots, const float* __restrict__ proj,
+                 const float* __restrict__ view, float fx, float fy, float tanfovx, float tanfovy,
+                 float* __restrict__ radii) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+  float hx = lr_dot3p(proj[0], proj[4], proj[8], p[0], p[1], p[2], proj[12]);
+  float hy = lr_dot3p(proj[1], proj[5], proj[9], p[0], p[1], p[2], proj[13]);
+  float hw = lr_dot3p(proj[3], proj[7], proj[11], p[0], p[1], p[2], proj[15]);
+  float pw = 1.0f / (hw + 0.0000001f);
+  float nx = hx * pw, ny = hy * pw;
+  float out = 0.f;
+  if (!(nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) {
+    float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+    float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    float R[9], Sg[6];
+    lr_cov3d(s, q, R, Sg);
+    LrEwa e;
+    lr_ewa(p, Sg, view, fx, fy, tanfovx, tanfovy, LOGRAST_FILTER_CLAMP, e);
+    float det = e.a * e.c - e.b * e.b;
+    if (det != 0.0f) out = lr_radius_from_cov(e.a, e.c, det);
+  }
+  radii[i] = out;
+}
+
+void lr_launch_radius(int P, const float* means, const float* scales, const float* rots, const float* proj,
+                      const float* view, float fx, float fy, float tanfovx, float tanfovy, float* radii,
+                      hipStream_t s) {
+  if (P <= 0) return;
+  lr_prof_begin(LRK_RADIUS, s);
+  hipLaunchKernelGGL(lr_radius_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means, scales, rots, proj,
+                     view, fx, fy, tanfovx, tanfovy, radii);
+  lr_prof_end(LRK_RADIUS, s);
+}
+
+// ---- A1 + A2 ----------------------------------------------------------------------------------------
+// One thread per Gaussian.  Writes radii[i] (0 = culled), the 48-byte record
+//   q0 = (mx, my, conicA, conicB)  q1 = (conicC, opacity, r, g)  q2 = (b, depth, rect_min, rect_max)
+// (q2 is written for every Gaussian, zero = culled/empty rect) and bumps the per-tile counters for
+// every tile of its rect.
+__global__ void __launch_bounds__(256)
+lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
+                  const float* __restrict__ rots, const float* __restrict__ opac,
+                  const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
+                  uint32_t* __restrict__ tile_counts) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float* __restrict__ V = v.view;
+  const float* __restrict__ Pm = v.proj;
+  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+  int rad = 0;
+  float4 g2 = {0.f, 0.f, 0.f, 0.f};  // culled: empty rect (the fill kernel reads only q2)
+  float tz = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
+  if (tz > 0.2f) {
+    float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
+    float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], p[0], p[1], p[2], Pm[13]);
+    float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], p[0], p[1], p[2], Pm[15]);
+    float pw = 1.0f / (hw + 0.0000001f);
+    float nx = hx * pw, ny = hy * pw;
+    bool culled = v.ndc_cull && (nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f);
+    if (!culled) {
+      float s[3] = {scales[3 * i] * v.scale_modifier, scales[3 * i + 1] * v.scale_modifier,
+                    scales[3 * i + 2] * v.scale_modifier};
+      const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+      float q[4] = {q4.x, q4.y, q4.z, q4.w};
+      float R[9], Sg[6];
+      lr_cov3d(s, q, R, Sg);
+      LrEwa e;
+      lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
+      float det = e.a * e.c - e.b * e.b;
+      if (det != 0.0f) {
+        float det_inv = 1.f / det;
+        float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
+        float rf = ceilf(lr_radius_from_cov(e.a, e.c, det));
+        float mx = ((nx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
+        float my = ((ny + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+        if ((rf <= 1048576.f) && (fabsf(mx) < 1.0e8f) && (fabsf(my) < 1.0e8f)) {
+          int x0 = (int)((mx - rf) / 16.f), y0 = (int)((my - rf) / 16.f);
+          int x1 = (int)(((mx + rf) + 15.f) / 16.f), y1 = (int)(((my + rf) + 15.f) / 16.f);
+          x0 = min(v.gx, max(0, x0)); x1 = min(v.gx, max(0, x1));
+          y0 = min(v.gy, max(0, y0)); y1 = min(v.gy, max(0, y1));
+          if ((x1 - x0) * (y1 - y0) > 0) {
+            rad = (int)rf;
+            float4 g0 = {mx, my, cA, cB};
+            float4 g1 = {cC, opac[i], colors[3 * i], colors[3 * i + 1]};
+            g2 = float4{colors[3 * i + 2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
+                        __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
+            geom[3 * (size_t)i + 0] = g0;
+            geom[3 * (size_t)i + 1] = g1;
+            for (int y = y0; y < y1; y++)
+              for (int x = x0; x < x1; x++) atomicAdd(&tile_counts[y * v.gx + x], 1u);
+          }
+        }
+      }
+    }
+  }
+  geom[3 * (size_t)i + 2] = g2;
+  radii[i] = rad;
+}
+
+void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
+                       const float* opac, const float* colors, int* radii, void* geom, uint32_t* tile_counts,
+                       hipStream_t s) {
+  if (N <= 0) return;
+  lr_prof_begin(LRK_PROJECT, s);
+  hipLaunchKernelGGL(lr_project_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, N, means, scales, rots, opac,
+                     colors, radii, reinterpret_cast<float4*>(geom), tile_counts);
+  lr_prof_end(LRK_PROJECT, s);
+}
+
+// ---- tile scan --------------------------------------------------------------------------------------
+// One 1024-thread workgroup: exclusive scan of the per-tile counts into offsets[T+1], cursor[T]=offsets,
+// header.num_instances = total.  T is 8160 at 1080p / 32400 at 4K, so one workgroup is enough.
+__global__ void __launch_bounds__(1024)
+lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
+  __shared__ uint32_t part[1024];
+  const uint32_t* counts = state + lr_counts_off();
+  uint32_t* offsets = state + lr_offsets_off(tiles);
+  uint32_t* cursor = state + lr_cursor_off(tiles);
+  uint32_t tid = threadIdx.x;
+  uint32_t chunk = (tiles + 1023u) / 1024u;
+  uint32_t b = tid * chunk, e = min(tiles, b + chunk);
+  uint32_t sum = 0;
+  for (uint32_t t = b; t < e; t++) sum += counts[t];
+  part[tid] = sum;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t add = (tid >= d) ? part[tid - d] : 0u;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;  // exclusive prefix of this thread's chunk
+  for (uint32_t t = b; t < e; t++) {
+    offsets[t] = run;
+    cursor[t] = run;
+    run += counts[t];
+  }
+  if (tid == 1023) {
+    offsets[tiles] = part[1023];
+    state[LR_HDR_NUM] = part[1023];
+    state[LR_HDR_OVERFLOW] = 0u;
+  }
+}
+
+void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
+  lr_prof_begin(LRK_SCAN, s);
+  hipLaunchKernelGGL(lr_scan_kernel, dim3(1), dim3(1024), 0, s, state, tiles);
+  lr_prof_end(LRK_SCAN, s);
+}
+
+// ---- A3: per-tile bucket fill ---------------------------------------------------------------------------
+// key = (fp32 bits of view depth) << 32 | Gaussian index; depth > 0.2 so the bit pattern is monotone.
+// Small rects are expanded by their own lane; rects with more than LR_COOP_TILES tiles are expanded by
+// the whole wave (ballot over the lanes that hold one, record broadcast with readlane) so that a single
+// screen-filling Gaussian does not serialise its wave.
+#define LR_COOP_TILES 16
+__global__ void __launch_bounds__(256)
+lr_fill_kernel(int N, int gx, const float4* __restrict__ geom,
+               uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys, uint32_t capacity) {
+  uint32_t total = state[LR_HDR_NUM];
+  if (total > capacity) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[LR_HDR_OVERFLOW] = 1u;
+    return;
+  }
+  uint32_t* cursor = state + lr_cursor_off(tiles);
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int lane = threadIdx.x & 63;
+  bool vis = (i < N);
+  uint32_t r0 = 0, r1 = 0, dbits = 0;
+  if (vis) {
+    float4 g2 = geom[3 * (size_t)i + 2];
+    dbits = __float_as_uint(g2.y);
+    r0 = __float_as_uint(g2.z);
+    r1 = __float_as_uint(g2.w);
+  }
+  int x0 = r0 & 0xffff, y0 = r0 >> 16, x1 = r1 & 0xffff, y1 = r1 >> 16;
+  int w = x1 - x0, h = y1 - y0;
+  int nt = vis ? w * h : 0;
+  uint64_t key = ((uint64_t)dbits << 32) | (uint32_t)i;
+  if (nt > 0 && nt <= LR_COOP_TILES) {
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) {
+        uint32_t pos = atomicAdd(&cursor[y * gx + x], 1u);
+        keys[pos] = key;
+      }
+  }
+  uint64_t big = __ballot(nt > LR_COOP_TILES);
+  while (big) {
+    int src = __builtin_ctzll(big);
+    big &= big - 1;
+    int bx0 = lr_readlane_i(x0, src), by0 = lr_readlane_i(y0, src);
+    int bw = lr_readlane_i(w, src), bn = lr_readlane_i(nt, src);
+    uint32_t klo = (uint32_t)lr_readlane_i((int)(uint32_t)key, src);
+    uint32_t khi = (uint32_t)lr_readlane_i((int)(uint32_t)(key >> 32), src);
+    uint64_t bkey = ((uint64_t)khi << 32) | klo;
+    for (int t = lane; t < bn; t += 64) {
+      int ty = t / bw, tx = t - ty * bw;
+      uint32_t pos = atomicAdd(&cursor[(by0 + ty) * gx + (bx0 + tx)], 1u);
+      keys[pos] = bkey;
+    }
+  }
+}
+
+void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles,
+                    uint64_t* keys, uint32_t capacity, hipStream_t s) {
+  if (N <= 0) return;
+  lr_prof_begin(LRK_FILL, s);
+  hipLaunchKernelGGL(lr_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, gx,
+                     reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity);
+  lr_prof_end(LRK_FILL, s);
+}

@@ -1,0 +1,300 @@
+"""Host-side mirror of the rasterizer packages LoG imports.
+
+Reproduces, name for name, the Python surface of ``diff_gaussian_rasterization`` (graphdeco upstream)
+and ``diff_gaussian_rasterization_wodilate`` (chingswy fork, branch ``antialias``) as LoG uses them
+(/root/reference/LoG/render/renderer.py:1,57-78,100-107,141-165,190-198;
+/root/reference/LoG/model/level_of_gaussian.py:59,73-78,207-221):
+
+  * ``GaussianRasterizationSettings`` -- 12-field NamedTuple, keyword constructed (renderer.py:63-76);
+  * ``GaussianRasterizer(raster_settings=...)`` -- nn.Module with ``.raster_settings``, ``__call__`` with the
+    keyword set of renderer.py:141-153 (+ ``use_filter`` for the fork), ``compute_radius`` (fork,
+    level_of_gaussian.py:59) and ``markVisible``;
+  * autograd: differentiable w.r.t. means3D, means2D (NDC-scaled screen-space gradient), colors_precomp,
+    opacities, scales, rotations;
+  * returns ``(image, radii)`` for the upstream flavour and
+    ``(image, radii, point_id_pixel, point_weight_pixel, point_weight)`` for the fork (renderer.py:154-165).
+
+All arithmetic runs in hand-written HIP kernels (log_amd/csrc) through the C ABI of liblograst.so
+(include/lograst.h).  Tensors must live on the MI355X; there is no CPU fallback.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class Flavour(NamedTuple):
+    """What distinguishes the two third-party packages on this path."""
+    name: str
+    filter_mode: int   # low-pass when use_filter is on
+    ndc_cull: int      # |ndc| > 1.3 cull (LoG/cuda/compute_radius_kernel.cu:131-134)
+    extras: int        # 5-tuple return
+
+
+UPSTREAM = Flavour("diff_gaussian_rasterization", _lib.FILTER_DILATE, 0, 0)
+WODILATE = Flavour("diff_gaussian_rasterization_wodilate", _lib.FILTER_CLAMP, 1, 1)
+
+# ---- instance-capacity policy ----------------------------------------------------------------------
+# Default (None): exact -- stage 1 reports the number of tile instances to the host (one 4-byte
+# read-back, as the third-party package does for `num_rendered`) and the buffers are sized exactly.
+# With a hint, no host synchronisation happens in forward(); the kernels refuse to write past the
+# capacity and raise the overflow flag, which `last_overflow()` / bench.py check afterwards.
+_capacity_hint = None
+_last_state = None
+
+
+def set_instance_capacity(n):
+    """n = int: sync-free forward with room for n tile instances; None: exact sizing (default)."""
+    global _capacity_hint
+    _capacity_hint = None if n is None else int(n)
+
+
+def last_overflow():
+    """(num_instances, overflowed) of the most recent forward on this process (synchronises)."""
+    if _last_state is None:
+        return 0, False
+    n = ctypes.c_uint32(0)
+    o = ctypes.c_uint32(0)
+    _lib.check(_lib.lib().lograst_read_state(_last_state.data_ptr(), ctypes.byref(n), ctypes.byref(o),
+                                             _stream_ptr(_last_state.device)))
+    return int(n.value), bool(o.value)
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def _dev_f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipBackend:
+    """Drives the kernels.  All buffers come from torch's caching allocator."""
+
+    @staticmethod
+    def require(device):
+        if device.type != "cuda":
+            raise _lib.LograstError(
+                f"log_amd rasterizer needs tensors on the MI355X (got device '{device}'); "
+                "the HIP kernels are the only implementation -- there is no CPU fallback")
+        return _lib.lib()
+
+    def make_view(self, rs, flavour, use_filter, device):
+        keep = (_dev_f32(rs.viewmatrix, device), _dev_f32(rs.projmatrix, device), _dev_f32(rs.bg, device).reshape(-1))
+        if keep[0].numel() != 16 or keep[1].numel() != 16 or keep[2].numel() != 3:
+            raise ValueError("viewmatrix/projmatrix must be 4x4 and bg must have 3 entries")
+        v = _lib.LograstView()
+        v.width, v.height = int(rs.image_width), int(rs.image_height)
+        v.tanfovx, v.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+        v.scale_modifier = float(rs.scale_modifier)
+        v.filter_mode = flavour.filter_mode if use_filter else _lib.FILTER_NONE
+        v.ndc_cull, v.extras = flavour.ndc_cull, flavour.extras
+        v.viewmatrix, v.projmatrix, v.bg = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+        return v, keep
+
+    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors):
+        global _last_state
+        device = means3D.device
+        L = self.require(device)
+        N = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        view, keep = self.make_view(rs, flavour, use_filter, device)
+        stream = _stream_ptr(device)
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        radii = torch.empty(N, **i32)
+        geom = torch.empty(N * _lib.REC_FLOATS, **f32)
+        state = torch.empty(L.lograst_tile_state_bytes(W, H) // 4, **i32)
+        with torch.cuda.device(device):
+            if _capacity_hint is None:
+                n_host = ctypes.c_uint32(0)
+                _lib.check(L.lograst_forward_project(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
+                                                     _ptr(opacities), _ptr(colors), _ptr(radii), _ptr(geom),
+                                                     _ptr(state), ctypes.byref(n_host), stream))
+                capacity = int(n_host.value)
+            else:
+                _lib.check(L.lograst_forward_project(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
+                                                     _ptr(opacities), _ptr(colors), _ptr(radii), _ptr(geom),
+                                                     _ptr(state), None, stream))
+                capacity = _capacity_hint
+            keys = torch.empty(capacity, dtype=torch.int64, device=device)
+            plist = torch.empty(capacity, **i32)
+            image = torch.empty(3, H, W, **f32)
+            final_T = torch.empty(H, W, **f32)
+            n_contrib = torch.empty(H, W, **i32)
+            if flavour.extras:
+                pid = torch.empty(H, W, **i32)
+                pwp = torch.empty(H, W, **f32)
+                pw = torch.empty(N, **f32)
+            else:
+                pid = pwp = pw = None
+            _lib.check(L.lograst_forward_render(ctypes.byref(view), N, _ptr(geom), _ptr(state), _ptr(keys), _ptr(plist),
+                                                capacity, _ptr(image), _ptr(final_T), _ptr(n_contrib), _ptr(pid),
+                                                _ptr(pwp), _ptr(pw), stream))
+        del keys, keep
+        _last_state = state
+        saved = dict(radii=radii, geom=geom, state=state, plist=plist, final_T=final_T, n_contrib=n_contrib)
+        return image, radii, pid, pwp, pw, saved
+
+    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image):
+        device = means3D.device
+        L = self.require(device)
+        N = means3D.shape[0]
+        view, keep = self.make_view(rs, flavour, use_filter, device)
+        f32 = dict(dtype=torch.float32, device=device)
+        g_means2D = torch.empty(N, 3, **f32)
+        g_conic = torch.empty(N, 4, **f32)
+        g_opac = torch.empty(N, **f32)
+        g_colors = torch.empty(N, 3, **f32)
+        g_means3D = torch.empty(N, 3, **f32)
+        g_scales = torch.empty(N, 3, **f32)
+        g_rot = torch.empty(N, 4, **f32)
+        grad_image = grad_image.to(torch.float32).contiguous()
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_backward(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
+                                          _ptr(saved["radii"]), _ptr(saved["geom"]), _ptr(saved["state"]),
+                                          _ptr(saved["plist"]), _ptr(saved["final_T"]), _ptr(saved["n_contrib"]),
+                                          _ptr(grad_image), _ptr(g_means2D), _ptr(g_conic), _ptr(g_opac),
+                                          _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot),
+                                          _stream_ptr(device)))
+        del keep
+        return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
+
+    def compute_radius(self, means3D, scales, rotations, projmatrix, viewmatrix, fx, fy, tanfovx, tanfovy):
+        device = means3D.device
+        L = self.require(device)
+        P = means3D.shape[0]
+        m, s, r = _dev_f32(means3D, device), _dev_f32(scales, device), _dev_f32(rotations, device)
+        pm, vm = _dev_f32(projmatrix, device), _dev_f32(viewmatrix, device)
+        out = torch.empty(P, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_compute_radius(P, _ptr(m), _ptr(s), _ptr(r), _ptr(pm), _ptr(vm), float(fx), float(fy),
+                                                float(tanfovx), float(tanfovy), _ptr(out), _stream_ptr(device)))
+        return out
+
+
+_backend = HipBackend()
+
+
+def _set_backend_for_tests(backend):
+    """TEST HOOK.  tests/ install a CPU double here to drive LoG's unmodified Python on machines without a
+    GPU (plumbing only).  Nothing in the product path calls this; the default is always HipBackend."""
+    global _backend
+    old = _backend
+    _backend = backend if backend is not None else HipBackend()
+    return old
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, rs, flavour, use_filter):
+        m = means3D.detach().to(torch.float32).contiguous()
+        s = scales.detach().to(torch.float32).contiguous()
+        r = rotations.detach().to(torch.float32).contiguous()
+        o = opacities.detach().to(torch.float32).contiguous().reshape(-1)
+        c = colors.detach().to(torch.float32).contiguous()
+        n = m.shape[0]
+        if not (s.shape == (n, 3) and r.shape == (n, 4) and c.shape == (n, 3) and o.shape[0] == n and m.shape == (n, 3)):
+            raise ValueError("rasterizer inputs must be means3D[N,3], scales[N,3], rotations[N,4], "
+                             "colors_precomp[N,3], opacities[N,1]")
+        image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c)
+        ctx.rs, ctx.flavour, ctx.use_filter = rs, flavour, use_filter
+        ctx.saved = saved
+        ctx.shapes = (means2D.shape, opacities.shape)
+        ctx.save_for_backward(m, s, r)
+        if flavour.extras:
+            ctx.mark_non_differentiable(radii, pid, pwp, pw)
+            return image, radii, pid, pwp, pw
+        ctx.mark_non_differentiable(radii)
+        return image, radii
+
+    @staticmethod
+    def backward(ctx, grad_image, *unused):
+        m, s, r = ctx.saved_tensors
+        g_m3, g_m2, g_c, g_o, g_s, g_r = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
+                                                           grad_image)
+        m2_shape, o_shape = ctx.shapes
+        return g_m3, g_m2.reshape(m2_shape), g_c, g_o.reshape(o_shape), g_s, g_r, None, None, None
+
+
+class GaussianRasterizer(nn.Module):
+    FLAVOUR = WODILATE
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum test of the third-party package (not called by LoG): view z > 0.2."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix.to(positions.device, torch.float32)
+            z = positions.to(torch.float32) @ vm[:3, 2] + vm[3, 2]
+            return z > 0.2
+
+    def compute_radius(self, xyz, scaling, rotation):
+        """Fork-only method (level_of_gaussian.py:59): projected radius per point, 0 = not visible."""
+        rs = self.raster_settings
+        fx = rs.image_width / (2.0 * rs.tanfovx)
+        fy = rs.image_height / (2.0 * rs.tanfovy)
+        with torch.no_grad():
+            return _backend.compute_radius(xyz, scaling * rs.scale_modifier, rotation, rs.projmatrix, rs.viewmatrix,
+                                           fx, fy, rs.tanfovx, rs.tanfovy)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, **kwargs):
+        flavour = self.FLAVOUR
+        use_filter = True
+        if "use_filter" in kwargs:
+            if not flavour.extras:
+                raise TypeError("forward() got an unexpected keyword argument 'use_filter'")
+            use_filter = bool(kwargs.pop("use_filter"))
+        if kwargs:
+            raise TypeError(f"forward() got unexpected keyword arguments {sorted(kwargs)}")
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if shs is not None:
+            raise NotImplementedError("log_amd: the `shs=` input is not on LoG's path (LoG evaluates SH in PyTorch and "
+                                      "passes colors_precomp, renderer.py:144-145); see DESIGN.md 'next' row N2")
+        if cov3D_precomp is not None:
+            raise NotImplementedError("log_amd: cov3D_precomp is not on LoG's path (renderer.py:134,149)")
+        return _RasterizeGaussians.apply(means3D, means2D, colors_precomp, opacities, scales, rotations,
+                                         self.raster_settings, flavour, use_filter)
+
+
+class UpstreamGaussianRasterizer(GaussianRasterizer):
+    FLAVOUR = UPSTREAM
+
+
+def tile_offsets_of(saved, width, height):
+    """Test/debug accessor: the per-tile exclusive offsets (tiles+1 entries) inside a tile_state tensor
+    (layout: log_amd/csrc/common.hpp)."""
+    gx, gy = (int(width) + 15) // 16, (int(height) + 15) // 16
+    tiles = gx * gy
+    tpad = (tiles + 1 + 15) & ~15
+    off = 16 + tpad
+    return saved["state"][off:off + tiles + 1]

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- Gaussians/s, forward+backward at 1080p, of the MI355X rasterizer hot path.
+
+  python bench.py --gpus 1 --steps K --warmup W                    (single GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W    (one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): 1,000,000 random Gaussians (seed 0,
+opacity 0.999, scales U(0, 0.5 N^-1/3)), 1920x1080, 8 orbit cameras PER GPU, through the drop-in
+``diff_gaussian_rasterization_wodilate`` package (5-tuple flavour), loss = sum(image * w), backward to all
+Gaussian attributes + means2D.  A "step" = every rank renders its 8 views forward+backward, gradients
+accumulate in one flat buffer per rank, and (N > 1) one reduce-scatter + all-gather sums them across ranks
+(view-sharded data parallelism, weak scaling: per-GPU work is fixed).  Inputs are resident in HBM before
+the timed region; the timed region contains no host synchronisation (tile-instance capacity comes from the
+warm-up, overflow is verified afterwards).
+
+Prints ONE JSON line on rank 0 (contract: see the task statement), including
+  roofline     : dominant kernel, algorithmic bytes/launch / average launch duration (HIP events on the
+                 launch stream, recorded during the timed region) vs the 8 TB/s HBM3E peak;
+  cpu_baseline : the CPU oracle (oracle/, OpenMP, all host cores) timed on ONE view of the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--views", type=int, default=8, help="views per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--opacity", type=float, default=0.999, help="<0: random opacities")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, V, I, Px):
+    """Per-view algorithmic HBM bytes per kernel (each datum counted once per producing /
+    consuming stage, fp32, no implementation overhead)."""
+    return {
+        "project": 56 * N + 4 * N + 40 * V,
+        "fill_keys": 8 * I,
+        "sort": 8 * I + 4 * I,
+        "blend_fwd": 44 * I + 28 * Px + 4 * V,
+        "blend_bwd": 44 * I + 20 * Px + 36 * V,
+        "project_bwd": 56 * N + 36 * V + 68 * N,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
+    from log_amd import _lib, rasterizer as R, scenes
+    from log_amd.dist import GradientBucket
+
+    N, W, H = args.gaussians, args.width, args.height
+    Px = W * H
+    sc = scenes.random_scene(N, seed=0, opacity=(None if args.opacity < 0 else args.opacity))
+    # this rank's cameras: world*views angles on the orbit, round-robin
+    all_cams = scenes.orbit_cameras(args.views * world, W=W, H=H, focal=2139.0 * W / 1920.0,
+                                    end_deg=360.0 * (1 - 1.0 / (args.views * world)))
+    cams = [all_cams[i] for i in range(rank, len(all_cams), world)]
+    T = lambda a, g=False: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=g)
+    params = dict(means3D=T(sc["xyz"], True), scales=T(sc["scaling"], True), rotations=T(sc["rotation"], True),
+                  opacities=T(sc["opacity"], True), colors=T(sc["colors"], True))
+    bucket = GradientBucket(N, dev, world)
+    bucket.attach(params)
+    bg = T([1.0, 1.0, 1.0])
+    wloss = torch.tensor(np.random.default_rng(1).random((3, H, W), dtype=np.float32), device=dev)
+    rasts = []
+    for cam in cams:
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam["FoVx"] * 0.5), tanfovy=math.tan(cam["FoVy"] * 0.5),
+            bg=bg, scale_modifier=1.0, viewmatrix=T(cam["world_view_transform"]),
+            projmatrix=T(cam["full_proj_transform"]), sh_degree=0, campos=T(cam["camera_center"]),
+            prefiltered=False, debug=False)
+        rasts.append(GaussianRasterizer(raster_settings=rs))
+
+    def one_view(rast):
+        means2D = torch.zeros(N, 3, device=dev, requires_grad=True)
+        out = rast(means3D=params["means3D"], means2D=means2D, shs=None, colors_precomp=params["colors"],
+                   opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
+                   cov3D_precomp=None)
+        (out[0] * wloss).sum().backward()
+        return out
+
+    def step():
+        bucket.zero()
+        for rast in rasts:
+            one_view(rast)
+        bucket.reduce()
+
+    # ---- measure V and I per view once (exact mode: one 4-byte read-back per view) ----
+    stats = []
+    for rast in rasts:
+        out = one_view(rast)
+        n_inst, over = R.last_overflow()
+        stats.append((int((out[1] > 0).sum().item()), n_inst))
+        assert not over
+    V = float(np.mean([s[0] for s in stats]))
+    I = float(np.mean([s[1] for s in stats]))
+    cap = int(max(s[1] for s in stats) * 1.02) + 1024
+    R.set_instance_capacity(cap)  # from here on: no host sync inside forward()
+
+    for _ in range(args.warmup):
+        step()
+    timing = not args.no_kernel_timing
+    if timing:
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if timing:
+        _lib.profile_enable(False)
+    n_inst, over = R.last_overflow()
+    assert not over and n_inst <= cap, "tile-instance capacity overflow inside the timed region: result invalid"
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_gaussians = float(N) * args.views * world * args.steps
+    value = total_gaussians / elapsed
+
+    result = {
+        "metric": "Gaussians/sec fwd+bwd @1080p", "value": value, "unit": "Gaussians/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "C2: %d random Gaussians (seed 0, opacity %s), %dx%d, %d orbit views per GPU, "
+                        "fwd+bwd of sum(image*w), wodilate (5-tuple) flavour" %
+                        (N, "rand" if args.opacity < 0 else args.opacity, W, H, args.views),
+            "gaussians": N, "width": W, "height": H, "views_per_gpu": args.views,
+            "visible_per_view": V, "tile_instances_per_view": I,
+            "parallelism": "view-sharded dp%d, 1 reduce-scatter+all-gather of %d floats/step" %
+                           (world, bucket.flat.numel()) if world > 1 else "single GPU",
+        },
+        "ms_per_view": 1e3 * elapsed / (args.steps * args.views),
+    }
+
+    if rank == 0:
+        alg = algorithmic_bytes(N, V, I, Px)
+        total_alg = 184 * N + 116 * V + 108 * I + 48 * Px
+        result["algorithmic_GBs_whole_view"] = total_alg / (elapsed / (args.steps * args.views)) / 1e9
+        if timing:
+            prof = _lib.profile_read()
+            kern = {}
+            for name, (ms, cnt) in prof.items():
+                kern[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt)}
+            sort_ms = sum(prof[k][0] for k in prof if k.startswith("sort"))
+            merged = {k: prof[k][0] for k in prof if not k.startswith("sort")}
+            if sort_ms:
+                merged["sort"] = sort_ms
+            dom = max(merged, key=merged.get)
+            launches = prof[dom][1] if dom in prof else prof["sort_small"][1]
+            avg_s = merged[dom] / launches / 1e3
+            achieved = alg.get(dom, 0) / avg_s / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                  "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_us": avg_s * 1e6}
+            result["kernels"] = kern
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sc, cams[0], wloss.cpu().numpy(), N)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, cam, wloss, N):
+    """The CPU oracle (test infrastructure; OpenMP over all host cores) on ONE view of the same workload."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    tfx, tfy = math.tan(cam["FoVx"] * 0.5), math.tan(cam["FoVy"] * 0.5)
+    v = oracle.make_view(cam["image_width"], cam["image_height"], tfx, tfy, cam["world_view_transform"],
+                         cam["full_proj_transform"], [1, 1, 1])
+    oracle.lib()
+    t0 = time.perf_counter()
+    f = oracle.forward(v, sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["colors"])
+    oracle.backward(v, f, wloss)
+    dt = time.perf_counter() - t0
+    return {"value": N / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": "1 of the 8 views, all %d Gaussians, forward+backward, %.1f s" % (N, dt)}
+
+
+if __name__ == "__main__":
+    main()

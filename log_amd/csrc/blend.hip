@@ -210,7 +210,9 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
             const float G = lr_exp(power);
             const float alpha = fminf(0.99f, op * G);
             if (!(alpha < 1.0f / 255.0f)) {
-              const float rc = __builtin_amdgcn_rcpf(1.f - alpha);
+              const float om = 1.f - alpha;
+              float rc = __builtin_amdgcn_rcpf(om);
+              rc = lr_fma(lr_fma(-om, rc, 1.f), rc, rc);  // one Newton step: v_rcp_f32's 1-ulp bias compounds over long lists
               T[q] = T[q] * rc;
               const float w = alpha * T[q];
               acc0[q] = lr_fma(lal[q], lc0[q], (1.f - lal[q]) * acc0[q]);

@@ -180,6 +180,7 @@ class HipBackend:
                                           _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot),
                                           _stream_ptr(device)))
         del keep
+        self.last_conic_grad = g_conic  # test/debug introspection only
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
     def compute_radius(self, means3D, scales, rotations, projmatrix, viewmatrix, fx, fy, tanfovx, tanfovy):

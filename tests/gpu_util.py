@@ -46,7 +46,7 @@ def hip_backward(hf, dL):
     g = torch.tensor(np.ascontiguousarray(dL, np.float32), device=m.device)
     g_m3, g_m2, g_c, g_o, g_s, g_r = R._backend.backward(rs, flavour, use_filter, m, s, r, saved, g)
     torch.cuda.synchronize()
-    return dict(means3D=g_m3.cpu().numpy(), means2D=g_m2.cpu().numpy(), colors=g_c.cpu().numpy(),
+    return dict(conic=R._backend.last_conic_grad.cpu().numpy(), means3D=g_m3.cpu().numpy(), means2D=g_m2.cpu().numpy(), colors=g_c.cpu().numpy(),
                 opacities=g_o.cpu().numpy().reshape(-1, 1), scales=g_s.cpu().numpy(), rotations=g_r.cpu().numpy())
 
 

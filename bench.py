@@ -198,27 +198,35 @@ def main():
                                   "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_us": avg_s * 1e6}
             result["kernels"] = kern
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sc, cams[0], wloss.cpu().numpy(), N)
+            result["cpu_baseline"] = cpu_baseline(sc, cams, wloss.cpu().numpy(), N)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, cam, wloss, N):
-    """The CPU oracle (test infrastructure; OpenMP over all host cores) on ONE view of the same workload."""
+def cpu_baseline(sc, cams, wloss, N, budget_s=12.0, max_passes=64):
+    """The CPU oracle (test infrastructure; OpenMP over all host cores) on a bounded sample of the same
+    workload: whole views (all N Gaussians, forward+backward), cycling through this rank's cameras until
+    ~budget_s seconds of CPU work have been spent."""
     from oracle import oracle
     cores = os.cpu_count() or 1
-    tfx, tfy = math.tan(cam["FoVx"] * 0.5), math.tan(cam["FoVy"] * 0.5)
-    v = oracle.make_view(cam["image_width"], cam["image_height"], tfx, tfy, cam["world_view_transform"],
-                         cam["full_proj_transform"], [1, 1, 1])
     oracle.lib()
-    t0 = time.perf_counter()
-    f = oracle.forward(v, sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["colors"])
-    oracle.backward(v, f, wloss)
+    views = []
+    for cam in cams:
+        tfx, tfy = math.tan(cam["FoVx"] * 0.5), math.tan(cam["FoVy"] * 0.5)
+        views.append(oracle.make_view(cam["image_width"], cam["image_height"], tfx, tfy,
+                                      cam["world_view_transform"], cam["full_proj_transform"], [1, 1, 1]))
+    passes, t0 = 0, time.perf_counter()
+    while passes < max_passes and (passes == 0 or time.perf_counter() - t0 < budget_s):
+        v = views[passes % len(views)]
+        f = oracle.forward(v, sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["colors"])
+        oracle.backward(v, f, wloss)
+        passes += 1
     dt = time.perf_counter() - t0
-    return {"value": N / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
-            "sample": "1 of the 8 views, all %d Gaussians, forward+backward, %.1f s" % (N, dt)}
+    return {"value": N * passes / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": "%d view passes (cycling the 8 views), all %d Gaussians each, forward+backward, %.1f s total"
+                      % (passes, N, dt)}
 
 
 if __name__ == "__main__":

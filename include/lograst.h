@@ -118,6 +118,15 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
                      void* stream);
 
+/* Stage A6b alone: the per-Gaussian chain rule, given dL/d(ndc mean) [n,3] and dL/d(conic) [n,4] (as left
+ * by the reverse walk).  Writes dl_dmeans3d/dl_dscales/dl_drotations.  lograst_backward = reverse walk +
+ * this call; exposed so the two halves can be checked separately (the chain rule is ill-conditioned for
+ * near-degenerate Gaussians, the walk is not). */
+int lograst_project_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                             const float* rotations, const int32_t* radii, const float* dl_dmeans2d,
+                             const float* dl_dconic, float* dl_dmeans3d, float* dl_dscales,
+                             float* dl_drotations, void* stream);
+
 /* ---- debugging / test access to intermediates --------------------------------------------------
  * Pointers into a tile_state block (device): offsets has tiles+1 entries. */
 const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height);

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblograst.so")
+LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblograst.so")  # env: experiment builds only
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
 REC_FLOATS = 12
@@ -49,6 +49,7 @@ _SIGNATURES = {
                                               c_void_p, c_void_p]),
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
     "lograst_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 18),
+    "lograst_project_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10),
     "lograst_profile_enable": (None, [ctypes.c_int]),
     "lograst_profile_reset": (None, []),
     "lograst_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

@@ -28,7 +28,19 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None, extra_flags=()):
+    """variant: name of an experimental build (liblograst_<variant>.so with extra_flags), used only by
+    tools/experiments; the product library is the default build."""
+    global LIB, OBJDIR
+    lib, objdir = LIB, OBJDIR
+    if variant:
+        lib = os.path.join(LIBDIR, f"liblograst_{variant}.so")
+        objdir = os.path.join(LIBDIR, f"obj_{variant}")
+        force = True
+    return _build(lib, objdir, force, verbose, list(extra_flags))
+
+
+def _build(LIB, OBJDIR, force, verbose, extra):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(os.path.dirname(HERE), "include", "lograst.h"),
                                                              os.path.abspath(__file__)]
@@ -41,7 +53,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -59,4 +71,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if args:   # python -m log_amd.build <variant> <flag> [<flag> ...]
+        print(build(variant=args[0], extra_flags=args[1:]))
+    else:
+        print(build(force="--force" in sys.argv))

@@ -166,9 +166,10 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
-  // zero header + counts (offsets/cursors are fully rewritten by the scan)
-  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)lr_offsets_off(tiles), s));
-  lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_counts_off(), s);
+  // zero header and counters (offsets/cursors are fully rewritten by the scan)
+  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * LR_HDR_WORDS, s));
+  LR_HIP(hipMemsetAsync(st + lr_counts_off(tiles), 0, sizeof(uint32_t) * (size_t)tiles * LR_CTR_STRIDE, s));
+  lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_counts_off(tiles), s);
   lr_launch_scan(st, tiles, s);
   LR_HIP(hipGetLastError());
   if (num_instances_host) {
@@ -240,6 +241,24 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
                       dl_dconic, dl_dopacities, dl_dcolors, s);
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
                         dl_drotations, s);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+int lograst_project_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                             const float* rotations, const int32_t* radii, const float* dl_dmeans2d,
+                             const float* dl_dconic, float* dl_dmeans3d, float* dl_dscales,
+                             float* dl_drotations, void* stream) {
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (n == 0) return LOGRAST_OK;
+  if (!means3d || !scales || !rotations || !radii || !dl_dmeans2d || !dl_dconic || !dl_dmeans3d || !dl_dscales ||
+      !dl_drotations)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
+                        dl_drotations, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

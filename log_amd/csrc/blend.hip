@@ -1,16 +1,21 @@
 // blend.hip -- A5/A7/A8 forward compositing and A6 backward reverse walk.
 //
-// CDNA4 mapping (not the 16x16-threads-per-tile CUDA shape): ONE 64-lane wave owns one 16x16 tile and
-// every lane owns 4 pixels, one in each 8x8 quadrant.  Per 64 list entries the wave gathers 64 projected
-// records into VGPRs (one per lane, ids read coalesced from the sorted list), then walks them with
-// v_readlane broadcasts: the current Gaussian lives in SGPRs, so it costs no LDS traffic, no barrier and
-// no VGPRs, and each broadcast is amortised over 4 pixels per lane.  A single-wave workgroup needs no
-// __syncthreads, terminates exactly when its own 256 pixels are done, and 8160 (1080p) independent
-// waves give the dispatcher enough slack to balance uneven tile lists.
+// CDNA4 mapping (not the 16x16-threads-per-tile CUDA shape with shared-memory staging and block barriers):
+//   * a 256-thread workgroup owns one 16x16 tile, but its four 64-lane waves never synchronise: wave q owns
+//     the 8x8 pixel quadrant q (one pixel per lane) and walks the tile's depth-sorted list on its own;
+//   * per 64 list entries a wave gathers 64 projected records into VGPRs (ids read coalesced from the
+//     sorted list; the four waves of a tile hit the same lines in their CU's L1), computes for each a
+//     conservative alpha-support box, and ballots which entries can touch ITS quadrant at all;
+//   * only those entries are visited (s_ff1 over the ballot mask), each broadcast with v_readlane: the current
+//     Gaussian lives in SGPRs -- no LDS traffic, no barrier, no VGPRs -- so culling a (Gaussian, quadrant)
+//     pair costs nothing, and every wave stops exactly when its own 64 pixels are saturated.
+// The support box only skips pixels whose alpha is provably below the 1/255 floor (1% margin on the
+// exponent, disabled for ill-conditioned conics), so results are identical to visiting every entry; the
+// oracle does not cull and the bit-exact parity tests check exactly that.
 //
-// Backward: same mapping; the per-(tile,Gaussian) gradient is reduced across the wave with DPP row
-// shifts/broadcasts and committed with ONE lane's atomics per (tile, Gaussian) -- not one atomic per
-// (pixel, Gaussian) as in the third-party kernel.
+// Backward: same mapping; each (wave, Gaussian) gradient is reduced across the wave with a packed
+// v_permlane32_swap / v_permlane16_swap + DPP row-rotate tree (28 VALU ops for 9 sums) and committed with
+// 3 atomic instructions -- not 9 atomics per (pixel, Gaussian) as in the third-party kernel.
 #include "common.hpp"
 
 // blockIdx -> tile.  mode 0: identity.  mode 1: XCD-banded -- workgroup b runs on XCD b%8 (observed
@@ -24,100 +29,114 @@ LR_DEV uint32_t lr_tile_of_block(uint32_t b, uint32_t tiles, int mode) {
   return b;
 }
 
+// Conservative test: can the Gaussian (record q0,q1) reach alpha >= 1/255 anywhere in the pixel box
+// [x0,x1]x[y0,y1]?  The alpha floor means power >= -tau, tau = ln(255*opacity); the level set
+// {d : 0.5 d^T Q d <= tau'} has the axis-aligned half extents sqrt(2 tau' cov_xx), sqrt(2 tau' cov_yy).
+// tau' = 1.01 tau + 0.01 absorbs the fp32 evaluation error of `power`; if that error could exceed the
+// margin (ill-conditioned conic, non-finite values) the answer is "yes" (never cull).
+LR_DEV bool lr_support_hits(const float4 g0, const float4 g1, float x0, float x1, float y0, float y1) {
+  const float A = g0.z, B = g0.w, C = g1.x, op = g1.y;
+  const float det = A * C - B * B;
+  const float tau = lr_fma(__logf(255.f * op), 1.01f, 0.01f);
+  if (!(op >= 1.0f / 512.0f)) return !(op < 1.0f / 512.0f);  // tiny opacity never reaches the floor; NaN -> keep
+  const float inv = 1.f / det;
+  const float ex2 = 2.f * tau * C * inv, ey2 = 2.f * tau * A * inv;  // squared half extents
+  const float mag = (fabsf(A) + fabsf(B) + fabsf(C)) * (ex2 + ey2);  // bound on the terms of `power` in the box
+  const bool safe = (det > 0.f) && (ex2 >= 0.f) && (ey2 >= 0.f) && (mag * 1.0e-6f < 0.005f * tau) && (mag < 1.0e30f);
+  if (!safe) return true;
+  const float ex = sqrtf(ex2) + 0.01f, ey = sqrtf(ey2) + 0.01f;
+  return (g0.x + ex >= x0) && (g0.x - ex <= x1) && (g0.y + ey >= y0) && (g0.y - ey <= y1);
+}
+
 template <bool EXTRAS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
-                    int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw, int xcd_mode) {
+                    int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw, int xcd_mode,
+                    int cull) {
   if (state[LR_HDR_NUM] > capacity) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, xcd_mode);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], end = offsets[tile + 1];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
-  const int bx = tx * 16 + (lane & 7), by = ty * 16 + (lane >> 3);
-
-  float pxf[4], pyf[4], T[4], C0[4], C1[4], C2[4], wmax[4];
-  int wid[4], last[4];
-  bool done[4], inside[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    int px = bx + (q & 1) * 8, py = by + (q >> 1) * 8;
-    pxf[q] = (float)px; pyf[q] = (float)py;
-    inside[q] = (px < v.W) && (py < v.H);
-    done[q] = !inside[q];
-    T[q] = 1.f; C0[q] = 0.f; C1[q] = 0.f; C2[q] = 0.f; wmax[q] = 0.f; wid[q] = -1; last[q] = 0;
-  }
+  const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)qx0, bx1 = (float)(qx0 + 7), by0 = (float)qy0, by1 = (float)(qy0 + 7);
+  const bool inside = (px < v.W) && (py < v.H);
+  bool done = !inside;
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, wmax = 0.f;
+  int wid = -1, last = 0;
 
   for (uint32_t base = beg; base < end; base += 64) {
-    if (__all(done[0] && done[1] && done[2] && done[3])) break;
+    if (__all(done)) break;
     const int cnt = (int)min(64u, end - base);
     uint32_t id = 0;
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
     float cb = 0.f;
+    bool rel = false;
     if (lane < cnt) {
       id = plist[base + lane];
       g0 = geom[3 * (size_t)id];
       g1 = geom[3 * (size_t)id + 1];
       cb = reinterpret_cast<const float*>(geom)[12 * (size_t)id + 8];
+      rel = cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true;
     }
+    uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
     const int pos0 = (int)(base - beg);
-    for (int j = 0; j < cnt; j++) {
-      if ((j & 7) == 0 && j && __all(done[0] && done[1] && done[2] && done[3])) break;
+    while (todo) {
+      const int j = __builtin_ctzll(todo);
+      todo &= todo - 1;
       const float mx = lr_readlane_f(g0.x, j), my = lr_readlane_f(g0.y, j);
       const float a = lr_readlane_f(hA, j), b = lr_readlane_f(nB, j), c = lr_readlane_f(hC, j);
       const float op = lr_readlane_f(g1.y, j);
-      const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
-      const int gid = lr_readlane_i((int)id, j);
-      float wbest = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (!done[q]) {
-          const float dx = mx - pxf[q], dy = my - pyf[q];
-          const float power = lr_power(a, b, c, dx, dy);
-          if (!(power > 0.f)) {
-            const float alpha = fminf(0.99f, op * lr_exp(power));
-            if (!(alpha < 1.0f / 255.0f)) {
-              const float test_T = T[q] * (1.f - alpha);
-              if (test_T < 0.0001f) {
-                done[q] = true;
-              } else {
-                const float w = alpha * T[q];
-                C0[q] = lr_fma(cr, w, C0[q]); C1[q] = lr_fma(cg, w, C1[q]); C2[q] = lr_fma(cbl, w, C2[q]);
-                if (w > wmax[q]) { wmax[q] = w; wid[q] = gid; }
-                wbest = fmaxf(wbest, w);
-                T[q] = test_T;
-                last[q] = pos0 + j + 1;
-              }
+      float w = 0.f;
+      if (!done) {
+        const float dx = mx - pxf, dy = my - pyf;
+        const float power = lr_power(a, b, c, dx, dy);
+        if (!(power > 0.f)) {
+          const float alpha = fminf(0.99f, op * lr_exp(power));
+          if (!(alpha < 1.0f / 255.0f)) {
+            const float test_T = T * (1.f - alpha);
+            if (test_T < 0.0001f) {
+              done = true;
+            } else {
+              w = alpha * T;
+              T = test_T;
+              last = pos0 + j + 1;
             }
           }
         }
       }
-      if (EXTRAS) {
-        if (__any(wbest > 0.f)) {
-          const float m = lr_wave_max_to63(wbest);
+      const uint64_t hit = __ballot(w > 0.f);
+      if (hit) {
+        const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
+        const int gid = lr_readlane_i((int)id, j);
+        if (w > 0.f) { C0 = lr_fma(cr, w, C0); C1 = lr_fma(cg, w, C1); C2 = lr_fma(cbl, w, C2); }
+        if (EXTRAS) {
+          if (w > wmax) { wmax = w; wid = gid; }
+          const float m = lr_wave_max_to63(w);
           if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, __float_as_uint(m));
         }
+      } else if (__all(done)) {
+        break;
       }
     }
   }
 
-  const size_t plane = (size_t)v.W * v.H;
-  const float bg0 = v.bg[0], bg1 = v.bg[1], bg2 = v.bg[2];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    if (inside[q]) {
-      const size_t pix = (size_t)(by + (q >> 1) * 8) * v.W + (bx + (q & 1) * 8);
-      final_T[pix] = T[q];
-      n_contrib[pix] = last[q];
-      image[pix] = lr_fma(T[q], bg0, C0[q]);
-      image[plane + pix] = lr_fma(T[q], bg1, C1[q]);
-      image[2 * plane + pix] = lr_fma(T[q], bg2, C2[q]);
-      if (EXTRAS) { pid[pix] = wid[q]; pwp[pix] = wmax[q]; }
-    }
+  if (inside) {
+    const size_t plane = (size_t)v.W * v.H;
+    const size_t pix = (size_t)py * v.W + px;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    image[pix] = lr_fma(T, v.bg[0], C0);
+    image[plane + pix] = lr_fma(T, v.bg[1], C1);
+    image[2 * plane + pix] = lr_fma(T, v.bg[2], C2);
+    if (EXTRAS) { pid[pix] = wid; pwp[pix] = wmax; }
   }
 }
 
@@ -125,133 +144,159 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
                          int* pid, float* pwp, float* pw, hipStream_t s) {
   static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 1);
+  static const int cull = lr_env_int("LOGRAST_CULL", 1);
   uint32_t grid = xcd_mode == 1 ? ((tiles + 7u) / 8u) * 8u : tiles;
   lr_prof_begin(LRK_BLEND_FWD, s);
   if (v.extras)
-    hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(64), 0, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode);
+    hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
   else
-    hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(64), 0, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode);
+    hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
   lr_prof_end(LRK_BLEND_FWD, s);
 }
 
 // ---- backward ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+// Packed wave64 reduction of 9 per-lane sums.  v_permlane32_swap(a,b) leaves a=[a.lo,b.lo], b=[a.hi,b.hi], so
+// ONE swap + ONE add halves two values at once (a's sum in lanes 0-31, b's in 32-63); v_permlane16_swap does
+// the same between odd/even 16-lane rows; the last four levels are DPP row rotations.  Result:
+//   r0 rows 0..3 = sums of (v0, v2, v1, v3);  r1 rows 0..3 = sums of (v4, v6, v5, v7);  r2 = sum of v8
+// (every lane of a row holds that row's total).
+LR_DEV float lr_swap_add32(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+LR_DEV float lr_swap_add16(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+LR_DEV float lr_row_ror_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return v + __int_as_float(moved);
+}
+LR_DEV float lr_row_sum(float v) {
+  v = lr_row_ror_add<0x128>(v);  // row_ror:8
+  v = lr_row_ror_add<0x124>(v);  // row_ror:4
+  v = lr_row_ror_add<0x122>(v);  // row_ror:2
+  v = lr_row_ror_add<0x121>(v);  // row_ror:1
+  return v;
+}
+LR_DEV void lr_reduce9(const float v[9], float& r0, float& r1, float& r2) {
+  const float p0 = lr_swap_add32(v[0], v[1]), p1 = lr_swap_add32(v[2], v[3]);
+  const float p2 = lr_swap_add32(v[4], v[5]), p3 = lr_swap_add32(v[6], v[7]);
+  const float s8 = lr_swap_add32(v[8], v[8]);
+  r0 = lr_row_sum(lr_swap_add16(p0, p1));
+  r1 = lr_row_sum(lr_swap_add16(p2, p3));
+  r2 = lr_row_sum(lr_swap_add16(s8, s8));
+}
+
+__global__ void __launch_bounds__(256)
 lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
                     const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
                     float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
-                    int xcd_mode) {
+                    int xcd_mode, int cull) {
   if (state[LR_HDR_NUM] > capacity) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, xcd_mode);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
-  const int bx = tx * 16 + (lane & 7), by = ty * 16 + (lane >> 3);
+  const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)qx0, bx1 = (float)(qx0 + 7), by0 = (float)qy0, by1 = (float)(qy0 + 7);
+  const bool in = (px < v.W) && (py < v.H);
   const size_t plane = (size_t)v.W * v.H;
-  const float bg0 = v.bg[0], bg1 = v.bg[1], bg2 = v.bg[2];
+  const size_t pix = in ? (size_t)py * v.W + px : 0;
   const float sx = 0.5f * (float)v.W, sy = 0.5f * (float)v.H;
-
-  float pxf[4], pyf[4], T[4], Tf[4], dp0[4], dp1[4], dp2[4], bgdot[4];
-  float acc0[4], acc1[4], acc2[4], lal[4], lc0[4], lc1[4], lc2[4];
-  int lastc[4];
-  int maxc = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    int px = bx + (q & 1) * 8, py = by + (q >> 1) * 8;
-    pxf[q] = (float)px; pyf[q] = (float)py;
-    bool in = (px < v.W) && (py < v.H);
-    size_t pix = in ? (size_t)py * v.W + px : 0;
-    Tf[q] = in ? final_T[pix] : 0.f;
-    lastc[q] = in ? n_contrib[pix] : 0;
-    dp0[q] = in ? dL_dimage[pix] : 0.f;
-    dp1[q] = in ? dL_dimage[plane + pix] : 0.f;
-    dp2[q] = in ? dL_dimage[2 * plane + pix] : 0.f;
-    bgdot[q] = lr_fma(bg0, dp0[q], lr_fma(bg1, dp1[q], bg2 * dp2[q]));
-    T[q] = Tf[q];
-    acc0[q] = acc1[q] = acc2[q] = 0.f; lal[q] = 0.f; lc0[q] = lc1[q] = lc2[q] = 0.f;
-    maxc = max(maxc, lastc[q]);
-  }
+  const float Tf = in ? final_T[pix] : 0.f;
+  const int lastc = in ? n_contrib[pix] : 0;
+  const float dp0 = in ? dL_dimage[pix] : 0.f;
+  const float dp1 = in ? dL_dimage[plane + pix] : 0.f;
+  const float dp2 = in ? dL_dimage[2 * plane + pix] : 0.f;
+  const float bgdot = lr_fma(v.bg[0], dp0, lr_fma(v.bg[1], dp1, v.bg[2] * dp2));
+  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lal = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+  int maxc = lastc;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
-  maxc = lr_readlane_i(maxc, 0);  // wave-uniform
+  maxc = lr_readlane_i(maxc, 0);  // wave-uniform: deepest contributor among this quadrant's pixels
+
+  // rows of the packed reduction -> destination addresses (see lr_reduce9)
+  const int row = lane >> 4;
 
   for (int hi = maxc; hi > 0; hi -= 64) {
     const int cnt = min(64, hi);
     uint32_t id = 0;
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
     float cb = 0.f;
+    bool rel = false;
     if (lane < cnt) {
       id = plist[beg + (uint32_t)(hi - 1 - lane)];
       g0 = geom[3 * (size_t)id];
       g1 = geom[3 * (size_t)id + 1];
       cb = reinterpret_cast<const float*>(geom)[12 * (size_t)id + 8];
+      rel = cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true;
     }
+    uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
-    for (int j = 0; j < cnt; j++) {
+    while (todo) {
+      const int j = __builtin_ctzll(todo);
+      todo &= todo - 1;
       const int k = hi - 1 - j;  // 0-based position in the tile list
       const float mx = lr_readlane_f(g0.x, j), my = lr_readlane_f(g0.y, j);
       const float a = lr_readlane_f(hA, j), b = lr_readlane_f(nB, j), c = lr_readlane_f(hC, j);
       const float op = lr_readlane_f(g1.y, j);
-      const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
-      const int gid = lr_readlane_i((int)id, j);
-      float s_c0 = 0.f, s_c1 = 0.f, s_c2 = 0.f, s_mx = 0.f, s_my = 0.f, s_A = 0.f, s_B = 0.f, s_C = 0.f, s_op = 0.f;
+      float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
       bool hit = false;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (k < lastc[q]) {
-          const float dx = mx - pxf[q], dy = my - pyf[q];
-          const float power = lr_power(a, b, c, dx, dy);
-          if (!(power > 0.f)) {
-            const float G = lr_exp(power);
-            const float alpha = fminf(0.99f, op * G);
-            if (!(alpha < 1.0f / 255.0f)) {
-              const float om = 1.f - alpha;
-              float rc = __builtin_amdgcn_rcpf(om);
-              rc = lr_fma(lr_fma(-om, rc, 1.f), rc, rc);  // one Newton step: v_rcp_f32's 1-ulp bias compounds over long lists
-              T[q] = T[q] * rc;
-              const float w = alpha * T[q];
-              acc0[q] = lr_fma(lal[q], lc0[q], (1.f - lal[q]) * acc0[q]);
-              acc1[q] = lr_fma(lal[q], lc1[q], (1.f - lal[q]) * acc1[q]);
-              acc2[q] = lr_fma(lal[q], lc2[q], (1.f - lal[q]) * acc2[q]);
-              lc0[q] = cr; lc1[q] = cg; lc2[q] = cbl;
-              float dL_dalpha = lr_fma(cr - acc0[q], dp0[q], lr_fma(cg - acc1[q], dp1[q], (cbl - acc2[q]) * dp2[q]));
-              dL_dalpha = lr_fma(dL_dalpha, T[q], -(Tf[q] * rc) * bgdot[q]);
-              lal[q] = alpha;
-              const float dL_dG = op * dL_dalpha;
-              const float gdx = G * dx, gdy = G * dy;
-              const float dG_ddx = lr_fma(2.f * a, gdx, b * gdy);   // -gdx*A - gdy*B
-              const float dG_ddy = lr_fma(2.f * c, gdy, b * gdx);   // -gdy*C - gdx*B
-              s_c0 = lr_fma(w, dp0[q], s_c0); s_c1 = lr_fma(w, dp1[q], s_c1); s_c2 = lr_fma(w, dp2[q], s_c2);
-              s_mx = lr_fma(dL_dG, dG_ddx, s_mx); s_my = lr_fma(dL_dG, dG_ddy, s_my);
-              s_A = lr_fma(-0.5f * gdx * dx, dL_dG, s_A);
-              s_B = lr_fma(-gdx * dy, dL_dG, s_B);
-              s_C = lr_fma(-0.5f * gdy * dy, dL_dG, s_C);
-              s_op = lr_fma(G, dL_dalpha, s_op);
-              hit = true;
-            }
-          }
+      if (k < lastc) {
+        dx = mx - pxf; dy = my - pyf;
+        const float power = lr_power(a, b, c, dx, dy);
+        if (!(power > 0.f)) {
+          G = lr_exp(power);
+          alpha = fminf(0.99f, op * G);
+          hit = !(alpha < 1.0f / 255.0f);
         }
       }
       if (__any(hit)) {
-        s_c0 = lr_wave_sum_to63(s_c0); s_c1 = lr_wave_sum_to63(s_c1); s_c2 = lr_wave_sum_to63(s_c2);
-        s_mx = lr_wave_sum_to63(s_mx); s_my = lr_wave_sum_to63(s_my);
-        s_A = lr_wave_sum_to63(s_A); s_B = lr_wave_sum_to63(s_B); s_C = lr_wave_sum_to63(s_C);
-        s_op = lr_wave_sum_to63(s_op);
-        if (lane == 63) {
-          atomicAdd(g_col + 3 * (size_t)gid + 0, s_c0);
-          atomicAdd(g_col + 3 * (size_t)gid + 1, s_c1);
-          atomicAdd(g_col + 3 * (size_t)gid + 2, s_c2);
-          atomicAdd(g_mean2d + 3 * (size_t)gid + 0, s_mx * sx);
-          atomicAdd(g_mean2d + 3 * (size_t)gid + 1, s_my * sy);
-          atomicAdd(g_conic + 4 * (size_t)gid + 0, s_A);
-          atomicAdd(g_conic + 4 * (size_t)gid + 1, s_B);
-          atomicAdd(g_conic + 4 * (size_t)gid + 2, s_C);
-          atomicAdd(g_opac + gid, s_op);
+        const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
+        const int gid = lr_readlane_i((int)id, j);
+        float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (hit) {
+          const float om = 1.f - alpha;
+          float rc = __builtin_amdgcn_rcpf(om);
+          rc = lr_fma(lr_fma(-om, rc, 1.f), rc, rc);  // one Newton step on v_rcp_f32
+          T = T * rc;
+          const float w = alpha * T;
+          acc0 = lr_fma(lal, lc0, (1.f - lal) * acc0);
+          acc1 = lr_fma(lal, lc1, (1.f - lal) * acc1);
+          acc2 = lr_fma(lal, lc2, (1.f - lal) * acc2);
+          lc0 = cr; lc1 = cg; lc2 = cbl;
+          float dL_dalpha = lr_fma(cr - acc0, dp0, lr_fma(cg - acc1, dp1, (cbl - acc2) * dp2));
+          dL_dalpha = lr_fma(dL_dalpha, T, -(Tf * rc) * bgdot);
+          lal = alpha;
+          const float dL_dG = op * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          const float dG_ddx = lr_fma(2.f * a, gdx, b * gdy);  // -gdx*A - gdy*B
+          const float dG_ddy = lr_fma(2.f * c, gdy, b * gdx);  // -gdy*C - gdx*B
+          // slot order chosen so that lr_reduce9's rows land on contiguous destinations:
+          //   r0 rows = (s0,s2,s1,s3) = (col r, col g, col b, opacity); r1 rows = (s4,s6,s5,s7) = (mean x, mean y, conic A, conic B); r2 = conic C
+          s[0] = w * dp0; s[2] = w * dp1; s[1] = w * dp2; s[3] = G * dL_dalpha;
+          s[4] = dL_dG * dG_ddx * sx; s[6] = dL_dG * dG_ddy * sy;
+          s[5] = -0.5f * gdx * dx * dL_dG; s[7] = -gdx * dy * dL_dG;
+          s[8] = -0.5f * gdy * dy * dL_dG;
+        }
+        float r0, r1, r2;
+        lr_reduce9(s, r0, r1, r2);
+        if ((lane & 15) == 0) {
+          float* d0 = (row < 3) ? (g_col + 3 * (size_t)gid + row) : (g_opac + gid);
+          float* d1 = (row < 2) ? (g_mean2d + 3 * (size_t)gid + row) : (g_conic + 4 * (size_t)gid + (row - 2));
+          atomicAdd(d0, r0);
+          atomicAdd(d1, r1);
+          if (row == 0) atomicAdd(g_conic + 4 * (size_t)gid + 2, r2);
         }
       }
     }
@@ -263,10 +308,11 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
                          hipStream_t s) {
   static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 1);
+  static const int cull = lr_env_int("LOGRAST_CULL", 1);
   uint32_t grid = xcd_mode == 1 ? ((tiles + 7u) / 8u) * 8u : tiles;
   lr_prof_begin(LRK_BLEND_BWD, s);
-  hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(64), 0, s, v, reinterpret_cast<const float4*>(geom), state,
+  hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom), state,
                      tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
-                     xcd_mode);
+                     xcd_mode, cull);
   lr_prof_end(LRK_BLEND_BWD, s);
 }

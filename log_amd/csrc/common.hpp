@@ -14,17 +14,21 @@
 
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
 // [0] num_instances  [1] overflow flag  [2..15] reserved
-// [16 .. 16+T)            per-tile counts
-// [16+Tp .. 16+Tp+T+1)    exclusive offsets (T+1 entries)
-// [16+2Tp .. 16+2Tp+T)    fill cursors
+// [16 .. 16+Tp)                    exclusive offsets (T+1 entries)          -- read by sort/blend
+// [16+Tp .. 16+Tp+T*S)             per-tile counters, one every S words     -- bumped by atomics (project)
+// [16+Tp+T*S .. 16+Tp+2*T*S)       per-tile fill cursors, one every S words -- bumped by atomics (fill)
+// S = LR_CTR_STRIDE spreads the atomic targets over more memory channels.
+#ifndef LR_CTR_STRIDE
+#define LR_CTR_STRIDE 1
+#endif
 #define LR_HDR_WORDS 16
 #define LR_HDR_NUM 0
 #define LR_HDR_OVERFLOW 1
 __host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
-__host__ __device__ inline uint32_t lr_counts_off() { return LR_HDR_WORDS; }
-__host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { return LR_HDR_WORDS + lr_tpad(tiles); }
-__host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return LR_HDR_WORDS + 2 * lr_tpad(tiles); }
-__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return LR_HDR_WORDS + 3 * lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { (void)tiles; return LR_HDR_WORDS; }
+__host__ __device__ inline uint32_t lr_counts_off(uint32_t tiles) { return LR_HDR_WORDS + lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_counts_off(tiles) + tiles * LR_CTR_STRIDE; }
+__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
 
 // Device-side view (kernel argument, by value).
 struct LrView {

@@ -99,7 +99,7 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
             geom[3 * (size_t)i + 0] = g0;
             geom[3 * (size_t)i + 1] = g1;
             for (int y = y0; y < y1; y++)
-              for (int x = x0; x < x1; x++) atomicAdd(&tile_counts[y * v.gx + x], 1u);
+              for (int x = x0; x < x1; x++) atomicAdd(&tile_counts[(y * v.gx + x) * LR_CTR_STRIDE], 1u);
           }
         }
       }
@@ -125,14 +125,14 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
 __global__ void __launch_bounds__(1024)
 lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   __shared__ uint32_t part[1024];
-  const uint32_t* counts = state + lr_counts_off();
+  const uint32_t* counts = state + lr_counts_off(tiles);
   uint32_t* offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   uint32_t tid = threadIdx.x;
   uint32_t chunk = (tiles + 1023u) / 1024u;
   uint32_t b = tid * chunk, e = min(tiles, b + chunk);
   uint32_t sum = 0;
-  for (uint32_t t = b; t < e; t++) sum += counts[t];
+  for (uint32_t t = b; t < e; t++) sum += counts[t * LR_CTR_STRIDE];
   part[tid] = sum;
   __syncthreads();
   // Hillis-Steele inclusive scan over 1024 partials
@@ -145,8 +145,8 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   uint32_t run = part[tid] - sum;  // exclusive prefix of this thread's chunk
   for (uint32_t t = b; t < e; t++) {
     offsets[t] = run;
-    cursor[t] = run;
-    run += counts[t];
+    cursor[t * LR_CTR_STRIDE] = run;
+    run += counts[t * LR_CTR_STRIDE];
   }
   if (tid == 1023) {
     offsets[tiles] = part[1023];
@@ -193,7 +193,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom,
   if (nt > 0 && nt <= LR_COOP_TILES) {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++) {
-        uint32_t pos = atomicAdd(&cursor[y * gx + x], 1u);
+        uint32_t pos = atomicAdd(&cursor[(y * gx + x) * LR_CTR_STRIDE], 1u);
         keys[pos] = key;
       }
   }
@@ -208,7 +208,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom,
     uint64_t bkey = ((uint64_t)khi << 32) | klo;
     for (int t = lane; t < bn; t += 64) {
       int ty = t / bw, tx = t - ty * bw;
-      uint32_t pos = atomicAdd(&cursor[(by0 + ty) * gx + (bx0 + tx)], 1u);
+      uint32_t pos = atomicAdd(&cursor[((by0 + ty) * gx + (bx0 + tx)) * LR_CTR_STRIDE], 1u);
       keys[pos] = bkey;
     }
   }

@@ -183,6 +183,21 @@ class HipBackend:
         self.last_conic_grad = g_conic  # test/debug introspection only
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
+    def project_backward(self, rs, flavour, use_filter, means3D, scales, rotations, radii, g_means2D, g_conic):
+        """Stage A6b alone (lograst_project_backward): used by the parity tests."""
+        device = means3D.device
+        L = self.require(device)
+        N = means3D.shape[0]
+        view, keep = self.make_view(rs, flavour, use_filter, device)
+        f32 = dict(dtype=torch.float32, device=device)
+        g_means3D, g_scales, g_rot = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 4, **f32)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_project_backward(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
+                                                  _ptr(radii), _ptr(g_means2D), _ptr(g_conic), _ptr(g_means3D),
+                                                  _ptr(g_scales), _ptr(g_rot), _stream_ptr(device)))
+        del keep
+        return g_means3D, g_scales, g_rot
+
     def compute_radius(self, means3D, scales, rotations, projmatrix, viewmatrix, fx, fy, tanfovx, tanfovy):
         device = means3D.device
         L = self.require(device)
@@ -296,6 +311,4 @@ def tile_offsets_of(saved, width, height):
     (layout: log_amd/csrc/common.hpp)."""
     gx, gy = (int(width) + 15) // 16, (int(height) + 15) // 16
     tiles = gx * gy
-    tpad = (tiles + 1 + 15) & ~15
-    off = 16 + tpad
-    return saved["state"][off:off + tiles + 1]
+    return saved["state"][16:16 + tiles + 1]

@@ -143,3 +143,18 @@ def backward(view, fwd, dL_dimage):
                       _p(fwd["radii"]), _p(g_mean2d), _p(g_conic), _p(g_means), _p(g_scales), _p(g_rots))
     return dict(means3D=g_means[:N], means2D=g_mean2d[:N], scales=g_scales[:N], rotations=g_rots[:N],
                 opacities=g_opac[:N].reshape(-1, 1), colors=g_col[:N], conic=g_conic[:N])
+
+
+def project_backward(view, fwd, g_mean2d, g_conic):
+    """A6b alone: chain rule from (dL/d ndc-mean [N,3], dL/d conic [N,4]) to means3D/scales/rotations."""
+    means, scales, rots, opac, colors = fwd["inputs"]
+    N = fwd["N"]
+    n = max(N, 1)
+    gm2 = np.zeros((n, 3), np.float32); gm2[:N] = g_mean2d
+    gc = np.zeros((n, 4), np.float32); gc[:N] = g_conic
+    g_means = np.zeros((n, 3), np.float32)
+    g_scales = np.zeros((n, 3), np.float32)
+    g_rots = np.zeros((n, 4), np.float32)
+    lib().ora_project_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots),
+                          _p(fwd["radii"]), _p(gm2), _p(gc), _p(g_means), _p(g_scales), _p(g_rots))
+    return dict(means3D=g_means[:N], scales=g_scales[:N], rotations=g_rots[:N])

@@ -34,6 +34,8 @@ def main():
                     hg = G.hip_backward(hf, dL)
                     og = oracle.backward(v, of, dL)
                     st["grad_rel_l2"] = {k: rel_l2(hg[k], og[k]) for k in og if k in hg}
+                    hp = G.hip_project_backward(hf, og["means2D"], og["conic"])
+                    st["a6b_isolated_rel_l2"] = {k: rel_l2(hp[k], og[k]) for k in hp}
                 out[key] = st
             except Exception:
                 out[key] = {"error": traceback.format_exc()}

@@ -50,6 +50,14 @@ def hip_backward(hf, dL):
                 opacities=g_o.cpu().numpy().reshape(-1, 1), scales=g_s.cpu().numpy(), rotations=g_r.cpu().numpy())
 
 
+def hip_project_backward(hf, g_mean2d, g_conic):
+    rs, flavour, use_filter, m, s, r, saved = hf["_torch"]
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=m.device)
+    g3, gs, gr = R._backend.project_backward(rs, flavour, use_filter, m, s, r, saved["radii"], t(g_mean2d), t(g_conic))
+    torch.cuda.synchronize()
+    return dict(means3D=g3.cpu().numpy(), scales=gs.cpu().numpy(), rotations=gr.cpu().numpy())
+
+
 def oracle_forward(oracle, cam, sc, bg, flavour=R.WODILATE, use_filter=True, scale_modifier=1.0):
     tfx, tfy = cam_tan(cam)
     fm = flavour.filter_mode if use_filter else _lib.FILTER_NONE

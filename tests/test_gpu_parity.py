@@ -54,6 +54,23 @@ def test_forward_bit_exact(oracle_mod, name, flavour_name):
         assert st["pid_mismatch"] == 0 and st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0, st
 
 
+def _ill_conditioned_rows(oracle_mod, v, of, og):
+    """Rows whose A6b chain rule amplifies a 1e-6 relative perturbation of dL/dconic by more than 1000x in
+    fp32 (pancake-flat Gaussians: one scale ~1e-4 of the others).  Their scale/rotation gradients are
+    numerical noise in ANY fp32 implementation -- the oracle's own result moves by O(1) when its atomics
+    reorder -- so the end-to-end comparison skips them; the A6b kernel itself is pinned on all rows by
+    test_project_backward_isolated, and the reverse walk (dL/dconic etc.) is compared on all rows."""
+    rng = np.random.default_rng(7)
+    pert = og["conic"] * (1 + 1e-6 * rng.standard_normal(og["conic"].shape).astype(np.float32))
+    g2 = oracle_mod.project_backward(v, of, og["means2D"], pert)
+    bad = np.zeros(len(og["scales"]), bool)
+    for k in ("means3D", "scales", "rotations"):
+        num = np.abs(g2[k] - og[k]).max(1)
+        den = np.abs(og[k]).max(1) + 1e-12
+        bad |= (num / den) > 1e-3
+    return bad
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_backward_vs_oracle(oracle_mod, name):
     import gpu_util as G
@@ -64,9 +81,31 @@ def test_backward_vs_oracle(oracle_mod, name):
     dL = np.random.default_rng(1).random(of["image"].shape, dtype=np.float32)
     hg = G.hip_backward(hf, dL)
     og = oracle_mod.backward(v, of, dL)
-    for k in ("means3D", "means2D", "scales", "rotations", "opacities", "colors"):
+    # A6, every row: outputs of the reverse walk
+    for k in ("means2D", "conic", "opacities", "colors"):
         assert rel_l2(hg[k], og[k]) < GRAD_TOL, (k, rel_l2(hg[k], og[k]))
     assert (hg["means2D"][:, 2] == 0).all()
+    # A6 + A6b end to end, rows where fp32 carries information
+    bad = _ill_conditioned_rows(oracle_mod, v, of, og)
+    assert bad.mean() < 0.02, bad.mean()
+    for k in ("means3D", "scales", "rotations"):
+        assert rel_l2(hg[k][~bad], og[k][~bad]) < GRAD_TOL, (k, rel_l2(hg[k][~bad], og[k][~bad]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_project_backward_isolated(oracle_mod, name):
+    """A6b alone on identical inputs (the oracle's dL/dmean2D, dL/dconic): same op sequence, so the
+    kernel must agree with the oracle to fp32 rounding on EVERY row, ill-conditioned ones included."""
+    import gpu_util as G
+    cam, sc = _case(name)
+    bg = (0.3, 0.6, 0.9)
+    hf = G.hip_forward(cam, sc, bg)
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    dL = np.random.default_rng(1).random(of["image"].shape, dtype=np.float32)
+    og = oracle_mod.backward(v, of, dL)
+    hg = G.hip_project_backward(hf, og["means2D"], og["conic"])
+    for k in ("means3D", "scales", "rotations"):
+        assert rel_l2(hg[k], og[k]) < 1e-6, (k, rel_l2(hg[k], og[k]))
 
 
 def test_use_filter_false_and_scale_modifier(oracle_mod):
@@ -109,7 +148,7 @@ def test_empty_and_all_culled(oracle_mod):
     assert hf["I"] == 0 and (hf["n_contrib"] == 0).all() and (hf["point_id_pixel"] == -1).all()
     np.testing.assert_array_equal(hf["image"][1], np.float32(0.2))
     behind = dict(sc)
-    behind["xyz"] = sc["xyz"] + np.array([100, 0, 0], np.float32)   # behind the camera on the +x orbit
+    behind["xyz"] = (sc["xyz"] + 3.0 * cam["camera_center"][None]).astype(np.float32)   # beyond the camera, behind it
     hf = G.hip_forward(cam, behind, (0.1, 0.2, 0.3))
     _, of = G.oracle_forward(oracle_mod, cam, behind, (0.1, 0.2, 0.3))
     assert hf["I"] == of["I"] and (hf["radii"] == of["radii"]).all()

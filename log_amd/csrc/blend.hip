@@ -18,15 +18,35 @@
 // 3 atomic instructions -- not 9 atomics per (pixel, Gaussian) as in the third-party kernel.
 #include "common.hpp"
 
-// blockIdx -> tile.  mode 0: identity.  mode 1: XCD-banded -- workgroup b runs on XCD b%8 (observed
-// dispatch rule), so XCD k gets the contiguous tile range [k*nper, (k+1)*nper): neighbouring tiles share
-// Gaussians and therefore share that XCD's private L2.
-LR_DEV uint32_t lr_tile_of_block(uint32_t b, uint32_t tiles, int mode) {
+// blockIdx -> tile.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness).
+//   mode 0: identity -- consecutive tiles round-robin over the XCDs: best balance, no L2 sharing;
+//   mode 1: XCD-banded -- XCD k gets the contiguous tile range [k*nper,(k+1)*nper): best L2 sharing, but a
+//           scene that fills only part of the screen leaves whole XCDs idle;
+//   mode 2: 4x4-tile super-blocks dealt round-robin to the XCDs: neighbouring tiles (which share Gaussians)
+//           share an L2, and every XCD still gets a slice of every screen region.
+LR_DEV uint32_t lr_tile_of_block(uint32_t b, uint32_t tiles, int gx, int gy, int mode) {
   if (mode == 1) {
     uint32_t nper = (tiles + 7u) >> 3;
-    return (b & 7u) * nper + (b >> 3);
+    uint32_t t = (b & 7u) * nper + (b >> 3);
+    return t < tiles ? t : 0xffffffffu;
   }
-  return b;
+  if (mode == 2) {
+    uint32_t nsbx = ((uint32_t)gx + 3u) >> 2, nsby = ((uint32_t)gy + 3u) >> 2;
+    uint32_t r = b >> 3, sb = (r >> 4) * 8u + (b & 7u), local = r & 15u;
+    if (sb >= nsbx * nsby) return 0xffffffffu;
+    uint32_t tx = (sb % nsbx) * 4u + (local & 3u), ty = (sb / nsbx) * 4u + (local >> 2);
+    if (tx >= (uint32_t)gx || ty >= (uint32_t)gy) return 0xffffffffu;
+    return ty * (uint32_t)gx + tx;
+  }
+  return b < tiles ? b : 0xffffffffu;
+}
+static inline __host__ __device__ uint32_t lr_blend_grid(uint32_t tiles, int gx, int gy, int mode) {
+  if (mode == 1) return ((tiles + 7u) / 8u) * 8u;
+  if (mode == 2) {
+    uint32_t nsb = (((uint32_t)gx + 3u) >> 2) * (((uint32_t)gy + 3u) >> 2);
+    return ((nsb + 7u) / 8u) * 8u * 16u;
+  }
+  return tiles;
 }
 
 // Conservative test: can the Gaussian (record q0,q1) reach alpha >= 1/255 anywhere in the pixel box
@@ -56,7 +76,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw, int xcd_mode,
                     int cull) {
   if (state[LR_HDR_NUM] > capacity) return;
-  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, xcd_mode);
+  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], end = offsets[tile + 1];
@@ -71,23 +91,31 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, wmax = 0.f;
   int wid = -1, last = 0;
 
-  for (uint32_t base = beg; base < end; base += 64) {
+  // Software pipeline over 64-entry chunks: ids are fetched two chunks ahead and records one chunk ahead, so
+  // the dependent id -> record gather of chunk c+1 is in flight while chunk c is composited.
+  const uint32_t nchunks = (end - beg + 63u) >> 6;
+  const float* geomf = reinterpret_cast<const float*>(geom);
+  auto load_id = [&](uint32_t c) -> uint32_t {
+    const uint32_t idx = beg + c * 64u + (uint32_t)lane;
+    return (c < nchunks && idx < end) ? plist[idx] : 0xffffffffu;
+  };
+  uint32_t id_n = load_id(0), id_nn = load_id(1);
+  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
+  float cb_n = 0.f;
+  if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+
+  for (uint32_t ch = 0; ch < nchunks; ch++) {
     if (__all(done)) break;
-    const int cnt = (int)min(64u, end - base);
-    uint32_t id = 0;
-    float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
-    float cb = 0.f;
-    bool rel = false;
-    if (lane < cnt) {
-      id = plist[base + lane];
-      g0 = geom[3 * (size_t)id];
-      g1 = geom[3 * (size_t)id + 1];
-      cb = reinterpret_cast<const float*>(geom)[12 * (size_t)id + 8];
-      rel = cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true;
-    }
+    const uint32_t id = id_n;
+    const float4 g0 = g0_n, g1 = g1_n;
+    const float cb = cb_n;
+    id_n = id_nn;
+    id_nn = load_id(ch + 2);
+    if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+    const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
-    const int pos0 = (int)(base - beg);
+    const int pos0 = (int)(ch * 64u);
     while (todo) {
       const int j = __builtin_ctzll(todo);
       todo &= todo - 1;
@@ -143,9 +171,9 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
                          int* pid, float* pwp, float* pw, hipStream_t s) {
-  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 1);
+  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 0);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
-  uint32_t grid = xcd_mode == 1 ? ((tiles + 7u) / 8u) * 8u : tiles;
+  uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_FWD, s);
   if (v.extras)
     hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
@@ -199,7 +227,7 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
                     int xcd_mode, int cull) {
   if (state[LR_HDR_NUM] > capacity) return;
-  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, xcd_mode);
+  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile];
@@ -228,19 +256,28 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   // rows of the packed reduction -> destination addresses (see lr_reduce9)
   const int row = lane >> 4;
 
-  for (int hi = maxc; hi > 0; hi -= 64) {
-    const int cnt = min(64, hi);
-    uint32_t id = 0;
-    float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
-    float cb = 0.f;
-    bool rel = false;
-    if (lane < cnt) {
-      id = plist[beg + (uint32_t)(hi - 1 - lane)];
-      g0 = geom[3 * (size_t)id];
-      g1 = geom[3 * (size_t)id + 1];
-      cb = reinterpret_cast<const float*>(geom)[12 * (size_t)id + 8];
-      rel = cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true;
-    }
+  // Reverse walk in 64-entry chunks from the deepest contributor; lane l of chunk ch holds list position
+  // maxc-1 - 64*ch - l.  Same two-stage prefetch as the forward pass.
+  const uint32_t nchunks = ((uint32_t)maxc + 63u) >> 6;
+  const float* geomf = reinterpret_cast<const float*>(geom);
+  auto load_id = [&](uint32_t c) -> uint32_t {
+    const int pos = maxc - 1 - (int)(c * 64u) - lane;
+    return (c < nchunks && pos >= 0) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
+  };
+  uint32_t id_n = load_id(0), id_nn = load_id(1);
+  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
+  float cb_n = 0.f;
+  if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+
+  for (uint32_t ch = 0; ch < nchunks; ch++) {
+    const int hi = maxc - (int)(ch * 64u);
+    const uint32_t id = id_n;
+    const float4 g0 = g0_n, g1 = g1_n;
+    const float cb = cb_n;
+    id_n = id_nn;
+    id_nn = load_id(ch + 2);
+    if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+    const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
     while (todo) {
@@ -307,9 +344,9 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
                          hipStream_t s) {
-  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 1);
+  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 0);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
-  uint32_t grid = xcd_mode == 1 ? ((tiles + 7u) / 8u) * 8u : tiles;
+  uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_BWD, s);
   hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom), state,
                      tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,

@@ -74,22 +74,27 @@ lr_sort_global_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64
   for (uint32_t i = tid; i < L; i += 256) plist[beg + i] = (uint32_t)s[i];
 }
 
-#define LR_SORT_SMALL_CAP 1024
-#define LR_SORT_LARGE_CAP 8192
+// Size classes: the LDS footprint (8 B/key) sets how many workgroups a CU can hold, and the network is
+// barrier-latency bound, so small lists must not pay for the largest class's 64 KB.
+#define LR_SORT_CAP0 512    //  4 KB
+#define LR_SORT_CAP1 2048   // 16 KB
+#define LR_SORT_CAP2 8192   // 64 KB
 
 void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     hipStream_t s) {
   if (tiles == 0) return;
   lr_prof_begin(LRK_SORT_SMALL, s);
-  hipLaunchKernelGGL(lr_sort_lds_kernel<LR_SORT_SMALL_CAP>, dim3(tiles), dim3(256), 0, s, state, tiles, keys, plist,
+  hipLaunchKernelGGL(lr_sort_lds_kernel<LR_SORT_CAP0>, dim3(tiles), dim3(256), 0, s, state, tiles, keys, plist,
                      0u, capacity);
   lr_prof_end(LRK_SORT_SMALL, s);
   lr_prof_begin(LRK_SORT_LARGE, s);
-  hipLaunchKernelGGL(lr_sort_lds_kernel<LR_SORT_LARGE_CAP>, dim3(tiles), dim3(256), 0, s, state, tiles, keys, plist,
-                     (uint32_t)LR_SORT_SMALL_CAP, capacity);
+  hipLaunchKernelGGL(lr_sort_lds_kernel<LR_SORT_CAP1>, dim3(tiles), dim3(256), 0, s, state, tiles, keys, plist,
+                     (uint32_t)LR_SORT_CAP0, capacity);
+  hipLaunchKernelGGL(lr_sort_lds_kernel<LR_SORT_CAP2>, dim3(tiles), dim3(256), 0, s, state, tiles, keys, plist,
+                     (uint32_t)LR_SORT_CAP1, capacity);
   lr_prof_end(LRK_SORT_LARGE, s);
   lr_prof_begin(LRK_SORT_HUGE, s);
   hipLaunchKernelGGL(lr_sort_global_kernel, dim3(tiles), dim3(256), 0, s, state, tiles, keys, plist,
-                     (uint32_t)LR_SORT_LARGE_CAP, capacity);
+                     (uint32_t)LR_SORT_CAP2, capacity);
   lr_prof_end(LRK_SORT_HUGE, s);
 }

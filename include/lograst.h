@@ -29,7 +29,7 @@ extern "C" {
 
 #define LOGRAST_VERSION 1
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
-#define LOGRAST_REC_FLOATS 12  /* floats per projected-Gaussian record (48 B) */
+#define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B) */
 
 /* 2-D low-pass flavours */
 #define LOGRAST_FILTER_NONE 0   /* use_filter=False of the fork (LoG/render/renderer.py:151-152) */

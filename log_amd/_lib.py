@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblograst.so")  # env: experiment builds only
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
-REC_FLOATS = 12
+REC_FLOATS = 16
 NUM_KERNELS = 12
 
 c_void_p, c_int32, c_uint32, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,

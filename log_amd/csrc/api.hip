@@ -17,8 +17,8 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
                       const float* view, float fx, float fy, float tanfovx, float tanfovy, float* radii,
                       hipStream_t s);
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
-                       const float* opac, const float* colors, int* radii, void* geom, uint32_t* tile_counts,
-                       hipStream_t s);
+                       const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
+                       uint32_t* big, hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, hipStream_t s);
@@ -168,8 +168,9 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
   // zero header and counters (offsets/cursors are fully rewritten by the scan)
   LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * LR_HDR_WORDS, s));
-  LR_HIP(hipMemsetAsync(st + lr_counts_off(tiles), 0, sizeof(uint32_t) * (size_t)tiles * LR_CTR_STRIDE, s));
-  lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_counts_off(tiles), s);
+  LR_HIP(hipMemsetAsync(st + lr_ranked_off(tiles), 0, sizeof(uint32_t) * 2 * (size_t)tiles * LR_CTR_STRIDE, s));
+  lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
+                    st + lr_big_off(tiles), s);
   lr_launch_scan(st, tiles, s);
   LR_HIP(hipGetLastError());
   if (num_instances_host) {

@@ -24,7 +24,11 @@
 //           scene that fills only part of the screen leaves whole XCDs idle;
 //   mode 2: 4x4-tile super-blocks dealt round-robin to the XCDs: neighbouring tiles (which share Gaussians)
 //           share an L2, and every XCD still gets a slice of every screen region.
-LR_DEV uint32_t lr_tile_of_block(uint32_t b, uint32_t tiles, int gx, int gy, int mode) {
+//   mode 3: longest list first (order[] written by the scan kernel): the dispatcher hands out workgroups in
+//           index order, so the serial walks of the longest lists start first instead of forming the tail.
+LR_DEV uint32_t lr_tile_of_block(uint32_t b, uint32_t tiles, int gx, int gy, int mode,
+                                 const uint32_t* __restrict__ state) {
+  if (mode == 3) return b < tiles ? state[lr_order_off(tiles) + b] : 0xffffffffu;
   if (mode == 1) {
     uint32_t nper = (tiles + 7u) >> 3;
     uint32_t t = (b & 7u) * nper + (b >> 3);
@@ -74,9 +78,9 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw, int xcd_mode,
-                    int cull) {
+                    int cull, int prio) {
   if (state[LR_HDR_NUM] > capacity) return;
-  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode);
+  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], end = offsets[tile + 1];
@@ -94,6 +98,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   // Software pipeline over 64-entry chunks: ids are fetched two chunks ahead and records one chunk ahead, so
   // the dependent id -> record gather of chunk c+1 is in flight while chunk c is composited.
   const uint32_t nchunks = (end - beg + 63u) >> 6;
+  if (prio && nchunks > 8) __builtin_amdgcn_s_setprio(2);  // long serial walks are the launch's critical path
   const float* geomf = reinterpret_cast<const float*>(geom);
   auto load_id = [&](uint32_t c) -> uint32_t {
     const uint32_t idx = beg + c * 64u + (uint32_t)lane;
@@ -102,7 +107,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   uint32_t id_n = load_id(0), id_nn = load_id(1);
   float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
   float cb_n = 0.f;
-  if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+  if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     if (__all(done)) break;
@@ -111,7 +116,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     const float cb = cb_n;
     id_n = id_nn;
     id_nn = load_id(ch + 2);
-    if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+    if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
     const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
@@ -147,8 +152,8 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (w > 0.f) { C0 = lr_fma(cr, w, C0); C1 = lr_fma(cg, w, C1); C2 = lr_fma(cbl, w, C2); }
         if (EXTRAS) {
           if (w > wmax) { wmax = w; wid = gid; }
-          const float m = lr_wave_max_to63(w);
-          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, __float_as_uint(m));
+          const uint32_t m = lr_wave_umax_to63(__float_as_uint(w));  // w >= 0: unsigned order == float order
+          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
         }
       } else if (__all(done)) {
         break;
@@ -171,16 +176,17 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
                          int* pid, float* pwp, float* pw, hipStream_t s) {
-  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 0);
+  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
+  static const int prio = lr_env_int("LOGRAST_PRIO", 0);
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_FWD, s);
   if (v.extras)
     hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull, prio);
   else
     hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull, prio);
   lr_prof_end(LRK_BLEND_FWD, s);
 }
 
@@ -225,9 +231,9 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
                     const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
                     float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
-                    int xcd_mode, int cull) {
+                    int xcd_mode, int cull, int prio) {
   if (state[LR_HDR_NUM] > capacity) return;
-  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode);
+  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile];
@@ -259,6 +265,7 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   // Reverse walk in 64-entry chunks from the deepest contributor; lane l of chunk ch holds list position
   // maxc-1 - 64*ch - l.  Same two-stage prefetch as the forward pass.
   const uint32_t nchunks = ((uint32_t)maxc + 63u) >> 6;
+  if (prio && nchunks > 8) __builtin_amdgcn_s_setprio(2);
   const float* geomf = reinterpret_cast<const float*>(geom);
   auto load_id = [&](uint32_t c) -> uint32_t {
     const int pos = maxc - 1 - (int)(c * 64u) - lane;
@@ -267,7 +274,7 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   uint32_t id_n = load_id(0), id_nn = load_id(1);
   float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
   float cb_n = 0.f;
-  if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+  if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     const int hi = maxc - (int)(ch * 64u);
@@ -276,7 +283,7 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     const float cb = cb_n;
     id_n = id_nn;
     id_nn = load_id(ch + 2);
-    if (id_n != 0xffffffffu) { g0_n = geom[3 * (size_t)id_n]; g1_n = geom[3 * (size_t)id_n + 1]; cb_n = geomf[12 * (size_t)id_n + 8]; }
+    if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
     const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
@@ -344,12 +351,13 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
                          hipStream_t s) {
-  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 0);
+  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
+  static const int prio = lr_env_int("LOGRAST_PRIO", 0);
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_BWD, s);
   hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom), state,
                      tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
-                     xcd_mode, cull);
+                     xcd_mode, cull, prio);
   lr_prof_end(LRK_BLEND_BWD, s);
 }

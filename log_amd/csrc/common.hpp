@@ -14,21 +14,29 @@
 
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
 // [0] num_instances  [1] overflow flag  [2..15] reserved
-// [16 .. 16+Tp)                    exclusive offsets (T+1 entries)          -- read by sort/blend
-// [16+Tp .. 16+Tp+T*S)             per-tile counters, one every S words     -- bumped by atomics (project)
-// [16+Tp+T*S .. 16+Tp+2*T*S)       per-tile fill cursors, one every S words -- bumped by atomics (fill)
-// S = LR_CTR_STRIDE spreads the atomic targets over more memory channels.
+// [16 .. 16+Tp)          exclusive offsets (T+1 entries)                              -- read by sort/blend
+// then three per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic
+// targets spread over the memory channels instead of 8160 counters sharing 32 KB):
+//   ranked[T*S]   instances of Gaussians touching <= LR_RANKED_TILES tiles; the returning atomic that counts
+//                 them also hands each instance its slot inside the tile (stored in the record's q3)
+//   big[T*S]      instances of larger Gaussians (counted only)
+//   cursor[T*S]   fill cursor for the big instances, initialised to offset + ranked
+// then order[T]: tile ids by descending list length (longest-first dispatch order for the blend kernels)
 #ifndef LR_CTR_STRIDE
-#define LR_CTR_STRIDE 1
+#define LR_CTR_STRIDE 16
 #endif
+#define LR_RANKED_TILES 4
 #define LR_HDR_WORDS 16
 #define LR_HDR_NUM 0
 #define LR_HDR_OVERFLOW 1
+#define LR_REC_QUADS 4  // float4 per projected record (64 B)
 __host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
 __host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { (void)tiles; return LR_HDR_WORDS; }
-__host__ __device__ inline uint32_t lr_counts_off(uint32_t tiles) { return LR_HDR_WORDS + lr_tpad(tiles); }
-__host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_counts_off(tiles) + tiles * LR_CTR_STRIDE; }
-__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
+__host__ __device__ inline uint32_t lr_ranked_off(uint32_t tiles) { return LR_HDR_WORDS + lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_big_off(uint32_t tiles) { return lr_ranked_off(tiles) + tiles * LR_CTR_STRIDE; }
+__host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_big_off(tiles) + tiles * LR_CTR_STRIDE; }
+__host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
+__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
 
 // Device-side view (kernel argument, by value).
 struct LrView {
@@ -184,6 +192,23 @@ LR_DEV float lr_wave_max_to63(float v) {
   v = lr_dpp_max<0x118, 0xf, 0xc>(v);
   v = lr_dpp_max<0x142, 0xa, 0xf>(v);
   v = lr_dpp_max<0x143, 0xc, 0xf>(v);
+  return v;
+}
+
+// Same tree on the raw bit patterns of NON-NEGATIVE floats (unsigned order == float order): v_max_u32
+// needs no NaN canonicalisation, so every step is one DPP-fused instruction.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+LR_DEV uint32_t lr_dpp_umax(uint32_t v) {
+  uint32_t moved = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+  return max(v, moved);
+}
+LR_DEV uint32_t lr_wave_umax_to63(uint32_t v) {
+  v = lr_dpp_umax<0x111, 0xf, 0xf>(v);
+  v = lr_dpp_umax<0x112, 0xf, 0xf>(v);
+  v = lr_dpp_umax<0x114, 0xf, 0xe>(v);
+  v = lr_dpp_umax<0x118, 0xf, 0xc>(v);
+  v = lr_dpp_umax<0x142, 0xa, 0xf>(v);
+  v = lr_dpp_umax<0x143, 0xc, 0xf>(v);
   return v;
 }
 

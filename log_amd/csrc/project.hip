@@ -1,6 +1,6 @@
 // project.hip -- per-Gaussian streaming kernels: A0 compute_radius, A1 projection (+ A2 tile counting),
 // tile scan, and A3 per-tile bucket fill.  HBM-bound: every Gaussian attribute is read exactly once,
-// coalesced; the 48-byte projected record is written once.
+// coalesced; the 64-byte projected record is written once.
 #include "common.hpp"
 
 // ---- A0 -------------------------------------------------------------------------------------------
@@ -45,15 +45,17 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
 }
 
 // ---- A1 + A2 ----------------------------------------------------------------------------------------
-// One thread per Gaussian.  Writes radii[i] (0 = culled), the 48-byte record
+// One thread per Gaussian.  Writes radii[i] (0 = culled) and the 64-byte record
 //   q0 = (mx, my, conicA, conicB)  q1 = (conicC, opacity, r, g)  q2 = (b, depth, rect_min, rect_max)
-// (q2 is written for every Gaussian, zero = culled/empty rect) and bumps the per-tile counters for
-// every tile of its rect.
+//   q3 = slots of its (<= 4) tile instances inside their tiles, row-major over the rect
+// (q2 is written for every Gaussian, zero = culled/empty rect).  Counting and slot assignment are one
+// returning atomic per instance, so the bucket fill needs no atomics for these Gaussians; larger rects are
+// only counted here (non-returning atomic) and placed by the fill kernel.
 __global__ void __launch_bounds__(256)
 lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
                   const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
-                  uint32_t* __restrict__ tile_counts) {
+                  uint32_t* __restrict__ ranked, uint32_t* __restrict__ big) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const float* __restrict__ V = v.view;
@@ -96,26 +98,40 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
             float4 g1 = {cC, opac[i], colors[3 * i], colors[3 * i + 1]};
             g2 = float4{colors[3 * i + 2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
                         __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
-            geom[3 * (size_t)i + 0] = g0;
-            geom[3 * (size_t)i + 1] = g1;
-            for (int y = y0; y < y1; y++)
-              for (int x = x0; x < x1; x++) atomicAdd(&tile_counts[(y * v.gx + x) * LR_CTR_STRIDE], 1u);
+            geom[LR_REC_QUADS * (size_t)i + 0] = g0;
+            geom[LR_REC_QUADS * (size_t)i + 1] = g1;
+            const int w = x1 - x0, nt = w * (y1 - y0);
+            if (nt <= LR_RANKED_TILES) {
+              uint32_t slot[LR_RANKED_TILES] = {0u, 0u, 0u, 0u};
+#pragma unroll
+              for (int k = 0; k < LR_RANKED_TILES; k++) {
+                if (k < nt) {
+                  const int ty = k / w, tx = k - ty * w;
+                  slot[k] = atomicAdd(&ranked[((y0 + ty) * v.gx + (x0 + tx)) * LR_CTR_STRIDE], 1u);
+                }
+              }
+              geom[LR_REC_QUADS * (size_t)i + 3] = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]),
+                                                          __uint_as_float(slot[2]), __uint_as_float(slot[3])};
+            } else {
+              for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) atomicAdd(&big[(y * v.gx + x) * LR_CTR_STRIDE], 1u);
+            }
           }
         }
       }
     }
   }
-  geom[3 * (size_t)i + 2] = g2;
+  geom[LR_REC_QUADS * (size_t)i + 2] = g2;
   radii[i] = rad;
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
-                       const float* opac, const float* colors, int* radii, void* geom, uint32_t* tile_counts,
-                       hipStream_t s) {
+                       const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
+                       uint32_t* big, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_PROJECT, s);
   hipLaunchKernelGGL(lr_project_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, N, means, scales, rots, opac,
-                     colors, radii, reinterpret_cast<float4*>(geom), tile_counts);
+                     colors, radii, reinterpret_cast<float4*>(geom), ranked, big);
   lr_prof_end(LRK_PROJECT, s);
 }
 
@@ -125,14 +141,15 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
 __global__ void __launch_bounds__(1024)
 lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   __shared__ uint32_t part[1024];
-  const uint32_t* counts = state + lr_counts_off(tiles);
+  const uint32_t* ranked = state + lr_ranked_off(tiles);
+  const uint32_t* big = state + lr_big_off(tiles);
   uint32_t* offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   uint32_t tid = threadIdx.x;
   uint32_t chunk = (tiles + 1023u) / 1024u;
   uint32_t b = tid * chunk, e = min(tiles, b + chunk);
   uint32_t sum = 0;
-  for (uint32_t t = b; t < e; t++) sum += counts[t * LR_CTR_STRIDE];
+  for (uint32_t t = b; t < e; t++) sum += ranked[t * LR_CTR_STRIDE] + big[t * LR_CTR_STRIDE];
   part[tid] = sum;
   __syncthreads();
   // Hillis-Steele inclusive scan over 1024 partials
@@ -145,13 +162,35 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   uint32_t run = part[tid] - sum;  // exclusive prefix of this thread's chunk
   for (uint32_t t = b; t < e; t++) {
     offsets[t] = run;
-    cursor[t * LR_CTR_STRIDE] = run;
-    run += counts[t * LR_CTR_STRIDE];
+    const uint32_t nr = ranked[t * LR_CTR_STRIDE];
+    cursor[t * LR_CTR_STRIDE] = run + nr;  // big instances go behind the ranked ones
+    run += nr + big[t * LR_CTR_STRIDE];
   }
   if (tid == 1023) {
     offsets[tiles] = part[1023];
     state[LR_HDR_NUM] = part[1023];
     state[LR_HDR_OVERFLOW] = 0u;
+  }
+  // Longest-processing-time-first dispatch order for the blend kernels: a tile's list is walked serially by
+  // its waves, so the longest lists must start first or they become the tail of the launch.  Counting sort
+  // of the tiles into 256 length buckets (16 entries wide), longest bucket first.
+  __shared__ uint32_t hist[256];
+  uint32_t* order = state + lr_order_off(tiles);
+  if (tid < 256) hist[tid] = 0u;
+  __syncthreads();
+  for (uint32_t t = b; t < e; t++) {
+    const uint32_t len = ranked[t * LR_CTR_STRIDE] + big[t * LR_CTR_STRIDE];
+    atomicAdd(&hist[min(255u, len >> 4)], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run2 = 0;
+    for (int k = 255; k >= 0; k--) { uint32_t c = hist[k]; hist[k] = run2; run2 += c; }
+  }
+  __syncthreads();
+  for (uint32_t t = b; t < e; t++) {
+    const uint32_t len = ranked[t * LR_CTR_STRIDE] + big[t * LR_CTR_STRIDE];
+    order[atomicAdd(&hist[min(255u, len >> 4)], 1u)] = t;
   }
 }
 
@@ -163,25 +202,27 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
 
 // ---- A3: per-tile bucket fill ---------------------------------------------------------------------------
 // key = (fp32 bits of view depth) << 32 | Gaussian index; depth > 0.2 so the bit pattern is monotone.
-// Small rects are expanded by their own lane; rects with more than LR_COOP_TILES tiles are expanded by
-// the whole wave (ballot over the lanes that hold one, record broadcast with readlane) so that a single
-// screen-filling Gaussian does not serialise its wave.
+// Gaussians with <= 4 tiles already own their slots (q3): position = offsets[tile] + slot, no atomics.  Larger
+// rects take positions from the per-tile cursor; up to LR_COOP_TILES tiles a lane expands its own rect,
+// beyond that the whole wave expands it (ballot over the lanes that hold one, record broadcast with
+// readlane) so that a single screen-filling Gaussian does not serialise its wave.
 #define LR_COOP_TILES 16
 __global__ void __launch_bounds__(256)
-lr_fill_kernel(int N, int gx, const float4* __restrict__ geom,
-               uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys, uint32_t capacity) {
+lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
+               uint64_t* __restrict__ keys, uint32_t capacity) {
   uint32_t total = state[LR_HDR_NUM];
   if (total > capacity) {
     if (blockIdx.x == 0 && threadIdx.x == 0) state[LR_HDR_OVERFLOW] = 1u;
     return;
   }
+  const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   int i = blockIdx.x * 256 + threadIdx.x;
   int lane = threadIdx.x & 63;
   bool vis = (i < N);
   uint32_t r0 = 0, r1 = 0, dbits = 0;
   if (vis) {
-    float4 g2 = geom[3 * (size_t)i + 2];
+    float4 g2 = geom[LR_REC_QUADS * (size_t)i + 2];
     dbits = __float_as_uint(g2.y);
     r0 = __float_as_uint(g2.z);
     r1 = __float_as_uint(g2.w);
@@ -190,17 +231,28 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom,
   int w = x1 - x0, h = y1 - y0;
   int nt = vis ? w * h : 0;
   uint64_t key = ((uint64_t)dbits << 32) | (uint32_t)i;
-  if (nt > 0 && nt <= LR_COOP_TILES) {
+  if (nt > 0 && nt <= LR_RANKED_TILES) {
+    const float4 g3 = geom[LR_REC_QUADS * (size_t)i + 3];
+    const uint32_t slot[LR_RANKED_TILES] = {__float_as_uint(g3.x), __float_as_uint(g3.y), __float_as_uint(g3.z),
+                                            __float_as_uint(g3.w)};
+#pragma unroll
+    for (int k = 0; k < LR_RANKED_TILES; k++) {
+      if (k < nt) {
+        const int ty = k / w, tx = k - ty * w;
+        keys[offsets[(y0 + ty) * gx + (x0 + tx)] + slot[k]] = key;
+      }
+    }
+  } else if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES) {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++) {
         uint32_t pos = atomicAdd(&cursor[(y * gx + x) * LR_CTR_STRIDE], 1u);
         keys[pos] = key;
       }
   }
-  uint64_t big = __ballot(nt > LR_COOP_TILES);
-  while (big) {
-    int src = __builtin_ctzll(big);
-    big &= big - 1;
+  uint64_t bigm = __ballot(nt > LR_COOP_TILES);
+  while (bigm) {
+    int src = __builtin_ctzll(bigm);
+    bigm &= bigm - 1;
     int bx0 = lr_readlane_i(x0, src), by0 = lr_readlane_i(y0, src);
     int bw = lr_readlane_i(w, src), bn = lr_readlane_i(nt, src);
     uint32_t klo = (uint32_t)lr_readlane_i((int)(uint32_t)key, src);
@@ -214,8 +266,8 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom,
   }
 }
 
-void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles,
-                    uint64_t* keys, uint32_t capacity, hipStream_t s) {
+void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
+                    uint32_t capacity, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   hipLaunchKernelGGL(lr_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, gx,

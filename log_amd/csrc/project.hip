@@ -177,21 +177,21 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   __shared__ uint32_t hist[256];
   uint32_t* order = state + lr_order_off(tiles);
   if (tid < 256) hist[tid] = 0u;
+  __syncthreads();  // also orders the offsets[] stores above before the reads below (same workgroup)
+  for (uint32_t t = b; t < e; t++) atomicAdd(&hist[min(255u, (offsets[t + 1] - offsets[t]) >> 4)], 1u);
   __syncthreads();
-  for (uint32_t t = b; t < e; t++) {
-    const uint32_t len = ranked[t * LR_CTR_STRIDE] + big[t * LR_CTR_STRIDE];
-    atomicAdd(&hist[min(255u, len >> 4)], 1u);
-  }
+  if (tid < 256) part[tid] = hist[255 - tid];  // descending bucket order
   __syncthreads();
-  if (tid == 0) {
-    uint32_t run2 = 0;
-    for (int k = 255; k >= 0; k--) { uint32_t c = hist[k]; hist[k] = run2; run2 += c; }
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t add = (tid < 256 && tid >= d) ? part[tid - d] : 0u;
+    __syncthreads();
+    if (tid < 256) part[tid] += add;
+    __syncthreads();
   }
+  if (tid < 256) hist[255 - tid] = part[tid] - hist[255 - tid];  // exclusive start of each bucket
   __syncthreads();
-  for (uint32_t t = b; t < e; t++) {
-    const uint32_t len = ranked[t * LR_CTR_STRIDE] + big[t * LR_CTR_STRIDE];
-    order[atomicAdd(&hist[min(255u, len >> 4)], 1u)] = t;
-  }
+  for (uint32_t t = b; t < e; t++)
+    order[atomicAdd(&hist[min(255u, (offsets[t + 1] - offsets[t]) >> 4)], 1u)] = t;
 }
 
 void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {

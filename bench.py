@@ -166,6 +166,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueued = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -198,6 +199,7 @@ def main():
                            ", %d views in flight per GPU (HIP streams)" % S,
         },
         "ms_per_view": 1e3 * elapsed / (args.steps * args.views),
+        "host_enqueue_ms_per_view": 1e3 * t_enqueued / (args.steps * args.views),
     }
 
     if rank == 0:

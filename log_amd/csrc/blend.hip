@@ -121,43 +121,66 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
     const int pos0 = (int)(ch * 64u);
+    // Two list entries per iteration, branch-free: the two alpha evaluations (power + exp polynomial, ~20 VALU
+    // each) are independent, so one wave can issue them back to back instead of waiting out each dependent
+    // result; T / done / last are then applied in list order.  Lane predicates stay in SGPR lane masks
+    // (v_cmp -> s_and/s_or -> v_cndmask), no exec-mask juggling.
     while (todo) {
-      const int j = __builtin_ctzll(todo);
+      const int j0 = __builtin_ctzll(todo);
       todo &= todo - 1;
-      const float mx = lr_readlane_f(g0.x, j), my = lr_readlane_f(g0.y, j);
-      const float a = lr_readlane_f(hA, j), b = lr_readlane_f(nB, j), c = lr_readlane_f(hC, j);
-      const float op = lr_readlane_f(g1.y, j);
-      float w = 0.f;
-      if (!done) {
-        const float dx = mx - pxf, dy = my - pyf;
-        const float power = lr_power(a, b, c, dx, dy);
-        if (!(power > 0.f)) {
-          const float alpha = fminf(0.99f, op * lr_exp(power));
-          if (!(alpha < 1.0f / 255.0f)) {
-            const float test_T = T * (1.f - alpha);
-            if (test_T < 0.0001f) {
-              done = true;
-            } else {
-              w = alpha * T;
-              T = test_T;
-              last = pos0 + j + 1;
-            }
-          }
-        }
-      }
-      const uint64_t hit = __ballot(w > 0.f);
-      if (hit) {
-        const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
-        const int gid = lr_readlane_i((int)id, j);
-        if (w > 0.f) { C0 = lr_fma(cr, w, C0); C1 = lr_fma(cg, w, C1); C2 = lr_fma(cbl, w, C2); }
+      const bool has1 = todo != 0;
+      const int j1 = has1 ? __builtin_ctzll(todo) : j0;
+      todo &= todo - 1;  // no-op when todo == 0
+      const float mx0 = lr_readlane_f(g0.x, j0), my0 = lr_readlane_f(g0.y, j0);
+      const float a0 = lr_readlane_f(hA, j0), b0 = lr_readlane_f(nB, j0), c0 = lr_readlane_f(hC, j0);
+      const float op0 = lr_readlane_f(g1.y, j0);
+      const float mx1 = lr_readlane_f(g0.x, j1), my1 = lr_readlane_f(g0.y, j1);
+      const float a1 = lr_readlane_f(hA, j1), b1 = lr_readlane_f(nB, j1), c1 = lr_readlane_f(hC, j1);
+      const float op1 = lr_readlane_f(g1.y, j1);
+      const float power0 = lr_power(a0, b0, c0, mx0 - pxf, my0 - pyf);
+      const float power1 = lr_power(a1, b1, c1, mx1 - pxf, my1 - pyf);
+      const float alpha0 = fminf(0.99f, op0 * lr_exp(power0));
+      const float alpha1 = fminf(0.99f, op1 * lr_exp(power1));
+      // entry j0
+      const bool ok0 = !done & !(power0 > 0.f) & !(alpha0 < 1.0f / 255.0f);
+      const float test0 = T * (1.f - alpha0);
+      const bool stop0 = ok0 & (test0 < 0.0001f);
+      const bool acc0 = ok0 & !stop0;
+      const float w0 = acc0 ? alpha0 * T : 0.f;
+      T = acc0 ? test0 : T;
+      last = acc0 ? pos0 + j0 + 1 : last;
+      done = done | stop0;
+      // entry j1 (masked out when the chunk had an odd number of relevant entries)
+      const bool ok1 = has1 & !done & !(power1 > 0.f) & !(alpha1 < 1.0f / 255.0f);
+      const float test1 = T * (1.f - alpha1);
+      const bool stop1 = ok1 & (test1 < 0.0001f);
+      const bool acc1 = ok1 & !stop1;
+      const float w1 = acc1 ? alpha1 * T : 0.f;
+      T = acc1 ? test1 : T;
+      last = acc1 ? pos0 + j1 + 1 : last;
+      done = done | stop1;
+      const bool hit0 = __any(acc0), hit1 = __any(acc1);
+      if (hit0) {
+        const float cr = lr_readlane_f(g1.z, j0), cg = lr_readlane_f(g1.w, j0), cbl = lr_readlane_f(cb, j0);
+        const int gid = lr_readlane_i((int)id, j0);
+        if (acc0) { C0 = lr_fma(cr, w0, C0); C1 = lr_fma(cg, w0, C1); C2 = lr_fma(cbl, w0, C2); }
         if (EXTRAS) {
-          if (w > wmax) { wmax = w; wid = gid; }
-          const uint32_t m = lr_wave_umax_to63(__float_as_uint(w));  // w >= 0: unsigned order == float order
+          if (w0 > wmax) { wmax = w0; wid = gid; }
+          const uint32_t m = lr_wave_umax_to63(__float_as_uint(w0));  // w >= 0: unsigned order == float order
           if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
         }
-      } else if (__all(done)) {
-        break;
       }
+      if (hit1) {
+        const float cr = lr_readlane_f(g1.z, j1), cg = lr_readlane_f(g1.w, j1), cbl = lr_readlane_f(cb, j1);
+        const int gid = lr_readlane_i((int)id, j1);
+        if (acc1) { C0 = lr_fma(cr, w1, C0); C1 = lr_fma(cg, w1, C1); C2 = lr_fma(cbl, w1, C2); }
+        if (EXTRAS) {
+          if (w1 > wmax) { wmax = w1; wid = gid; }
+          const uint32_t m = lr_wave_umax_to63(__float_as_uint(w1));
+          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
+        }
+      }
+      if (!(hit0 | hit1) && __all(done)) break;
     }
   }
 
@@ -287,25 +310,35 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
     const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
+    // Two entries per iteration: both alpha evaluations are issued together (independent chains), the
+    // gradient bodies then run in list order.
     while (todo) {
-      const int j = __builtin_ctzll(todo);
+      const int j0 = __builtin_ctzll(todo);
       todo &= todo - 1;
-      const int k = hi - 1 - j;  // 0-based position in the tile list
-      const float mx = lr_readlane_f(g0.x, j), my = lr_readlane_f(g0.y, j);
-      const float a = lr_readlane_f(hA, j), b = lr_readlane_f(nB, j), c = lr_readlane_f(hC, j);
-      const float op = lr_readlane_f(g1.y, j);
-      float G = 0.f, alpha = 0.f, dx = 0.f, dy = 0.f;
-      bool hit = false;
-      if (k < lastc) {
-        dx = mx - pxf; dy = my - pyf;
-        const float power = lr_power(a, b, c, dx, dy);
-        if (!(power > 0.f)) {
-          G = lr_exp(power);
-          alpha = fminf(0.99f, op * G);
-          hit = !(alpha < 1.0f / 255.0f);
-        }
-      }
-      if (__any(hit)) {
+      const bool has1 = todo != 0;
+      const int j1 = has1 ? __builtin_ctzll(todo) : j0;
+      todo &= todo - 1;
+      const float mx0 = lr_readlane_f(g0.x, j0), my0 = lr_readlane_f(g0.y, j0);
+      const float a0 = lr_readlane_f(hA, j0), b0 = lr_readlane_f(nB, j0), c0 = lr_readlane_f(hC, j0);
+      const float op0 = lr_readlane_f(g1.y, j0);
+      const float mx1 = lr_readlane_f(g0.x, j1), my1 = lr_readlane_f(g0.y, j1);
+      const float a1 = lr_readlane_f(hA, j1), b1 = lr_readlane_f(nB, j1), c1 = lr_readlane_f(hC, j1);
+      const float op1 = lr_readlane_f(g1.y, j1);
+      const float dx0 = mx0 - pxf, dy0 = my0 - pyf, dx1 = mx1 - pxf, dy1 = my1 - pyf;
+      const float power0 = lr_power(a0, b0, c0, dx0, dy0);
+      const float power1 = lr_power(a1, b1, c1, dx1, dy1);
+      const float G0 = lr_exp(power0), G1 = lr_exp(power1);
+      const float alpha0 = fminf(0.99f, op0 * G0), alpha1 = fminf(0.99f, op1 * G1);
+      const int k0 = hi - 1 - j0, k1 = hi - 1 - j1;  // 0-based positions in the tile list
+      const bool hit0 = (k0 < lastc) & !(power0 > 0.f) & !(alpha0 < 1.0f / 255.0f);
+      const bool hit1 = has1 & (k1 < lastc) & !(power1 > 0.f) & !(alpha1 < 1.0f / 255.0f);
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const bool hit = e ? hit1 : hit0;
+        if (!__any(hit)) continue;
+        const int j = e ? j1 : j0;
+        const float a = e ? a1 : a0, b = e ? b1 : b0, c = e ? c1 : c0, op = e ? op1 : op0;
+        const float G = e ? G1 : G0, alpha = e ? alpha1 : alpha0, dx = e ? dx1 : dx0, dy = e ? dy1 : dy0;
         const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
         const int gid = lr_readlane_i((int)id, j);
         float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -199,7 +199,7 @@ LR_DEV float lr_wave_max_to63(float v) {
 // needs no NaN canonicalisation, so every step is one DPP-fused instruction.
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 LR_DEV uint32_t lr_dpp_umax(uint32_t v) {
-  uint32_t moved = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+  uint32_t moved = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, true);  // 0 = umax identity
   return max(v, moved);
 }
 LR_DEV uint32_t lr_wave_umax_to63(uint32_t v) {

@@ -78,7 +78,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw, int xcd_mode,
-                    int cull, int prio) {
+                    int cull) {
   if (state[LR_HDR_NUM] > capacity) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
@@ -98,7 +98,6 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   // Software pipeline over 64-entry chunks: ids are fetched two chunks ahead and records one chunk ahead, so
   // the dependent id -> record gather of chunk c+1 is in flight while chunk c is composited.
   const uint32_t nchunks = (end - beg + 63u) >> 6;
-  if (prio && nchunks > 8) __builtin_amdgcn_s_setprio(2);  // long serial walks are the launch's critical path
   const float* geomf = reinterpret_cast<const float*>(geom);
   auto load_id = [&](uint32_t c) -> uint32_t {
     const uint32_t idx = beg + c * 64u + (uint32_t)lane;
@@ -201,15 +200,14 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
                          int* pid, float* pwp, float* pw, hipStream_t s) {
   static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
-  static const int prio = lr_env_int("LOGRAST_PRIO", 0);
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_FWD, s);
   if (v.extras)
     hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull, prio);
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
   else
     hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull, prio);
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
   lr_prof_end(LRK_BLEND_FWD, s);
 }
 
@@ -254,7 +252,7 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
                     const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
                     float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
-                    int xcd_mode, int cull, int prio) {
+                    int xcd_mode, int cull) {
   if (state[LR_HDR_NUM] > capacity) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
@@ -288,7 +286,6 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   // Reverse walk in 64-entry chunks from the deepest contributor; lane l of chunk ch holds list position
   // maxc-1 - 64*ch - l.  Same two-stage prefetch as the forward pass.
   const uint32_t nchunks = ((uint32_t)maxc + 63u) >> 6;
-  if (prio && nchunks > 8) __builtin_amdgcn_s_setprio(2);
   const float* geomf = reinterpret_cast<const float*>(geom);
   auto load_id = [&](uint32_t c) -> uint32_t {
     const int pos = maxc - 1 - (int)(c * 64u) - lane;
@@ -386,11 +383,10 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          hipStream_t s) {
   static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
-  static const int prio = lr_env_int("LOGRAST_PRIO", 0);
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_BWD, s);
   hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom), state,
                      tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
-                     xcd_mode, cull, prio);
+                     xcd_mode, cull);
   lr_prof_end(LRK_BLEND_BWD, s);
 }

@@ -18,7 +18,10 @@ ARCH = "gfx950"
 # -munsafe-fp-atomics    : float atomicAdd -> global_atomic_add_f32 instead of a CAS loop
 # -mcode-object-version=5: loadable by both the ROCm 7.2 runtime and torch's bundled 7.0 runtime
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
-         "-mcode-object-version=5", "-Wall", "-Wno-unused-function"]
+         "-mcode-object-version=5", "-Wall", "-Wno-unused-function",
+         # the kernels do their own wave-level reductions before every atomic; LLVM's atomic optimizer would
+         # wrap each (single-lane) atomic in a second, scalar reduction loop
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _newer(target, deps):

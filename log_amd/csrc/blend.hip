@@ -280,8 +280,17 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
   maxc = lr_readlane_i(maxc, 0);  // wave-uniform: deepest contributor among this quadrant's pixels
 
-  // rows of the packed reduction -> destination addresses (see lr_reduce9)
+  // Destinations of the packed reduction (see lr_reduce9), as loop-invariant per-lane (base, stride) pairs so
+  // the per-Gaussian address is one multiply-add, no divergence:
+  //   atomic #1, lanes 0/16/32/48 (rows 0..3): colour r,g,b (g_col + 3*gid + row) and opacity (g_opac + gid)
+  //   atomic #2, rows 0..3: mean x,y (g_mean2d + 3*gid + row), conic A,B (g_conic + 4*gid + row-2);
+  //              lane 1 additionally carries conic C (g_conic + 4*gid + 2) so no third instruction is needed.
   const int row = lane >> 4;
+  float* const base0 = (row < 3) ? (g_col + row) : g_opac;
+  const int mul0 = (row < 3) ? 3 : 1;
+  float* const base1 = (lane == 1) ? (g_conic + 2) : ((row < 2) ? (g_mean2d + row) : (g_conic + (row - 2)));
+  const int mul1 = (lane == 1 || row >= 2) ? 4 : 3;
+  const bool lead = (lane & 15) == 0;
 
   // Reverse walk in 64-entry chunks from the deepest contributor; lane l of chunk ch holds list position
   // maxc-1 - 64*ch - l.  Same two-stage prefetch as the forward pass.
@@ -365,13 +374,8 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         }
         float r0, r1, r2;
         lr_reduce9(s, r0, r1, r2);
-        if ((lane & 15) == 0) {
-          float* d0 = (row < 3) ? (g_col + 3 * (size_t)gid + row) : (g_opac + gid);
-          float* d1 = (row < 2) ? (g_mean2d + 3 * (size_t)gid + row) : (g_conic + 4 * (size_t)gid + (row - 2));
-          atomicAdd(d0, r0);
-          atomicAdd(d1, r1);
-          if (row == 0) atomicAdd(g_conic + 4 * (size_t)gid + 2, r2);
-        }
+        if (lead) atomicAdd(base0 + (size_t)gid * mul0, r0);
+        if (lead || lane == 1) atomicAdd(base1 + (size_t)gid * mul1, lane == 1 ? r2 : r1);
       }
     }
   }

@@ -146,10 +146,20 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   uint32_t* offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   uint32_t tid = threadIdx.x;
+  uint32_t* order = state + lr_order_off(tiles);
+  // pass 1: the counters sit one per 64-byte line; gather them with independent, unrolled loads into the
+  // compact arrays (order[] = total, offsets[] = ranked count, both rewritten below)
+#pragma unroll 4
+  for (uint32_t t = tid; t < tiles; t += 1024u) {
+    const uint32_t nr = ranked[t * LR_CTR_STRIDE], nb = big[t * LR_CTR_STRIDE];
+    order[t] = nr + nb;
+    offsets[t] = nr;
+  }
+  __syncthreads();
   uint32_t chunk = (tiles + 1023u) / 1024u;
   uint32_t b = tid * chunk, e = min(tiles, b + chunk);
   uint32_t sum = 0;
-  for (uint32_t t = b; t < e; t++) sum += ranked[t * LR_CTR_STRIDE] + big[t * LR_CTR_STRIDE];
+  for (uint32_t t = b; t < e; t++) sum += order[t];
   part[tid] = sum;
   __syncthreads();
   // Hillis-Steele inclusive scan over 1024 partials
@@ -161,10 +171,10 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   }
   uint32_t run = part[tid] - sum;  // exclusive prefix of this thread's chunk
   for (uint32_t t = b; t < e; t++) {
+    const uint32_t nr = offsets[t], tot = order[t];
     offsets[t] = run;
-    const uint32_t nr = ranked[t * LR_CTR_STRIDE];
     cursor[t * LR_CTR_STRIDE] = run + nr;  // big instances go behind the ranked ones
-    run += nr + big[t * LR_CTR_STRIDE];
+    run += tot;
   }
   if (tid == 1023) {
     offsets[tiles] = part[1023];
@@ -175,7 +185,6 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   // its waves, so the longest lists must start first or they become the tail of the launch.  Counting sort
   // of the tiles into 256 length buckets (16 entries wide), longest bucket first.
   __shared__ uint32_t hist[256];
-  uint32_t* order = state + lr_order_off(tiles);
   if (tid < 256) hist[tid] = 0u;
   __syncthreads();  // also orders the offsets[] stores above before the reads below (same workgroup)
   for (uint32_t t = b; t < e; t++) atomicAdd(&hist[min(255u, (offsets[t + 1] - offsets[t]) >> 4)], 1u);

@@ -160,16 +160,28 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   uint32_t b = tid * chunk, e = min(tiles, b + chunk);
   uint32_t sum = 0;
   for (uint32_t t = b; t < e; t++) sum += order[t];
-  part[tid] = sum;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t add = (tid >= d) ? part[tid - d] : 0u;
-    __syncthreads();
-    part[tid] += add;
-    __syncthreads();
+  // inclusive scan of the 1024 per-thread sums: shuffle scan inside each wave, then the 16 wave totals
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(inc, d);
+    if ((int)(tid & 63u) >= d) inc += up;
   }
-  uint32_t run = part[tid] - sum;  // exclusive prefix of this thread's chunk
+  if ((tid & 63u) == 63u) part[tid >> 6] = inc;
+  __syncthreads();
+  if (tid < 16u) {
+    uint32_t w = part[tid];
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t up = __shfl_up(w, d);
+      if ((int)tid >= d) w += up;
+    }
+    part[32 + tid] = w;  // inclusive wave totals
+  }
+  __syncthreads();
+  inc += (tid >> 6) ? part[32 + (tid >> 6) - 1] : 0u;
+  const uint32_t grand = part[32 + 15];
+  uint32_t run = inc - sum;  // exclusive prefix of this thread's chunk
   for (uint32_t t = b; t < e; t++) {
     const uint32_t nr = offsets[t], tot = order[t];
     offsets[t] = run;
@@ -177,8 +189,8 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
     run += tot;
   }
   if (tid == 1023) {
-    offsets[tiles] = part[1023];
-    state[LR_HDR_NUM] = part[1023];
+    offsets[tiles] = grand;
+    state[LR_HDR_NUM] = grand;
     state[LR_HDR_OVERFLOW] = 0u;
   }
   // Longest-processing-time-first dispatch order for the blend kernels: a tile's list is walked serially by
@@ -189,15 +201,20 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   __syncthreads();  // also orders the offsets[] stores above before the reads below (same workgroup)
   for (uint32_t t = b; t < e; t++) atomicAdd(&hist[min(255u, (offsets[t + 1] - offsets[t]) >> 4)], 1u);
   __syncthreads();
-  if (tid < 256) part[tid] = hist[255 - tid];  // descending bucket order
-  __syncthreads();
-  for (uint32_t d = 1; d < 256; d <<= 1) {
-    uint32_t add = (tid < 256 && tid >= d) ? part[tid - d] : 0u;
-    __syncthreads();
-    if (tid < 256) part[tid] += add;
-    __syncthreads();
+  if (tid < 64u) {  // one wave turns the 256 bucket counts into exclusive starts, longest bucket first
+    uint32_t c[4], tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c[i] = hist[255 - (4 * (int)tid + i)]; tot += c[i]; }
+    uint32_t incw = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incw, d);
+      if ((int)tid >= d) incw += up;
+    }
+    uint32_t start = incw - tot;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { hist[255 - (4 * (int)tid + i)] = start; start += c[i]; }
   }
-  if (tid < 256) hist[255 - tid] = part[tid] - hist[255 - tid];  // exclusive start of each bucket
   __syncthreads();
   for (uint32_t t = b; t < e; t++)
     order[atomicAdd(&hist[min(255u, (offsets[t + 1] - offsets[t]) >> 4)], 1u)] = t;

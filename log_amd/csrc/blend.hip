@@ -57,7 +57,8 @@ static inline __host__ __device__ uint32_t lr_blend_grid(uint32_t tiles, int gx,
 // [x0,x1]x[y0,y1]?  The alpha floor means power >= -tau, tau = ln(255*opacity); the level set
 // {d : 0.5 d^T Q d <= tau'} has the axis-aligned half extents sqrt(2 tau' cov_xx), sqrt(2 tau' cov_yy).
 // tau' = 1.01 tau + 0.01 absorbs the fp32 evaluation error of `power`; if that error could exceed the
-// margin (ill-conditioned conic, non-finite values) the answer is "yes" (never cull).
+// margin (ill-conditioned conic, non-finite values) the answer is "yes" (never cull).  Two stages: the cheap
+// box-vs-box test, then the exact ellipse-vs-box test (the box of an elongated, tilted ellipse is mostly empty).
 LR_DEV bool lr_support_hits(const float4 g0, const float4 g1, float x0, float x1, float y0, float y1) {
   const float A = g0.z, B = g0.w, C = g1.x, op = g1.y;
   const float det = A * C - B * B;
@@ -69,7 +70,25 @@ LR_DEV bool lr_support_hits(const float4 g0, const float4 g1, float x0, float x1
   const bool safe = (det > 0.f) && (ex2 >= 0.f) && (ey2 >= 0.f) && (mag * 1.0e-6f < 0.005f * tau) && (mag < 1.0e30f);
   if (!safe) return true;
   const float ex = sqrtf(ex2) + 0.01f, ey = sqrtf(ey2) + 0.01f;
-  return (g0.x + ex >= x0) && (g0.x - ex <= x1) && (g0.y + ey >= y0) && (g0.y - ey <= y1);
+  if (!((g0.x + ex >= x0) && (g0.x - ex <= x1) && (g0.y + ey >= y0) && (g0.y - ey <= y1))) return false;
+  // The axis-aligned box of the ellipse overlaps; now the ellipse itself: min over the pixel box of
+  // q(d) = 0.5 d^T Q d.  If the centre is inside the (0.01-inflated) box the minimum is 0; otherwise it lies on
+  // one of the four edges, where q is a 1-D parabola whose clamped vertex is closed-form.
+  const float dx0 = (x0 - 0.01f) - g0.x, dx1 = (x1 + 0.01f) - g0.x;
+  const float dy0 = (y0 - 0.01f) - g0.y, dy1 = (y1 + 0.01f) - g0.y;
+  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
+  const float iA = 1.f / A, iC = 1.f / C;
+  float best = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const float dx = e ? dx1 : dx0;
+    const float dy = fminf(dy1, fmaxf(dy0, -B * dx * iC));
+    best = fminf(best, 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy);
+    const float ey_ = e ? dy1 : dy0;
+    const float ex_ = fminf(dx1, fmaxf(dx0, -B * ey_ * iA));
+    best = fminf(best, 0.5f * (A * ex_ * ex_ + C * ey_ * ey_) + B * ex_ * ey_);
+  }
+  return !(best > tau);
 }
 
 template <bool EXTRAS>
@@ -136,10 +155,11 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       const float mx1 = lr_readlane_f(g0.x, j1), my1 = lr_readlane_f(g0.y, j1);
       const float a1 = lr_readlane_f(hA, j1), b1 = lr_readlane_f(nB, j1), c1 = lr_readlane_f(hC, j1);
       const float op1 = lr_readlane_f(g1.y, j1);
-      const float power0 = lr_power(a0, b0, c0, mx0 - pxf, my0 - pyf);
-      const float power1 = lr_power(a1, b1, c1, mx1 - pxf, my1 - pyf);
-      const float alpha0 = fminf(0.99f, op0 * lr_exp(power0));
-      const float alpha1 = fminf(0.99f, op1 * lr_exp(power1));
+      const lr_f2 pw2 = lr_power2(lr_f2{a0, a1}, lr_f2{b0, b1}, lr_f2{c0, c1}, lr_f2{mx0, mx1} - pxf,
+                                  lr_f2{my0, my1} - pyf);
+      const lr_f2 al2 = lr_f2{op0, op1} * lr_exp2(pw2);
+      const float power0 = pw2.x, power1 = pw2.y;
+      const float alpha0 = fminf(0.99f, al2.x), alpha1 = fminf(0.99f, al2.y);
       // entry j0
       const bool ok0 = !done & !(power0 > 0.f) & !(alpha0 < 1.0f / 255.0f);
       const float test0 = T * (1.f - alpha0);
@@ -158,7 +178,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       T = acc1 ? test1 : T;
       last = acc1 ? pos0 + j1 + 1 : last;
       done = done | stop1;
-      const bool hit0 = __any(acc0), hit1 = __any(acc1);
+      const bool hit0 = __builtin_amdgcn_ballot_w64(acc0) != 0, hit1 = __builtin_amdgcn_ballot_w64(acc1) != 0;
       if (hit0) {
         const float cr = lr_readlane_f(g1.z, j0), cg = lr_readlane_f(g1.w, j0), cbl = lr_readlane_f(cb, j0);
         const int gid = lr_readlane_i((int)id, j0);
@@ -330,18 +350,20 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       const float mx1 = lr_readlane_f(g0.x, j1), my1 = lr_readlane_f(g0.y, j1);
       const float a1 = lr_readlane_f(hA, j1), b1 = lr_readlane_f(nB, j1), c1 = lr_readlane_f(hC, j1);
       const float op1 = lr_readlane_f(g1.y, j1);
-      const float dx0 = mx0 - pxf, dy0 = my0 - pyf, dx1 = mx1 - pxf, dy1 = my1 - pyf;
-      const float power0 = lr_power(a0, b0, c0, dx0, dy0);
-      const float power1 = lr_power(a1, b1, c1, dx1, dy1);
-      const float G0 = lr_exp(power0), G1 = lr_exp(power1);
-      const float alpha0 = fminf(0.99f, op0 * G0), alpha1 = fminf(0.99f, op1 * G1);
+      const lr_f2 dx2 = lr_f2{mx0, mx1} - pxf, dy2 = lr_f2{my0, my1} - pyf;
+      const lr_f2 pw2 = lr_power2(lr_f2{a0, a1}, lr_f2{b0, b1}, lr_f2{c0, c1}, dx2, dy2);
+      const lr_f2 G2 = lr_exp2(pw2);
+      const lr_f2 al2 = lr_f2{op0, op1} * G2;
+      const float dx0 = dx2.x, dx1 = dx2.y, dy0 = dy2.x, dy1 = dy2.y;
+      const float power0 = pw2.x, power1 = pw2.y, G0 = G2.x, G1 = G2.y;
+      const float alpha0 = fminf(0.99f, al2.x), alpha1 = fminf(0.99f, al2.y);
       const int k0 = hi - 1 - j0, k1 = hi - 1 - j1;  // 0-based positions in the tile list
       const bool hit0 = (k0 < lastc) & !(power0 > 0.f) & !(alpha0 < 1.0f / 255.0f);
       const bool hit1 = has1 & (k1 < lastc) & !(power1 > 0.f) & !(alpha1 < 1.0f / 255.0f);
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         const bool hit = e ? hit1 : hit0;
-        if (!__any(hit)) continue;
+        if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
         const int j = e ? j1 : j0;
         const float a = e ? a1 : a0, b = e ? b1 : b0, c = e ? c1 : c0, op = e ? op1 : op0;
         const float G = e ? G1 : G0, alpha = e ? alpha1 : alpha0, dx = e ? dx1 : dx0, dy = e ? dy1 : dy0;

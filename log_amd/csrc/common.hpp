@@ -81,6 +81,33 @@ LR_DEV float lr_power(float hA, float nB, float hC, float dx, float dy) {
   return lr_fma(hA * dx, dx, lr_fma(hC * dy, dy, (nB * dx) * dy));
 }
 
+// Two-wide versions (one list entry per half).  Element for element these are the SAME IEEE op sequences as
+// lr_power / lr_exp -- v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 round each half exactly like the scalar
+// instruction -- so results stay bit-identical to the oracle while the VALU issues half as many instructions
+// for the multiply/add/fma part.
+typedef float lr_f2 __attribute__((ext_vector_type(2)));
+typedef int lr_i2 __attribute__((ext_vector_type(2)));
+typedef unsigned int lr_u2 __attribute__((ext_vector_type(2)));
+LR_DEV lr_f2 lr_fma2(lr_f2 a, lr_f2 b, lr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+LR_DEV lr_f2 lr_power2(lr_f2 hA, lr_f2 nB, lr_f2 hC, lr_f2 dx, lr_f2 dy) {
+  return lr_fma2(hA * dx, dx, lr_fma2(hC * dy, dy, (nB * dx) * dy));
+}
+LR_DEV lr_f2 lr_exp2(lr_f2 x) {
+  lr_f2 t = x * 1.44269504088896341f;
+  t = lr_f2{fmaxf(t.x, -125.0f), fmaxf(t.y, -125.0f)};
+  const lr_f2 n = lr_f2{rintf(t.x), rintf(t.y)};
+  const lr_f2 f = t - n;
+  lr_f2 p = lr_f2{0x1.5c08e4p-10f, 0x1.5c08e4p-10f};
+  p = lr_fma2(p, f, lr_f2{0x1.3d0c52p-7f, 0x1.3d0c52p-7f});
+  p = lr_fma2(p, f, lr_f2{0x1.c6b6e4p-5f, 0x1.c6b6e4p-5f});
+  p = lr_fma2(p, f, lr_f2{0x1.ebf918p-3f, 0x1.ebf918p-3f});
+  p = lr_fma2(p, f, lr_f2{0x1.62e428p-1f, 0x1.62e428p-1f});
+  p = lr_fma2(p, f, lr_f2{0x1.000002p+0f, 0x1.000002p+0f});
+  const int n0 = (int)n.x, n1 = (int)n.y;
+  return lr_f2{__uint_as_float(__float_as_uint(p.x) + ((uint32_t)n0 << 23)),
+               __uint_as_float(__float_as_uint(p.y) + ((uint32_t)n1 << 23))};
+}
+
 // cov3D = R diag(s^2) R^T; quaternion (r,x,y,z) is NOT normalised
 // (/root/reference/LoG/cuda/compute_radius_kernel.cu:28-58, :36).
 LR_DEV void lr_cov3d(const float s[3], const float q[4], float R[9], float Sg[6]) {

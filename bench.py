@@ -109,6 +109,7 @@ def main():
     bucket = lanes[0][1]
     bg = T([1.0, 1.0, 1.0])
     wloss = torch.tensor(np.random.default_rng(1).random((3, H, W), dtype=np.float32), device=dev)
+    wflat = wloss.reshape(-1)
     rasts = []
     for cam in cams:
         rs = GaussianRasterizationSettings(
@@ -123,7 +124,7 @@ def main():
         out = rast(means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors"],
                    opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
                    cov3D_precomp=None)
-        (out[0] * wloss).sum().backward()
+        torch.dot(out[0].reshape(-1), wflat).backward()   # loss = sum(image * w)
         return out
 
     def step():

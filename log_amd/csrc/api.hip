@@ -221,7 +221,7 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
                      const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
-                     void* stream) {
+                     int32_t accumulators_zeroed, void* stream) {
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
@@ -233,10 +233,12 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   const uint32_t* st = reinterpret_cast<const uint32_t*>(tile_state);
-  LR_HIP(hipMemsetAsync(dl_dmeans2d, 0, sizeof(float) * 3 * (size_t)n, s));
-  LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * 4 * (size_t)n, s));
-  LR_HIP(hipMemsetAsync(dl_dopacities, 0, sizeof(float) * (size_t)n, s));
-  LR_HIP(hipMemsetAsync(dl_dcolors, 0, sizeof(float) * 3 * (size_t)n, s));
+  if (!accumulators_zeroed) {
+    LR_HIP(hipMemsetAsync(dl_dmeans2d, 0, sizeof(float) * 3 * (size_t)n, s));
+    LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * 4 * (size_t)n, s));
+    LR_HIP(hipMemsetAsync(dl_dopacities, 0, sizeof(float) * (size_t)n, s));
+    LR_HIP(hipMemsetAsync(dl_dcolors, 0, sizeof(float) * 3 * (size_t)n, s));
+  }
   // capacity check is a forward concern: a list that rendered is by construction within capacity
   lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dmeans2d,
                       dl_dconic, dl_dopacities, dl_dcolors, s);

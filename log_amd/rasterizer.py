@@ -164,10 +164,12 @@ class HipBackend:
         N = means3D.shape[0]
         view, keep = self.make_view(rs, flavour, use_filter, device)
         f32 = dict(dtype=torch.float32, device=device)
-        g_means2D = torch.empty(N, 3, **f32)
-        g_conic = torch.empty(N, 4, **f32)
-        g_opac = torch.empty(N, **f32)
-        g_colors = torch.empty(N, 3, **f32)
+        # the four accumulators the reverse walk adds into come from ONE zeroed block (one memset, not four)
+        acc = torch.zeros(N * 11, **f32)
+        g_means2D = acc[:3 * N].view(N, 3)
+        g_conic = acc[3 * N:7 * N].view(N, 4)
+        g_opac = acc[7 * N:8 * N]
+        g_colors = acc[8 * N:].view(N, 3)
         g_means3D = torch.empty(N, 3, **f32)
         g_scales = torch.empty(N, 3, **f32)
         g_rot = torch.empty(N, 4, **f32)
@@ -178,7 +180,7 @@ class HipBackend:
                                           _ptr(saved["plist"]), _ptr(saved["final_T"]), _ptr(saved["n_contrib"]),
                                           _ptr(grad_image), _ptr(g_means2D), _ptr(g_conic), _ptr(g_opac),
                                           _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot),
-                                          _stream_ptr(device)))
+                                          1, _stream_ptr(device)))
         del keep
         self.last_conic_grad = g_conic  # test/debug introspection only
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot

@@ -221,7 +221,8 @@ def main():
             avg_s = merged[dom] / launches / 1e3
             achieved = alg.get(dom, 0) / avg_s / 1e9
             result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                  "traffic": pmc_traffic(dom, N, W, H),
                                   "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_us": avg_s * 1e6}
             result["kernels"] = kern
         if not args.no_cpu_baseline:
@@ -230,6 +231,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, N, W, H):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json,
+    FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md prescribes); None when no profile of this
+    exact workload is committed -- counters cannot be collected from inside the timed run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            wl = d.get("workload", {})
+            if (wl.get("gaussians"), wl.get("width"), wl.get("height")) == (N, W, H) and kernel in d["kernels"]:
+                return d["kernels"][kernel]["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def cpu_baseline(sc, cams, wloss, N, budget_s=12.0, max_passes=64):

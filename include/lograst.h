@@ -128,6 +128,14 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
                              const float* dl_dconic, float* dl_dmeans3d, float* dl_dscales,
                              float* dl_drotations, void* stream);
 
+/* ---- "next" row N1: simple_knn._C.distCUDA2 ----------------------------------------------------------
+ * Replaces distCUDA2 (third-party simple-knn, un-vendored; called at /root/reference/LoG/utils/file.py:88-91 and
+ * LoG/model/base_gaussian.py:39-42): out[i] = mean squared distance from point i to its 3 nearest other
+ * points (exact, fp32).  scratch: lograst_knn_scratch_bytes(p) bytes of device memory. */
+size_t lograst_knn_scratch_bytes(int32_t p);
+int lograst_knn_mean_dist2(int32_t p, const float* points, float* out, void* scratch, size_t scratch_bytes,
+                           void* stream);
+
 /* ---- debugging / test access to intermediates --------------------------------------------------
  * Pointers into a tile_state block (device): offsets has tiles+1 entries. */
 const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height);

@@ -35,6 +35,9 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
                            const int* radii, const float* g_mean2d, const float* g_conic, float* g_means3d,
                            float* g_scales, float* g_rots, hipStream_t s);
 
+size_t lr_knn_scratch_bytes(int P);
+hipError_t lr_launch_knn(int P, const float* pts, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
+
 static thread_local std::string g_err;
 static int lr_fail(int code, const std::string& msg) {
   g_err = msg;
@@ -55,7 +58,7 @@ int lr_env_int(const char* name, int dflt) {
 // ---- profiling ------------------------------------------------------------------------------------------
 static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
     "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
-    "blend_fwd", "blend_bwd", "project_bwd", "misc", "reserved"};
+    "blend_fwd", "blend_bwd", "project_bwd", "knn3", "reserved"};
 struct ProfRec { int slot; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_open;     // begin recorded, waiting for end
@@ -263,6 +266,18 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
                         dl_drotations, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+size_t lograst_knn_scratch_bytes(int32_t p) { return lr_knn_scratch_bytes(p); }
+
+int lograst_knn_mean_dist2(int32_t p, const float* points, float* out, void* scratch, size_t scratch_bytes,
+                           void* stream) {
+  if (p < 0) return lr_fail(LOGRAST_ERR_ARG, "negative point count");
+  if (p == 0) return LOGRAST_OK;
+  if (!points || !out || !scratch) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (scratch_bytes < lr_knn_scratch_bytes(p)) return lr_fail(LOGRAST_ERR_ARG, "knn scratch too small");
+  LR_HIP(lr_launch_knn(p, points, out, scratch, scratch_bytes, (hipStream_t)stream));
   return LOGRAST_OK;
 }
 

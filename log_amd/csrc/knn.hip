@@ -154,7 +154,7 @@ lr_knn_search_kernel(int P, const float4* __restrict__ spts, const float* __rest
     __syncthreads();
     if (want) {
       for (int k = 0; k < cnt; k++) {
-        if (base + k == i) continue;
+        if (abs(base + k - i) <= 3) continue;  // itself and the +-3 Morton neighbours already seeded above
         const float4 q = stage[k];
         const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
         lr_best3(dx * dx + dy * dy + dz * dz, best);

@@ -38,6 +38,11 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
 size_t lr_knn_scratch_bytes(int P);
 hipError_t lr_launch_knn(int P, const float* pts, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
 
+void lr_launch_sh_fwd(int N, int deg, int M, const float* means, const float* campos, const float* shs, float* colors,
+                      uint8_t* clamped, hipStream_t s);
+void lr_launch_sh_bwd(int N, int deg, int M, const float* means, const float* campos, const float* shs,
+                      const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means, hipStream_t s);
+
 static thread_local std::string g_err;
 static int lr_fail(int code, const std::string& msg) {
   g_err = msg;
@@ -278,6 +283,39 @@ int lograst_knn_mean_dist2(int32_t p, const float* points, float* out, void* scr
   if (!points || !out || !scratch) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   if (scratch_bytes < lr_knn_scratch_bytes(p)) return lr_fail(LOGRAST_ERR_ARG, "knn scratch too small");
   LR_HIP(lr_launch_knn(p, points, out, scratch, scratch_bytes, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+static int lr_sh_check(int32_t n, int32_t degree, int32_t max_coeffs) {
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (degree < 0 || degree > 3) return lr_fail(LOGRAST_ERR_ARG, "SH degree must be 0..3");
+  if (max_coeffs < (degree + 1) * (degree + 1) || max_coeffs > 16)
+    return lr_fail(LOGRAST_ERR_ARG, "shs must hold (degree+1)^2 .. 16 coefficients per Gaussian");
+  return LOGRAST_OK;
+}
+
+int lograst_sh_forward(int32_t n, int32_t degree, int32_t max_coeffs, const float* means3d, const float* campos,
+                       const float* shs, float* colors, uint8_t* clamped, void* stream) {
+  int rc = lr_sh_check(n, degree, max_coeffs);
+  if (rc) return rc;
+  if (n == 0) return LOGRAST_OK;
+  if (!means3d || !campos || !shs || !colors || !clamped) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  lr_launch_sh_fwd(n, degree, max_coeffs, means3d, campos, shs, colors, clamped, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+int lograst_sh_backward(int32_t n, int32_t degree, int32_t max_coeffs, const float* means3d, const float* campos,
+                        const float* shs, const uint8_t* clamped, const float* dl_dcolors, float* dl_dshs,
+                        float* dl_dmeans3d, void* stream) {
+  int rc = lr_sh_check(n, degree, max_coeffs);
+  if (rc) return rc;
+  if (n == 0) return LOGRAST_OK;
+  if (!means3d || !campos || !shs || !clamped || !dl_dcolors || !dl_dshs || !dl_dmeans3d)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  lr_launch_sh_bwd(n, degree, max_coeffs, means3d, campos, shs, clamped, dl_dcolors, dl_dshs, dl_dmeans3d,
+                   (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
 

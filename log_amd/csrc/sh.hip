@@ -1,0 +1,116 @@
+// sh.hip -- "next" row N2: the rasterizer packages' native `shs=` / `sh_degree` / `campos`
+// inputs.  colour = max(0, 0.5 + sum_k basis_k(dir) * sh_k), dir = normalise(mean - campos), degrees 0..3,
+// with the clamp mask cutting the gradient (published behaviour of the third-party kernel).  LoG itself never
+// takes this path (it evaluates the same polynomial in PyTorch -- /root/reference/LoG/model/sh_utils.py:31-68,
+// LoG/model/activation.py:27-34 -- and passes colors_precomp, LoG/render/renderer.py:144-145); the basis is
+// pinned against that file in tests/test_sh.py.  Streaming, one thread per Gaussian.
+#include "common.hpp"
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__constant__ float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                             -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                             -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+// basis values b[0..15] and their partial derivatives w.r.t. the unit direction (x,y,z)
+LR_DEV void lr_sh_basis(int deg, float x, float y, float z, float b[16], float bx[16], float by[16], float bz[16]) {
+#pragma unroll
+  for (int k = 0; k < 16; k++) { b[k] = 0.f; bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+  b[0] = SH_C0;
+  if (deg > 0) {
+    b[1] = -SH_C1 * y; by[1] = -SH_C1;
+    b[2] = SH_C1 * z; bz[2] = SH_C1;
+    b[3] = -SH_C1 * x; bx[3] = -SH_C1;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      b[4] = kC2[0] * xy; bx[4] = kC2[0] * y; by[4] = kC2[0] * x;
+      b[5] = kC2[1] * yz; by[5] = kC2[1] * z; bz[5] = kC2[1] * y;
+      b[6] = kC2[2] * (2.f * zz - xx - yy); bx[6] = -2.f * kC2[2] * x; by[6] = -2.f * kC2[2] * y; bz[6] = 4.f * kC2[2] * z;
+      b[7] = kC2[3] * xz; bx[7] = kC2[3] * z; bz[7] = kC2[3] * x;
+      b[8] = kC2[4] * (xx - yy); bx[8] = 2.f * kC2[4] * x; by[8] = -2.f * kC2[4] * y;
+      if (deg > 2) {
+        b[9] = kC3[0] * y * (3.f * xx - yy); bx[9] = kC3[0] * 6.f * xy; by[9] = kC3[0] * (3.f * xx - 3.f * yy);
+        b[10] = kC3[1] * xy * z; bx[10] = kC3[1] * yz; by[10] = kC3[1] * xz; bz[10] = kC3[1] * xy;
+        b[11] = kC3[2] * y * (4.f * zz - xx - yy); bx[11] = -2.f * kC3[2] * xy;
+        by[11] = kC3[2] * (4.f * zz - xx - 3.f * yy); bz[11] = 8.f * kC3[2] * yz;
+        b[12] = kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); bx[12] = -6.f * kC3[3] * xz; by[12] = -6.f * kC3[3] * yz;
+        bz[12] = kC3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+        b[13] = kC3[4] * x * (4.f * zz - xx - yy); bx[13] = kC3[4] * (4.f * zz - 3.f * xx - yy);
+        by[13] = -2.f * kC3[4] * xy; bz[13] = 8.f * kC3[4] * xz;
+        b[14] = kC3[5] * z * (xx - yy); bx[14] = 2.f * kC3[5] * xz; by[14] = -2.f * kC3[5] * yz; bz[14] = kC3[5] * (xx - yy);
+        b[15] = kC3[6] * x * (xx - 3.f * yy); bx[15] = kC3[6] * (3.f * xx - 3.f * yy); by[15] = -6.f * kC3[6] * xy;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+lr_sh_fwd_kernel(int N, int deg, int M, const float* __restrict__ means, const float* __restrict__ campos,
+                 const float* __restrict__ shs, float* __restrict__ colors, uint8_t* __restrict__ clamped) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float vx = means[3 * i] - campos[0], vy = means[3 * i + 1] - campos[1], vz = means[3 * i + 2] - campos[2];
+  const float inv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
+  const float x = vx * inv, y = vy * inv, z = vz * inv;
+  float b[16], bx[16], by[16], bz[16];
+  lr_sh_basis(deg, x, y, z, b, bx, by, bz);
+  const int nk = (deg + 1) * (deg + 1);
+  const float* sh = shs + (size_t)i * M * 3;
+  float c[3] = {0.5f, 0.5f, 0.5f};
+  for (int k = 0; k < nk; k++) {
+    c[0] = lr_fma(b[k], sh[3 * k], c[0]); c[1] = lr_fma(b[k], sh[3 * k + 1], c[1]); c[2] = lr_fma(b[k], sh[3 * k + 2], c[2]);
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) {
+    clamped[3 * (size_t)i + ch] = c[ch] < 0.f;
+    colors[3 * (size_t)i + ch] = fmaxf(c[ch], 0.f);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+lr_sh_bwd_kernel(int N, int deg, int M, const float* __restrict__ means, const float* __restrict__ campos,
+                 const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
+                 const float* __restrict__ g_colors, float* __restrict__ g_shs, float* __restrict__ g_means) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float vx = means[3 * i] - campos[0], vy = means[3 * i + 1] - campos[1], vz = means[3 * i + 2] - campos[2];
+  const float n2 = vx * vx + vy * vy + vz * vz;
+  const float inv = 1.f / sqrtf(n2);
+  const float x = vx * inv, y = vy * inv, z = vz * inv;
+  float b[16], bx[16], by[16], bz[16];
+  lr_sh_basis(deg, x, y, z, b, bx, by, bz);
+  const int nk = (deg + 1) * (deg + 1);
+  const float* sh = shs + (size_t)i * M * 3;
+  float* gs = g_shs + (size_t)i * M * 3;
+  float g[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) g[ch] = clamped[3 * (size_t)i + ch] ? 0.f : g_colors[3 * (size_t)i + ch];
+  float gdx = 0.f, gdy = 0.f, gdz = 0.f;  // dL/d(unit direction)
+  for (int k = 0; k < M; k++) {
+    if (k < nk) {
+      gs[3 * k] = b[k] * g[0]; gs[3 * k + 1] = b[k] * g[1]; gs[3 * k + 2] = b[k] * g[2];
+      const float s = sh[3 * k] * g[0] + sh[3 * k + 1] * g[1] + sh[3 * k + 2] * g[2];
+      gdx = lr_fma(bx[k], s, gdx); gdy = lr_fma(by[k], s, gdy); gdz = lr_fma(bz[k], s, gdz);
+    } else {
+      gs[3 * k] = 0.f; gs[3 * k + 1] = 0.f; gs[3 * k + 2] = 0.f;
+    }
+  }
+  // d = v/|v|  ->  dL/dv = (dL/dd - d (d . dL/dd)) / |v|
+  const float dot = x * gdx + y * gdy + z * gdz;
+  g_means[3 * (size_t)i + 0] += (gdx - x * dot) * inv;
+  g_means[3 * (size_t)i + 1] += (gdy - y * dot) * inv;
+  g_means[3 * (size_t)i + 2] += (gdz - z * dot) * inv;
+}
+
+void lr_launch_sh_fwd(int N, int deg, int M, const float* means, const float* campos, const float* shs, float* colors,
+                      uint8_t* clamped, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(lr_sh_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, deg, M, means, campos, shs, colors, clamped);
+}
+void lr_launch_sh_bwd(int N, int deg, int M, const float* means, const float* campos, const float* shs,
+                      const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(lr_sh_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, deg, M, means, campos, shs, clamped,
+                     g_colors, g_shs, g_means);
+}

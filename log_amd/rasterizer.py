@@ -185,6 +185,31 @@ class HipBackend:
         self.last_conic_grad = g_conic  # test/debug introspection only
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
+    def sh_forward(self, means3D, campos, shs, degree):
+        """Native `shs=` path (lograst_sh_forward): colours[N,3] and the clamp mask u8[N,3]."""
+        device = means3D.device
+        L = self.require(device)
+        N, M = shs.shape[0], shs.shape[1]
+        cp = _dev_f32(campos, device).reshape(-1)
+        colors = torch.empty(N, 3, dtype=torch.float32, device=device)
+        clamped = torch.empty(N, 3, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_sh_forward(N, int(degree), M, _ptr(means3D), _ptr(cp), _ptr(shs), _ptr(colors),
+                                            _ptr(clamped), _stream_ptr(device)))
+        return colors, clamped
+
+    def sh_backward(self, means3D, campos, shs, degree, clamped, g_colors, g_means3D):
+        """dL/dshs (new tensor); the view-direction gradient is added into g_means3D in place."""
+        device = means3D.device
+        L = self.require(device)
+        N, M = shs.shape[0], shs.shape[1]
+        cp = _dev_f32(campos, device).reshape(-1)
+        g_shs = torch.empty(N, M, 3, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_sh_backward(N, int(degree), M, _ptr(means3D), _ptr(cp), _ptr(shs), _ptr(clamped),
+                                             _ptr(g_colors), _ptr(g_shs), _ptr(g_means3D), _stream_ptr(device)))
+        return g_shs
+
     def project_backward(self, rs, flavour, use_filter, means3D, scales, rotations, radii, g_means2D, g_conic):
         """Stage A6b alone (lograst_project_backward): used by the parity tests."""
         device = means3D.device
@@ -227,19 +252,27 @@ def _set_backend_for_tests(backend):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, rs, flavour, use_filter):
+    def forward(ctx, means3D, means2D, colors, shs, opacities, scales, rotations, rs, flavour, use_filter):
         m = means3D.detach().to(torch.float32).contiguous()
         s = scales.detach().to(torch.float32).contiguous()
         r = rotations.detach().to(torch.float32).contiguous()
         o = opacities.detach().to(torch.float32).contiguous().reshape(-1)
-        c = colors.detach().to(torch.float32).contiguous()
         n = m.shape[0]
+        sh = clamped = None
+        if shs is not None:   # the packages' native SH input (not LoG's path)
+            sh = shs.detach().to(torch.float32).contiguous()
+            if sh.dim() != 3 or sh.shape[0] != n or sh.shape[2] != 3 or sh.shape[1] < (int(rs.sh_degree) + 1) ** 2:
+                raise ValueError("shs must be [N, >=(sh_degree+1)^2, 3]")
+            c, clamped = _backend.sh_forward(m, rs.campos, sh, int(rs.sh_degree))
+        else:
+            c = colors.detach().to(torch.float32).contiguous()
         if not (s.shape == (n, 3) and r.shape == (n, 4) and c.shape == (n, 3) and o.shape[0] == n and m.shape == (n, 3)):
             raise ValueError("rasterizer inputs must be means3D[N,3], scales[N,3], rotations[N,4], "
                              "colors_precomp[N,3], opacities[N,1]")
         image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c)
         ctx.rs, ctx.flavour, ctx.use_filter = rs, flavour, use_filter
         ctx.saved = saved
+        ctx.sh = (sh, clamped)
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.save_for_backward(m, s, r)
         if flavour.extras:
@@ -254,7 +287,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_m3, g_m2, g_c, g_o, g_s, g_r = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
                                                            grad_image)
         m2_shape, o_shape = ctx.shapes
-        return g_m3, g_m2.reshape(m2_shape), g_c, g_o.reshape(o_shape), g_s, g_r, None, None, None
+        sh, clamped = ctx.sh
+        g_sh = None
+        if sh is not None:
+            g_sh = _backend.sh_backward(m, ctx.rs.campos, sh, int(ctx.rs.sh_degree), clamped, g_c.contiguous(), g_m3)
+            g_c = None
+        return g_m3, g_m2.reshape(m2_shape), g_c, g_sh, g_o.reshape(o_shape), g_s, g_r, None, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -295,12 +333,11 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        if shs is not None:
-            raise NotImplementedError("log_amd: the `shs=` input is not on LoG's path (LoG evaluates SH in PyTorch and "
-                                      "passes colors_precomp, renderer.py:144-145); see DESIGN.md 'next' row N2")
+        if shs is not None and not 0 <= int(self.raster_settings.sh_degree) <= 3:
+            raise ValueError("sh_degree must be 0..3")
         if cov3D_precomp is not None:
             raise NotImplementedError("log_amd: cov3D_precomp is not on LoG's path (renderer.py:134,149)")
-        return _RasterizeGaussians.apply(means3D, means2D, colors_precomp, opacities, scales, rotations,
+        return _RasterizeGaussians.apply(means3D, means2D, colors_precomp, shs, opacities, scales, rotations,
                                          self.raster_settings, flavour, use_filter)
 
 

@@ -158,3 +158,27 @@ def project_backward(view, fwd, g_mean2d, g_conic):
     lib().ora_project_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots),
                           _p(fwd["radii"]), _p(gm2), _p(gc), _p(g_means), _p(g_scales), _p(g_rots))
     return dict(means3D=g_means[:N], scales=g_scales[:N], rotations=g_rots[:N])
+
+
+def sh_forward(means, campos, shs, degree):
+    """N2: colours[N,3], clamped[N,3] for shs[N,M,3]."""
+    means, campos, shs = _f32(means), _f32(campos).reshape(-1), _f32(shs)
+    N, M = shs.shape[0], shs.shape[1]
+    colors = np.zeros((max(N, 1), 3), np.float32)
+    clamped = np.zeros((max(N, 1), 3), np.uint8)
+    lib().ora_sh_fwd(ctypes.c_int32(N), ctypes.c_int32(degree), ctypes.c_int32(M), _p(means), _p(campos), _p(shs),
+                     _p(colors), _p(clamped))
+    return colors[:N], clamped[:N]
+
+
+def sh_backward(means, campos, shs, degree, clamped, g_colors):
+    """N2 backward: (dL/dshs[N,M,3], dL/dmeans3D contribution [N,3])."""
+    means, campos, shs = _f32(means), _f32(campos).reshape(-1), _f32(shs)
+    N, M = shs.shape[0], shs.shape[1]
+    g_colors = _f32(g_colors)
+    cl = np.ascontiguousarray(clamped, np.uint8)
+    g_shs = np.zeros((max(N, 1), M, 3), np.float32)
+    g_means = np.zeros((max(N, 1), 3), np.float32)
+    lib().ora_sh_bwd(ctypes.c_int32(N), ctypes.c_int32(degree), ctypes.c_int32(M), _p(means), _p(campos), _p(shs),
+                     _p(cl), _p(g_colors), _p(g_shs), _p(g_means))
+    return g_shs[:N], g_means[:N]

@@ -133,3 +133,27 @@ def render(width, height, tanfovx, tanfovy, viewmatrix, projmatrix, bg, means3D,
     aux = dict(point_id_pixel=pid.reshape(H, W), point_weight_pixel=wmax.reshape(H, W), point_weight=pw_g,
                final_T=T_final.detach().reshape(H, W), n_used=n_used.reshape(H, W))
     return image, radii, aux
+
+
+def sh_colors(means3D, campos, shs, degree):
+    """N2 in float64 torch (autograd supplies the gradients): max(0, 0.5 + sum_k basis_k(dir) sh_k)."""
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+    C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435]
+    d = means3D - campos[None]
+    d = d / d.norm(dim=-1, keepdim=True)
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    r = 0.5 + C0 * shs[:, 0]
+    if degree > 0:
+        r = r - C1 * y * shs[:, 1] + C1 * z * shs[:, 2] - C1 * x * shs[:, 3]
+    if degree > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        r = r + C2[0] * xy * shs[:, 4] + C2[1] * yz * shs[:, 5] + C2[2] * (2 * zz - xx - yy) * shs[:, 6] + \
+            C2[3] * xz * shs[:, 7] + C2[4] * (xx - yy) * shs[:, 8]
+    if degree > 2:
+        r = r + C3[0] * y * (3 * xx - yy) * shs[:, 9] + C3[1] * xy * z * shs[:, 10] + \
+            C3[2] * y * (4 * zz - xx - yy) * shs[:, 11] + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * shs[:, 12] + \
+            C3[4] * x * (4 * zz - xx - yy) * shs[:, 13] + C3[5] * z * (xx - yy) * shs[:, 14] + \
+            C3[6] * x * (xx - 3 * yy) * shs[:, 15]
+    return torch.clamp_min(r, 0.0)

@@ -41,3 +41,13 @@ class OracleBackend:
         r = oracle.compute_radius(n(means3D), n(scales), n(rotations), n(projmatrix), n(viewmatrix), float(fx),
                                   float(fy), float(tanfovx), float(tanfovy))
         return torch.from_numpy(r)
+
+    def sh_forward(self, means3D, campos, shs, degree):
+        c, cl = oracle.sh_forward(means3D.numpy(), campos.detach().cpu().numpy(), shs.numpy(), int(degree))
+        return torch.from_numpy(c.copy()), torch.from_numpy(cl.copy())
+
+    def sh_backward(self, means3D, campos, shs, degree, clamped, g_colors, g_means3D):
+        g_shs, g_m = oracle.sh_backward(means3D.numpy(), campos.detach().cpu().numpy(), shs.numpy(), int(degree),
+                                        clamped.numpy(), g_colors.numpy())
+        g_means3D += torch.from_numpy(g_m.copy())
+        return torch.from_numpy(g_shs.copy())

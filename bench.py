@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--opacity", type=float, default=0.999, help="<0: random opacities")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("LOGRAST_BENCH_STREAMS", "2")),
                     help="independent views in flight per GPU (one HIP stream each)")
+    ap.add_argument("--no-fused-accumulate", action="store_true",
+                    help="let autograd accumulate each view's gradients (5 extra passes per view) instead of the "
+                         "rasterizer adding them straight into the step's gradient bucket")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -127,6 +130,8 @@ def main():
         torch.dot(out[0].reshape(-1), wflat).backward()   # loss = sum(image * w)
         return out
 
+    fused = not args.no_fused_accumulate
+
     def step():
         main = torch.cuda.current_stream(dev)
         for st in streams:
@@ -134,8 +139,13 @@ def main():
         for li, (leaves, bk) in enumerate(lanes):
             with torch.cuda.stream(streams[li]):
                 bk.zero()
-                for rast in rasts[li::S]:
-                    one_view(rast, leaves)
+                if fused:
+                    with R.accumulate_grads_into(bk.views):
+                        for rast in rasts[li::S]:
+                            one_view(rast, leaves)
+                else:
+                    for rast in rasts[li::S]:
+                        one_view(rast, leaves)
         for st in streams:
             main.wait_stream(st)
         for _, bk in lanes[1:]:
@@ -194,7 +204,7 @@ def main():
                         (N, "rand" if args.opacity < 0 else args.opacity, W, H, args.views),
             "gaussians": N, "width": W, "height": H, "views_per_gpu": args.views,
             "visible_per_view": V, "tile_instances_per_view": I,
-            "streams_per_gpu": S,
+            "streams_per_gpu": S, "fused_gradient_accumulation": fused,
             "parallelism": ("view-sharded dp%d, 1 reduce-scatter+all-gather of %d floats/step" %
                             (world, bucket.flat.numel()) if world > 1 else "single GPU") +
                            ", %d views in flight per GPU (HIP streams)" % S,

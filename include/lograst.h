@@ -110,14 +110,21 @@ int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uin
  * (LoG/utils/trainer.py:158).  dL_dimage[3,H,W] in; all gradient outputs are overwritten:
  *   dL_dmeans2d[n,3]  (x,y = d/d ndc, z = 0; consumed at LoG/model/counter.py:40,46)
  *   dL_dmeans3d[n,3], dL_dscales[n,3], dL_drotations[n,4], dL_dopacities[n], dL_dcolors[n,3]
- * dL_dconic[n,4] is scratch.  accumulators_zeroed != 0: the caller has already zeroed dl_dmeans2d / dl_dconic /
- * dl_dopacities / dl_dcolors (e.g. one memset over a block holding all four); 0: the library zeroes them. */
+ * dL_dconic[n,4] is scratch.  flags:
+ *   LOGRAST_BWD_SCRATCH_ZEROED  the caller already zeroed dl_dmeans2d / dl_dconic (and, unless accumulating,
+ *                               dl_dopacities / dl_dcolors) -- e.g. one memset over a block holding all of them;
+ *   LOGRAST_BWD_ACCUMULATE      multi-view accumulation (new, not in the reference): dl_dopacities, dl_dcolors,
+ *                               dl_dmeans3d, dl_dscales, dl_drotations are running sums that this call ADDS to
+ *                               (the reverse walk's atomics and the chain-rule kernel write straight into the
+ *                               caller's per-step gradient bucket; no separate accumulate pass). */
+#define LOGRAST_BWD_SCRATCH_ZEROED 1
+#define LOGRAST_BWD_ACCUMULATE 2
 int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                      const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
                      const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
-                     int32_t accumulators_zeroed, void* stream);
+                     int32_t flags, void* stream);
 
 /* Stage A6b alone: the per-Gaussian chain rule, given dL/d(ndc mean) [n,3] and dL/d(conic) [n,4] (as left
  * by the reverse walk).  Writes dl_dmeans3d/dl_dscales/dl_drotations.  lograst_backward = reverse walk +

@@ -33,7 +33,7 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          hipStream_t s);
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, float* g_means3d,
-                           float* g_scales, float* g_rots, hipStream_t s);
+                           float* g_scales, float* g_rots, bool accumulate, hipStream_t s);
 
 size_t lr_knn_scratch_bytes(int P);
 hipError_t lr_launch_knn(int P, const float* pts, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
@@ -229,7 +229,7 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
                      const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
-                     int32_t accumulators_zeroed, void* stream) {
+                     int32_t flags, void* stream) {
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
@@ -241,17 +241,20 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   const uint32_t* st = reinterpret_cast<const uint32_t*>(tile_state);
-  if (!accumulators_zeroed) {
+  const bool accumulate = (flags & LOGRAST_BWD_ACCUMULATE) != 0;
+  if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED)) {
     LR_HIP(hipMemsetAsync(dl_dmeans2d, 0, sizeof(float) * 3 * (size_t)n, s));
     LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * 4 * (size_t)n, s));
-    LR_HIP(hipMemsetAsync(dl_dopacities, 0, sizeof(float) * (size_t)n, s));
-    LR_HIP(hipMemsetAsync(dl_dcolors, 0, sizeof(float) * 3 * (size_t)n, s));
+    if (!accumulate) {
+      LR_HIP(hipMemsetAsync(dl_dopacities, 0, sizeof(float) * (size_t)n, s));
+      LR_HIP(hipMemsetAsync(dl_dcolors, 0, sizeof(float) * 3 * (size_t)n, s));
+    }
   }
   // capacity check is a forward concern: a list that rendered is by construction within capacity
   lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dmeans2d,
                       dl_dconic, dl_dopacities, dl_dcolors, s);
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
-                        dl_drotations, s);
+                        dl_drotations, accumulate, s);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
@@ -269,7 +272,7 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
       !dl_drotations)
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
-                        dl_drotations, (hipStream_t)stream);
+                        dl_drotations, false, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

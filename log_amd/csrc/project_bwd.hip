@@ -5,6 +5,7 @@
 // radius formula carry no gradient; the fork's max(.,0.3) low-pass has the standard sub-gradient.
 #include "common.hpp"
 
+template <bool ACCUMULATE>
 __global__ void __launch_bounds__(256)
 lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                       const float* __restrict__ rots, const int* __restrict__ radii,
@@ -106,17 +107,31 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     gq[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2.f * y * gR[8]);
     gq[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
   }
-  g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];
-  g_scales[3 * (size_t)i + 0] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2];
-  reinterpret_cast<float4*>(g_rots)[i] = float4{gq[0], gq[1], gq[2], gq[3]};
+  if (ACCUMULATE) {  // running sums over views (log_amd.dist): culled Gaussians contribute nothing, skip the traffic
+    if (radii[i] > 0) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { g_means3d[3 * (size_t)i + k] += gm[k]; g_scales[3 * (size_t)i + k] += gs[k]; }
+      float4 q = reinterpret_cast<float4*>(g_rots)[i];
+      q.x += gq[0]; q.y += gq[1]; q.z += gq[2]; q.w += gq[3];
+      reinterpret_cast<float4*>(g_rots)[i] = q;
+    }
+  } else {
+    g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];
+    g_scales[3 * (size_t)i + 0] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2];
+    reinterpret_cast<float4*>(g_rots)[i] = float4{gq[0], gq[1], gq[2], gq[3]};
+  }
 }
 
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, float* g_means3d,
-                           float* g_scales, float* g_rots, hipStream_t s) {
+                           float* g_scales, float* g_rots, bool accumulate, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_PROJECT_BWD, s);
-  hipLaunchKernelGGL(lr_project_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, N, means, scales, rots, radii,
-                     g_mean2d, g_conic, g_means3d, g_scales, g_rots);
+  if (accumulate)
+    hipLaunchKernelGGL(lr_project_bwd_kernel<true>, dim3((N + 255) / 256), dim3(256), 0, s, v, N, means, scales, rots,
+                       radii, g_mean2d, g_conic, g_means3d, g_scales, g_rots);
+  else
+    hipLaunchKernelGGL(lr_project_bwd_kernel<false>, dim3((N + 255) / 256), dim3(256), 0, s, v, N, means, scales, rots,
+                       radii, g_mean2d, g_conic, g_means3d, g_scales, g_rots);
   lr_prof_end(LRK_PROJECT_BWD, s);
 }

@@ -158,31 +158,40 @@ class HipBackend:
         saved = dict(radii=radii, geom=geom, state=state, plist=plist, final_T=final_T, n_contrib=n_contrib)
         return image, radii, pid, pwp, pw, saved
 
-    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image):
+    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None):
+        """sink: optional dict of running-sum tensors (means3D, scales, rotations, opacities, colors) that this call
+        adds into (LOGRAST_BWD_ACCUMULATE); the corresponding returned gradients are then None."""
         device = means3D.device
         L = self.require(device)
         N = means3D.shape[0]
         view, keep = self.make_view(rs, flavour, use_filter, device)
         f32 = dict(dtype=torch.float32, device=device)
-        # the four accumulators the reverse walk adds into come from ONE zeroed block (one memset, not four)
-        acc = torch.zeros(N * 11, **f32)
+        grad_image = grad_image.to(torch.float32).contiguous()
+        if sink is None:
+            # the four accumulators the reverse walk adds into come from ONE zeroed block (one memset, not four)
+            acc = torch.zeros(N * 11, **f32)
+            g_opac = acc[7 * N:8 * N]
+            g_colors = acc[8 * N:].view(N, 3)
+            g_means3D, g_scales, g_rot = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 4, **f32)
+            flags = 1
+        else:
+            acc = torch.zeros(N * 7, **f32)
+            g_opac, g_colors = sink["opacities"], sink["colors"]
+            g_means3D, g_scales, g_rot = sink["means3D"], sink["scales"], sink["rotations"]
+            flags = 1 | 2
         g_means2D = acc[:3 * N].view(N, 3)
         g_conic = acc[3 * N:7 * N].view(N, 4)
-        g_opac = acc[7 * N:8 * N]
-        g_colors = acc[8 * N:].view(N, 3)
-        g_means3D = torch.empty(N, 3, **f32)
-        g_scales = torch.empty(N, 3, **f32)
-        g_rot = torch.empty(N, 4, **f32)
-        grad_image = grad_image.to(torch.float32).contiguous()
         with torch.cuda.device(device):
             _lib.check(L.lograst_backward(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
                                           _ptr(saved["radii"]), _ptr(saved["geom"]), _ptr(saved["state"]),
                                           _ptr(saved["plist"]), _ptr(saved["final_T"]), _ptr(saved["n_contrib"]),
                                           _ptr(grad_image), _ptr(g_means2D), _ptr(g_conic), _ptr(g_opac),
                                           _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot),
-                                          1, _stream_ptr(device)))
+                                          flags, _stream_ptr(device)))
         del keep
         self.last_conic_grad = g_conic  # test/debug introspection only
+        if sink is not None:
+            return None, g_means2D, None, None, None, None
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
     def sh_forward(self, means3D, campos, shs, degree):
@@ -250,6 +259,41 @@ def _set_backend_for_tests(backend):
     return old
 
 
+# ---- multi-view gradient accumulation (new design; not part of the reference's API) ---------------
+_grad_sink = None
+
+
+class accumulate_grads_into:
+    """Context manager.  While active, every rasterizer backward ADDS its gradients w.r.t. means3D / scales /
+    rotations / opacities / colors_precomp straight into the given fp32 tensors (e.g. the views of a
+    log_amd.dist.GradientBucket) instead of returning them to autograd: the reverse walk's atomics and the
+    chain-rule kernel write into the step's running sums, so a multi-view step needs no per-view accumulate pass.
+    means2D (per-view, consumed by LoG's Counter) is still returned normally.  The sink tensors must be
+    contiguous fp32 [N,3],[N,3],[N,4],[N,1] or [N],[N,3] on the inputs' device; inputs routed through the sink get
+    no autograd gradient."""
+
+    def __init__(self, sink):
+        need = ("means3D", "scales", "rotations", "opacities", "colors")
+        missing = [k for k in need if k not in sink]
+        if missing:
+            raise KeyError(f"gradient sink lacks {missing}")
+        for k in need:
+            t = sink[k]
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"gradient sink '{k}' must be a contiguous float32 tensor")
+        self.sink = dict(sink)
+
+    def __enter__(self):
+        global _grad_sink
+        self.prev, _grad_sink = _grad_sink, self.sink
+        return self
+
+    def __exit__(self, *exc):
+        global _grad_sink
+        _grad_sink = self.prev
+        return False
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, colors, shs, opacities, scales, rotations, rs, flavour, use_filter):
@@ -284,10 +328,20 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_image, *unused):
         m, s, r = ctx.saved_tensors
-        g_m3, g_m2, g_c, g_o, g_s, g_r = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
-                                                           grad_image)
         m2_shape, o_shape = ctx.shapes
         sh, clamped = ctx.sh
+        sink = _grad_sink
+        if sink is not None and sh is None:
+            n = m.shape[0]
+            if not (sink["means3D"].shape == (n, 3) and sink["scales"].shape == (n, 3) and
+                    sink["rotations"].shape == (n, 4) and sink["opacities"].numel() == n and
+                    sink["colors"].shape == (n, 3) and sink["means3D"].device == m.device):
+                raise ValueError("gradient sink does not match the rasterizer inputs")
+            _, g_m2, _, _, _, _ = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved, grad_image,
+                                                    sink=sink)
+            return None, g_m2.reshape(m2_shape), None, None, None, None, None, None, None, None
+        g_m3, g_m2, g_c, g_o, g_s, g_r = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
+                                                           grad_image)
         g_sh = None
         if sh is not None:
             g_sh = _backend.sh_backward(m, ctx.rs.campos, sh, int(ctx.rs.sh_degree), clamped, g_c.contiguous(), g_m3)

@@ -29,7 +29,8 @@ class OracleBackend:
             return image, radii, t(f["point_id_pixel"]), t(f["point_weight_pixel"]), t(f["point_weight"].copy()), (v, f)
         return image, radii, None, None, None, (v, f)
 
-    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image):
+    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None):
+        assert sink is None, 'the CPU test double does not implement the accumulate path'
         v, f = saved
         g = oracle.backward(v, f, grad_image.detach().cpu().numpy())
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a))

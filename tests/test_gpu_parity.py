@@ -226,3 +226,45 @@ def test_capacity_hint_and_overflow_flag():
         assert n == exact["I"] and over
     finally:
         R.set_instance_capacity(None)
+
+
+def test_fused_multi_view_accumulation_matches_autograd():
+    """log_amd.rasterizer.accumulate_grads_into (LOGRAST_BWD_ACCUMULATE): two views added straight into a
+    GradientBucket == the sum autograd accumulates view by view."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R, scenes
+    from log_amd.dist import GradientBucket
+    import gpu_util as G
+    dev = torch.device("cuda:0")
+    cams = scenes.orbit_cameras(3, W=160, H=112, focal=170.0)
+    sc = scenes.random_scene(4000, seed=11, opacity=None, smax=0.07)
+    n = 4000
+    w = torch.tensor(np.random.default_rng(3).random((3, 112, 160), dtype=np.float32), device=dev)
+    names = dict(means3D="xyz", scales="scaling", rotations="rotation", opacities="opacity", colors="colors")
+
+    def run(fused):
+        leaves = {k: torch.tensor(sc[v], device=dev, requires_grad=True) for k, v in names.items()}
+        bucket = GradientBucket(n, dev)
+        bucket.attach(leaves)
+        m2s = []
+        for cam in cams[:2]:
+            rast = GaussianRasterizer(raster_settings=G.settings(cam, (1, 1, 1), dev))
+            m2 = torch.zeros(n, 3, device=dev, requires_grad=True)
+            kw = dict(means3D=leaves["means3D"], means2D=m2, shs=None, colors_precomp=leaves["colors"],
+                      opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                      cov3D_precomp=None)
+            if fused:
+                with R.accumulate_grads_into(bucket.views):
+                    (rast(**kw)[0] * w).sum().backward()
+            else:
+                (rast(**kw)[0] * w).sum().backward()
+            m2s.append(m2.grad.clone())
+        torch.cuda.synchronize()
+        return bucket.flat.clone(), m2s
+
+    a, m2a = run(False)
+    b, m2b = run(True)
+    assert float(a.abs().sum()) > 0
+    assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    for x, y in zip(m2a, m2b):
+        assert rel_l2(y.cpu().numpy(), x.cpu().numpy()) < 1e-5

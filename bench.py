@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--opacity", type=float, default=0.999, help="<0: random opacities")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("LOGRAST_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("LOGRAST_BENCH_STREAMS", "3")),
                     help="independent views in flight per GPU (one HIP stream each)")
     ap.add_argument("--no-fused-accumulate", action="store_true",
                     help="let autograd accumulate each view's gradients (5 extra passes per view) instead of the "

@@ -114,7 +114,9 @@ static void lr_prof_drain_locked() {
 static int lr_make_view(const lograst_view* in, LrView* out) {
   if (!in) return lr_fail(LOGRAST_ERR_ARG, "view is NULL");
   if (in->width <= 0 || in->height <= 0) return lr_fail(LOGRAST_ERR_ARG, "image size must be positive");
-  if (in->width > 65535 * 16 || in->height > 65535 * 16) return lr_fail(LOGRAST_ERR_ARG, "image too large");
+  if (in->width > 65535 * 16 || in->height > 65535 * 16 ||
+      (size_t)((in->width + 15) / 16) * (size_t)((in->height + 15) / 16) > 131072)
+    return lr_fail(LOGRAST_ERR_ARG, "image too large (more than 131072 tiles)");
   if (!in->viewmatrix || !in->projmatrix || !in->bg) return lr_fail(LOGRAST_ERR_ARG, "viewmatrix/projmatrix/bg must be device pointers");
   if (in->filter_mode < 0 || in->filter_mode > 2) return lr_fail(LOGRAST_ERR_ARG, "bad filter_mode");
   out->W = in->width; out->H = in->height;

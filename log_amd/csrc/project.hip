@@ -136,30 +136,34 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
 }
 
 // ---- tile scan --------------------------------------------------------------------------------------
-// One 1024-thread workgroup: exclusive scan of the per-tile counts into offsets[T+1], cursor[T]=offsets,
-// header.num_instances = total.  T is 8160 at 1080p / 32400 at 4K, so one workgroup is enough.
+// One 1024-thread workgroup: exclusive scan of the per-tile counts into offsets[T+1], fill cursors, header, and
+// the longest-first dispatch order.  T is 8160 at 1080p / 32400 at 4K, so one workgroup is enough -- but then the
+// kernel is a pure latency chain, so every per-tile value is loaded ONCE (independent loads, one 64-byte counter
+// line each) and kept in registers: thread t owns tiles [t*CH, (t+1)*CH), CH = ceil(T/1024) <= CHMAX.
+template <int CHMAX>
 __global__ void __launch_bounds__(1024)
 lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[64];
+  __shared__ uint32_t hist[256];
   const uint32_t* ranked = state + lr_ranked_off(tiles);
   const uint32_t* big = state + lr_big_off(tiles);
   uint32_t* offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
-  uint32_t tid = threadIdx.x;
   uint32_t* order = state + lr_order_off(tiles);
-  // pass 1: the counters sit one per 64-byte line; gather them with independent, unrolled loads into the
-  // compact arrays (order[] = total, offsets[] = ranked count, both rewritten below)
-#pragma unroll 4
-  for (uint32_t t = tid; t < tiles; t += 1024u) {
-    const uint32_t nr = ranked[t * LR_CTR_STRIDE], nb = big[t * LR_CTR_STRIDE];
-    order[t] = nr + nb;
-    offsets[t] = nr;
-  }
-  __syncthreads();
-  uint32_t chunk = (tiles + 1023u) / 1024u;
-  uint32_t b = tid * chunk, e = min(tiles, b + chunk);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (tiles + 1023u) / 1024u;
+  const uint32_t b = tid * chunk;
+  if (tid < 256) hist[tid] = 0u;
+  uint32_t nr[CHMAX], tot[CHMAX];
   uint32_t sum = 0;
-  for (uint32_t t = b; t < e; t++) sum += order[t];
+#pragma unroll
+  for (int k = 0; k < CHMAX; k++) {
+    const uint32_t t = b + (uint32_t)k;
+    const bool in = (uint32_t)k < chunk && t < tiles;
+    nr[k] = in ? ranked[t * LR_CTR_STRIDE] : 0u;
+    tot[k] = nr[k] + (in ? big[t * LR_CTR_STRIDE] : 0u);
+    sum += tot[k];
+  }
   // inclusive scan of the 1024 per-thread sums: shuffle scan inside each wave, then the 16 wave totals
   uint32_t inc = sum;
 #pragma unroll
@@ -168,7 +172,7 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
     if ((int)(tid & 63u) >= d) inc += up;
   }
   if ((tid & 63u) == 63u) part[tid >> 6] = inc;
-  __syncthreads();
+  __syncthreads();  // also publishes the zeroed hist[]
   if (tid < 16u) {
     uint32_t w = part[tid];
 #pragma unroll
@@ -182,11 +186,15 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   inc += (tid >> 6) ? part[32 + (tid >> 6) - 1] : 0u;
   const uint32_t grand = part[32 + 15];
   uint32_t run = inc - sum;  // exclusive prefix of this thread's chunk
-  for (uint32_t t = b; t < e; t++) {
-    const uint32_t nr = offsets[t], tot = order[t];
-    offsets[t] = run;
-    cursor[t * LR_CTR_STRIDE] = run + nr;  // big instances go behind the ranked ones
-    run += tot;
+#pragma unroll
+  for (int k = 0; k < CHMAX; k++) {
+    const uint32_t t = b + (uint32_t)k;
+    if ((uint32_t)k < chunk && t < tiles) {
+      offsets[t] = run;
+      cursor[t * LR_CTR_STRIDE] = run + nr[k];  // big instances go behind the ranked ones
+      run += tot[k];
+      atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u);
+    }
   }
   if (tid == 1023) {
     offsets[tiles] = grand;
@@ -196,33 +204,38 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   // Longest-processing-time-first dispatch order for the blend kernels: a tile's list is walked serially by
   // its waves, so the longest lists must start first or they become the tail of the launch.  Counting sort
   // of the tiles into 256 length buckets (16 entries wide), longest bucket first.
-  __shared__ uint32_t hist[256];
-  if (tid < 256) hist[tid] = 0u;
-  __syncthreads();  // also orders the offsets[] stores above before the reads below (same workgroup)
-  for (uint32_t t = b; t < e; t++) atomicAdd(&hist[min(255u, (offsets[t + 1] - offsets[t]) >> 4)], 1u);
   __syncthreads();
   if (tid < 64u) {  // one wave turns the 256 bucket counts into exclusive starts, longest bucket first
-    uint32_t c[4], tot = 0;
+    uint32_t c[4], tt = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) { c[i] = hist[255 - (4 * (int)tid + i)]; tot += c[i]; }
-    uint32_t incw = tot;
+    for (int i = 0; i < 4; i++) { c[i] = hist[255 - (4 * (int)tid + i)]; tt += c[i]; }
+    uint32_t incw = tt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const uint32_t up = __shfl_up(incw, d);
       if ((int)tid >= d) incw += up;
     }
-    uint32_t start = incw - tot;
+    uint32_t start = incw - tt;
 #pragma unroll
     for (int i = 0; i < 4; i++) { hist[255 - (4 * (int)tid + i)] = start; start += c[i]; }
   }
   __syncthreads();
-  for (uint32_t t = b; t < e; t++)
-    order[atomicAdd(&hist[min(255u, (offsets[t + 1] - offsets[t]) >> 4)], 1u)] = t;
+#pragma unroll
+  for (int k = 0; k < CHMAX; k++) {
+    const uint32_t t = b + (uint32_t)k;
+    if ((uint32_t)k < chunk && t < tiles) order[atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u)] = t;
+  }
 }
 
 void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
   lr_prof_begin(LRK_SCAN, s);
-  hipLaunchKernelGGL(lr_scan_kernel, dim3(1), dim3(1024), 0, s, state, tiles);
+  const uint32_t chunk = (tiles + 1023u) / 1024u;
+  if (chunk <= 8)
+    hipLaunchKernelGGL(lr_scan_kernel<8>, dim3(1), dim3(1024), 0, s, state, tiles);
+  else if (chunk <= 32)
+    hipLaunchKernelGGL(lr_scan_kernel<32>, dim3(1), dim3(1024), 0, s, state, tiles);
+  else
+    hipLaunchKernelGGL(lr_scan_kernel<128>, dim3(1), dim3(1024), 0, s, state, tiles);  // up to 131072 tiles (8K x 4K)
   lr_prof_end(LRK_SCAN, s);
 }
 

@@ -268,3 +268,18 @@ def test_fused_multi_view_accumulation_matches_autograd():
     assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
     for x, y in zip(m2a, m2b):
         assert rel_l2(y.cpu().numpy(), x.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("W,H", [(3840, 2160), (7680, 4320)], ids=["4k_scan32", "8k_scan128"])
+def test_large_tile_grids(oracle_mod, W, H):
+    """Tile counts beyond 8192 use the wider scan variants (32 / 128 tiles per thread)."""
+    import gpu_util as G
+    from log_amd import scenes
+    cam = scenes.orbit_cameras(1, W=W, H=H, focal=2139.0 * W / 1920.0)[0]
+    sc = scenes.random_scene(20000, seed=9, opacity=None, smax=0.02)
+    hf = G.hip_forward(cam, sc, (0.5, 0.5, 0.5))
+    _, of = G.oracle_forward(oracle_mod, cam, sc, (0.5, 0.5, 0.5))
+    st = G.compare_forward(hf, of)
+    for k in ("radii_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch", "image_bits_mismatch",
+              "pid_mismatch"):
+        assert st[k] == 0, (k, st)

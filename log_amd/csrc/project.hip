@@ -56,8 +56,9 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
                   const float* __restrict__ rots, const float* __restrict__ opac,
                   const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                   uint32_t* __restrict__ ranked, uint32_t* __restrict__ big) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+  // Grid-stride: the kernel is bound by memory-side atomic throughput, which a few hundred waves in flight
+  // already saturate; a small resident grid leaves the remaining wave slots to whatever runs on other streams.
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
   const float* __restrict__ V = v.view;
   const float* __restrict__ Pm = v.proj;
   float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
@@ -123,14 +124,18 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
   }
   geom[LR_REC_QUADS * (size_t)i + 2] = g2;
   radii[i] = rad;
+  }
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
                        uint32_t* big, hipStream_t s) {
   if (N <= 0) return;
+  static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 0);
+  int blocks = (N + 255) / 256;
+  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   lr_prof_begin(LRK_PROJECT, s);
-  hipLaunchKernelGGL(lr_project_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, N, means, scales, rots, opac,
+  hipLaunchKernelGGL(lr_project_kernel, dim3(blocks), dim3(256), 0, s, v, N, means, scales, rots, opac,
                      colors, radii, reinterpret_cast<float4*>(geom), ranked, big);
   lr_prof_end(LRK_PROJECT, s);
 }

@@ -131,7 +131,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
                        uint32_t* big, hipStream_t s) {
   if (N <= 0) return;
-  static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 0);
+  static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 512);  // 2 workgroups per CU: measured optimum
   int blocks = (N + 255) / 256;
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   lr_prof_begin(LRK_PROJECT, s);

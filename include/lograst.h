@@ -29,7 +29,7 @@ extern "C" {
 
 #define LOGRAST_VERSION 1
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
-#define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B) */
+#define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
 
 /* 2-D low-pass flavours */
 #define LOGRAST_FILTER_NONE 0   /* use_filter=False of the fork (LoG/render/renderer.py:151-152) */
@@ -40,7 +40,6 @@ extern "C" {
 #define LOGRAST_OK 0
 #define LOGRAST_ERR_ARG -1
 #define LOGRAST_ERR_HIP -2
-#define LOGRAST_ERR_CAPACITY -3
 
 /* Per-call view description.  Stands for GaussianRasterizationSettings
  * (/root/reference/LoG/render/renderer.py:63-76): image_height/width, tanfovx/y, bg, scale_modifier,
@@ -91,9 +90,10 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
 
 /* ---- forward, stage 2: per-tile bucketing + per-tile depth sort + compositing (A3, A4, A5, A7, A8)
  * keys: scratch of lograst_keys_bytes(capacity) (dead after the call); point_list: lograst_list_bytes
- * (capacity), kept for backward.  If the real instance count exceeds `capacity` nothing is rendered,
- * LOGRAST_ERR_CAPACITY is NOT detectable without a sync, so: when the caller passed the exact count
- * from stage 1 this cannot happen; when it passed a guess it must check lograst_read_overflow later.
+ * (capacity), kept for backward.  `capacity` = number of tile instances the two buffers can hold.  With the
+ * exact count from stage 1 it always suffices.  With a guess (sync-free operation) the kernels never write past
+ * it: if the real count is larger NOTHING is rendered, the overflow flag in tile_state is raised, and the
+ * caller finds out from lograst_read_state() (the call itself cannot know without a host sync).
  * Outputs: image[3,H,W], final_T[H,W], n_contrib[H,W] (both kept for backward), and when
  * view->extras: point_id_pixel[H,W] (i32, -1 = none), point_weight_pixel[H,W], point_weight[n]. */
 int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,

@@ -116,7 +116,10 @@ def test_non_finite_inputs_are_contained(oracle_mod):
     bad["scaling"][13, 1] = np.inf
     bad["rotation"][14] = np.nan
     hf = G.hip_forward(cam, bad, (0, 0, 0))
-    assert (hf["radii"][10:15] == 0).all()
+    _, ob = G.oracle_forward(oracle_mod, cam, bad, (0, 0, 0))
+    assert (hf["radii"] == ob["radii"]).all()             # same decisions as the oracle on garbage, too
+    assert (hf["radii"][10:12] == 0).all()                # non-finite positions are culled
+    assert (hf["point_weight"][10:15] == 0).all()         # non-finite covariances never contribute
     keep = np.ones(1000, bool)
     keep[10:15] = False
     clean = {k: v[keep] for k, v in sc.items()}
@@ -124,8 +127,9 @@ def test_non_finite_inputs_are_contained(oracle_mod):
     assert (hf["image"].view(np.uint32) == of["image"].view(np.uint32)).all()
     assert np.isfinite(hf["image"]).all()
     hg = G.hip_backward(hf, np.ones_like(hf["image"]))
-    for k in ("means3D", "scales", "rotations"):
-        assert (hg[k][10:15] == 0).all() and np.isfinite(hg[k][keep]).all(), k
+    for k in ("means3D", "scales", "rotations", "opacities", "colors"):
+        assert np.isfinite(hg[k][keep]).all(), k
+    assert (hg["means3D"][10:12] == 0).all()
 
 
 def test_mark_visible_and_settings_fields():

@@ -222,6 +222,9 @@ def main():
             kern = {}
             for name, (ms, cnt) in prof.items():
                 kern[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt)}
+                if name in alg:   # per-kernel algorithmic GB/s against the same 8 TB/s roof
+                    gbs = alg[name] / (1e-3 * ms / cnt) / 1e9
+                    kern[name].update(alg_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS)
             sort_ms = sum(prof[k][0] for k in prof if k.startswith("sort"))
             merged = {k: prof[k][0] for k in prof if not k.startswith("sort")}
             if sort_ms:

@@ -294,7 +294,7 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   const float dp1 = in ? dL_dimage[plane + pix] : 0.f;
   const float dp2 = in ? dL_dimage[2 * plane + pix] : 0.f;
   const float bgdot = lr_fma(v.bg[0], dp0, lr_fma(v.bg[1], dp1, v.bg[2] * dp2));
-  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lal = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // acc = colour composited behind the current entry
   int maxc = lastc;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
@@ -366,34 +366,36 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
         const int j = e ? j1 : j0;
         const float a = e ? a1 : a0, b = e ? b1 : b0, c = e ? c1 : c0, op = e ? op1 : op0;
-        const float G = e ? G1 : G0, alpha = e ? alpha1 : alpha0, dx = e ? dx1 : dx0, dy = e ? dy1 : dy0;
+        const float dx = e ? dx1 : dx0, dy = e ? dy1 : dy0;
         const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
         const int gid = lr_readlane_i((int)id, j);
-        float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hit) {
-          const float om = 1.f - alpha;
-          float rc = __builtin_amdgcn_rcpf(om);
-          rc = lr_fma(lr_fma(-om, rc, 1.f), rc, rc);  // one Newton step on v_rcp_f32
-          T = T * rc;
-          const float w = alpha * T;
-          acc0 = lr_fma(lal, lc0, (1.f - lal) * acc0);
-          acc1 = lr_fma(lal, lc1, (1.f - lal) * acc1);
-          acc2 = lr_fma(lal, lc2, (1.f - lal) * acc2);
-          lc0 = cr; lc1 = cg; lc2 = cbl;
-          float dL_dalpha = lr_fma(cr - acc0, dp0, lr_fma(cg - acc1, dp1, (cbl - acc2) * dp2));
-          dL_dalpha = lr_fma(dL_dalpha, T, -(Tf * rc) * bgdot);
-          lal = alpha;
-          const float dL_dG = op * dL_dalpha;
-          const float gdx = G * dx, gdy = G * dy;
-          const float dG_ddx = lr_fma(2.f * a, gdx, b * gdy);  // -gdx*A - gdy*B
-          const float dG_ddy = lr_fma(2.f * c, gdy, b * gdx);  // -gdy*C - gdx*B
-          // slot order chosen so that lr_reduce9's rows land on contiguous destinations:
-          //   r0 rows = (s0,s2,s1,s3) = (col r, col g, col b, opacity); r1 rows = (s4,s6,s5,s7) = (mean x, mean y, conic A, conic B); r2 = conic C
-          s[0] = w * dp0; s[2] = w * dp1; s[1] = w * dp2; s[3] = G * dL_dalpha;
-          s[4] = dL_dG * dG_ddx * sx; s[6] = dL_dG * dG_ddy * sy;
-          s[5] = -0.5f * gdx * dx * dL_dG; s[7] = -gdx * dy * dL_dG;
-          s[8] = -0.5f * gdy * dy * dL_dG;
-        }
+        // Branch-free body: lanes that do not contribute run it with alpha = G = 0, which leaves their state
+        // untouched exactly (T*1, 0*c + 1*acc) and makes all nine of their partial sums exact zeros -- no exec
+        // masking, no zero-initialised accumulators.  The colour behind the current entry is folded eagerly
+        // (acc <- alpha c + (1-alpha) acc after use), the same operations the lazy form performs one hit later.
+        const float alpha = hit ? (e ? alpha1 : alpha0) : 0.f;
+        const float G = hit ? (e ? G1 : G0) : 0.f;
+        const float om = 1.f - alpha;
+        float rc = __builtin_amdgcn_rcpf(om);
+        rc = lr_fma(lr_fma(-om, rc, 1.f), rc, rc);  // one Newton step on v_rcp_f32
+        T = T * rc;
+        const float w = alpha * T;
+        float dL_dalpha = lr_fma(cr - acc0, dp0, lr_fma(cg - acc1, dp1, (cbl - acc2) * dp2));
+        dL_dalpha = lr_fma(dL_dalpha, T, -(Tf * rc) * bgdot);
+        acc0 = lr_fma(alpha, cr, om * acc0);
+        acc1 = lr_fma(alpha, cg, om * acc1);
+        acc2 = lr_fma(alpha, cbl, om * acc2);
+        const float dL_dG = op * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddx = lr_fma(2.f * a, gdx, b * gdy);  // -gdx*A - gdy*B
+        const float dG_ddy = lr_fma(2.f * c, gdy, b * gdx);  // -gdy*C - gdx*B
+        // slot order chosen so that lr_reduce9's rows land on contiguous destinations:
+        //   r0 rows = (s0,s2,s1,s3) = (col r, col g, col b, opacity); r1 rows = (s4,s6,s5,s7) = (mean x, mean y, conic A, conic B); r2 = conic C
+        float s[9];
+        s[0] = w * dp0; s[2] = w * dp1; s[1] = w * dp2; s[3] = G * dL_dalpha;
+        s[4] = dL_dG * dG_ddx * sx; s[6] = dL_dG * dG_ddy * sy;
+        s[5] = -0.5f * gdx * dx * dL_dG; s[7] = -gdx * dy * dL_dG;
+        s[8] = -0.5f * gdy * dy * dL_dG;
         float r0, r1, r2;
         lr_reduce9(s, r0, r1, r2);
         if (lead) atomicAdd(base0 + (size_t)gid * mul0, r0);

@@ -9,15 +9,17 @@ Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): 1,000,000 random Gaussia
 opacity 0.999, scales U(0, 0.5 N^-1/3)), 1920x1080, 8 orbit cameras PER GPU, through the drop-in
 ``diff_gaussian_rasterization_wodilate`` package (5-tuple flavour), loss = sum(image * w), backward to all
 Gaussian attributes + means2D.  A "step" = every rank renders its 8 views forward+backward, gradients
-accumulate in one flat buffer per rank, and (N > 1) one reduce-scatter + all-gather sums them across ranks
-(view-sharded data parallelism, weak scaling: per-GPU work is fixed).  Inputs are resident in HBM before
+are added by the backward kernels into one flat buffer per stream, summed per rank, and (N > 1) one
+reduce-scatter + all-gather sums them across ranks (view-sharded data parallelism, weak scaling: per-GPU work
+is fixed).  --streams S (default 3) views are in flight per GPU on S HIP streams.  Inputs are resident in HBM before
 the timed region; the timed region contains no host synchronisation (tile-instance capacity comes from the
 warm-up, overflow is verified afterwards).
 
 Prints ONE JSON line on rank 0 (contract: see the task statement), including
   roofline     : dominant kernel, algorithmic bytes/launch / average launch duration (HIP events on the
-                 launch stream, recorded during the timed region) vs the 8 TB/s HBM3E peak;
-  cpu_baseline : the CPU oracle (oracle/, OpenMP, all host cores) timed on ONE view of the same workload.
+                 launch stream; with S > 1 from a single-stream step right after the timed region, the
+                 time-shared durations are in roofline_timed_region) vs the 8 TB/s HBM3E peak;
+  cpu_baseline : the CPU oracle (oracle/, OpenMP, all host cores) timed on whole views of the same workload (~12 s).
 """
 import argparse
 import json

@@ -191,39 +191,9 @@ LR_DEV float lr_readlane_f(float v, int lane) {
 }
 LR_DEV int lr_readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// DPP wave64 sum; the total ends up in lane 63 (row_shr within 16-lane rows, then row broadcasts).
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-LR_DEV float lr_dpp_add(float v) {
-  int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
-  return v + __int_as_float(moved);
-}
-LR_DEV float lr_wave_sum_to63(float v) {
-  v = lr_dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
-  v = lr_dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
-  v = lr_dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4, banks 1-3
-  v = lr_dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
-  v = lr_dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 -> rows 1,3
-  v = lr_dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 -> rows 2,3
-  return v;
-}
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-LR_DEV float lr_dpp_max(float v) {
-  // old = v for lanes that receive nothing (bound_ctrl=false keeps `old`)
-  int moved = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
-  return fmaxf(v, __int_as_float(moved));
-}
-LR_DEV float lr_wave_max_to63(float v) {
-  v = lr_dpp_max<0x111, 0xf, 0xf>(v);
-  v = lr_dpp_max<0x112, 0xf, 0xf>(v);
-  v = lr_dpp_max<0x114, 0xf, 0xe>(v);
-  v = lr_dpp_max<0x118, 0xf, 0xc>(v);
-  v = lr_dpp_max<0x142, 0xa, 0xf>(v);
-  v = lr_dpp_max<0x143, 0xc, 0xf>(v);
-  return v;
-}
-
-// Same tree on the raw bit patterns of NON-NEGATIVE floats (unsigned order == float order): v_max_u32
-// needs no NaN canonicalisation, so every step is one DPP-fused instruction.
+// DPP wave64 max; the result ends up in lane 63 (row_shr within 16-lane rows, then row broadcasts).
+// Done on the raw bit patterns of NON-NEGATIVE floats (unsigned order == float order): v_max_u32 needs no NaN
+// canonicalisation, so every step is one DPP-fused instruction.
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 LR_DEV uint32_t lr_dpp_umax(uint32_t v) {
   uint32_t moved = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, true);  // 0 = umax identity

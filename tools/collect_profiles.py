@@ -1,0 +1,72 @@
+"""Turns the rocprofv3 / bench outputs that a gpurun call left in gpurun_out/ into the committed summaries under
+profiles/ (round tag as argument, default r01).  python tools/collect_profiles.py [r01]"""
+import collections
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def stats(path, title, out):
+    rows = list(csv.DictReader(open(path)))
+    o = ["# " + title, "", "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
+    for r in rows:
+        name = r["Name"].split("(")[0].replace("void ", "")
+        o.append(f"| `{name[:60]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
+                 f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | "
+                 f"{float(r['Percentage']):.2f} |")
+    open(out, "w").write("\n".join(o) + "\n")
+
+
+for n, t in (("b_default", "default"), ("b_s1", "streams1")):
+    f = os.path.join(G, n + ".log")
+    if os.path.exists(f):
+        line = [l for l in open(f) if l.startswith("{")][-1]
+        json.dump(json.loads(line), open(os.path.join(P, f"{tag}_bench_{t}.json"), "w"), indent=1)
+cmd = "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+for d, suffix, extra in ((f"{tag}_trace", "", " --streams 1 (serialized kernels)"), (f"{tag}_trace_default", "_default", " (default: 3 streams)")):
+    src = os.path.join(G, d, "c2_kernel_stats.csv")
+    if os.path.exists(src):
+        stats(src, f"rocprofv3 --kernel-trace --stats -- {cmd}{extra}; C2 workload", os.path.join(P, f"{tag}_kernel_stats{suffix}.md"))
+        shutil.copy(src, os.path.join(P, f"{tag}_kernel_stats{suffix}.csv"))
+pm = os.path.join(ROOT, "tools", "pmc_summary.py")
+sq = os.path.join(G, f"{tag}_pmc_sq", "c2_counter_collection.csv")
+fe = os.path.join(G, f"{tag}_pmc_fetch", "c2_counter_collection.csv")
+wr = os.path.join(G, f"{tag}_pmc_write", "c2_counter_collection.csv")
+if all(os.path.exists(x) for x in (sq, fe, wr)):
+    out = ["# rocprofv3 --pmc (separate passes), mean per launch, C2 workload serialized (--streams 1)", "", "## SQ",
+           subprocess.check_output([sys.executable, pm, sq], text=True), "",
+           "## TCC FETCH_SIZE / WRITE_SIZE (KB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, see "
+           "MI355X_MICROARCH.md)", subprocess.check_output([sys.executable, pm, fe, wr], text=True)]
+    open(os.path.join(P, f"{tag}_pmc.md"), "w").write("\n".join(out))
+
+    def load(path, counter):
+        agg, cnt = collections.defaultdict(float), collections.Counter()
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg[k] += float(r["Counter_Value"])
+                cnt[k] += 1
+        return {k: agg[k] / cnt[k] for k in agg}
+    f, w = load(fe, "FETCH_SIZE"), load(wr, "WRITE_SIZE")
+    names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_fwd_kernel<true>": "blend_fwd", "lr_project_kernel": "project",
+             "lr_fill_kernel": "fill_keys", "lr_project_bwd_kernel<true>": "project_bwd"}
+    tj = os.path.join(P, f"{tag}_traffic.json")
+    d = json.load(open(tj)) if os.path.exists(tj) else {
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --streams 1",
+        "correction": "traffic_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section)",
+        "workload": {"gaussians": 1000000, "width": 1920, "height": 1080}}
+    d["kernels"] = {s: {"fetch_kb": f[k], "write_kb": w[k], "traffic_bytes": (2 * f[k] + w[k]) * 1024}
+                    for k, s in names.items() if k in f and k in w}
+    json.dump(d, open(tj, "w"), indent=1)
+for f in os.listdir(G):
+    if f.startswith("radius_") and f.endswith(".json"):
+        shutil.copy(os.path.join(G, f), os.path.join(P, f"{tag}_{f}"))
+print(sorted(os.listdir(P)))

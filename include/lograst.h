@@ -82,11 +82,12 @@ int lograst_compute_radius(int32_t p, const float* means3d, const float* scales,
  * LoG/model/level_of_gaussian.py:211-219).  Writes radii[n] (API output), geom (n records), and
  * tile_state (per-tile counts/offsets).  The total number of tile instances is left in
  * tile_state and, if num_instances_host != NULL (pinned or pageable host memory), also copied there
- * after a stream synchronise so the caller can size the key/list buffers exactly. */
+ * after a stream synchronise so the caller can size the key/list buffers exactly; max_tile_len_host (optional)
+ * receives the longest tile list, which stage 2 uses to launch only the sort levels that are needed. */
 int lograst_forward_project(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                             const float* rotations, const float* opacities, const float* colors,
                             int32_t* radii, void* geom, void* tile_state, uint32_t* num_instances_host,
-                            void* stream);
+                            uint32_t* max_tile_len_host, void* stream);
 
 /* ---- forward, stage 2: per-tile bucketing + per-tile depth sort + compositing (A3, A4, A5, A7, A8)
  * keys: scratch of lograst_keys_bytes(capacity) (dead after the call); point_list: lograst_list_bytes
@@ -94,16 +95,19 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
  * exact count from stage 1 it always suffices.  With a guess (sync-free operation) the kernels never write past
  * it: if the real count is larger NOTHING is rendered, the overflow flag in tile_state is raised, and the
  * caller finds out from lograst_read_state() (the call itself cannot know without a host sync).
+ * max_tile_len: host-side upper bound on the longest tile list (from stage 1, or a hint; 0 = unknown, treated
+ * as `capacity`): lists longer than 8192 keys take a multi-pass sort whose number of launches depends on it.  An
+ * under-estimate leaves such lists partially sorted, so pass 0 when in doubt.
  * Outputs: image[3,H,W], final_T[H,W], n_contrib[H,W] (both kept for backward), and when
  * view->extras: point_id_pixel[H,W] (i32, -1 = none), point_weight_pixel[H,W], point_weight[n]. */
 int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
-                           uint64_t* keys, uint32_t* point_list, uint32_t capacity, float* image,
-                           float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
+                           uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
+                           float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
                            float* point_weight_pixel, float* point_weight, void* stream);
 
-/* Copies {num_instances, overflow_flag} of a tile_state to host (synchronises the stream). */
+/* Copies {num_instances, overflow_flag, longest tile list} of a tile_state to host (synchronises the stream). */
 int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uint32_t* overflow_host,
-                       void* stream);
+                       uint32_t* max_tile_len_host, void* stream);
 
 /* ---- backward (A6, A6b) ------------------------------------------------------------------------
  * Stands for _RasterizeGaussians.backward of the third-party package, triggered by loss.backward()

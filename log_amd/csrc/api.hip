@@ -23,7 +23,7 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, hipStream_t s);
 void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
-                    hipStream_t s);
+                    uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
                          int* pid, float* pwp, float* pw, hipStream_t s);
@@ -165,7 +165,7 @@ int lograst_compute_radius(int32_t p, const float* means3d, const float* scales,
 int lograst_forward_project(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                             const float* rotations, const float* opacities, const float* colors,
                             int32_t* radii, void* geom, void* tile_state, uint32_t* num_instances_host,
-                            void* stream) {
+                            uint32_t* max_tile_len_host, void* stream) {
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
@@ -183,16 +183,19 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
                     st + lr_big_off(tiles), s);
   lr_launch_scan(st, tiles, s);
   LR_HIP(hipGetLastError());
-  if (num_instances_host) {
-    LR_HIP(hipMemcpyAsync(num_instances_host, st + LR_HDR_NUM, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  if (num_instances_host || max_tile_len_host) {
+    uint32_t hdr[LR_HDR_WORDS] = {0};
+    LR_HIP(hipMemcpyAsync(hdr, st, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     LR_HIP(hipStreamSynchronize(s));
+    if (num_instances_host) *num_instances_host = hdr[LR_HDR_NUM];
+    if (max_tile_len_host) *max_tile_len_host = hdr[LR_HDR_MAXLEN];
   }
   return LOGRAST_OK;
 }
 
 int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
-                           uint64_t* keys, uint32_t* point_list, uint32_t capacity, float* image,
-                           float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
+                           uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
+                           float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
                            float* point_weight_pixel, float* point_weight, void* stream) {
   LrView v;
   int rc = lr_make_view(view, &v);
@@ -207,7 +210,7 @@ int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
   if (v.extras && n > 0) LR_HIP(hipMemsetAsync(point_weight, 0, sizeof(float) * (size_t)n, s));
   lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, s);
-  lr_launch_sort(st, tiles, keys, point_list, capacity, s);
+  lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
                       point_weight_pixel, point_weight, s);
   LR_HIP(hipGetLastError());
@@ -215,14 +218,15 @@ int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom
 }
 
 int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uint32_t* overflow_host,
-                       void* stream) {
+                       uint32_t* max_tile_len_host, void* stream) {
   if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
-  uint32_t hdr[2] = {0, 0};
+  uint32_t hdr[4] = {0, 0, 0, 0};
   hipStream_t s = (hipStream_t)stream;
   LR_HIP(hipMemcpyAsync(hdr, tile_state, sizeof(hdr), hipMemcpyDeviceToHost, s));
   LR_HIP(hipStreamSynchronize(s));
-  if (num_instances_host) *num_instances_host = hdr[0];
-  if (overflow_host) *overflow_host = hdr[1];
+  if (num_instances_host) *num_instances_host = hdr[LR_HDR_NUM];
+  if (overflow_host) *overflow_host = hdr[LR_HDR_OVERFLOW];
+  if (max_tile_len_host) *max_tile_len_host = hdr[LR_HDR_MAXLEN];
   return LOGRAST_OK;
 }
 

@@ -13,7 +13,8 @@
 #define LR_WAVE 64
 
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
-// [0] num_instances  [1] overflow flag  [2..15] reserved
+// [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_SORT_BLOCK
+// [4..15] reserved
 // [16 .. 16+Tp)          exclusive offsets (T+1 entries)                              -- read by sort/blend
 // then three per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic
 // targets spread over the memory channels instead of 8160 counters sharing 32 KB):
@@ -22,6 +23,7 @@
 //   big[T*S]      instances of larger Gaussians (counted only)
 //   cursor[T*S]   fill cursor for the big instances, initialised to offset + ranked
 // then order[T]: tile ids by descending list length (longest-first dispatch order for the blend kernels)
+// then biglist[T]: ids of the tiles whose list exceeds LR_SORT_BLOCK keys (multi-block sort path)
 #ifndef LR_CTR_STRIDE
 #define LR_CTR_STRIDE 16
 #endif
@@ -29,6 +31,9 @@
 #define LR_HDR_WORDS 16
 #define LR_HDR_NUM 0
 #define LR_HDR_OVERFLOW 1
+#define LR_HDR_MAXLEN 2
+#define LR_HDR_NBIG 3
+#define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_REC_QUADS 4  // float4 per projected record (64 B)
 __host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
 __host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { (void)tiles; return LR_HDR_WORDS; }
@@ -36,7 +41,8 @@ __host__ __device__ inline uint32_t lr_ranked_off(uint32_t tiles) { return LR_HD
 __host__ __device__ inline uint32_t lr_big_off(uint32_t tiles) { return lr_ranked_off(tiles) + tiles * LR_CTR_STRIDE; }
 __host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_big_off(tiles) + tiles * LR_CTR_STRIDE; }
 __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
-__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_biglist_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return lr_biglist_off(tiles) + lr_tpad(tiles); }
 
 // Device-side view (kernel argument, by value).
 struct LrView {

@@ -157,7 +157,9 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   uint32_t* offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   uint32_t* order = state + lr_order_off(tiles);
+  uint32_t* biglist = state + lr_biglist_off(tiles);
   const uint32_t tid = threadIdx.x;
+  uint32_t lmax = 0;
   const uint32_t chunk = (tiles + 1023u) / 1024u;
   const uint32_t b = tid * chunk;
   if (tid < 256) hist[tid] = 0u;
@@ -201,8 +203,13 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
       cursor[t * LR_CTR_STRIDE] = run + nr[k];  // big instances go behind the ranked ones
       run += tot[k];
       atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u);
+      lmax = max(lmax, tot[k]);
+      if (tot[k] > LR_SORT_BLOCK) biglist[atomicAdd(&state[LR_HDR_NBIG], 1u)] = t;  // rare: multi-block sort path
     }
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d));
+  if ((tid & 63u) == 0u && lmax) atomicMax(&state[LR_HDR_MAXLEN], lmax);
   if (tid == 1023) {
     offsets[tiles] = grand;
     state[LR_HDR_NUM] = grand;

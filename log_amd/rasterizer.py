@@ -58,24 +58,33 @@ WODILATE = Flavour("diff_gaussian_rasterization_wodilate", _lib.FILTER_CLAMP, 1,
 # With a hint, no host synchronisation happens in forward(); the kernels refuse to write past the
 # capacity and raise the overflow flag, which `last_overflow()` / bench.py check afterwards.
 _capacity_hint = None
+_max_len_hint = 0
 _last_state = None
 
 
-def set_instance_capacity(n):
-    """n = int: sync-free forward with room for n tile instances; None: exact sizing (default)."""
-    global _capacity_hint
+def set_instance_capacity(n, max_tile_len=0):
+    """n = int: sync-free forward with room for n tile instances; None: exact sizing (default).
+    max_tile_len: upper bound on the longest per-tile list in sync-free mode (0 = unknown: the sort then launches
+    every multi-block level the capacity allows; only lists longer than 8192 entries care)."""
+    global _capacity_hint, _max_len_hint
     _capacity_hint = None if n is None else int(n)
+    _max_len_hint = int(max_tile_len) if n is not None else 0
 
 
 def last_overflow():
     """(num_instances, overflowed) of the most recent forward on this process (synchronises)."""
+    n, o, _ = last_state_info()
+    return n, o
+
+
+def last_state_info():
+    """(num_instances, overflowed, longest_tile_list) of the most recent forward (synchronises)."""
     if _last_state is None:
-        return 0, False
-    n = ctypes.c_uint32(0)
-    o = ctypes.c_uint32(0)
+        return 0, False, 0
+    n, o, m = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
     _lib.check(_lib.lib().lograst_read_state(_last_state.data_ptr(), ctypes.byref(n), ctypes.byref(o),
-                                             _stream_ptr(_last_state.device)))
-    return int(n.value), bool(o.value)
+                                             ctypes.byref(m), _stream_ptr(_last_state.device)))
+    return int(n.value), bool(o.value), int(m.value)
 
 
 def _stream_ptr(device):
@@ -129,16 +138,16 @@ class HipBackend:
         state = torch.empty(L.lograst_tile_state_bytes(W, H) // 4, **i32)
         with torch.cuda.device(device):
             if _capacity_hint is None:
-                n_host = ctypes.c_uint32(0)
+                n_host, m_host = ctypes.c_uint32(0), ctypes.c_uint32(0)
                 _lib.check(L.lograst_forward_project(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
                                                      _ptr(opacities), _ptr(colors), _ptr(radii), _ptr(geom),
-                                                     _ptr(state), ctypes.byref(n_host), stream))
-                capacity = int(n_host.value)
+                                                     _ptr(state), ctypes.byref(n_host), ctypes.byref(m_host), stream))
+                capacity, max_len = int(n_host.value), max(int(m_host.value), 1)
             else:
                 _lib.check(L.lograst_forward_project(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
                                                      _ptr(opacities), _ptr(colors), _ptr(radii), _ptr(geom),
-                                                     _ptr(state), None, stream))
-                capacity = _capacity_hint
+                                                     _ptr(state), None, None, stream))
+                capacity, max_len = _capacity_hint, _max_len_hint
             keys = torch.empty(capacity, dtype=torch.int64, device=device)
             plist = torch.empty(capacity, **i32)
             image = torch.empty(3, H, W, **f32)
@@ -151,7 +160,7 @@ class HipBackend:
             else:
                 pid = pwp = pw = None
             _lib.check(L.lograst_forward_render(ctypes.byref(view), N, _ptr(geom), _ptr(state), _ptr(keys), _ptr(plist),
-                                                capacity, _ptr(image), _ptr(final_T), _ptr(n_contrib), _ptr(pid),
+                                                capacity, max_len, _ptr(image), _ptr(final_T), _ptr(n_contrib), _ptr(pid),
                                                 _ptr(pwp), _ptr(pw), stream))
         del keys, keep
         _last_state = state

@@ -29,10 +29,19 @@ def _case(name):
         cam, sc = small_case(n=12000, W=64, H=64, focal=70.0, seed=6, smax=0.01)
         sc["xyz"] *= 0.05
         return cam, sc
+    if name == "huge_tiles":  # several lists beyond one LDS block (8192): hybrid multi-block sort, 1..3 merge phases
+        cam, sc = small_case(n=70000, W=96, H=64, focal=100.0, seed=8, smax=0.004)
+        n = [40000, 20000, 9000, 1000]
+        centers = np.array([[0.0, -0.2, 0.1], [0.0, 0.25, -0.1], [0.0, 0.0, -0.25], [0.0, 0.1, 0.3]], np.float32)
+        start = 0
+        for c, k in zip(centers, n):
+            sc["xyz"][start:start + k] = sc["xyz"][start:start + k] * 0.02 + c
+            start += k
+        return cam, sc
     raise KeyError(name)
 
 
-CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "dense_tile"]
+CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "dense_tile", "huge_tiles"]
 
 
 @pytest.mark.parametrize("name", CASES)

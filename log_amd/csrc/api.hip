@@ -19,7 +19,7 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
                        uint32_t* big, hipStream_t s);
-void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t gx, hipStream_t s);
+void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, hipStream_t s);
 void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
@@ -181,7 +181,7 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   LR_HIP(hipMemsetAsync(st + lr_ranked_off(tiles), 0, sizeof(uint32_t) * 2 * (size_t)tiles * LR_CTR_STRIDE, s));
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
                     st + lr_big_off(tiles), s);
-  lr_launch_scan(st, tiles, (uint32_t)v.gx, s);
+  lr_launch_scan(st, tiles, s);
   LR_HIP(hipGetLastError());
   if (num_instances_host || max_tile_len_host) {
     uint32_t hdr[LR_HDR_WORDS] = {0};

@@ -19,9 +19,7 @@
 // then three per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic
 // targets spread over the memory channels instead of 8160 counters sharing 32 KB):
 //   ranked[T*S]   instances of Gaussians touching <= LR_RANKED_TILES tiles; the returning atomic that counts
-//                 them also hands each instance its slot inside the tile (stored in the record's q3).  Laid out
-//                 as one 64-bit word per horizontal tile pair (word index (ty*ceil(gx/2) + tx/2)*S/2; low half =
-//                 even tx), so one atomic serves both tiles of an aligned pair
+//                 them also hands each instance its slot inside the tile (stored in the record's q3)
 //   big[T*S]      instances of larger Gaussians (counted only)
 //   cursor[T*S]   fill cursor for the big instances, initialised to offset + ranked
 // then order[T]: tile ids by descending list length (longest-first dispatch order for the blend kernels)

@@ -51,9 +51,8 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
 //   q0 = (mx, my, conicA, conicB)  q1 = (conicC, opacity, r, g)  q2 = (b, depth, rect_min, rect_max)
 //   q3 = slots of its (<= 4) tile instances inside their tiles, row-major over the rect
 // (q2 is written for every Gaussian, zero = culled/empty rect).  Counting and slot assignment are one
-// returning atomic per instance (per PAIR of instances where a rect row covers an aligned tile pair), so the
-// bucket fill needs no atomics for these Gaussians; larger rects are only counted here (non-returning atomic)
-// and placed by the fill kernel.
+// returning atomic per instance, so the bucket fill needs no atomics for these Gaussians; larger rects are
+// only counted here (non-returning atomic) and placed by the fill kernel.
 __global__ void __launch_bounds__(256)
 lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
@@ -106,29 +105,12 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
             geom[LR_REC_QUADS * (size_t)i + 1] = g1;
             const int w = x1 - x0, nt = w * (y1 - y0);
             if (nt <= LR_RANKED_TILES) {
-              // The counters of a horizontal tile pair (even x, x+1) share one 64-bit word, so a rect row that
-              // covers both halves of a pair is counted AND ranked by ONE returning 64-bit atomic (low word = even
-              // tile, high word = odd tile): a quarter fewer memory-side atomics, which is what bounds this kernel.
               uint32_t slot[LR_RANKED_TILES] = {0u, 0u, 0u, 0u};
-              unsigned long long* pairs = reinterpret_cast<unsigned long long*>(ranked);
-              const int gxp = (v.gx + 1) >> 1;
-              bool taken = false;  // tile k was already handled together with tile k-1
 #pragma unroll
               for (int k = 0; k < LR_RANKED_TILES; k++) {
-                if (k < nt && !taken) {
-                  const int ty = k / w, tx = k - ty * w, x = x0 + tx;
-                  unsigned long long* ctr = pairs + (size_t)((y0 + ty) * gxp + (x >> 1)) * (LR_CTR_STRIDE / 2);
-                  if (!(x & 1) && tx + 1 < w) {
-                    const unsigned long long old = atomicAdd(ctr, 0x0000000100000001ull);
-                    slot[k] = (uint32_t)old;
-                    if (k + 1 < LR_RANKED_TILES) slot[k + 1] = (uint32_t)(old >> 32);
-                    taken = true;
-                  } else {
-                    const unsigned long long old = atomicAdd(ctr, (x & 1) ? (1ull << 32) : 1ull);
-                    slot[k] = (x & 1) ? (uint32_t)(old >> 32) : (uint32_t)old;
-                  }
-                } else {
-                  taken = false;
+                if (k < nt) {
+                  const int ty = k / w, tx = k - ty * w;
+                  slot[k] = atomicAdd(&ranked[((y0 + ty) * v.gx + (x0 + tx)) * LR_CTR_STRIDE], 1u);
                 }
               }
               geom[LR_REC_QUADS * (size_t)i + 3] = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]),
@@ -167,7 +149,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
 // line each) and kept in registers: thread t owns tiles [t*CH, (t+1)*CH), CH = ceil(T/1024) <= CHMAX.
 template <int CHMAX>
 __global__ void __launch_bounds__(1024)
-lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t gx) {
+lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   __shared__ uint32_t part[64];
   __shared__ uint32_t hist[256];
   const uint32_t* ranked = state + lr_ranked_off(tiles);
@@ -178,7 +160,7 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t gx) {
   uint32_t* biglist = state + lr_biglist_off(tiles);
   const uint32_t tid = threadIdx.x;
   uint32_t lmax = 0;
-  const uint32_t chunk = (tiles + 1023u) / 1024u, gxp = (gx + 1u) >> 1;
+  const uint32_t chunk = (tiles + 1023u) / 1024u;
   const uint32_t b = tid * chunk;
   if (tid < 256) hist[tid] = 0u;
   uint32_t nr[CHMAX], tot[CHMAX];
@@ -187,9 +169,7 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t gx) {
   for (int k = 0; k < CHMAX; k++) {
     const uint32_t t = b + (uint32_t)k;
     const bool in = (uint32_t)k < chunk && t < tiles;
-    // ranked counters: one 64-bit word per horizontal tile pair (low half = even x)
-    const uint32_t ty = t / gx, tx = t - ty * gx;
-    nr[k] = in ? ranked[(ty * gxp + (tx >> 1)) * LR_CTR_STRIDE + (tx & 1u)] : 0u;
+    nr[k] = in ? ranked[t * LR_CTR_STRIDE] : 0u;
     tot[k] = nr[k] + (in ? big[t * LR_CTR_STRIDE] : 0u);
     sum += tot[k];
   }
@@ -261,15 +241,15 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t gx) {
   }
 }
 
-void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t gx, hipStream_t s) {
+void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
   lr_prof_begin(LRK_SCAN, s);
   const uint32_t chunk = (tiles + 1023u) / 1024u;
   if (chunk <= 8)
-    hipLaunchKernelGGL(lr_scan_kernel<8>, dim3(1), dim3(1024), 0, s, state, tiles, gx);
+    hipLaunchKernelGGL(lr_scan_kernel<8>, dim3(1), dim3(1024), 0, s, state, tiles);
   else if (chunk <= 32)
-    hipLaunchKernelGGL(lr_scan_kernel<32>, dim3(1), dim3(1024), 0, s, state, tiles, gx);
+    hipLaunchKernelGGL(lr_scan_kernel<32>, dim3(1), dim3(1024), 0, s, state, tiles);
   else
-    hipLaunchKernelGGL(lr_scan_kernel<128>, dim3(1), dim3(1024), 0, s, state, tiles, gx);  // up to 131072 tiles (8K x 4K)
+    hipLaunchKernelGGL(lr_scan_kernel<128>, dim3(1), dim3(1024), 0, s, state, tiles);  // up to 131072 tiles (8K x 4K)
   lr_prof_end(LRK_SCAN, s);
 }
 

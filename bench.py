@@ -158,11 +158,12 @@ def main():
     stats = []
     for rast in rasts:
         out = one_view(rast, lanes[0][0])
-        n_inst, over, max_len = R.last_state_info()
-        stats.append((int((out[1] > 0).sum().item()), n_inst, max_len))
+        n_inst, over, max_len, n_rect = R.last_state_info()
+        stats.append((int((out[1] > 0).sum().item()), n_inst, max_len, n_rect))
         assert not over
     V = float(np.mean([s[0] for s in stats]))
-    I = float(np.mean([s[1] for s in stats]))
+    I = float(np.mean([s[1] for s in stats]))        # binned tile instances (after the support cull): what the kernels move
+    I_rect = float(np.mean([s[3] for s in stats]))   # the reference's rect rule (its num_rendered)
     cap = int(max(s[1] for s in stats) * 1.02) + 1024
     # from here on: no host sync inside forward(); the longest tile list (it picks the sort's multi-block levels)
     # comes from the same measurement, with the same margin
@@ -223,7 +224,7 @@ def main():
                         "fwd+bwd of sum(image*w), wodilate (5-tuple) flavour" %
                         (N, "rand" if args.opacity < 0 else args.opacity, W, H, args.views),
             "gaussians": N, "width": W, "height": H, "views_per_gpu": args.views,
-            "visible_per_view": V, "tile_instances_per_view": I,
+            "visible_per_view": V, "tile_instances_per_view": I, "tile_instances_per_view_reference_rect_rule": I_rect,
             "streams_per_gpu": S, "fused_gradient_accumulation": fused,
             "parallelism": ("view-sharded dp%d, 1 reduce-scatter+all-gather of %d floats/step" %
                             (world, bucket.flat.numel()) if world > 1 else "single GPU") +

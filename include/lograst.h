@@ -105,9 +105,17 @@ int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom
                            float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
                            float* point_weight_pixel, float* point_weight, void* stream);
 
-/* Copies {num_instances, overflow_flag, longest tile list} of a tile_state to host (synchronises the stream). */
+/* Copies {num_instances, overflow_flag, longest tile list, rect instances} of a tile_state to host (synchronises
+ * the stream; any pointer may be NULL).  rect_instances = what the plain rect rule of the reference would have
+ * binned (num_rendered of the third-party package); num_instances <= rect_instances when the support cull is on. */
 int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uint32_t* overflow_host,
-                       uint32_t* max_tile_len_host, void* stream);
+                       uint32_t* max_tile_len_host, uint32_t* rect_instances_host, void* stream);
+
+/* Support cull in the binning stage (default on; also LOGRAST_TILE_CULL=0): a tile of a Gaussian's rect becomes
+ * a list entry only if the Gaussian can reach alpha >= 1/255 somewhere inside it.  Result-preserving (dropped
+ * entries fail the alpha floor at every pixel of the tile); with it off the tile lists are exactly the
+ * reference's rect lists.  Process-wide; returns the previous setting. */
+int lograst_set_tile_cull(int enabled);
 
 /* ---- backward (A6, A6b) ------------------------------------------------------------------------
  * Stands for _RasterizeGaussians.backward of the third-party package, triggered by loss.backward()

@@ -48,7 +48,8 @@ _SIGNATURES = {
                                               c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p]),
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),
-                                          ctypes.POINTER(c_uint32), c_void_p]),
+                                          ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_set_tile_cull": (ctypes.c_int, [ctypes.c_int]),
     "lograst_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 17 + [c_int32, c_void_p]),
     "lograst_project_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10),
     "lograst_sh_forward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 6),

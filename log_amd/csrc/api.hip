@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -18,7 +19,7 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
                       hipStream_t s);
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
-                       uint32_t* big, hipStream_t s);
+                       uint32_t* big, uint32_t* hdr, int tile_cull, hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, hipStream_t s);
@@ -58,6 +59,16 @@ static int lr_fail(int code, const std::string& msg) {
 int lr_env_int(const char* name, int dflt) {
   const char* e = std::getenv(name);
   return (e && *e) ? std::atoi(e) : dflt;
+}
+// Support cull in the binning kernels (project.hip): on unless LOGRAST_TILE_CULL=0 or lograst_set_tile_cull(0).
+static std::atomic<int> g_tile_cull{-1};
+static int lr_tile_cull() {
+  int c = g_tile_cull.load(std::memory_order_relaxed);
+  if (c < 0) {
+    c = lr_env_int("LOGRAST_TILE_CULL", 1) ? 1 : 0;
+    g_tile_cull.store(c, std::memory_order_relaxed);
+  }
+  return c;
 }
 
 // ---- profiling ------------------------------------------------------------------------------------------
@@ -180,7 +191,7 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * LR_HDR_WORDS, s));
   LR_HIP(hipMemsetAsync(st + lr_ranked_off(tiles), 0, sizeof(uint32_t) * 2 * (size_t)tiles * LR_CTR_STRIDE, s));
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
-                    st + lr_big_off(tiles), s);
+                    st + lr_big_off(tiles), st, lr_tile_cull(), s);
   lr_launch_scan(st, tiles, s);
   LR_HIP(hipGetLastError());
   if (num_instances_host || max_tile_len_host) {
@@ -217,16 +228,23 @@ int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom
   return LOGRAST_OK;
 }
 
+int lograst_set_tile_cull(int enabled) {
+  const int old = lr_tile_cull();
+  g_tile_cull.store(enabled ? 1 : 0, std::memory_order_relaxed);
+  return old;
+}
+
 int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uint32_t* overflow_host,
-                       uint32_t* max_tile_len_host, void* stream) {
+                       uint32_t* max_tile_len_host, uint32_t* rect_instances_host, void* stream) {
   if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
-  uint32_t hdr[4] = {0, 0, 0, 0};
+  uint32_t hdr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t s = (hipStream_t)stream;
   LR_HIP(hipMemcpyAsync(hdr, tile_state, sizeof(hdr), hipMemcpyDeviceToHost, s));
   LR_HIP(hipStreamSynchronize(s));
   if (num_instances_host) *num_instances_host = hdr[LR_HDR_NUM];
   if (overflow_host) *overflow_host = hdr[LR_HDR_OVERFLOW];
   if (max_tile_len_host) *max_tile_len_host = hdr[LR_HDR_MAXLEN];
+  if (rect_instances_host) *rect_instances_host = hdr[LR_HDR_RECT];
   return LOGRAST_OK;
 }
 

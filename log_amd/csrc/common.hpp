@@ -11,15 +11,18 @@
 #include "../../include/lograst.h"
 
 #define LR_WAVE 64
+#define LR_TILE 16
 
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
 // [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_SORT_BLOCK
-// [4..15] reserved
+// [4] tile instances of the plain rect rule (before the support cull; reporting only)
+// [5] support cull applied by the projection kernel (0/1)  [6..15] reserved
 // [16 .. 16+Tp)          exclusive offsets (T+1 entries)                              -- read by sort/blend
 // then three per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic
 // targets spread over the memory channels instead of 8160 counters sharing 32 KB):
 //   ranked[T*S]   instances of Gaussians touching <= LR_RANKED_TILES tiles; the returning atomic that counts
-//                 them also hands each instance its slot inside the tile (stored in the record's q3)
+//                 them also hands each instance its slot inside the tile (stored in the record's q3;
+//                 0xffffffff = this tile of the rect was dropped by the support cull)
 //   big[T*S]      instances of larger Gaussians (counted only)
 //   cursor[T*S]   fill cursor for the big instances, initialised to offset + ranked
 // then order[T]: tile ids by descending list length (longest-first dispatch order for the blend kernels)
@@ -33,6 +36,8 @@
 #define LR_HDR_OVERFLOW 1
 #define LR_HDR_MAXLEN 2
 #define LR_HDR_NBIG 3
+#define LR_HDR_CULL 5  // 1 if lr_project_kernel applied the support cull (the fill kernel must repeat it)
+#define LR_HDR_RECT 4  // tile instances of the plain rect rule (what the reference would sort), before the support cull
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_REC_QUADS 4  // float4 per projected record (64 B)
 __host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
@@ -189,6 +194,56 @@ LR_DEV float lr_radius_from_cov(float a, float c, float det) {
   float sq = sqrtf(disc);
   float l1 = mid + sq, l2 = mid - sq;
   return 3.f * sqrtf(fmaxf(l1, l2));
+}
+
+// ---- alpha-support test against a pixel box, prepared once per Gaussian ------------------------------
+// Can the Gaussian reach alpha >= 1/255 anywhere in the pixel box [x0,x1]x[y0,y1]?  Same conservative rule as
+// blend.hip:lr_support_hits (level set 0.5 d^T Q d <= 1.01 ln(255 opacity) + 0.01, "yes" whenever the fp32
+// evaluation of `power` could exceed that margin), split so that the binning kernels can test every tile of a
+// rect against one prepared Gaussian.  Used by project + fill, which must agree bit for bit (same inputs: the
+// stored record; same code: this function).
+struct LrSupport {
+  float mx, my, A, B, C, tau, ex, ey, iA, iC;
+  int mode;  // 0 never visible (opacity below the floor), 1 cannot cull safely, 2 test the box
+};
+LR_DEV LrSupport lr_support_prepare(float mx, float my, float A, float B, float C, float op) {
+  LrSupport s;
+  s.mx = mx; s.my = my; s.A = A; s.B = B; s.C = C;
+  s.tau = lr_fma(__logf(255.f * op), 1.01f, 0.01f);
+  s.ex = 0.f; s.ey = 0.f; s.iA = 0.f; s.iC = 0.f;
+  if (!(op >= 1.0f / 512.0f)) { s.mode = (op < 1.0f / 512.0f) ? 0 : 1; return s; }  // NaN -> keep
+  const float det = A * C - B * B;
+  const float inv = 1.f / det;
+  const float ex2 = 2.f * s.tau * C * inv, ey2 = 2.f * s.tau * A * inv;  // squared half extents
+  const float mag = (fabsf(A) + fabsf(B) + fabsf(C)) * (ex2 + ey2);       // bound on the terms of `power` in the box
+  const bool safe = (det > 0.f) && (ex2 >= 0.f) && (ey2 >= 0.f) && (mag * 1.0e-6f < 0.005f * s.tau) && (mag < 1.0e30f);
+  if (!safe) { s.mode = 1; return s; }
+  s.ex = sqrtf(ex2) + 0.01f; s.ey = sqrtf(ey2) + 0.01f;
+  s.iA = 1.f / A; s.iC = 1.f / C;
+  s.mode = 2;
+  return s;
+}
+LR_DEV bool lr_support_box(const LrSupport& s, float x0, float x1, float y0, float y1) {
+  if (s.mode != 2) return s.mode != 0;
+  if (!((s.mx + s.ex >= x0) && (s.mx - s.ex <= x1) && (s.my + s.ey >= y0) && (s.my - s.ey <= y1))) return false;
+  const float dx0 = (x0 - 0.01f) - s.mx, dx1 = (x1 + 0.01f) - s.mx;
+  const float dy0 = (y0 - 0.01f) - s.my, dy1 = (y1 + 0.01f) - s.my;
+  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
+  float best = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {  // the minimum of the quadratic over the box lies on one of its four edges
+    const float dx = e ? dx1 : dx0;
+    const float dy = fminf(dy1, fmaxf(dy0, -s.B * dx * s.iC));
+    best = fminf(best, 0.5f * (s.A * dx * dx + s.C * dy * dy) + s.B * dx * dy);
+    const float ey_ = e ? dy1 : dy0;
+    const float ex_ = fminf(dx1, fmaxf(dx0, -s.B * ey_ * s.iA));
+    best = fminf(best, 0.5f * (s.A * ex_ * ex_ + s.C * ey_ * ey_) + s.B * ex_ * ey_);
+  }
+  return !(best > s.tau);
+}
+LR_DEV bool lr_support_tile(const LrSupport& s, int tx, int ty) {
+  const float x0 = (float)(tx * LR_TILE), y0 = (float)(ty * LR_TILE);
+  return lr_support_box(s, x0, x0 + (float)(LR_TILE - 1), y0, y0 + (float)(LR_TILE - 1));
 }
 
 // ---- wave64 helpers ------------------------------------------------------------------------------

@@ -53,11 +53,19 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
 // (q2 is written for every Gaussian, zero = culled/empty rect).  Counting and slot assignment are one
 // returning atomic per instance, so the bucket fill needs no atomics for these Gaussians; larger rects are
 // only counted here (non-returning atomic) and placed by the fill kernel.
+// Support cull (tile_cull): a tile of the rect becomes an instance only if the Gaussian can reach alpha >= 1/255
+// somewhere inside it (lr_support_tile, conservative).  The rect is the bounding square of the 3-sigma circle of
+// the LARGER eigenvalue, so for elongated splats a good part of its tiles can never contribute; dropping them
+// changes no output (they fail the alpha floor at every pixel) but shortens every list that is counted, filled,
+// sorted and walked.  radii[] keeps the reference meaning (rect non-empty).
 __global__ void __launch_bounds__(256)
 lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
                   const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
-                  uint32_t* __restrict__ ranked, uint32_t* __restrict__ big) {
+                  uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
+                  int tile_cull) {
+  uint32_t rect_instances = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u;
   // Grid-stride: the kernel is bound by memory-side atomic throughput, which a few hundred waves in flight
   // already saturate; a small resident grid leaves the remaining wave slots to whatever runs on other streams.
   for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
@@ -104,20 +112,25 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
             geom[LR_REC_QUADS * (size_t)i + 0] = g0;
             geom[LR_REC_QUADS * (size_t)i + 1] = g1;
             const int w = x1 - x0, nt = w * (y1 - y0);
+            rect_instances += (uint32_t)nt;
+            const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, g1.y);
             if (nt <= LR_RANKED_TILES) {
               uint32_t slot[LR_RANKED_TILES] = {0u, 0u, 0u, 0u};
 #pragma unroll
               for (int k = 0; k < LR_RANKED_TILES; k++) {
                 if (k < nt) {
                   const int ty = k / w, tx = k - ty * w;
-                  slot[k] = atomicAdd(&ranked[((y0 + ty) * v.gx + (x0 + tx)) * LR_CTR_STRIDE], 1u);
+                  slot[k] = (!tile_cull || lr_support_tile(sup, x0 + tx, y0 + ty))
+                                ? atomicAdd(&ranked[((y0 + ty) * v.gx + (x0 + tx)) * LR_CTR_STRIDE], 1u)
+                                : 0xffffffffu;
                 }
               }
               geom[LR_REC_QUADS * (size_t)i + 3] = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]),
                                                           __uint_as_float(slot[2]), __uint_as_float(slot[3])};
             } else {
               for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) atomicAdd(&big[(y * v.gx + x) * LR_CTR_STRIDE], 1u);
+                for (int x = x0; x < x1; x++)
+                  if (!tile_cull || lr_support_tile(sup, x, y)) atomicAdd(&big[(y * v.gx + x) * LR_CTR_STRIDE], 1u);
             }
           }
         }
@@ -127,18 +140,21 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
   geom[LR_REC_QUADS * (size_t)i + 2] = g2;
   radii[i] = rad;
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) rect_instances += (uint32_t)__shfl_xor((int)rect_instances, d);
+  if ((threadIdx.x & 63) == 0 && rect_instances) atomicAdd(&hdr[LR_HDR_RECT], rect_instances);
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
-                       uint32_t* big, hipStream_t s) {
+                       uint32_t* big, uint32_t* hdr, int tile_cull, hipStream_t s) {
   if (N <= 0) return;
   static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 512);  // 2 workgroups per CU: measured optimum
   int blocks = (N + 255) / 256;
   if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   lr_prof_begin(LRK_PROJECT, s);
   hipLaunchKernelGGL(lr_project_kernel, dim3(blocks), dim3(256), 0, s, v, N, means, scales, rots, opac,
-                     colors, radii, reinterpret_cast<float4*>(geom), ranked, big);
+                     colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr, tile_cull);
   lr_prof_end(LRK_PROJECT, s);
 }
 
@@ -263,6 +279,7 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity) {
+  const bool tile_cull = state[LR_HDR_CULL] != 0u;
   uint32_t total = state[LR_HDR_NUM];
   if (total > capacity) {
     if (blockIdx.x == 0 && threadIdx.x == 0) state[LR_HDR_OVERFLOW] = 1u;
@@ -290,17 +307,26 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
                                             __float_as_uint(g3.w)};
 #pragma unroll
     for (int k = 0; k < LR_RANKED_TILES; k++) {
-      if (k < nt) {
+      if (k < nt && slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in lr_project_kernel
         const int ty = k / w, tx = k - ty * w;
         keys[offsets[(y0 + ty) * gx + (x0 + tx)] + slot[k]] = key;
       }
     }
-  } else if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES) {
+  }
+  // Larger rects were only counted; repeat the projection kernel's support test (same record, same code) so the
+  // same tiles are filled.
+  LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};  // mode 1: every tile of the rect
+  if (nt > LR_RANKED_TILES && tile_cull) {
+    const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
+    sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
+  }
+  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES) {
     for (int y = y0; y < y1; y++)
-      for (int x = x0; x < x1; x++) {
-        uint32_t pos = atomicAdd(&cursor[(y * gx + x) * LR_CTR_STRIDE], 1u);
-        keys[pos] = key;
-      }
+      for (int x = x0; x < x1; x++)
+        if (lr_support_tile(sup, x, y)) {
+          uint32_t pos = atomicAdd(&cursor[(y * gx + x) * LR_CTR_STRIDE], 1u);
+          keys[pos] = key;
+        }
   }
   uint64_t bigm = __ballot(nt > LR_COOP_TILES);
   while (bigm) {
@@ -311,10 +337,18 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     uint32_t klo = (uint32_t)lr_readlane_i((int)(uint32_t)key, src);
     uint32_t khi = (uint32_t)lr_readlane_i((int)(uint32_t)(key >> 32), src);
     uint64_t bkey = ((uint64_t)khi << 32) | klo;
+    LrSupport bs;
+    bs.mx = lr_readlane_f(sup.mx, src); bs.my = lr_readlane_f(sup.my, src);
+    bs.A = lr_readlane_f(sup.A, src); bs.B = lr_readlane_f(sup.B, src); bs.C = lr_readlane_f(sup.C, src);
+    bs.tau = lr_readlane_f(sup.tau, src); bs.ex = lr_readlane_f(sup.ex, src); bs.ey = lr_readlane_f(sup.ey, src);
+    bs.iA = lr_readlane_f(sup.iA, src); bs.iC = lr_readlane_f(sup.iC, src);
+    bs.mode = lr_readlane_i(sup.mode, src);
     for (int t = lane; t < bn; t += 64) {
       int ty = t / bw, tx = t - ty * bw;
-      uint32_t pos = atomicAdd(&cursor[((by0 + ty) * gx + (bx0 + tx)) * LR_CTR_STRIDE], 1u);
-      keys[pos] = bkey;
+      if (lr_support_tile(bs, bx0 + tx, by0 + ty)) {
+        uint32_t pos = atomicAdd(&cursor[((by0 + ty) * gx + (bx0 + tx)) * LR_CTR_STRIDE], 1u);
+        keys[pos] = bkey;
+      }
     }
   }
 }

@@ -73,18 +73,26 @@ def set_instance_capacity(n, max_tile_len=0):
 
 def last_overflow():
     """(num_instances, overflowed) of the most recent forward on this process (synchronises)."""
-    n, o, _ = last_state_info()
+    n, o = last_state_info()[:2]
     return n, o
 
 
+def set_tile_cull(enabled):
+    """Support cull in the binning stage (default on): tiles of a Gaussian's rect in which it cannot reach
+    alpha >= 1/255 are not binned.  Result-preserving; off = the reference's exact rect lists.  Returns the
+    previous setting."""
+    return bool(_lib.lib().lograst_set_tile_cull(1 if enabled else 0))
+
+
 def last_state_info():
-    """(num_instances, overflowed, longest_tile_list) of the most recent forward (synchronises)."""
+    """(num_instances, overflowed, longest_tile_list, rect_instances) of the most recent forward (synchronises).
+    rect_instances = instances of the reference's plain rect rule (>= num_instances when the support cull is on)."""
     if _last_state is None:
-        return 0, False, 0
-    n, o, m = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+        return 0, False, 0, 0
+    n, o, m, r = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
     _lib.check(_lib.lib().lograst_read_state(_last_state.data_ptr(), ctypes.byref(n), ctypes.byref(o),
-                                             ctypes.byref(m), _stream_ptr(_last_state.device)))
-    return int(n.value), bool(o.value), int(m.value)
+                                             ctypes.byref(m), ctypes.byref(r), _stream_ptr(_last_state.device)))
+    return int(n.value), bool(o.value), int(m.value), int(r.value)
 
 
 def _stream_ptr(device):

@@ -120,6 +120,14 @@ def forward(view, means, scales, rots, opac, colors, extras=True):
                 inputs=(means, scales, rots, opac, colors))
 
 
+def instance_support(view, fwd):
+    """uint8[I]: 1 where the tile instance can pass the alpha floor at some pixel of its tile (see the C header)."""
+    flags = np.zeros(max(fwd["I"], 1), np.uint8)
+    lib().ora_instance_support(ctypes.byref(view), _p(fwd["rec"]), _p(fwd["tile_offsets"]), _p(fwd["point_list"]),
+                               _p(flags))
+    return flags[:fwd["I"]]
+
+
 def backward(view, fwd, dL_dimage):
     """Full backward for a forward() result.  Returns grads dict."""
     means, scales, rots, opac, colors = fwd["inputs"]

@@ -66,7 +66,56 @@ def oracle_forward(oracle, cam, sc, bg, flavour=R.WODILATE, use_filter=True, sca
                          ndc_cull=flavour.ndc_cull)
     f = oracle.forward(v, sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["colors"],
                        extras=bool(flavour.extras))
+    f["_view"] = v
     return v, f
+
+
+def _pairs(offsets, plist):
+    """(tile << 32 | id) per list entry, in list order."""
+    lens = np.diff(offsets.astype(np.int64))
+    tile = np.repeat(np.arange(len(lens), dtype=np.uint64), lens)
+    return (tile << np.uint64(32)) | plist.astype(np.uint64)
+
+
+def _compare_culled_lists(hf, of):
+    """Support cull on (log_amd/csrc/project.hip): every HIP tile list must be the oracle's list of that tile
+    minus entries that cannot pass the alpha floor anywhere in the tile (oracle.instance_support), in the same
+    order; n_contrib then counts positions in the shorter list, so it is compared through the identity of the
+    last contributor.  Same keys as the exact comparison, counting violations."""
+    from oracle import oracle
+    st = {}
+    ph, po = _pairs(hf["tile_offsets"], hf["point_list"]), _pairs(of["tile_offsets"], of["point_list"])
+    # the oracle's pairs are unique and, per tile, in list order; position of every HIP pair in the oracle list
+    srt = np.argsort(po, kind="stable")
+    idx = np.searchsorted(po[srt], ph)
+    idx = np.minimum(idx, len(po) - 1) if len(po) else idx
+    found = (po[srt][idx] == ph) if len(po) else np.zeros(len(ph), bool)
+    pos = srt[idx] if len(po) else idx                       # index into the oracle's point_list
+    not_subset = int((~found).sum())
+    # order: within a tile, oracle positions must be strictly increasing (pairs carry the tile in the high bits, and
+    # oracle positions grow with the tile, so one global check covers tile boundaries too)
+    disorder = int((np.diff(pos.astype(np.int64)) <= 0).sum()) if len(pos) > 1 else 0
+    kept = np.zeros(len(po), bool)
+    kept[pos[found]] = True
+    support = oracle.instance_support(of["_view"], of).astype(bool)
+    wrongly_dropped = int((support & ~kept).sum())
+    st["culled_instances"] = int((~kept).sum())
+    st["offsets_mismatch"] = not_subset + (0 if hf["tile_offsets"][-1] == len(hf["point_list"]) else 1)
+    st["list_mismatch"] = not_subset + disorder + wrongly_dropped
+    # last contributor per pixel: same Gaussian (or none) on both sides
+    H, W = of["n_contrib"].shape
+    gx = (W + 15) // 16
+    ys, xs = np.mgrid[0:H, 0:W]
+    tile = (ys // 16) * gx + xs // 16
+
+    def last_id(f):
+        n = f["n_contrib"].astype(np.int64)
+        at = f["tile_offsets"].astype(np.int64)[tile] + n - 1
+        return np.where(n > 0, f["point_list"][np.clip(at, 0, max(len(f["point_list"]) - 1, 0))].astype(np.int64), -1)
+
+    st["n_contrib_mismatch"] = int((last_id(hf) != last_id(of)).sum()) if len(of["point_list"]) and len(hf["point_list"]) \
+        else int(((hf["n_contrib"] > 0) != (of["n_contrib"] > 0)).sum())
+    return st
 
 
 def compare_forward(hf, of):
@@ -78,10 +127,14 @@ def compare_forward(hf, of):
     rec_h, rec_o = hf["rec"][: len(vis)][vis], of["rec"][vis]
     st["rec_bits_mismatch"] = int((rec_h.view(np.uint32) != rec_o.view(np.uint32)).sum()) if vis.any() else 0
     st["rec_max_abs"] = float(np.abs(rec_h[:, :10] - rec_o[:, :10]).max()) if vis.any() else 0.0
-    st["offsets_mismatch"] = int((hf["tile_offsets"] != of["tile_offsets"]).sum())
-    same_len = len(hf["point_list"]) == len(of["point_list"])
-    st["list_mismatch"] = int((hf["point_list"] != of["point_list"]).sum()) if same_len else -1
-    st["n_contrib_mismatch"] = int((hf["n_contrib"] != of["n_contrib"]).sum())
+    if hf["I"] == of["I"]:
+        # same instance count: the lists must be the oracle's lists, entry for entry
+        st["offsets_mismatch"] = int((hf["tile_offsets"] != of["tile_offsets"]).sum())
+        st["list_mismatch"] = int((hf["point_list"] != of["point_list"]).sum())
+        st["n_contrib_mismatch"] = int((hf["n_contrib"] != of["n_contrib"]).sum())
+        st["culled_instances"] = 0
+    else:
+        st.update(_compare_culled_lists(hf, of))
     for k in ("image", "final_T"):
         st[k + "_bits_mismatch"] = int((hf[k].view(np.uint32) != of[k].view(np.uint32)).sum())
         st[k + "_max_abs"] = float(np.abs(hf[k] - of[k]).max())

@@ -63,6 +63,44 @@ def test_forward_bit_exact(oracle_mod, name, flavour_name):
         assert st["pid_mismatch"] == 0 and st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0, st
 
 
+@pytest.mark.parametrize("name", ["ragged", "c1", "big_splats", "huge_tiles"])
+def test_exact_reference_lists_without_tile_cull(oracle_mod, name):
+    """With the binning-stage support cull off, the tile lists ARE the reference's rect lists: offsets, order and
+    n_contrib identical to the oracle's.  With it on (default) they are a result-preserving subset -- checked by
+    compare_forward in every other test -- and something is actually culled."""
+    from log_amd import rasterizer as R
+    import gpu_util as G
+    cam, sc = _case(name)
+    bg = (0.3, 0.6, 0.9)
+    _, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    prev = R.set_tile_cull(False)
+    try:
+        hf = G.hip_forward(cam, sc, bg)
+        n_inst, _, _, n_rect = R.last_state_info()
+    finally:
+        R.set_tile_cull(prev)
+    st = G.compare_forward(hf, of)
+    assert hf["I"] == of["I"] == n_inst == n_rect
+    for k in ("offsets_mismatch", "list_mismatch", "n_contrib_mismatch", "image_bits_mismatch", "pid_mismatch"):
+        assert st[k] == 0, (k, st)
+    hf2 = G.hip_forward(cam, sc, bg)
+    n_inst, _, _, n_rect = R.last_state_info()
+    assert n_rect == of["I"] and n_inst == hf2["I"] <= n_rect
+    if name in ("c1", "big_splats"):
+        assert hf2["I"] < of["I"]          # elongated splats: part of the rect can never reach the alpha floor
+    assert (hf2["image"].view(np.uint32) == hf["image"].view(np.uint32)).all()
+    # gradients are the same sums with the never-contributing entries left out
+    dL = np.random.default_rng(0).standard_normal(hf["image"].shape).astype(np.float32)
+    g_on = G.hip_backward(hf2, dL)
+    prev = R.set_tile_cull(False)
+    try:
+        g_off = G.hip_backward(hf, dL)
+    finally:
+        R.set_tile_cull(prev)
+    for k in ("conic", "means2D", "colors", "opacities"):
+        assert rel_l2(g_on[k], g_off[k]) < 1e-5, k
+
+
 def _ill_conditioned_rows(oracle_mod, v, of, og):
     """Rows whose A6b chain rule amplifies a 1e-6 relative perturbation of dL/dconic by more than 1000x in
     fp32 (pancake-flat Gaussians: one scale ~1e-4 of the others).  Their scale/rotation gradients are

@@ -77,7 +77,9 @@ def test_properties_at_scale(n, W, H):
     rs, flavour, use_filter, m, s, r, saved = hf["_torch"]
     ok, I = _tile_sorted_ok(saved, W, H, dev)
     assert ok and I > n                                # every tile list sorted by (depth, id)
-    assert _rects_total(saved) == I                    # instance conservation: sum of rect areas == list total
+    n_inst, over, _, n_rect = R.last_state_info()
+    assert n_inst == I and not over
+    assert _rects_total(saved) == n_rect >= I          # instance conservation: sum of rect areas == the rect-rule count
     assert int((saved["radii"] > 0).sum()) > 0.9 * n
     img = hf["image"]
     assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0 + 1e-5
@@ -96,6 +98,17 @@ def test_properties_at_scale(n, W, H):
     assert (hf2["image"].view(np.uint32) == img.view(np.uint32)).all()
     assert (hf2["point_list"] == hf["point_list"]).all()
     del hf2
+    # the binning-stage support cull changes no output: without it every rect tile is an instance, same image bits
+    prev = R.set_tile_cull(False)
+    try:
+        hf3 = G.hip_forward(cam, sc, (0.5, 0.5, 0.5))
+    finally:
+        R.set_tile_cull(prev)
+    assert hf3["I"] == n_rect
+    assert (hf3["image"].view(np.uint32) == img.view(np.uint32)).all()
+    assert (hf3["point_id_pixel"] == hf["point_id_pixel"]).all()
+    assert (hf3["point_weight"].view(np.uint32) == hf["point_weight"].view(np.uint32)).all()
+    del hf3
     # backward: zero in -> zero out; homogeneous of degree 1 in dL
     dL = np.random.default_rng(2).random(img.shape, dtype=np.float32)
     g1 = G.hip_backward(hf, dL)

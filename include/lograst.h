@@ -99,11 +99,16 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
  * as `capacity`): lists longer than 8192 keys take a multi-pass sort whose number of launches depends on it.  An
  * under-estimate leaves such lists partially sorted, so pass 0 when in doubt.
  * Outputs: image[3,H,W], final_T[H,W], n_contrib[H,W] (both kept for backward), and when
- * view->extras: point_id_pixel[H,W] (i32, -1 = none), point_weight_pixel[H,W], point_weight[n]. */
+ * view->extras: point_id_pixel[H,W] (i32, -1 = none), point_weight_pixel[H,W], point_weight[n].
+ * bwd_scratch (optional, NULL/0 = none): a block of bwd_scratch_floats * n fp32 that this call zero-fills (inside
+ * a kernel it launches anyway) for a caller that will run lograst_backward on this view: carve dL_dmeans2d[n,3],
+ * dL_dconic[n,4] (7 floats per Gaussian) and, without LOGRAST_BWD_ACCUMULATE, dL_dopacities[n], dL_dcolors[n,3]
+ * (11) out of it and pass LOGRAST_BWD_SCRATCH_ZEROED -- no separate memset launches. */
 int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
                            uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
                            float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
-                           float* point_weight_pixel, float* point_weight, void* stream);
+                           float* point_weight_pixel, float* point_weight, float* bwd_scratch,
+                           int32_t bwd_scratch_floats, void* stream);
 
 /* Copies {num_instances, overflow_flag, longest tile list, rect instances} of a tile_state to host (synchronises
  * the stream; any pointer may be NULL).  rect_instances = what the plain rect rule of the reference would have

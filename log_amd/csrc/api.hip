@@ -22,7 +22,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        uint32_t* big, uint32_t* hdr, int tile_cull, hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
-                    uint32_t capacity, hipStream_t s);
+                    uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s);
 void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
@@ -188,8 +188,7 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
   // zero header and counters (offsets/cursors are fully rewritten by the scan)
-  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * LR_HDR_WORDS, s));
-  LR_HIP(hipMemsetAsync(st + lr_ranked_off(tiles), 0, sizeof(uint32_t) * 2 * (size_t)tiles * LR_CTR_STRIDE, s));
+  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)lr_offsets_off(tiles), s));  // header + ranked + big
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
                     st + lr_big_off(tiles), st, lr_tile_cull(), s);
   lr_launch_scan(st, tiles, s);
@@ -207,7 +206,8 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
 int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
                            uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
                            float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
-                           float* point_weight_pixel, float* point_weight, void* stream) {
+                           float* point_weight_pixel, float* point_weight, float* bwd_scratch,
+                           int32_t bwd_scratch_floats, void* stream) {
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
@@ -219,8 +219,11 @@ int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
-  if (v.extras && n > 0) LR_HIP(hipMemsetAsync(point_weight, 0, sizeof(float) * (size_t)n, s));
-  lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, s);
+  if (bwd_scratch_floats < 0 || bwd_scratch_floats > 16 || (bwd_scratch_floats > 0 && n > 0 && !bwd_scratch))
+    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch: 0..16 floats per Gaussian and a non-NULL block");
+  // point_weight (atomicMax target) and the optional backward scratch are cleared by the fill kernel
+  lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, v.extras ? point_weight : nullptr,
+                 bwd_scratch_floats > 0 ? bwd_scratch : nullptr, bwd_scratch_floats, s);
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
                       point_weight_pixel, point_weight, s);

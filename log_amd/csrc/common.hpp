@@ -17,13 +17,14 @@
 // [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_SORT_BLOCK
 // [4] tile instances of the plain rect rule (before the support cull; reporting only)
 // [5] support cull applied by the projection kernel (0/1)  [6..15] reserved
-// [16 .. 16+Tp)          exclusive offsets (T+1 entries)                              -- read by sort/blend
-// then three per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic
-// targets spread over the memory channels instead of 8160 counters sharing 32 KB):
+// then per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic targets
+// spread over the memory channels instead of 8160 counters sharing 32 KB); header, ranked and big are
+// contiguous so that ONE memset prepares a forward:
 //   ranked[T*S]   instances of Gaussians touching <= LR_RANKED_TILES tiles; the returning atomic that counts
 //                 them also hands each instance its slot inside the tile (stored in the record's q3;
 //                 0xffffffff = this tile of the rect was dropped by the support cull)
 //   big[T*S]      instances of larger Gaussians (counted only)
+// then offsets[Tp]: exclusive offsets (T+1 entries)                                   -- read by sort/blend
 //   cursor[T*S]   fill cursor for the big instances, initialised to offset + ranked
 // then order[T]: tile ids by descending list length (longest-first dispatch order for the blend kernels)
 // then biglist[T]: ids of the tiles whose list exceeds LR_SORT_BLOCK keys (multi-block sort path)
@@ -41,10 +42,11 @@
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_REC_QUADS 4  // float4 per projected record (64 B)
 __host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
-__host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { (void)tiles; return LR_HDR_WORDS; }
-__host__ __device__ inline uint32_t lr_ranked_off(uint32_t tiles) { return LR_HDR_WORDS + lr_tpad(tiles); }
+// header | ranked | big are contiguous: one memset clears everything a forward needs zeroed
+__host__ __device__ inline uint32_t lr_ranked_off(uint32_t tiles) { (void)tiles; return LR_HDR_WORDS; }
 __host__ __device__ inline uint32_t lr_big_off(uint32_t tiles) { return lr_ranked_off(tiles) + tiles * LR_CTR_STRIDE; }
-__host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_big_off(tiles) + tiles * LR_CTR_STRIDE; }
+__host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { return lr_big_off(tiles) + tiles * LR_CTR_STRIDE; }
+__host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_offsets_off(tiles) + lr_tpad(tiles); }
 __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
 __host__ __device__ inline uint32_t lr_biglist_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
 __host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return lr_biglist_off(tiles) + lr_tpad(tiles); }

@@ -271,6 +271,7 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
 
 // ---- A3: per-tile bucket fill ---------------------------------------------------------------------------
 // key = (fp32 bits of view depth) << 32 | Gaussian index; depth > 0.2 so the bit pattern is monotone.
+// (Also clears point_weight[N] and the caller's backward scratch: see the top of the kernel.)
 // Gaussians with <= 4 tiles already own their slots (q3): position = offsets[tile] + slot, no atomics.  Larger
 // rects take positions from the per-tile cursor; up to LR_COOP_TILES tiles a lane expands its own rect,
 // beyond that the whole wave expands it (ballot over the lanes that hold one, record broadcast with
@@ -278,7 +279,17 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
 #define LR_COOP_TILES 16
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
-               uint64_t* __restrict__ keys, uint32_t capacity) {
+               uint64_t* __restrict__ keys, uint32_t capacity, float* __restrict__ zero_n,
+               float* __restrict__ zero_block, int zero_block_floats) {
+  // Per-Gaussian buffers that later kernels accumulate into with atomics (point_weight; the backward scratch)
+  // are cleared here, in a kernel that already has one thread per Gaussian, instead of by separate memsets.
+  {
+    const int zi = blockIdx.x * 256 + threadIdx.x;
+    if (zi < N) {
+      if (zero_n) zero_n[zi] = 0.f;
+      for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + zi] = 0.f;
+    }
+  }
   const bool tile_cull = state[LR_HDR_CULL] != 0u;
   uint32_t total = state[LR_HDR_NUM];
   if (total > capacity) {
@@ -354,10 +365,11 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 }
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
-                    uint32_t capacity, hipStream_t s) {
+                    uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   hipLaunchKernelGGL(lr_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, gx,
-                     reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity);
+                     reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, zero_n, zero_block,
+                     zero_block_floats);
   lr_prof_end(LRK_FILL, s);
 }

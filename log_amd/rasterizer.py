@@ -131,7 +131,9 @@ class HipBackend:
         v.viewmatrix, v.projmatrix, v.bg = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
         return v, keep
 
-    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors):
+    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0):
+        """scratch_floats: 0, or the fp32 words per Gaussian of backward scratch to allocate and have the forward
+        zero-fill (7 with a gradient sink, 11 without): saved as `bwd_scratch` and consumed by the first backward."""
         global _last_state
         device = means3D.device
         L = self.require(device)
@@ -167,12 +169,15 @@ class HipBackend:
                 pw = torch.empty(N, **f32)
             else:
                 pid = pwp = pw = None
+            scratch = torch.empty(N * scratch_floats, **f32) if scratch_floats and N else None
             _lib.check(L.lograst_forward_render(ctypes.byref(view), N, _ptr(geom), _ptr(state), _ptr(keys), _ptr(plist),
                                                 capacity, max_len, _ptr(image), _ptr(final_T), _ptr(n_contrib), _ptr(pid),
-                                                _ptr(pwp), _ptr(pw), stream))
+                                                _ptr(pwp), _ptr(pw), _ptr(scratch),
+                                                scratch_floats if scratch is not None else 0, stream))
         del keys, keep
         _last_state = state
-        saved = dict(radii=radii, geom=geom, state=state, plist=plist, final_T=final_T, n_contrib=n_contrib)
+        saved = dict(radii=radii, geom=geom, state=state, plist=plist, final_T=final_T, n_contrib=n_contrib,
+                     bwd_scratch=scratch)
         return image, radii, pid, pwp, pw, saved
 
     def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None):
@@ -184,15 +189,18 @@ class HipBackend:
         view, keep = self.make_view(rs, flavour, use_filter, device)
         f32 = dict(dtype=torch.float32, device=device)
         grad_image = grad_image.to(torch.float32).contiguous()
+        need = 11 if sink is None else 7
+        # The accumulators the reverse walk adds into come from ONE zeroed block: the one the forward already
+        # cleared for this purpose (first backward of this forward), else a fresh torch.zeros.
+        acc = saved.pop("bwd_scratch", None)
+        if acc is None or acc.numel() < need * N:
+            acc = torch.zeros(N * need, **f32)
         if sink is None:
-            # the four accumulators the reverse walk adds into come from ONE zeroed block (one memset, not four)
-            acc = torch.zeros(N * 11, **f32)
             g_opac = acc[7 * N:8 * N]
-            g_colors = acc[8 * N:].view(N, 3)
+            g_colors = acc[8 * N:11 * N].view(N, 3)
             g_means3D, g_scales, g_rot = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 4, **f32)
             flags = 1
         else:
-            acc = torch.zeros(N * 7, **f32)
             g_opac, g_colors = sink["opacities"], sink["colors"]
             g_means3D, g_scales, g_rot = sink["means3D"], sink["scales"], sink["rotations"]
             flags = 1 | 2
@@ -330,7 +338,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if not (s.shape == (n, 3) and r.shape == (n, 4) and c.shape == (n, 3) and o.shape[0] == n and m.shape == (n, 3)):
             raise ValueError("rasterizer inputs must be means3D[N,3], scales[N,3], rotations[N,4], "
                              "colors_precomp[N,3], opacities[N,1]")
-        image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c)
+        wants_grad = any(ctx.needs_input_grad[:7])   # all False under torch.no_grad()
+        scratch_floats = 0 if not wants_grad else (7 if (_grad_sink is not None and sh is None) else 11)
+        image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c,
+                                                             scratch_floats=scratch_floats)
         ctx.rs, ctx.flavour, ctx.use_filter = rs, flavour, use_filter
         ctx.saved = saved
         ctx.sh = (sh, clamped)

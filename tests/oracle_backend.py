@@ -19,7 +19,7 @@ class OracleBackend:
                                 rs.bg.detach().cpu().numpy(), scale_modifier=float(rs.scale_modifier),
                                 filter_mode=fm, ndc_cull=flavour.ndc_cull)
 
-    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors):
+    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0):
         v = self._view(rs, flavour, use_filter)
         f = oracle.forward(v, means3D.numpy(), scales.numpy(), rotations.numpy(), opacities.numpy(), colors.numpy(),
                            extras=bool(flavour.extras))

@@ -203,6 +203,36 @@ def test_empty_and_all_culled(oracle_mod):
     assert all(np.abs(v).max() == 0 for v in hg.values())
 
 
+def test_backward_scratch_lifecycle():
+    """The forward zero-fills the backward's accumulators when a gradient is wanted; a second backward through the
+    same graph (retain_graph) must not reuse the consumed block, and a no_grad forward allocates none."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    import gpu_util as G
+    cam, sc = _case("ragged")
+    dev = torch.device("cuda:0")
+    rs = G.settings(cam, (0.2, 0.3, 0.4), dev)
+    t = lambda a, g=True: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=g)
+    leaves = dict(means3D=t(sc["xyz"]), colors_precomp=t(sc["colors"]), opacities=t(sc["opacity"]),
+                  scales=t(sc["scaling"]), rotations=t(sc["rotation"]))
+    m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    rast = GaussianRasterizer(raster_settings=rs)
+    w = torch.rand(3, cam["image_height"], cam["image_width"], device=dev)
+    img = rast(means2D=m2, shs=None, cov3D_precomp=None, **leaves)[0]
+    img.backward(gradient=w, retain_graph=True)
+    first = {k: v.grad.clone() for k, v in leaves.items()}
+    first_m2 = m2.grad.clone()
+    for v in leaves.values():
+        v.grad = None
+    m2.grad = None
+    img.backward(gradient=w)
+    for k, v in leaves.items():
+        assert rel_l2(v.grad.cpu().numpy(), first[k].cpu().numpy()) < 1e-5, k
+    assert rel_l2(m2.grad.cpu().numpy(), first_m2.cpu().numpy()) < 1e-5
+    with torch.no_grad():
+        img2 = rast(means2D=m2, shs=None, cov3D_precomp=None, **leaves)[0]
+    assert (img2 == img).all() and not img2.requires_grad
+
+
 def test_module_autograd_contract():
     """The nn.Module / autograd surface LoG drives (renderer.py:135-165,190-198; counter.py:40,46)."""
     from diff_gaussian_rasterization_wodilate import GaussianRasterizer

@@ -432,4 +432,7 @@ def tile_offsets_of(saved, width, height):
     (layout: log_amd/csrc/common.hpp)."""
     gx, gy = (int(width) + 15) // 16, (int(height) + 15) // 16
     tiles = gx * gy
-    return saved["state"][16:16 + tiles + 1]
+    st = saved["state"]
+    L = _lib.lib()
+    first = (L.lograst_tile_offsets(ctypes.c_void_p(st.data_ptr()), int(width), int(height)) - st.data_ptr()) // 4
+    return st[first:first + tiles + 1]

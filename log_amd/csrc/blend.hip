@@ -220,13 +220,14 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
                          int* pid, float* pwp, float* pw, hipStream_t s) {
   static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
+  static const size_t lds_fwd = (size_t)lr_env_int("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_FWD, s);
   if (v.extras)
-    hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
+    hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, reinterpret_cast<const float4*>(geom),
                        state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
   else
-    hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom),
+    hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, reinterpret_cast<const float4*>(geom),
                        state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
   lr_prof_end(LRK_BLEND_FWD, s);
 }
@@ -411,9 +412,10 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          hipStream_t s) {
   static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
+  static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   lr_prof_begin(LRK_BLEND_BWD, s);
-  hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), 0, s, v, reinterpret_cast<const float4*>(geom), state,
+  hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom), state,
                      tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
                      xcd_mode, cull);
   lr_prof_end(LRK_BLEND_BWD, s);

@@ -64,16 +64,27 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
                   const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                   uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
                   int tile_cull) {
+  // Records leave through LDS: a lane's four quads are 64 B apart from its neighbour's, so storing them
+  // directly makes every store instruction touch 64 different lines with 16 B each (partial-line writes that the
+  // L2 can only merge while few waves are in flight).  Staged, each instruction writes 1 KB of contiguous memory.
+  __shared__ float4 stage[256 * LR_REC_QUADS];
+  float4* wstage = stage + (threadIdx.x & ~63) * LR_REC_QUADS;
+  const int lane = threadIdx.x & 63;
   uint32_t rect_instances = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u;
-  // Grid-stride: the kernel is bound by memory-side atomic throughput, which a few hundred waves in flight
-  // already saturate; a small resident grid leaves the remaining wave slots to whatever runs on other streams.
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+  // Grid-stride: the kernel is bound by memory-side atomic throughput (measured: ~60 us without its atomics,
+  // ~180 us with them = 24 G atomics/s, the rate a bare atomic microbenchmark reaches on random tile counters),
+  // which a few hundred waves in flight already saturate; a small resident grid leaves the remaining wave slots
+  // to whatever runs on other streams.
+  for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < N; i0 += gridDim.x * 256) {  // i0: the wave's first Gaussian
+  const int i = i0 + lane;
   const float* __restrict__ V = v.view;
   const float* __restrict__ Pm = v.proj;
-  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
   int rad = 0;
+  float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g3 = g0;
   float4 g2 = {0.f, 0.f, 0.f, 0.f};  // culled: empty rect (the fill kernel reads only q2)
+  if (i < N) {
+  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
   float tz = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
   if (tz > 0.2f) {
     float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
@@ -105,12 +116,10 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
           y0 = min(v.gy, max(0, y0)); y1 = min(v.gy, max(0, y1));
           if ((x1 - x0) * (y1 - y0) > 0) {
             rad = (int)rf;
-            float4 g0 = {mx, my, cA, cB};
-            float4 g1 = {cC, opac[i], colors[3 * i], colors[3 * i + 1]};
+            g0 = float4{mx, my, cA, cB};
+            g1 = float4{cC, opac[i], colors[3 * i], colors[3 * i + 1]};
             g2 = float4{colors[3 * i + 2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
                         __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
-            geom[LR_REC_QUADS * (size_t)i + 0] = g0;
-            geom[LR_REC_QUADS * (size_t)i + 1] = g1;
             const int w = x1 - x0, nt = w * (y1 - y0);
             rect_instances += (uint32_t)nt;
             const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, g1.y);
@@ -125,8 +134,8 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
                                 : 0xffffffffu;
                 }
               }
-              geom[LR_REC_QUADS * (size_t)i + 3] = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]),
-                                                          __uint_as_float(slot[2]), __uint_as_float(slot[3])};
+              g3 = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]),
+                          __uint_as_float(slot[3])};
             } else {
               for (int y = y0; y < y1; y++)
                 for (int x = x0; x < x1; x++)
@@ -137,12 +146,35 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
       }
     }
   }
-  geom[LR_REC_QUADS * (size_t)i + 2] = g2;
   radii[i] = rad;
+  }  // i < N
+  wstage[lane * LR_REC_QUADS + 0] = g0;
+  wstage[lane * LR_REC_QUADS + 1] = g1;
+  wstage[lane * LR_REC_QUADS + 2] = g2;
+  wstage[lane * LR_REC_QUADS + 3] = g3;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int nq = min(64, N - i0) * LR_REC_QUADS;  // quads this wave owns
+#pragma unroll
+  for (int k = 0; k < LR_REC_QUADS; k++) {
+    const int qd = k * 64 + lane;
+    if (qd < nq) geom[LR_REC_QUADS * (size_t)i0 + qd] = wstage[qd];
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  }
+  // rect-rule instance count (reporting only): one atomic per WORKGROUP -- 15 K same-address atomics, one per
+  // wave, cost the full-grid launch 40 us
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) rect_instances += (uint32_t)__shfl_xor((int)rect_instances, d);
-  if ((threadIdx.x & 63) == 0 && rect_instances) atomicAdd(&hdr[LR_HDR_RECT], rect_instances);
+  __shared__ uint32_t rect_part[4];
+  if (lane == 0) rect_part[threadIdx.x >> 6] = rect_instances;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t r = rect_part[0] + rect_part[1] + rect_part[2] + rect_part[3];
+    if (r) atomicAdd(&hdr[LR_HDR_RECT], r);
+  }
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,

@@ -6,9 +6,10 @@
 //   * per 64 list entries a wave gathers 64 projected records into VGPRs (ids read coalesced from the
 //     sorted list; the four waves of a tile hit the same lines in their CU's L1), computes for each a
 //     conservative alpha-support box, and ballots which entries can touch ITS quadrant at all;
-//   * only those entries are visited (s_ff1 over the ballot mask), each broadcast with v_readlane: the current
-//     Gaussian lives in SGPRs -- no LDS traffic, no barrier, no VGPRs -- so culling a (Gaussian, quadrant)
-//     pair costs nothing, and every wave stops exactly when its own 64 pixels are saturated.
+//   * only those entries are visited (s_ff1 over the ballot mask): one v_readlane fetches the entry's id and its
+//     record then comes through the SCALAR cache (uniform address -> s_load_dwordx8), so the current Gaussian
+//     lives in SGPRs -- no VALU broadcast, no LDS traffic, no barrier, no VGPRs -- culling a (Gaussian,
+//     quadrant) pair costs nothing, and every wave stops exactly when its own 64 pixels are saturated.
 // The support box only skips pixels whose alpha is provably below the 1/255 floor (1% margin on the
 // exponent, disabled for ill-conditioned conics), so results are identical to visiting every entry; the
 // oracle does not cull and the bit-exact parity tests check exactly that.
@@ -59,7 +60,7 @@ static inline __host__ __device__ uint32_t lr_blend_grid(uint32_t tiles, int gx,
 // tau' = 1.01 tau + 0.01 absorbs the fp32 evaluation error of `power`; if that error could exceed the
 // margin (ill-conditioned conic, non-finite values) the answer is "yes" (never cull).  Two stages: the cheap
 // box-vs-box test, then the exact ellipse-vs-box test (the box of an elongated, tilted ellipse is mostly empty).
-LR_DEV bool lr_support_hits(const float4 g0, const float4 g1, float x0, float x1, float y0, float y1) {
+LR_DEV bool lr_support_hits(const float4 g0, const float2 g1, float x0, float x1, float y0, float y1) {
   const float A = g0.z, B = g0.w, C = g1.x, op = g1.y;
   const float det = A * C - B * B;
   const float tau = lr_fma(__logf(255.f * op), 1.01f, 0.01f);
@@ -117,27 +118,25 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   // Software pipeline over 64-entry chunks: ids are fetched two chunks ahead and records one chunk ahead, so
   // the dependent id -> record gather of chunk c+1 is in flight while chunk c is composited.
   const uint32_t nchunks = (end - beg + 63u) >> 6;
-  const float* geomf = reinterpret_cast<const float*>(geom);
   auto load_id = [&](uint32_t c) -> uint32_t {
     const uint32_t idx = beg + c * 64u + (uint32_t)lane;
     return (c < nchunks && idx < end) ? plist[idx] : 0xffffffffu;
   };
   uint32_t id_n = load_id(0), id_nn = load_id(1);
-  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
-  float cb_n = 0.f;
-  if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
+  float4 g0_n = {0.f, 0.f, 0.f, 0.f};
+  float2 g1_n = {0.f, 0.f};  // (conic C, opacity): all the support test needs of q1
+  if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     if (__all(done)) break;
     const uint32_t id = id_n;
-    const float4 g0 = g0_n, g1 = g1_n;
-    const float cb = cb_n;
+    const float4 g0 = g0_n;
+    const float2 g1 = g1_n;
     id_n = id_nn;
     id_nn = load_id(ch + 2);
-    if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
+    if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
     const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
-    const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
     const int pos0 = (int)(ch * 64u);
     // Two list entries per iteration, branch-free: the two alpha evaluations (power + exp polynomial, ~20 VALU
     // each) are independent, so one wave can issue them back to back instead of waiting out each dependent
@@ -149,14 +148,20 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       const bool has1 = todo != 0;
       const int j1 = has1 ? __builtin_ctzll(todo) : j0;
       todo &= todo - 1;  // no-op when todo == 0
-      const float mx0 = lr_readlane_f(g0.x, j0), my0 = lr_readlane_f(g0.y, j0);
-      const float a0 = lr_readlane_f(hA, j0), b0 = lr_readlane_f(nB, j0), c0 = lr_readlane_f(hC, j0);
-      const float op0 = lr_readlane_f(g1.y, j0);
-      const float mx1 = lr_readlane_f(g0.x, j1), my1 = lr_readlane_f(g0.y, j1);
-      const float a1 = lr_readlane_f(hA, j1), b1 = lr_readlane_f(nB, j1), c1 = lr_readlane_f(hC, j1);
-      const float op1 = lr_readlane_f(g1.y, j1);
-      const lr_f2 pw2 = lr_power2(lr_f2{a0, a1}, lr_f2{b0, b1}, lr_f2{c0, c1}, lr_f2{mx0, mx1} - pxf,
-                                  lr_f2{my0, my1} - pyf);
+      // The two entries' records come straight from memory through the scalar cache (uniform address -> s_load):
+      // no VALU broadcast at all.  -0.5 and the sign of B move to the pixel side, where they are exact scalings:
+      // fma(A*dx, -0.5*dx, .) rounds the same real number as fma((-0.5*A)*dx, dx, .).
+      const int gid0 = lr_readlane_i((int)id, j0), gid1 = lr_readlane_i((int)id, j1);
+      const float4* __restrict__ r0 = geom + LR_REC_QUADS * (size_t)(uint32_t)gid0;
+      const float4* __restrict__ r1 = geom + LR_REC_QUADS * (size_t)(uint32_t)gid1;
+      const float4 q00 = r0[0], q01 = r0[1], q10 = r1[0], q11 = r1[1];
+      const float cbl0 = reinterpret_cast<const float*>(r0)[8], cbl1 = reinterpret_cast<const float*>(r1)[8];
+      const float op0 = q01.y, op1 = q11.y;
+      const lr_f2 dx2 = lr_f2{q00.x, q10.x} - pxf, dy2 = lr_f2{q00.y, q10.y} - pyf;
+      const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
+      const lr_f2 bdx = lr_f2{q00.w, q10.w} * dx2;
+      const lr_f2 pw2 = lr_fma2(lr_f2{q00.z, q10.z} * dx2, hdx2,
+                                lr_fma2(lr_f2{q01.x, q11.x} * dy2, hdy2, lr_f2{-bdx.x, -bdx.y} * dy2));
       const lr_f2 al2 = lr_f2{op0, op1} * lr_exp2(pw2);
       const float power0 = pw2.x, power1 = pw2.y;
       const float alpha0 = fminf(0.99f, al2.x), alpha1 = fminf(0.99f, al2.y);
@@ -180,8 +185,8 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       done = done | stop1;
       const bool hit0 = __builtin_amdgcn_ballot_w64(acc0) != 0, hit1 = __builtin_amdgcn_ballot_w64(acc1) != 0;
       if (hit0) {
-        const float cr = lr_readlane_f(g1.z, j0), cg = lr_readlane_f(g1.w, j0), cbl = lr_readlane_f(cb, j0);
-        const int gid = lr_readlane_i((int)id, j0);
+        const float cr = q01.z, cg = q01.w, cbl = cbl0;
+        const int gid = gid0;
         if (acc0) { C0 = lr_fma(cr, w0, C0); C1 = lr_fma(cg, w0, C1); C2 = lr_fma(cbl, w0, C2); }
         if (EXTRAS) {
           if (w0 > wmax) { wmax = w0; wid = gid; }
@@ -190,8 +195,8 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         }
       }
       if (hit1) {
-        const float cr = lr_readlane_f(g1.z, j1), cg = lr_readlane_f(g1.w, j1), cbl = lr_readlane_f(cb, j1);
-        const int gid = lr_readlane_i((int)id, j1);
+        const float cr = q11.z, cg = q11.w, cbl = cbl1;
+        const int gid = gid1;
         if (acc1) { C0 = lr_fma(cr, w1, C0); C1 = lr_fma(cg, w1, C1); C2 = lr_fma(cbl, w1, C2); }
         if (EXTRAS) {
           if (w1 > wmax) { wmax = w1; wid = gid; }
@@ -316,27 +321,25 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   // Reverse walk in 64-entry chunks from the deepest contributor; lane l of chunk ch holds list position
   // maxc-1 - 64*ch - l.  Same two-stage prefetch as the forward pass.
   const uint32_t nchunks = ((uint32_t)maxc + 63u) >> 6;
-  const float* geomf = reinterpret_cast<const float*>(geom);
   auto load_id = [&](uint32_t c) -> uint32_t {
     const int pos = maxc - 1 - (int)(c * 64u) - lane;
     return (c < nchunks && pos >= 0) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
   };
   uint32_t id_n = load_id(0), id_nn = load_id(1);
-  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
-  float cb_n = 0.f;
-  if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
+  float4 g0_n = {0.f, 0.f, 0.f, 0.f};
+  float2 g1_n = {0.f, 0.f};  // (conic C, opacity): all the support test needs of q1
+  if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     const int hi = maxc - (int)(ch * 64u);
     const uint32_t id = id_n;
-    const float4 g0 = g0_n, g1 = g1_n;
-    const float cb = cb_n;
+    const float4 g0 = g0_n;
+    const float2 g1 = g1_n;
     id_n = id_nn;
     id_nn = load_id(ch + 2);
-    if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = geom[LR_REC_QUADS * (size_t)id_n + 1]; cb_n = geomf[4 * LR_REC_QUADS * (size_t)id_n + 8]; }
+    if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
     const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
-    const float hA = -0.5f * g0.z, nB = -g0.w, hC = -0.5f * g1.x;
     // Two entries per iteration: both alpha evaluations are issued together (independent chains), the
     // gradient bodies then run in list order.
     while (todo) {
@@ -345,14 +348,17 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       const bool has1 = todo != 0;
       const int j1 = has1 ? __builtin_ctzll(todo) : j0;
       todo &= todo - 1;
-      const float mx0 = lr_readlane_f(g0.x, j0), my0 = lr_readlane_f(g0.y, j0);
-      const float a0 = lr_readlane_f(hA, j0), b0 = lr_readlane_f(nB, j0), c0 = lr_readlane_f(hC, j0);
-      const float op0 = lr_readlane_f(g1.y, j0);
-      const float mx1 = lr_readlane_f(g0.x, j1), my1 = lr_readlane_f(g0.y, j1);
-      const float a1 = lr_readlane_f(hA, j1), b1 = lr_readlane_f(nB, j1), c1 = lr_readlane_f(hC, j1);
-      const float op1 = lr_readlane_f(g1.y, j1);
-      const lr_f2 dx2 = lr_f2{mx0, mx1} - pxf, dy2 = lr_f2{my0, my1} - pyf;
-      const lr_f2 pw2 = lr_power2(lr_f2{a0, a1}, lr_f2{b0, b1}, lr_f2{c0, c1}, dx2, dy2);
+      const int gid0 = lr_readlane_i((int)id, j0), gid1 = lr_readlane_i((int)id, j1);
+      const float4* __restrict__ rr0 = geom + LR_REC_QUADS * (size_t)(uint32_t)gid0;
+      const float4* __restrict__ rr1 = geom + LR_REC_QUADS * (size_t)(uint32_t)gid1;
+      const float4 q00 = rr0[0], q01 = rr0[1], q10 = rr1[0], q11 = rr1[1];
+      const float cbl0 = reinterpret_cast<const float*>(rr0)[8], cbl1 = reinterpret_cast<const float*>(rr1)[8];
+      const float op0 = q01.y, op1 = q11.y;
+      const lr_f2 dx2 = lr_f2{q00.x, q10.x} - pxf, dy2 = lr_f2{q00.y, q10.y} - pyf;
+      const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
+      const lr_f2 bdx = lr_f2{q00.w, q10.w} * dx2;
+      const lr_f2 pw2 = lr_fma2(lr_f2{q00.z, q10.z} * dx2, hdx2,
+                                lr_fma2(lr_f2{q01.x, q11.x} * dy2, hdy2, lr_f2{-bdx.x, -bdx.y} * dy2));
       const lr_f2 G2 = lr_exp2(pw2);
       const lr_f2 al2 = lr_f2{op0, op1} * G2;
       const float dx0 = dx2.x, dx1 = dx2.y, dy0 = dy2.x, dy1 = dy2.y;
@@ -366,10 +372,11 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         const bool hit = e ? hit1 : hit0;
         if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
         const int j = e ? j1 : j0;
-        const float a = e ? a1 : a0, b = e ? b1 : b0, c = e ? c1 : c0, op = e ? op1 : op0;
+        const float Ar = e ? q10.z : q00.z, Br = e ? q10.w : q00.w, Cr = e ? q11.x : q01.x, op = e ? op1 : op0;
         const float dx = e ? dx1 : dx0, dy = e ? dy1 : dy0;
-        const float cr = lr_readlane_f(g1.z, j), cg = lr_readlane_f(g1.w, j), cbl = lr_readlane_f(cb, j);
-        const int gid = lr_readlane_i((int)id, j);
+        const float cr = e ? q11.z : q01.z, cg = e ? q11.w : q01.w, cbl = e ? cbl1 : cbl0;
+        const int gid = e ? gid1 : gid0;
+        (void)j;
         // Branch-free body: lanes that do not contribute run it with alpha = G = 0, which leaves their state
         // untouched exactly (T*1, 0*c + 1*acc) and makes all nine of their partial sums exact zeros -- no exec
         // masking, no zero-initialised accumulators.  The colour behind the current entry is folded eagerly
@@ -388,8 +395,8 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         acc2 = lr_fma(alpha, cbl, om * acc2);
         const float dL_dG = op * dL_dalpha;
         const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddx = lr_fma(2.f * a, gdx, b * gdy);  // -gdx*A - gdy*B
-        const float dG_ddy = lr_fma(2.f * c, gdy, b * gdx);  // -gdy*C - gdx*B
+        const float dG_ddx = lr_fma(-Ar, gdx, -(Br * gdy));  // -gdx*A - gdy*B
+        const float dG_ddy = lr_fma(-Cr, gdy, -(Br * gdx));  // -gdy*C - gdx*B
         // slot order chosen so that lr_reduce9's rows land on contiguous destinations:
         //   r0 rows = (s0,s2,s1,s3) = (col r, col g, col b, opacity); r1 rows = (s4,s6,s5,s7) = (mean x, mean y, conic A, conic B); r2 = conic C
         float s[9];

@@ -88,7 +88,8 @@ def test_backward_twice_with_retain_graph():
     loss.backward(retain_graph=True)
     g1 = lv["means3D"].grad.clone()
     loss.backward()
-    assert torch.allclose(lv["means3D"].grad, 2 * g1, rtol=1e-4, atol=1e-6)
+    # atomics reorder the sums between the two passes: compare in relative L2, like every other gradient test
+    assert rel_l2(lv["means3D"].grad.cpu().numpy(), (2 * g1).cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("W,H", [(1, 1), (15, 17), (16, 16), (33, 5)])

@@ -25,9 +25,9 @@ def stats(path, title, out):
     open(out, "w").write("\n".join(o) + "\n")
 
 
-for n, t in (("b_default", "default"), ("b_s1", "streams1")):
+for n, t in (("b_default", "default"), ("b_s1", "streams1"), ("b_10M", "10M"), ("b_30M", "30M")):
     f = os.path.join(G, n + ".log")
-    if os.path.exists(f):
+    if os.path.exists(f) and any(l.startswith("{") for l in open(f)):
         line = [l for l in open(f) if l.startswith("{")][-1]
         json.dump(json.loads(line), open(os.path.join(P, f"{tag}_bench_{t}.json"), "w"), indent=1)
 cmd = "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
@@ -66,7 +66,8 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
     d["kernels"] = {s: {"fetch_kb": f[k], "write_kb": w[k], "traffic_bytes": (2 * f[k] + w[k]) * 1024}
                     for k, s in names.items() if k in f and k in w}
     json.dump(d, open(tj, "w"), indent=1)
-for f in os.listdir(G):
-    if f.startswith("radius_") and f.endswith(".json"):
-        shutil.copy(os.path.join(G, f), os.path.join(P, f"{tag}_{f}"))
+for n, out in (("knn_bench.log", "knn_bench.json"), ("radius_10M.log", "radius_10000000.json")):
+    f = os.path.join(G, n)
+    if os.path.exists(f) and any(l.startswith("{") for l in open(f)):
+        json.dump(json.loads([l for l in open(f) if l.startswith("{")][-1]), open(os.path.join(P, f"{tag}_{out}"), "w"), indent=1)
 print(sorted(os.listdir(P)))

@@ -258,6 +258,9 @@ def main():
                 return kern, {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                               "traffic": pmc_traffic(dom, N, W, H),
+                              # the compositing kernels are bound by fp32 VALU issue, which the hbm/mfma vocabulary of
+                              # this object cannot name: fraction of SIMD issue cycles spent in VALU ops (PMC pass)
+                              "valu_issue_frac": pmc_traffic(dom, N, W, H, "valu_active_frac_at_2p4GHz"),
                               "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_us": avg_s * 1e6}
             if prof_serial is None:
                 result["kernels"], result["roofline"] = roof(prof_timed)
@@ -279,7 +282,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, N, W, H):
+def pmc_traffic(kernel, N, W, H, field="traffic_bytes"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic.json,
     FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md prescribes); None when no profile of this
     exact workload is committed -- counters cannot be collected from inside the timed run."""
@@ -290,7 +293,7 @@ def pmc_traffic(kernel, N, W, H):
                 d = json.load(f)
             wl = d.get("workload", {})
             if (wl.get("gaussians"), wl.get("width"), wl.get("height")) == (N, W, H) and kernel in d["kernels"]:
-                return d["kernels"][kernel]["traffic_bytes"]
+                return d["kernels"][kernel][field]
         except (OSError, ValueError, KeyError):
             continue
     return None

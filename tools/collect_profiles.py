@@ -65,6 +65,14 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
         "workload": {"gaussians": 1000000, "width": 1920, "height": 1080}}
     d["kernels"] = {s: {"fetch_kb": f[k], "write_kb": w[k], "traffic_bytes": (2 * f[k] + w[k]) * 1024}
                     for k, s in names.items() if k in f and k in w}
+    # VALU issue utilisation from the SQ pass: SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD; 1024 SIMDs, 2.4 GHz peak
+    act, durs = load(sq, "SQ_ACTIVE_INST_VALU"), collections.defaultdict(list)
+    for r in csv.DictReader(open(sq)):
+        durs[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    for k, sname in names.items():
+        if k in act and sname in d["kernels"] and durs.get(k):
+            avg = sum(durs[k]) / len(durs[k])
+            d["kernels"][sname]["valu_active_frac_at_2p4GHz"] = act[k] * 4.0 / (1024 * avg * 2.4e9)
     json.dump(d, open(tj, "w"), indent=1)
 for n, out in (("knn_bench.log", "knn_bench.json"), ("radius_10M.log", "radius_10000000.json")):
     f = os.path.join(G, n)

@@ -79,11 +79,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
-    dev = torch.device("cuda", local_rank)
+    # LOGRAST_DIST_BACKEND=gloo + LOGRAST_SHARE_GPU=1: diagnostics only -- lets several ranks share one GPU (RCCL
+    # refuses that) to exercise the multi-process path on a single-GPU box; the driver's runs use RCCL, one GPU each.
+    backend = os.environ.get("LOGRAST_DIST_BACKEND", "nccl")
+    share = os.environ.get("LOGRAST_SHARE_GPU", "0") == "1"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
     from log_amd import _lib, rasterizer as R, scenes

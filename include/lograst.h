@@ -61,8 +61,9 @@ int lograst_version(void);
 const char* lograst_last_error(void);
 
 /* ---- sizing helpers --------------------------------------------------------------------------- */
-/* bytes of the per-tile state block for a WxH image (counts, offsets, cursors, header) */
-size_t lograst_tile_state_bytes(int32_t width, int32_t height);
+/* bytes of the per-tile state block for a WxH image and n Gaussians (header, counters, offsets, cursors, dispatch
+ * order, and the per-batch slot reservations of the projection stage, which grow with n) */
+size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n);
 /* bytes of the projected-record array for N Gaussians */
 size_t lograst_geom_bytes(int32_t n);
 /* bytes of the (depth,id) key buffer / the sorted id list for `capacity` tile instances */

@@ -34,7 +34,7 @@ _lib = None
 _SIGNATURES = {
     "lograst_version": (ctypes.c_int, []),
     "lograst_last_error": (ctypes.c_char_p, []),
-    "lograst_tile_state_bytes": (c_size_t, [c_int32, c_int32]),
+    "lograst_tile_state_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "lograst_geom_bytes": (c_size_t, [c_int32]),
     "lograst_keys_bytes": (c_size_t, [c_uint32]),
     "lograst_list_bytes": (c_size_t, [c_uint32]),

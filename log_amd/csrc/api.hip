@@ -19,7 +19,7 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
                       hipStream_t s);
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
-                       uint32_t* big, uint32_t* hdr, int tile_cull, hipStream_t s);
+                       uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int tile_cull, hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s);
@@ -62,6 +62,20 @@ int lr_env_int(const char* name, int dflt) {
 }
 // Support cull in the binning kernels (project.hip): on unless LOGRAST_TILE_CULL=0 or lograst_set_tile_cull(0).
 static std::atomic<int> g_tile_cull{-1};
+// Gaussians per projection batch (project.hip: lr_project_batched_kernel), 0 = unbatched kernel.  One batch per
+// workgroup; big enough that a batch puts several instances into a tile (that is what it saves in memory-side
+// atomics), small enough to leave a few hundred workgroups.  LOGRAST_BATCH overrides (0 disables batching).
+static uint32_t lr_pick_batch(int32_t n, uint32_t tiles) {
+  static const int forced = lr_env_int("LOGRAST_BATCH", -1);
+  if (n <= 0 || tiles > LR_BATCH_MAX_TILES || forced == 0) return 0u;
+  if (forced > 0) return (uint32_t)((forced + 1023) / 1024 * 1024);
+  uint32_t b = ((uint32_t)n / 256u + 1023u) / 1024u * 1024u;
+  if (b < 4096u) b = 4096u;
+  if (b > 32768u) b = 32768u;
+  return b;
+}
+static uint32_t lr_batches(int32_t n, uint32_t batch) { return batch ? ((uint32_t)n + batch - 1u) / batch : 0u; }
+
 static int lr_tile_cull() {
   int c = g_tile_cull.load(std::memory_order_relaxed);
   if (c < 0) {
@@ -147,9 +161,9 @@ extern "C" {
 int lograst_version(void) { return LOGRAST_VERSION; }
 const char* lograst_last_error(void) { return g_err.c_str(); }
 
-size_t lograst_tile_state_bytes(int32_t width, int32_t height) {
+size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
-  return sizeof(uint32_t) * (size_t)lr_state_words(gx * gy);
+  return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy)));
 }
 size_t lograst_geom_bytes(int32_t n) { return sizeof(float) * LOGRAST_REC_FLOATS * (size_t)(n > 0 ? n : 0); }
 size_t lograst_keys_bytes(uint32_t capacity) { return sizeof(uint64_t) * (size_t)capacity; }
@@ -190,7 +204,7 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   // zero header and counters (offsets/cursors are fully rewritten by the scan)
   LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)lr_offsets_off(tiles), s));  // header + ranked + big
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
-                    st + lr_big_off(tiles), st, lr_tile_cull(), s);
+                    st + lr_big_off(tiles), st, st + lr_basetab_off(tiles), (int)lr_pick_batch(n, tiles), lr_tile_cull(), s);
   lr_launch_scan(st, tiles, s);
   LR_HIP(hipGetLastError());
   if (num_instances_host || max_tile_len_host) {

@@ -16,7 +16,7 @@
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
 // [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_SORT_BLOCK
 // [4] tile instances of the plain rect rule (before the support cull; reporting only)
-// [5] support cull applied by the projection kernel (0/1)  [6..15] reserved
+// [5] support cull applied by the projection kernel (0/1)  [6] projection batch size (0 = unbatched)  [7..15] reserved
 // then per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic targets
 // spread over the memory channels instead of 8160 counters sharing 32 KB); header, ranked and big are
 // contiguous so that ONE memset prepares a forward:
@@ -37,6 +37,7 @@
 #define LR_HDR_OVERFLOW 1
 #define LR_HDR_MAXLEN 2
 #define LR_HDR_NBIG 3
+#define LR_HDR_BATCH 6  // Gaussians per projection batch (0 = unbatched kernel: slots in q3 are absolute)
 #define LR_HDR_CULL 5  // 1 if lr_project_kernel applied the support cull (the fill kernel must repeat it)
 #define LR_HDR_RECT 4  // tile instances of the plain rect rule (what the reference would sort), before the support cull
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
@@ -49,7 +50,13 @@ __host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { return lr_b
 __host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_offsets_off(tiles) + lr_tpad(tiles); }
 __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
 __host__ __device__ inline uint32_t lr_biglist_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
-__host__ __device__ inline uint32_t lr_state_words(uint32_t tiles) { return lr_biglist_off(tiles) + lr_tpad(tiles); }
+// then basetab[batches][T]: start of every projection batch's reservation inside each tile's ranked range
+__host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_biglist_off(tiles) + lr_tpad(tiles); }
+__host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batches) {
+  return (size_t)lr_basetab_off(tiles) + (size_t)batches * tiles;
+}
+#define LR_BATCH_THREADS 1024
+#define LR_BATCH_MAX_TILES 16384  // 2 x 4 B x tiles of LDS counters must fit one workgroup (128 KB of 160)
 
 // Device-side view (kernel argument, by value).
 struct LrView {

@@ -58,6 +58,108 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
 // the LARGER eigenvalue, so for elongated splats a good part of its tiles can never contribute; dropping them
 // changes no output (they fail the alpha floor at every pixel) but shortens every list that is counted, filled,
 // sorted and walked.  radii[] keeps the reference meaning (rect non-empty).
+// Counter policies: where the per-tile counters that rank / count the tile instances live.
+struct LrGlobalCounters {  // one memory-side atomic per instance (any tile grid)
+  uint32_t* ranked;
+  uint32_t* big;
+  LR_DEV uint32_t rank(int tile) const { return atomicAdd(&ranked[tile * LR_CTR_STRIDE], 1u); }
+  LR_DEV void count_big(int tile) const { atomicAdd(&big[tile * LR_CTR_STRIDE], 1u); }
+};
+struct LrLdsCounters {  // per-workgroup counters in LDS (batched kernel): 170x the rate of memory-side atomics
+  uint32_t* ranked;
+  uint32_t* big;
+  LR_DEV uint32_t rank(int tile) const { return atomicAdd(&ranked[tile], 1u); }
+  LR_DEV void count_big(int tile) const { atomicAdd(&big[tile], 1u); }
+};
+
+// Projection of Gaussian i (A1) + counting / ranking of its tile instances (A2) against `ctr`.  Outputs the four
+// record quads, the integer radius (0 = culled) and the rect-rule instance count.
+template <typename Counters>
+LR_DEV void lr_project_one(const LrView& v, int i, const float* __restrict__ means, const float* __restrict__ scales,
+                           const float* __restrict__ rots, const float* __restrict__ opac,
+                           const float* __restrict__ colors, int tile_cull, const Counters& ctr, float4& g0,
+                           float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances) {
+  const float* __restrict__ V = v.view;
+  const float* __restrict__ Pm = v.proj;
+  rad = 0;
+  g0 = float4{0.f, 0.f, 0.f, 0.f};
+  g1 = g0; g3 = g0;
+  g2 = g0;  // culled: empty rect (the fill kernel reads only q2)
+  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+  float tz = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
+  if (!(tz > 0.2f)) return;
+  float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
+  float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], p[0], p[1], p[2], Pm[13]);
+  float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], p[0], p[1], p[2], Pm[15]);
+  float pw = 1.0f / (hw + 0.0000001f);
+  float nx = hx * pw, ny = hy * pw;
+  if (v.ndc_cull && (nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) return;
+  float s[3] = {scales[3 * i] * v.scale_modifier, scales[3 * i + 1] * v.scale_modifier,
+                scales[3 * i + 2] * v.scale_modifier};
+  const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+  float q[4] = {q4.x, q4.y, q4.z, q4.w};
+  float R[9], Sg[6];
+  lr_cov3d(s, q, R, Sg);
+  LrEwa e;
+  lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
+  float det = e.a * e.c - e.b * e.b;
+  if (det == 0.0f) return;
+  float det_inv = 1.f / det;
+  float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
+  float rf = ceilf(lr_radius_from_cov(e.a, e.c, det));
+  float mx = ((nx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
+  float my = ((ny + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+  if (!((rf <= 1048576.f) && (fabsf(mx) < 1.0e8f) && (fabsf(my) < 1.0e8f))) return;
+  int x0 = (int)((mx - rf) / 16.f), y0 = (int)((my - rf) / 16.f);
+  int x1 = (int)(((mx + rf) + 15.f) / 16.f), y1 = (int)(((my + rf) + 15.f) / 16.f);
+  x0 = min(v.gx, max(0, x0)); x1 = min(v.gx, max(0, x1));
+  y0 = min(v.gy, max(0, y0)); y1 = min(v.gy, max(0, y1));
+  if ((x1 - x0) * (y1 - y0) <= 0) return;
+  rad = (int)rf;
+  g0 = float4{mx, my, cA, cB};
+  g1 = float4{cC, opac[i], colors[3 * i], colors[3 * i + 1]};
+  g2 = float4{colors[3 * i + 2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
+              __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
+  const int w = x1 - x0, nt = w * (y1 - y0);
+  rect_instances += (uint32_t)nt;
+  const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, g1.y);
+  if (nt <= LR_RANKED_TILES) {
+    uint32_t slot[LR_RANKED_TILES] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < LR_RANKED_TILES; k++) {
+      if (k < nt) {
+        const int ty = k / w, tx = k - ty * w;
+        slot[k] = (!tile_cull || lr_support_tile(sup, x0 + tx, y0 + ty)) ? ctr.rank((y0 + ty) * v.gx + (x0 + tx))
+                                                                        : 0xffffffffu;
+      }
+    }
+    g3 = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]),
+                __uint_as_float(slot[3])};
+  } else {
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++)
+        if (!tile_cull || lr_support_tile(sup, x, y)) ctr.count_big(y * v.gx + x);
+  }
+}
+
+// rect-rule instance count (reporting only): one atomic per WORKGROUP -- one per wave (15 K same-address atomics
+// at 1 M Gaussians) cost a full-grid launch 40 us
+template <int WAVES>
+LR_DEV void lr_commit_rect_count(uint32_t rect_instances, uint32_t* hdr) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) rect_instances += (uint32_t)__shfl_xor((int)rect_instances, d);
+  __shared__ uint32_t rect_part[WAVES];
+  if ((threadIdx.x & 63) == 0) rect_part[threadIdx.x >> 6] = rect_instances;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < WAVES; k++) r += rect_part[k];
+    if (r) atomicAdd(&hdr[LR_HDR_RECT], r);
+  }
+}
+
+// Unbatched kernel (any tile grid): counters in memory, one returning atomic per ranked instance.
 __global__ void __launch_bounds__(256)
 lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                   const float* __restrict__ rots, const float* __restrict__ opac,
@@ -65,128 +167,108 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
                   uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
                   int tile_cull) {
   // Records leave through LDS: a lane's four quads are 64 B apart from its neighbour's, so storing them
-  // directly makes every store instruction touch 64 different lines with 16 B each (partial-line writes that the
-  // L2 can only merge while few waves are in flight).  Staged, each instruction writes 1 KB of contiguous memory.
+  // directly makes every store instruction touch 64 different lines with 16 B each.  Staged, each instruction
+  // writes 1 KB of contiguous memory.
   __shared__ float4 stage[256 * LR_REC_QUADS];
   float4* wstage = stage + (threadIdx.x & ~63) * LR_REC_QUADS;
   const int lane = threadIdx.x & 63;
   uint32_t rect_instances = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = 0u; }
+  const LrGlobalCounters ctr{ranked, big};
   // Grid-stride: the kernel is bound by memory-side atomic throughput (measured: ~60 us without its atomics,
   // ~180 us with them = 24 G atomics/s, the rate a bare atomic microbenchmark reaches on random tile counters),
-  // which a few hundred waves in flight already saturate; a small resident grid leaves the remaining wave slots
-  // to whatever runs on other streams.
+  // which a few hundred waves in flight already saturate.
   for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < N; i0 += gridDim.x * 256) {  // i0: the wave's first Gaussian
-  const int i = i0 + lane;
-  const float* __restrict__ V = v.view;
-  const float* __restrict__ Pm = v.proj;
-  int rad = 0;
-  float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g3 = g0;
-  float4 g2 = {0.f, 0.f, 0.f, 0.f};  // culled: empty rect (the fill kernel reads only q2)
-  if (i < N) {
-  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-  float tz = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
-  if (tz > 0.2f) {
-    float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
-    float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], p[0], p[1], p[2], Pm[13]);
-    float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], p[0], p[1], p[2], Pm[15]);
-    float pw = 1.0f / (hw + 0.0000001f);
-    float nx = hx * pw, ny = hy * pw;
-    bool culled = v.ndc_cull && (nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f);
-    if (!culled) {
-      float s[3] = {scales[3 * i] * v.scale_modifier, scales[3 * i + 1] * v.scale_modifier,
-                    scales[3 * i + 2] * v.scale_modifier};
-      const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
-      float q[4] = {q4.x, q4.y, q4.z, q4.w};
-      float R[9], Sg[6];
-      lr_cov3d(s, q, R, Sg);
-      LrEwa e;
-      lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
-      float det = e.a * e.c - e.b * e.b;
-      if (det != 0.0f) {
-        float det_inv = 1.f / det;
-        float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
-        float rf = ceilf(lr_radius_from_cov(e.a, e.c, det));
-        float mx = ((nx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
-        float my = ((ny + 1.0f) * (float)v.H - 1.0f) * 0.5f;
-        if ((rf <= 1048576.f) && (fabsf(mx) < 1.0e8f) && (fabsf(my) < 1.0e8f)) {
-          int x0 = (int)((mx - rf) / 16.f), y0 = (int)((my - rf) / 16.f);
-          int x1 = (int)(((mx + rf) + 15.f) / 16.f), y1 = (int)(((my + rf) + 15.f) / 16.f);
-          x0 = min(v.gx, max(0, x0)); x1 = min(v.gx, max(0, x1));
-          y0 = min(v.gy, max(0, y0)); y1 = min(v.gy, max(0, y1));
-          if ((x1 - x0) * (y1 - y0) > 0) {
-            rad = (int)rf;
-            g0 = float4{mx, my, cA, cB};
-            g1 = float4{cC, opac[i], colors[3 * i], colors[3 * i + 1]};
-            g2 = float4{colors[3 * i + 2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
-                        __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
-            const int w = x1 - x0, nt = w * (y1 - y0);
-            rect_instances += (uint32_t)nt;
-            const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, g1.y);
-            if (nt <= LR_RANKED_TILES) {
-              uint32_t slot[LR_RANKED_TILES] = {0u, 0u, 0u, 0u};
-#pragma unroll
-              for (int k = 0; k < LR_RANKED_TILES; k++) {
-                if (k < nt) {
-                  const int ty = k / w, tx = k - ty * w;
-                  slot[k] = (!tile_cull || lr_support_tile(sup, x0 + tx, y0 + ty))
-                                ? atomicAdd(&ranked[((y0 + ty) * v.gx + (x0 + tx)) * LR_CTR_STRIDE], 1u)
-                                : 0xffffffffu;
-                }
-              }
-              g3 = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]),
-                          __uint_as_float(slot[3])};
-            } else {
-              for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++)
-                  if (!tile_cull || lr_support_tile(sup, x, y)) atomicAdd(&big[(y * v.gx + x) * LR_CTR_STRIDE], 1u);
-            }
-          }
-        }
-      }
+    const int i = i0 + lane;
+    float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+    if (i < N) {
+      int rad;
+      lr_project_one(v, i, means, scales, rots, opac, colors, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
+      radii[i] = rad;
     }
-  }
-  radii[i] = rad;
-  }  // i < N
-  wstage[lane * LR_REC_QUADS + 0] = g0;
-  wstage[lane * LR_REC_QUADS + 1] = g1;
-  wstage[lane * LR_REC_QUADS + 2] = g2;
-  wstage[lane * LR_REC_QUADS + 3] = g3;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int nq = min(64, N - i0) * LR_REC_QUADS;  // quads this wave owns
+    wstage[lane * LR_REC_QUADS + 0] = g0;
+    wstage[lane * LR_REC_QUADS + 1] = g1;
+    wstage[lane * LR_REC_QUADS + 2] = g2;
+    wstage[lane * LR_REC_QUADS + 3] = g3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nq = min(64, N - i0) * LR_REC_QUADS;  // quads this wave owns
 #pragma unroll
-  for (int k = 0; k < LR_REC_QUADS; k++) {
-    const int qd = k * 64 + lane;
-    if (qd < nq) geom[LR_REC_QUADS * (size_t)i0 + qd] = wstage[qd];
+    for (int k = 0; k < LR_REC_QUADS; k++) {
+      const int qd = k * 64 + lane;
+      if (qd < nq) geom[LR_REC_QUADS * (size_t)i0 + qd] = wstage[qd];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  }
-  // rect-rule instance count (reporting only): one atomic per WORKGROUP -- 15 K same-address atomics, one per
-  // wave, cost the full-grid launch 40 us
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) rect_instances += (uint32_t)__shfl_xor((int)rect_instances, d);
-  __shared__ uint32_t rect_part[4];
-  if (lane == 0) rect_part[threadIdx.x >> 6] = rect_instances;
+  lr_commit_rect_count<4>(rect_instances, hdr);
+}
+
+// Batched kernel (tile grids whose counters fit in LDS): workgroup b owns Gaussians [b*B, (b+1)*B).  Its instances
+// are counted and ranked in LDS counters (integer LDS atomics run at ~4 T/s chip-wide, memory-side atomics at
+// 0.025 T/s); afterwards ONE memory-side atomic per non-empty (batch, tile) reserves the batch's range of slots
+// in that tile, and its start goes to basetab[b][tile].  An instance's slot is basetab[batch][tile] + its rank
+// inside the batch (stored in q3 as before) -- the fill kernel adds the two.  With B >> tiles / (instances per
+// Gaussian) the memory-side atomics shrink by the average number of instances a batch puts into a tile.
+__global__ void __launch_bounds__(LR_BATCH_THREADS)
+lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
+                          const float* __restrict__ rots, const float* __restrict__ opac,
+                          const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
+                          uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
+                          uint32_t* __restrict__ basetab, int tile_cull, int B) {
+  extern __shared__ uint32_t lr_lds_ctr[];  // [tiles] ranked counts, [tiles] big counts
+  const int tiles = v.gx * v.gy;
+  uint32_t* const lranked = lr_lds_ctr;
+  uint32_t* const lbig = lr_lds_ctr + tiles;
+  for (int t = threadIdx.x; t < 2 * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t r = rect_part[0] + rect_part[1] + rect_part[2] + rect_part[3];
-    if (r) atomicAdd(&hdr[LR_HDR_RECT], r);
+  const LrLdsCounters ctr{lranked, lbig};
+  uint32_t rect_instances = 0;
+  const int i_begin = blockIdx.x * B, i_end = min(N, i_begin + B);
+  for (int i = i_begin + (int)threadIdx.x; i < i_end; i += LR_BATCH_THREADS) {
+    float4 g0, g1, g2, g3;
+    int rad;
+    lr_project_one(v, i, means, scales, rots, opac, colors, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
+    radii[i] = rad;
+    float4* rec = geom + LR_REC_QUADS * (size_t)i;
+    rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;
   }
+  __syncthreads();
+  uint32_t* const mybase = basetab + (size_t)blockIdx.x * tiles;
+  for (int t = threadIdx.x; t < tiles; t += LR_BATCH_THREADS) {
+    const uint32_t c = lranked[t], cb = lbig[t];
+    mybase[t] = c ? atomicAdd(&ranked[t * LR_CTR_STRIDE], c) : 0u;
+    if (cb) atomicAdd(&big[t * LR_CTR_STRIDE], cb);
+  }
+  lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
-                       uint32_t* big, uint32_t* hdr, int tile_cull, hipStream_t s) {
+                       uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int tile_cull, hipStream_t s) {
   if (N <= 0) return;
-  static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 512);  // 2 workgroups per CU: measured optimum
-  int blocks = (N + 255) / 256;
-  if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
   lr_prof_begin(LRK_PROJECT, s);
-  hipLaunchKernelGGL(lr_project_kernel, dim3(blocks), dim3(256), 0, s, v, N, means, scales, rots, opac,
-                     colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr, tile_cull);
+  if (batch > 0) {
+    const int tiles = v.gx * v.gy;
+    const size_t lds = sizeof(uint32_t) * 2 * (size_t)tiles;
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(lr_project_batched_kernel, dim3((N + batch - 1) / batch), dim3(LR_BATCH_THREADS), lds, s, v, N,
+                       means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
+                       basetab, tile_cull, batch);
+  } else {
+    static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 512);  // 2 workgroups per CU: measured optimum
+    int blocks = (N + 255) / 256;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(lr_project_kernel, dim3(blocks), dim3(256), 0, s, v, N, means, scales, rots, opac, colors, radii,
+                       reinterpret_cast<float4*>(geom), ranked, big, hdr, tile_cull);
+  }
   lr_prof_end(LRK_PROJECT, s);
 }
 
@@ -331,6 +413,10 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   int i = blockIdx.x * 256 + threadIdx.x;
+  // batched projection: a ranked instance's slot is relative to its batch's reservation in the tile
+  const uint32_t batch = state[LR_HDR_BATCH];
+  const uint32_t* __restrict__ bbase =
+      batch ? state + lr_basetab_off(tiles) + (size_t)((uint32_t)i / batch) * tiles : nullptr;
   int lane = threadIdx.x & 63;
   bool vis = (i < N);
   uint32_t r0 = 0, r1 = 0, dbits = 0;
@@ -352,7 +438,8 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     for (int k = 0; k < LR_RANKED_TILES; k++) {
       if (k < nt && slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in lr_project_kernel
         const int ty = k / w, tx = k - ty * w;
-        keys[offsets[(y0 + ty) * gx + (x0 + tx)] + slot[k]] = key;
+        const int t = (y0 + ty) * gx + (x0 + tx);
+        keys[offsets[t] + (batch ? bbase[t] : 0u) + slot[k]] = key;
       }
     }
   }

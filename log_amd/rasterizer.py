@@ -145,7 +145,7 @@ class HipBackend:
         f32 = dict(dtype=torch.float32, device=device)
         radii = torch.empty(N, **i32)
         geom = torch.empty(N * _lib.REC_FLOATS, **f32)
-        state = torch.empty(L.lograst_tile_state_bytes(W, H) // 4, **i32)
+        state = torch.empty(L.lograst_tile_state_bytes(W, H, N) // 4, **i32)
         with torch.cuda.device(device):
             if _capacity_hint is None:
                 n_host, m_host = ctypes.c_uint32(0), ctypes.c_uint32(0)

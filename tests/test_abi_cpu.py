@@ -32,7 +32,7 @@ def test_sizing_helpers_and_error_text_work_without_gpu():
     L = _lib.lib()
     assert L.lograst_version() == 1
     tiles = 120 * 68
-    assert L.lograst_tile_state_bytes(1920, 1080) >= 4 * (tiles + 1)
+    assert L.lograst_tile_state_bytes(1920, 1080, 1000000) >= 4 * (tiles + 1)
     assert L.lograst_geom_bytes(10) == 10 * 64
     assert L.lograst_keys_bytes(7) == 56 and L.lograst_list_bytes(7) == 28
     # argument validation happens before any device work

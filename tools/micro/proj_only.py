@@ -12,7 +12,7 @@ m, s, r, o, c = t(sc["xyz"]), t(sc["scaling"]), t(sc["rotation"]), t(sc["opacity
 B = R._backend; L = B.require(dev)
 view, keep = B.make_view(rs, R.WODILATE, True, dev)
 radii = torch.empty(N, dtype=torch.int32, device=dev); geom = torch.empty(N*16, device=dev)
-state = torch.empty(L.lograst_tile_state_bytes(1920,1080)//4, dtype=torch.int32, device=dev)
+state = torch.empty(L.lograst_tile_state_bytes(1920,1080,N)//4, dtype=torch.int32, device=dev)
 _lib.profile_reset(); _lib.profile_enable(True)
 for _ in range(10):
     _lib.check(L.lograst_forward_project(ctypes.byref(view), N, R._ptr(m), R._ptr(s), R._ptr(r), R._ptr(o), R._ptr(c), R._ptr(radii), R._ptr(geom), R._ptr(state), None, None, R._stream_ptr(dev)))

@@ -216,19 +216,21 @@ struct LrSupport {
   int mode;  // 0 never visible (opacity below the floor), 1 cannot cull safely, 2 test the box
 };
 LR_DEV LrSupport lr_support_prepare(float mx, float my, float A, float B, float C, float op) {
+  // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE sequences: the test only has to be conservative and
+  // reproducible (project and fill run this same code on the same record), and its margins are 1 % wide.
   LrSupport s;
   s.mx = mx; s.my = my; s.A = A; s.B = B; s.C = C;
   s.tau = lr_fma(__logf(255.f * op), 1.01f, 0.01f);
   s.ex = 0.f; s.ey = 0.f; s.iA = 0.f; s.iC = 0.f;
   if (!(op >= 1.0f / 512.0f)) { s.mode = (op < 1.0f / 512.0f) ? 0 : 1; return s; }  // NaN -> keep
   const float det = A * C - B * B;
-  const float inv = 1.f / det;
+  const float inv = __builtin_amdgcn_rcpf(det);
   const float ex2 = 2.f * s.tau * C * inv, ey2 = 2.f * s.tau * A * inv;  // squared half extents
   const float mag = (fabsf(A) + fabsf(B) + fabsf(C)) * (ex2 + ey2);       // bound on the terms of `power` in the box
   const bool safe = (det > 0.f) && (ex2 >= 0.f) && (ey2 >= 0.f) && (mag * 1.0e-6f < 0.005f * s.tau) && (mag < 1.0e30f);
   if (!safe) { s.mode = 1; return s; }
-  s.ex = sqrtf(ex2) + 0.01f; s.ey = sqrtf(ey2) + 0.01f;
-  s.iA = 1.f / A; s.iC = 1.f / C;
+  s.ex = __builtin_amdgcn_sqrtf(ex2) * 1.0001f + 0.01f; s.ey = __builtin_amdgcn_sqrtf(ey2) * 1.0001f + 0.01f;
+  s.iA = __builtin_amdgcn_rcpf(A); s.iC = __builtin_amdgcn_rcpf(C);
   s.mode = 2;
   return s;
 }

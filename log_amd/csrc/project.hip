@@ -72,12 +72,28 @@ struct LrLdsCounters {  // per-workgroup counters in LDS (batched kernel): 170x 
   LR_DEV void count_big(int tile) const { atomicAdd(&big[tile], 1u); }
 };
 
-// Projection of Gaussian i (A1) + counting / ranking of its tile instances (A2) against `ctr`.  Outputs the four
+// The 56 input bytes of one Gaussian, requested together (five independent loads in flight per lane).
+struct LrInputs {
+  float p[3], s[3], c[3];
+  float4 q;
+  float op;
+};
+LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const float* __restrict__ scales,
+                               const float* __restrict__ rots, const float* __restrict__ opac,
+                               const float* __restrict__ colors) {
+  LrInputs in;
+  in.p[0] = means[3 * i]; in.p[1] = means[3 * i + 1]; in.p[2] = means[3 * i + 2];
+  in.s[0] = scales[3 * i]; in.s[1] = scales[3 * i + 1]; in.s[2] = scales[3 * i + 2];
+  in.q = reinterpret_cast<const float4*>(rots)[i];
+  in.op = opac[i];
+  in.c[0] = colors[3 * i]; in.c[1] = colors[3 * i + 1]; in.c[2] = colors[3 * i + 2];
+  return in;
+}
+
+// Projection of one Gaussian (A1) + counting / ranking of its tile instances (A2) against `ctr`.  Outputs the four
 // record quads, the integer radius (0 = culled) and the rect-rule instance count.
 template <typename Counters>
-LR_DEV void lr_project_one(const LrView& v, int i, const float* __restrict__ means, const float* __restrict__ scales,
-                           const float* __restrict__ rots, const float* __restrict__ opac,
-                           const float* __restrict__ colors, int tile_cull, const Counters& ctr, float4& g0,
+LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, const Counters& ctr, float4& g0,
                            float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances) {
   const float* __restrict__ V = v.view;
   const float* __restrict__ Pm = v.proj;
@@ -85,7 +101,7 @@ LR_DEV void lr_project_one(const LrView& v, int i, const float* __restrict__ mea
   g0 = float4{0.f, 0.f, 0.f, 0.f};
   g1 = g0; g3 = g0;
   g2 = g0;  // culled: empty rect (the fill kernel reads only q2)
-  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+  const float p[3] = {in.p[0], in.p[1], in.p[2]};
   float tz = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
   if (!(tz > 0.2f)) return;
   float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
@@ -94,10 +110,8 @@ LR_DEV void lr_project_one(const LrView& v, int i, const float* __restrict__ mea
   float pw = 1.0f / (hw + 0.0000001f);
   float nx = hx * pw, ny = hy * pw;
   if (v.ndc_cull && (nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) return;
-  float s[3] = {scales[3 * i] * v.scale_modifier, scales[3 * i + 1] * v.scale_modifier,
-                scales[3 * i + 2] * v.scale_modifier};
-  const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
-  float q[4] = {q4.x, q4.y, q4.z, q4.w};
+  float s[3] = {in.s[0] * v.scale_modifier, in.s[1] * v.scale_modifier, in.s[2] * v.scale_modifier};
+  float q[4] = {in.q.x, in.q.y, in.q.z, in.q.w};
   float R[9], Sg[6];
   lr_cov3d(s, q, R, Sg);
   LrEwa e;
@@ -117,8 +131,8 @@ LR_DEV void lr_project_one(const LrView& v, int i, const float* __restrict__ mea
   if ((x1 - x0) * (y1 - y0) <= 0) return;
   rad = (int)rf;
   g0 = float4{mx, my, cA, cB};
-  g1 = float4{cC, opac[i], colors[3 * i], colors[3 * i + 1]};
-  g2 = float4{colors[3 * i + 2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
+  g1 = float4{cC, in.op, in.c[0], in.c[1]};
+  g2 = float4{in.c[2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
               __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
   const int w = x1 - x0, nt = w * (y1 - y0);
   rect_instances += (uint32_t)nt;
@@ -128,9 +142,11 @@ LR_DEV void lr_project_one(const LrView& v, int i, const float* __restrict__ mea
 #pragma unroll
     for (int k = 0; k < LR_RANKED_TILES; k++) {
       if (k < nt) {
-        const int ty = k / w, tx = k - ty * w;
-        slot[k] = (!tile_cull || lr_support_tile(sup, x0 + tx, y0 + ty)) ? ctr.rank((y0 + ty) * v.gx + (x0 + tx))
-                                                                        : 0xffffffffu;
+        // nt <= 4: the rect is one row (w >= nt), one column (w == 1) or 2x2 -- no integer division
+        const int ty = (w == 1) ? k : ((w == 2 && nt == 4) ? (k >> 1) : 0), tx = k - ty * w;
+        // a single-tile rect holds the centre's neighbourhood: testing it would almost never drop it
+        const bool keep = !tile_cull || nt == 1 || lr_support_tile(sup, x0 + tx, y0 + ty);
+        slot[k] = keep ? ctr.rank((y0 + ty) * v.gx + (x0 + tx)) : 0xffffffffu;
       }
     }
     g3 = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]),
@@ -183,7 +199,8 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
     if (i < N) {
       int rad;
-      lr_project_one(v, i, means, scales, rots, opac, colors, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
+      const LrInputs in = lr_load_inputs(i, means, scales, rots, opac, colors);
+      lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
       radii[i] = rad;
     }
     wstage[lane * LR_REC_QUADS + 0] = g0;
@@ -227,20 +244,39 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   const LrLdsCounters ctr{lranked, lbig};
   uint32_t rect_instances = 0;
   const int i_begin = blockIdx.x * B, i_end = min(N, i_begin + B);
-  for (int i = i_begin + (int)threadIdx.x; i < i_end; i += LR_BATCH_THREADS) {
+  // software pipeline: the next Gaussian's inputs are requested before the current one is projected (a workgroup
+  // is 16 waves on one CU, so there is little other work to hide the loads behind)
+  int i = i_begin + (int)threadIdx.x;
+  LrInputs nxt;
+  if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors);
+  for (; i < i_end; i += LR_BATCH_THREADS) {
+    const LrInputs in = nxt;
+    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors);
     float4 g0, g1, g2, g3;
     int rad;
-    lr_project_one(v, i, means, scales, rots, opac, colors, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
+    lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
     radii[i] = rad;
     float4* rec = geom + LR_REC_QUADS * (size_t)i;
     rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;
   }
   __syncthreads();
+  // reservations: eight tiles per thread per round, all eight returning atomics in flight before the first result
+  // is stored (one memory round trip per round, not eight)
   uint32_t* const mybase = basetab + (size_t)blockIdx.x * tiles;
-  for (int t = threadIdx.x; t < tiles; t += LR_BATCH_THREADS) {
-    const uint32_t c = lranked[t], cb = lbig[t];
-    mybase[t] = c ? atomicAdd(&ranked[t * LR_CTR_STRIDE], c) : 0u;
-    if (cb) atomicAdd(&big[t * LR_CTR_STRIDE], cb);
+  for (int t0 = threadIdx.x; t0 < tiles; t0 += 8 * LR_BATCH_THREADS) {
+    uint32_t base[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t0 + u * LR_BATCH_THREADS;
+      const uint32_t c = t < tiles ? lranked[t] : 0u, cb = t < tiles ? lbig[t] : 0u;
+      base[u] = c ? atomicAdd(&ranked[t * LR_CTR_STRIDE], c) : 0u;
+      if (cb) atomicAdd(&big[t * LR_CTR_STRIDE], cb);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t0 + u * LR_BATCH_THREADS;
+      if (t < tiles) mybase[t] = base[u];
+    }
   }
   lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
 }

@@ -263,7 +263,8 @@ def test_module_autograd_contract():
     # second pass through the same rasterizer / same leaves accumulates (depth pass, renderer.py:186-201)
     rast(**kw)[0].sum().backward()
     for k, t in dict(m3=m3, m2=m2, sca=sca, rot=rot, op=op, col=col).items():
-        assert torch.allclose(t.grad, 2 * g1[k], rtol=1e-3, atol=1e-5), k
+        # the two passes are separate atomic sums: compare in relative L2 (elementwise, ill-conditioned rows flake)
+        assert rel_l2(t.grad.cpu().numpy(), (2 * g1[k]).cpu().numpy()) < 1e-4, k
     # eval-mode kwarg of the fork and the 2-tuple upstream flavour
     with torch.no_grad():
         assert len(rast(use_filter=False, **kw)) == 5

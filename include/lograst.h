@@ -164,13 +164,14 @@ int lograst_knn_mean_dist2(int32_t p, const float* points, float* out, void* scr
 /* ---- "next" row N2: the packages' native `shs=` input --------------------------------------------------
  * colours[n,3] = max(0, 0.5 + sum_{k < (deg+1)^2} basis_k(normalise(mean - campos)) * shs[n,k,:]), shs laid out
  * [n, max_coeffs, 3]; clamped[n*3] (u8) records which channels hit the clamp.  Backward: dl_dshs[n,max_coeffs,3]
- * is overwritten, the direction gradient is ADDED to dl_dmeans3d.  (Third-party package's computeColorFromSH;
+ * is overwritten (accumulate = 0) or added to (accumulate != 0: running sums over views), the direction gradient
+ * is ADDED to dl_dmeans3d.  (Third-party package's computeColorFromSH;
  * LoG passes colors_precomp instead, LoG/render/renderer.py:144-145.) */
 int lograst_sh_forward(int32_t n, int32_t degree, int32_t max_coeffs, const float* means3d, const float* campos,
                        const float* shs, float* colors, uint8_t* clamped, void* stream);
 int lograst_sh_backward(int32_t n, int32_t degree, int32_t max_coeffs, const float* means3d, const float* campos,
                         const float* shs, const uint8_t* clamped, const float* dl_dcolors, float* dl_dshs,
-                        float* dl_dmeans3d, void* stream);
+                        float* dl_dmeans3d, int32_t accumulate, void* stream);
 
 /* ---- debugging / test access to intermediates --------------------------------------------------
  * Pointers into a tile_state block (device): offsets has tiles+1 entries. */

@@ -53,7 +53,7 @@ _SIGNATURES = {
     "lograst_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 17 + [c_int32, c_void_p]),
     "lograst_project_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10),
     "lograst_sh_forward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 6),
-    "lograst_sh_backward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 8),
+    "lograst_sh_backward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p]),
     "lograst_knn_scratch_bytes": (c_size_t, [c_int32]),
     "lograst_knn_mean_dist2": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lograst_profile_enable": (None, [ctypes.c_int]),

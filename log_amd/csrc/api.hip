@@ -42,7 +42,8 @@ hipError_t lr_launch_knn(int P, const float* pts, float* out, void* scratch, siz
 void lr_launch_sh_fwd(int N, int deg, int M, const float* means, const float* campos, const float* shs, float* colors,
                       uint8_t* clamped, hipStream_t s);
 void lr_launch_sh_bwd(int N, int deg, int M, const float* means, const float* campos, const float* shs,
-                      const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means, hipStream_t s);
+                      const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means, bool accumulate,
+                      hipStream_t s);
 
 static thread_local std::string g_err;
 static int lr_fail(int code, const std::string& msg) {
@@ -351,14 +352,14 @@ int lograst_sh_forward(int32_t n, int32_t degree, int32_t max_coeffs, const floa
 
 int lograst_sh_backward(int32_t n, int32_t degree, int32_t max_coeffs, const float* means3d, const float* campos,
                         const float* shs, const uint8_t* clamped, const float* dl_dcolors, float* dl_dshs,
-                        float* dl_dmeans3d, void* stream) {
+                        float* dl_dmeans3d, int32_t accumulate, void* stream) {
   int rc = lr_sh_check(n, degree, max_coeffs);
   if (rc) return rc;
   if (n == 0) return LOGRAST_OK;
   if (!means3d || !campos || !shs || !clamped || !dl_dcolors || !dl_dshs || !dl_dmeans3d)
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   lr_launch_sh_bwd(n, degree, max_coeffs, means3d, campos, shs, clamped, dl_dcolors, dl_dshs, dl_dmeans3d,
-                   (hipStream_t)stream);
+                   accumulate != 0, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

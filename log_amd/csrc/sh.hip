@@ -3,7 +3,7 @@
 // with the clamp mask cutting the gradient (published behaviour of the third-party kernel).  LoG itself never
 // takes this path (it evaluates the same polynomial in PyTorch -- /root/reference/LoG/model/sh_utils.py:31-68,
 // LoG/model/activation.py:27-34 -- and passes colors_precomp, LoG/render/renderer.py:144-145); the basis is
-// pinned against that file in tests/test_sh.py.  Streaming, one thread per Gaussian.
+// pinned against that file in tests/test_sh.py.  Streaming, one thread per Gaussian, coefficients staged per wave.
 #include "common.hpp"
 
 #define SH_C0 0.28209479177387814f
@@ -45,10 +45,58 @@ LR_DEV void lr_sh_basis(int deg, float x, float y, float z, float b[16], float b
   }
 }
 
+// Memory layout is [Gaussian][coefficient][channel] (L = 3*M floats per Gaussian): a lane walking its own
+// coefficients reads 4 bytes out of every 192 (M = 16), one cache line per instruction per lane.  Instead every wave
+// moves the 64*L contiguous floats of its 64 Gaussians with full-width coalesced accesses and transposes through
+// LDS (row stride L+1 floats: odd, so the per-lane row walks are bank-conflict free).  Measured at 10 M Gaussians,
+// degree 3: forward 2.68 -> 0.6 ms, backward 4.51 -> 1.25 ms (3.1 TB/s).
+
+// wave-cooperative copy of `count` floats between global memory (contiguous) and the wave's LDS rows
+template <bool TO_LDS, bool ADD = false>
+LR_DEV void lr_sh_wave_copy(float* __restrict__ lds, float* __restrict__ glob, int L, int count, int lane) {
+  const uint32_t magic = 0xffffffffu / (uint32_t)L + 1u;  // e / L for e < 65536
+  if ((L & 3) == 0) {
+    for (int e = 4 * lane; e < count; e += 256) {  // count is a multiple of L, L of 4: float4s never straddle rows
+      const int g = (int)__umulhi((uint32_t)e, magic), j = e - g * L;
+      float* row = lds + g * (L + 1) + j;
+      if (TO_LDS) {
+        const float4 v = *reinterpret_cast<const float4*>(glob + e);
+        row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+      } else {
+        float4 o = float4{row[0], row[1], row[2], row[3]};
+        if (ADD) {
+          const float4 old = *reinterpret_cast<const float4*>(glob + e);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(glob + e) = o;
+      }
+    }
+  } else {
+    for (int e = lane; e < count; e += 64) {
+      const int g = (int)__umulhi((uint32_t)e, magic), j = e - g * L;
+      if (TO_LDS) lds[g * (L + 1) + j] = glob[e];
+      else glob[e] = lds[g * (L + 1) + j] + (ADD ? glob[e] : 0.f);
+    }
+  }
+}
+LR_DEV void lr_sh_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ void __launch_bounds__(256)
 lr_sh_fwd_kernel(int N, int deg, int M, const float* __restrict__ means, const float* __restrict__ campos,
                  const float* __restrict__ shs, float* __restrict__ colors, uint8_t* __restrict__ clamped) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  extern __shared__ float lr_sh_lds[];  // 4 waves x 64 rows x (L+1)
+  const int L = 3 * M, lane = threadIdx.x & 63;
+  float* const wl = lr_sh_lds + (threadIdx.x >> 6) * 64 * (L + 1);
+  const int i0 = blockIdx.x * 256 + (threadIdx.x & ~63);  // the wave's first Gaussian
+  if (i0 >= N) return;
+  const int rows = min(64, N - i0);
+  lr_sh_wave_copy<true>(wl, const_cast<float*>(shs) + (size_t)i0 * L, L, rows * L, lane);
+  lr_sh_wave_sync();
+  const int i = i0 + lane;
   if (i >= N) return;
   float vx = means[3 * i] - campos[0], vy = means[3 * i + 1] - campos[1], vz = means[3 * i + 2] - campos[2];
   const float inv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
@@ -56,10 +104,13 @@ lr_sh_fwd_kernel(int N, int deg, int M, const float* __restrict__ means, const f
   float b[16], bx[16], by[16], bz[16];
   lr_sh_basis(deg, x, y, z, b, bx, by, bz);
   const int nk = (deg + 1) * (deg + 1);
-  const float* sh = shs + (size_t)i * M * 3;
+  const float* sh = wl + lane * (L + 1);
   float c[3] = {0.5f, 0.5f, 0.5f};
-  for (int k = 0; k < nk; k++) {
-    c[0] = lr_fma(b[k], sh[3 * k], c[0]); c[1] = lr_fma(b[k], sh[3 * k + 1], c[1]); c[2] = lr_fma(b[k], sh[3 * k + 2], c[2]);
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    if (k < nk) {
+      c[0] = lr_fma(b[k], sh[3 * k], c[0]); c[1] = lr_fma(b[k], sh[3 * k + 1], c[1]); c[2] = lr_fma(b[k], sh[3 * k + 2], c[2]);
+    }
   }
 #pragma unroll
   for (int ch = 0; ch < 3; ch++) {
@@ -68,49 +119,67 @@ lr_sh_fwd_kernel(int N, int deg, int M, const float* __restrict__ means, const f
   }
 }
 
+template <bool ACCUMULATE>  // true: g_shs += (running sums over views), false: g_shs = (overwritten)
 __global__ void __launch_bounds__(256)
 lr_sh_bwd_kernel(int N, int deg, int M, const float* __restrict__ means, const float* __restrict__ campos,
                  const float* __restrict__ shs, const uint8_t* __restrict__ clamped,
                  const float* __restrict__ g_colors, float* __restrict__ g_shs, float* __restrict__ g_means) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const float vx = means[3 * i] - campos[0], vy = means[3 * i + 1] - campos[1], vz = means[3 * i + 2] - campos[2];
-  const float n2 = vx * vx + vy * vy + vz * vz;
-  const float inv = 1.f / sqrtf(n2);
-  const float x = vx * inv, y = vy * inv, z = vz * inv;
-  float b[16], bx[16], by[16], bz[16];
-  lr_sh_basis(deg, x, y, z, b, bx, by, bz);
-  const int nk = (deg + 1) * (deg + 1);
-  const float* sh = shs + (size_t)i * M * 3;
-  float* gs = g_shs + (size_t)i * M * 3;
-  float g[3];
+  extern __shared__ float lr_sh_lds[];
+  const int L = 3 * M, lane = threadIdx.x & 63;
+  float* const wl = lr_sh_lds + (threadIdx.x >> 6) * 64 * (L + 1);
+  const int i0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (i0 >= N) return;
+  const int rows = min(64, N - i0);
+  lr_sh_wave_copy<true>(wl, const_cast<float*>(shs) + (size_t)i0 * L, L, rows * L, lane);
+  lr_sh_wave_sync();
+  const int i = i0 + lane;
+  if (i < N) {
+    const float vx = means[3 * i] - campos[0], vy = means[3 * i + 1] - campos[1], vz = means[3 * i + 2] - campos[2];
+    const float n2 = vx * vx + vy * vy + vz * vz;
+    const float inv = 1.f / sqrtf(n2);
+    const float x = vx * inv, y = vy * inv, z = vz * inv;
+    float b[16], bx[16], by[16], bz[16];
+    lr_sh_basis(deg, x, y, z, b, bx, by, bz);
+    const int nk = (deg + 1) * (deg + 1);
+    float* row = wl + lane * (L + 1);  // coefficients in, their gradients out (each slot is consumed before it is overwritten)
+    float g[3];
 #pragma unroll
-  for (int ch = 0; ch < 3; ch++) g[ch] = clamped[3 * (size_t)i + ch] ? 0.f : g_colors[3 * (size_t)i + ch];
-  float gdx = 0.f, gdy = 0.f, gdz = 0.f;  // dL/d(unit direction)
-  for (int k = 0; k < M; k++) {
-    if (k < nk) {
-      gs[3 * k] = b[k] * g[0]; gs[3 * k + 1] = b[k] * g[1]; gs[3 * k + 2] = b[k] * g[2];
-      const float s = sh[3 * k] * g[0] + sh[3 * k + 1] * g[1] + sh[3 * k + 2] * g[2];
-      gdx = lr_fma(bx[k], s, gdx); gdy = lr_fma(by[k], s, gdy); gdz = lr_fma(bz[k], s, gdz);
-    } else {
-      gs[3 * k] = 0.f; gs[3 * k + 1] = 0.f; gs[3 * k + 2] = 0.f;
+    for (int ch = 0; ch < 3; ch++) g[ch] = clamped[3 * (size_t)i + ch] ? 0.f : g_colors[3 * (size_t)i + ch];
+    float gdx = 0.f, gdy = 0.f, gdz = 0.f;  // dL/d(unit direction)
+    for (int k = 0; k < M; k++) {
+      if (k < nk) {
+        const float s = row[3 * k] * g[0] + row[3 * k + 1] * g[1] + row[3 * k + 2] * g[2];
+        row[3 * k] = b[k] * g[0]; row[3 * k + 1] = b[k] * g[1]; row[3 * k + 2] = b[k] * g[2];
+        gdx = lr_fma(bx[k], s, gdx); gdy = lr_fma(by[k], s, gdy); gdz = lr_fma(bz[k], s, gdz);
+      } else {
+        row[3 * k] = 0.f; row[3 * k + 1] = 0.f; row[3 * k + 2] = 0.f;
+      }
     }
+    // d = v/|v|  ->  dL/dv = (dL/dd - d (d . dL/dd)) / |v|
+    const float dot = x * gdx + y * gdy + z * gdz;
+    g_means[3 * (size_t)i + 0] += (gdx - x * dot) * inv;
+    g_means[3 * (size_t)i + 1] += (gdy - y * dot) * inv;
+    g_means[3 * (size_t)i + 2] += (gdz - z * dot) * inv;
   }
-  // d = v/|v|  ->  dL/dv = (dL/dd - d (d . dL/dd)) / |v|
-  const float dot = x * gdx + y * gdy + z * gdz;
-  g_means[3 * (size_t)i + 0] += (gdx - x * dot) * inv;
-  g_means[3 * (size_t)i + 1] += (gdy - y * dot) * inv;
-  g_means[3 * (size_t)i + 2] += (gdz - z * dot) * inv;
+  lr_sh_wave_sync();
+  lr_sh_wave_copy<false, ACCUMULATE>(wl, g_shs + (size_t)i0 * L, L, rows * L, lane);
 }
 
 void lr_launch_sh_fwd(int N, int deg, int M, const float* means, const float* campos, const float* shs, float* colors,
                       uint8_t* clamped, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(lr_sh_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, deg, M, means, campos, shs, colors, clamped);
+  const size_t lds = sizeof(float) * 4 * 64 * (size_t)(3 * M + 1);
+  hipLaunchKernelGGL(lr_sh_fwd_kernel, dim3((N + 255) / 256), dim3(256), lds, s, N, deg, M, means, campos, shs, colors, clamped);
 }
 void lr_launch_sh_bwd(int N, int deg, int M, const float* means, const float* campos, const float* shs,
-                      const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means, hipStream_t s) {
+                      const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means, bool accumulate,
+                      hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(lr_sh_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, deg, M, means, campos, shs, clamped,
-                     g_colors, g_shs, g_means);
+  const size_t lds = sizeof(float) * 4 * 64 * (size_t)(3 * M + 1);
+  if (accumulate)
+    hipLaunchKernelGGL(lr_sh_bwd_kernel<true>, dim3((N + 255) / 256), dim3(256), lds, s, N, deg, M, means, campos, shs,
+                       clamped, g_colors, g_shs, g_means);
+  else
+    hipLaunchKernelGGL(lr_sh_bwd_kernel<false>, dim3((N + 255) / 256), dim3(256), lds, s, N, deg, M, means, campos, shs,
+                       clamped, g_colors, g_shs, g_means);
 }

@@ -232,17 +232,19 @@ class HipBackend:
                                             _ptr(clamped), _stream_ptr(device)))
         return colors, clamped
 
-    def sh_backward(self, means3D, campos, shs, degree, clamped, g_colors, g_means3D):
-        """dL/dshs (new tensor); the view-direction gradient is added into g_means3D in place."""
+    def sh_backward(self, means3D, campos, shs, degree, clamped, g_colors, g_means3D, into=None):
+        """dL/dshs: a new tensor, or added into `into` (running sum; returns None).  The view-direction gradient is
+        added into g_means3D in place."""
         device = means3D.device
         L = self.require(device)
         N, M = shs.shape[0], shs.shape[1]
         cp = _dev_f32(campos, device).reshape(-1)
-        g_shs = torch.empty(N, M, 3, dtype=torch.float32, device=device)
+        g_shs = torch.empty(N, M, 3, dtype=torch.float32, device=device) if into is None else into
         with torch.cuda.device(device):
             _lib.check(L.lograst_sh_backward(N, int(degree), M, _ptr(means3D), _ptr(cp), _ptr(shs), _ptr(clamped),
-                                             _ptr(g_colors), _ptr(g_shs), _ptr(g_means3D), _stream_ptr(device)))
-        return g_shs
+                                             _ptr(g_colors), _ptr(g_shs), _ptr(g_means3D), 0 if into is None else 1,
+                                             _stream_ptr(device)))
+        return g_shs if into is None else None
 
     def project_backward(self, rs, flavour, use_filter, means3D, scales, rotations, radii, g_means2D, g_conic):
         """Stage A6b alone (lograst_project_backward): used by the parity tests."""
@@ -290,7 +292,7 @@ _grad_sink = None
 
 class accumulate_grads_into:
     """Context manager.  While active, every rasterizer backward ADDS its gradients w.r.t. means3D / scales /
-    rotations / opacities / colors_precomp straight into the given fp32 tensors (e.g. the views of a
+    rotations / opacities / colors_precomp (or, with an "shs" entry, the SH coefficients) straight into the given fp32 tensors (e.g. the views of a
     log_amd.dist.GradientBucket) instead of returning them to autograd: the reverse walk's atomics and the
     chain-rule kernel write into the step's running sums, so a multi-view step needs no per-view accumulate pass.
     means2D (per-view, consumed by LoG's Counter) is still returned normally.  The sink tensors must be
@@ -298,11 +300,11 @@ class accumulate_grads_into:
     no autograd gradient."""
 
     def __init__(self, sink):
-        need = ("means3D", "scales", "rotations", "opacities", "colors")
+        need = ("means3D", "scales", "rotations", "opacities") + (() if "shs" in sink else ("colors",))
         missing = [k for k in need if k not in sink]
         if missing:
             raise KeyError(f"gradient sink lacks {missing}")
-        for k in need:
+        for k in need + (("shs",) if "shs" in sink else ()):
             t = sink[k]
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError(f"gradient sink '{k}' must be a contiguous float32 tensor")
@@ -339,7 +341,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise ValueError("rasterizer inputs must be means3D[N,3], scales[N,3], rotations[N,4], "
                              "colors_precomp[N,3], opacities[N,1]")
         wants_grad = any(ctx.needs_input_grad[:7])   # all False under torch.no_grad()
-        scratch_floats = 0 if not wants_grad else (7 if (_grad_sink is not None and sh is None) else 11)
+        scratch_floats = 0 if not wants_grad else (7 if (_grad_sink is not None and (sh is None or "shs" in _grad_sink)) else 11)
         image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c,
                                                              scratch_floats=scratch_floats)
         ctx.rs, ctx.flavour, ctx.use_filter = rs, flavour, use_filter
@@ -359,14 +361,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         m2_shape, o_shape = ctx.shapes
         sh, clamped = ctx.sh
         sink = _grad_sink
-        if sink is not None and sh is None:
+        if sink is not None and (sh is None or "shs" in sink):
             n = m.shape[0]
             if not (sink["means3D"].shape == (n, 3) and sink["scales"].shape == (n, 3) and
                     sink["rotations"].shape == (n, 4) and sink["opacities"].numel() == n and
-                    sink["colors"].shape == (n, 3) and sink["means3D"].device == m.device):
+                    (sh is not None or sink["colors"].shape == (n, 3)) and sink["means3D"].device == m.device):
                 raise ValueError("gradient sink does not match the rasterizer inputs")
-            _, g_m2, _, _, _, _ = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved, grad_image,
-                                                    sink=sink)
+            if sh is None:
+                _, g_m2, _, _, _, _ = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
+                                                        grad_image, sink=sink)
+            else:
+                # colours are an intermediate here: their gradient goes to a zeroed scratch, then through the SH
+                # polynomial into the running dL/dshs (and the direction term into the running dL/dmeans3D)
+                if sink["shs"].shape != sh.shape or not sink["shs"].is_contiguous():
+                    raise ValueError("gradient sink 'shs' must be a contiguous tensor shaped like shs")
+                g_c = torch.zeros(n, 3, dtype=torch.float32, device=m.device)
+                _, g_m2, _, _, _, _ = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
+                                                        grad_image, sink=dict(sink, colors=g_c))
+                _backend.sh_backward(m, ctx.rs.campos, sh, int(ctx.rs.sh_degree), clamped, g_c, sink["means3D"],
+                                     into=sink["shs"])
             return None, g_m2.reshape(m2_shape), None, None, None, None, None, None, None, None
         g_m3, g_m2, g_c, g_o, g_s, g_r = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
                                                            grad_image)

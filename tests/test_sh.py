@@ -105,3 +105,45 @@ def test_module_shs_input_matches_colors_precomp_path(oracle_mod):
     ogs, ogm = oracle_mod.sh_backward(sc["xyz"], cam["camera_center"], shs_np, 2, ocl, colb.grad.cpu().numpy())
     assert rel_l2(shs.grad.cpu().numpy(), ogs) < 1e-4
     assert rel_l2((m3.grad - m3b.grad).cpu().numpy(), ogm) < 1e-3
+
+
+@pytest.mark.gpu
+def test_shs_gradients_through_the_running_sum_sink():
+    """accumulate_grads_into with an "shs" entry: two views add dL/dshs (and every other attribute) straight into the
+    step's running sums; same numbers as summing the per-view autograd gradients."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R
+    import gpu_util as G
+    cam, sc = small_case(n=1200, W=80, H=64, focal=90.0, seed=9, smax=0.08)
+    cam2, _ = small_case(n=1200, W=80, H=64, focal=90.0, seed=9, smax=0.08, view=2)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    shs_np = ((rng.random((1200, 16, 3), dtype=np.float32) - 0.5) * 1.5).astype(np.float32)
+    w = torch.tensor(rng.random((3, 64, 80), dtype=np.float32), device=dev)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=True)
+
+    def leaves():
+        return dict(means3D=T(sc["xyz"]), scales=T(sc["scaling"]), rotations=T(sc["rotation"]), opacities=T(sc["opacity"]),
+                    shs=T(shs_np))
+
+    def run(lv, sink):
+        for c in (cam, cam2):
+            rs = G.settings(c, (0.1, 0.2, 0.3), dev)._replace(sh_degree=3)
+            m2 = torch.zeros(1200, 3, device=dev, requires_grad=True)
+            out = GaussianRasterizer(raster_settings=rs)(means3D=lv["means3D"], means2D=m2, shs=lv["shs"],
+                                                         colors_precomp=None, opacities=lv["opacities"],
+                                                         scales=lv["scales"], rotations=lv["rotations"])
+            if sink is None:
+                out[0].backward(gradient=w)
+            else:
+                with R.accumulate_grads_into(sink):
+                    out[0].backward(gradient=w)
+
+    a = leaves()
+    run(a, None)
+    b = leaves()
+    sink = {k: torch.zeros_like(v) for k, v in b.items()}
+    run(b, sink)
+    for k in a:
+        assert b[k].grad is None
+        assert rel_l2(sink[k].cpu().numpy(), a[k].grad.cpu().numpy()) < 1e-5, k

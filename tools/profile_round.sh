@@ -25,5 +25,6 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLE
   SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $D/${TAG}_pmc_sq -o c2 -- $P > $D/${TAG}_pmc_sq.log 2>&1
 timeout 300 python tools/bench_knn.py > $D/knn_bench.log 2>&1
 timeout 300 python tools/bench_radius.py 10000000 > $D/radius_10M.log 2>&1
+timeout 300 python tools/bench_sh.py 10000000 3 8 > $D/sh_10M.log 2>&1
 tail -n 3 $D/pytest.log
 grep -h '^{' $D/b_default.log | cut -c1-400

@@ -66,7 +66,8 @@ const char* lograst_last_error(void);
 size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n);
 /* bytes of the projected-record array for N Gaussians */
 size_t lograst_geom_bytes(int32_t n);
-/* bytes of the (depth,id) key buffer / the sorted id list for `capacity` tile instances */
+/* bytes of the (depth,id) key buffer (keys + an equally large scratch half used by the long-list sort) / of the
+ * sorted id list, for `capacity` tile instances */
 size_t lograst_keys_bytes(uint32_t capacity);
 size_t lograst_list_bytes(uint32_t capacity);
 

@@ -23,7 +23,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
 void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s);
-void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
+void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
@@ -167,7 +167,7 @@ size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy)));
 }
 size_t lograst_geom_bytes(int32_t n) { return sizeof(float) * LOGRAST_REC_FLOATS * (size_t)(n > 0 ? n : 0); }
-size_t lograst_keys_bytes(uint32_t capacity) { return sizeof(uint64_t) * (size_t)capacity; }
+size_t lograst_keys_bytes(uint32_t capacity) { return 2 * sizeof(uint64_t) * (size_t)capacity; }  // keys + sort scratch
 size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }
 
 const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height) {

@@ -14,7 +14,7 @@
 #define LR_TILE 16
 
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
-// [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_SORT_BLOCK
+// [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_LONG_LIST
 // [4] tile instances of the plain rect rule (before the support cull; reporting only)
 // [5] support cull applied by the projection kernel (0/1)  [6] projection batch size (0 = unbatched)  [7..15] reserved
 // then per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic targets
@@ -27,7 +27,7 @@
 // then offsets[Tp]: exclusive offsets (T+1 entries)                                   -- read by sort/blend
 //   cursor[T*S]   fill cursor for the big instances, initialised to offset + ranked
 // then order[T]: tile ids by descending list length (longest-first dispatch order for the blend kernels)
-// then biglist[T]: ids of the tiles whose list exceeds LR_SORT_BLOCK keys (multi-block sort path)
+// then biglist[T]: ids of the tiles whose list exceeds LR_LONG_LIST keys (long-list sort paths; bit 31 = sorted)
 #ifndef LR_CTR_STRIDE
 #define LR_CTR_STRIDE 16
 #endif
@@ -41,6 +41,8 @@
 #define LR_HDR_CULL 5  // 1 if lr_project_kernel applied the support cull (the fill kernel must repeat it)
 #define LR_HDR_RECT 4  // tile instances of the plain rect rule (what the reference would sort), before the support cull
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
+#define LR_LONG_LIST 4096   // lists longer than this go to biglist[] (long-list sort paths)
+#define LR_LONG_DONE 0x80000000u  // biglist entry flag: the depth-bucket sort finished this tile
 #define LR_REC_QUADS 4  // float4 per projected record (64 B)
 __host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
 // header | ranked | big are contiguous: one memset clears everything a forward needs zeroed

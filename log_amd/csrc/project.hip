@@ -370,7 +370,7 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
       run += tot[k];
       atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u);
       lmax = max(lmax, tot[k]);
-      if (tot[k] > LR_SORT_BLOCK) biglist[atomicAdd(&state[LR_HDR_NBIG], 1u)] = t;  // rare: multi-block sort path
+      if (tot[k] > LR_LONG_LIST) biglist[atomicAdd(&state[LR_HDR_NBIG], 1u)] = t;  // long-list sort paths
     }
   }
 #pragma unroll

@@ -124,6 +124,305 @@ lr_sort_rb_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint
   for (uint32_t i = tid; i < L; i += NT) plist[beg + i] = (uint32_t)s[lr_phys(i)];
 }
 
+// ---- depth-bucket path -----------------------------------------------------------------------------------------
+// The keys of a tile are (depth, id) with depths spread over the tile's depth range, so a distribution sort does in
+// O(L) what the network does in O(L log^2 L): one workgroup per tile,
+//   1. keys -> LDS, min / max depth (LDS atomics);
+//   2. bucket = floor((depth - min) / (max - min) * nb), nb ~ L/2..L/4 buckets; the returning LDS atomic that counts the
+//      bucket also ranks the key inside it (integer LDS atomics run at ~7 per clock per CU);
+//   3. exclusive scan of the nb counts;
+//   4. scatter into bucket order;
+//   5. every key counts the keys of its own bucket that are smaller (full 64-bit compare: ties in depth fall in
+//      the same bucket and are ordered by id) and writes its id to list position bucket_start + that count.
+// Same total order, hence the same list as the network, bit for bit.  If the depths are so clustered that a bucket
+// holds more than LR_BUCKET_MAX keys the workgroup falls back to the network on the keys it already staged.
+#define LR_BUCKET_MAX 32
+// Final order inside buckets, one thread per BUCKET: consecutive threads read consecutive LDS addresses (every key
+// once, no bank conflicts -- ranking every key against its bucket read each key ~6 times from random banks and was
+// LDS-bandwidth bound), sort up to 8 keys in registers with the network's 8-key kernel, and write the ids in order.
+// Larger buckets (rare: the mean is 2-5 keys) are ranked by the same thread key by key.
+LR_DEV void lr_emit_bucket(const uint64_t* __restrict__ bk, uint32_t st, uint32_t en, uint32_t* __restrict__ out) {
+  const uint32_t n = en - st;   // bk[] and out[] are indexed by list position
+  if (n <= 8u) {
+    uint64_t r[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) r[m] = (uint32_t)m < n ? bk[st + m] : ~0ull;
+    lr_sort8(r);
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+      if ((uint32_t)m < n) out[st + m] = (uint32_t)r[m];
+  } else {
+    for (uint32_t a = st; a < en; a++) {
+      const uint64_t key = bk[a];
+      uint32_t smaller = 0;
+      for (uint32_t j = st; j < en; j++) smaller += bk[j] < key ? 1u : 0u;
+      out[st + smaller] = (uint32_t)key;
+    }
+  }
+}
+// LONG = false: blockIdx.x is the tile; the keys are also staged in network layout so that the workgroup can fall
+// back to the network by itself.  LONG = true: blockIdx.x indexes biglist[] (tiles above LR_LONG_LIST keys); no
+// staging (LDS budget) -- on clustered depths the entry is simply left unflagged for the fallback kernels.
+template <int NT, int KPT, bool LONG>
+__global__ void __launch_bounds__(NT)
+lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
+                      uint32_t* __restrict__ plist, uint32_t lo, uint32_t capacity) {
+  constexpr uint32_t CAP = NT * KPT;                       // longest list of this class (a power of two)
+  extern __shared__ __attribute__((aligned(16))) uint64_t s[];  // [A[CAP + CAP/8] (network layout)] | B[CAP] | cnt[CAP/4]
+  uint64_t* const A = s;
+  uint64_t* const Bk = LONG ? s : s + (CAP + (CAP >> 3));
+  uint32_t* const cnt = reinterpret_cast<uint32_t*>(Bk + CAP);
+  __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[NT / 64];
+  if (state[LR_HDR_NUM] > capacity) return;
+  if (LONG && blockIdx.x >= state[LR_HDR_NBIG]) return;
+  const uint32_t* offsets = state + lr_offsets_off(tiles);
+  const uint32_t tile = LONG ? (state[lr_biglist_off(tiles) + blockIdx.x] & ~LR_LONG_DONE) : blockIdx.x;
+  const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg;
+  if (L <= lo || L > CAP) return;
+  const uint32_t tid = threadIdx.x;
+  uint32_t P2 = 8;
+  while (P2 < L) P2 <<= 1;
+  const uint32_t nb = max(P2 >> 2, 8u);                    // buckets (power of two, >= L/4; cnt[] holds CAP/4)
+  if (tid == 0) { sh_min = 0xffffffffu; sh_max = 0u; sh_maxcnt = 0u; }
+  for (uint32_t b = tid; b < nb; b += NT) cnt[b] = 0u;
+  uint64_t key[KPT];
+  uint32_t dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+  for (int k = 0; k < KPT; k++) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    key[k] = i < L ? keys[beg + i] : ~0ull;
+    if (!LONG && i < P2) A[lr_phys(i)] = key[k];           // staged for the fallback
+    if (i < L) { const uint32_t d = (uint32_t)(key[k] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
+  }
+  __syncthreads();
+  atomicMin(&sh_min, dmin);
+  atomicMax(&sh_max, dmax);
+  __syncthreads();
+  const float fmin = __uint_as_float(sh_min), range = __uint_as_float(sh_max) - fmin;
+  const float scale = (float)nb / range;                   // inf / nan when range == 0: every key lands in bucket 0
+  uint32_t bkt[KPT], rnk[KPT];
+#pragma unroll
+  for (int k = 0; k < KPT; k++) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    bkt[k] = 0u; rnk[k] = 0u;
+    if (i < L) {
+      const float rel = (__uint_as_float((uint32_t)(key[k] >> 32)) - fmin) * scale;
+      const uint32_t b = rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;   // NaN (range == 0) -> 0
+      bkt[k] = b;
+      rnk[k] = atomicAdd(&cnt[b], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of cnt[0..nb): thread t owns counters [t*per, (t+1)*per)
+  const uint32_t per = (nb + NT - 1) / NT;
+  uint32_t local = 0, lmax = 0;
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t b = tid * per + q;
+    const uint32_t c = b < nb ? cnt[b] : 0u;
+    local += c; lmax = max(lmax, c);
+  }
+  uint32_t inc = local;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(inc, d);
+    if ((int)(tid & 63u) >= d) inc += up;
+  }
+  if ((tid & 63u) == 63u) wave_tot[tid >> 6] = inc;
+  atomicMax(&sh_maxcnt, lmax);
+  __syncthreads();
+  uint32_t run = inc - local;
+  for (uint32_t w = 0; w < (tid >> 6); w++) run += wave_tot[w];
+  if (sh_maxcnt > LR_BUCKET_MAX) {                         // clustered depths: the network, on the staged keys
+    if (LONG) return;                                       // ... or the fallback kernels
+    __syncthreads();
+    lr_lds_sort<NT>(A, P2, tid);
+    for (uint32_t i = tid; i < L; i += NT) plist[beg + i] = (uint32_t)A[lr_phys(i)];
+    return;
+  }
+  __syncthreads();                                          // every thread has read its counts
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t b = tid * per + q;
+    if (b < nb) { const uint32_t c = cnt[b]; cnt[b] = run; run += c; }   // cnt becomes the bucket start
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < KPT; k++) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    if (i < L) Bk[cnt[bkt[k]] + rnk[k]] = key[k];
+  }
+  __syncthreads();
+  // every key counts the smaller keys of its own bucket (short lists: more threads than buckets, so one thread per
+  // key beats one per bucket here -- measured both ways)
+#pragma unroll
+  for (int k = 0; k < KPT; k++) {
+    const uint32_t i = tid + (uint32_t)k * NT;
+    if (i < L) {
+      const uint32_t b = bkt[k], st = cnt[b], en = (b + 1u < nb) ? cnt[b + 1u] : L;
+      uint32_t smaller = 0;
+      for (uint32_t j = st; j < en; j++) smaller += Bk[j] < key[k] ? 1u : 0u;
+      plist[beg + st + smaller] = (uint32_t)key[k];
+    }
+  }
+  if (LONG && tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
+}
+static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
+  return (staged ? sizeof(uint64_t) * (size_t)(cap + (cap >> 3)) : 0) + sizeof(uint64_t) * cap + sizeof(uint32_t) * (cap >> 2);
+}
+
+// ---- long lists: the same depth-bucket sort, keys in memory ----------------------------------------------------
+// One 1024-thread workgroup per long tile (biglist entry); bucket counters in LDS, keys streamed from memory:
+//   pass 1  min / max depth;
+//   pass 2  bucket + rank of every key (returning LDS atomic); a 4-byte (bucket, rank) code per key goes to the
+//           scratch half of the key buffer (coalesced);
+//   scan    bucket starts;
+//   then, window by window (LR_LONG_WIN list positions, cut at bucket boundaries): every key whose destination falls
+//           into the window (known from its code: 4 B re-read per key and window, cache-resident) is fetched and
+//           dropped into an LDS copy of that window, ranked inside its bucket there, and its id written to its final
+//           list position.
+// Nothing is scattered through memory except the final ids inside one window at a time (an earlier version scattered
+// the keys into a bucket-ordered scratch copy: 8-byte stores all over a 160 KB region from 512 concurrent workgroups
+// cost more HBM traffic than the whole network sort).  O(L) work instead of n log^2 n; a tile whose depths are too
+// clustered (a bucket above LR_BUCKET_MAX keys) is left to the network paths below, a finished one is flagged in
+// its biglist entry so that they skip it.
+#define LR_LONG_NB 4096     // bucket counters in LDS
+#define LR_LONG_WIN 6144    // list positions ranked in LDS at a time
+__global__ void __launch_bounds__(1024)
+lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
+                    uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity) {
+  extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
+  uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
+  __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[16];
+  if (state[LR_HDR_NUM] > capacity || blockIdx.x >= state[LR_HDR_NBIG]) return;
+  const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
+  if (entry & LR_LONG_DONE) return;                        // (LR_LONG_LIST, LR_SORT_BLOCK]: done in LDS
+  const uint32_t tile = entry;
+  const uint32_t* offsets = state + lr_offsets_off(tiles);
+  const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg, tid = threadIdx.x;
+  const uint64_t* k = keys + beg;
+  uint32_t* rk = ranks + beg;
+  uint32_t* pl = plist + beg;
+  uint32_t P2 = 8;
+  while (P2 < L) P2 <<= 1;
+  const uint32_t nb = min((uint32_t)LR_LONG_NB, P2 >> 1);
+  if (tid == 0) { sh_min = 0xffffffffu; sh_max = 0u; sh_maxcnt = 0u; }
+  for (uint32_t b = tid; b < nb; b += 1024) lcnt[b] = 0u;
+  uint32_t dmin = 0xffffffffu, dmax = 0u;
+  // (the streaming loops are unrolled by hand: four independent loads in flight per thread)
+  for (uint32_t i = tid; i < L; i += 4096) {
+    uint64_t kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + u * 1024u < L) { const uint32_t d = (uint32_t)(kk[u] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
+  }
+  __syncthreads();
+  atomicMin(&sh_min, dmin);
+  atomicMax(&sh_max, dmax);
+  __syncthreads();
+  const float fmin = __uint_as_float(sh_min), range = __uint_as_float(sh_max) - fmin;
+  const float scale = (float)nb / range;
+  auto bucket_of = [&](uint64_t key) -> uint32_t {
+    const float rel = (__uint_as_float((uint32_t)(key >> 32)) - fmin) * scale;
+    return rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;  // NaN (range == 0) -> bucket 0
+  };
+  for (uint32_t i = tid; i < L; i += 4096) {               // rank inside the bucket
+    uint64_t kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + u * 1024u < L) {                             // (bucket, rank) code: all a window pass needs to skip a key
+        const uint32_t b = bucket_of(kk[u]);
+        rk[i + u * 1024u] = (b << 8) | min(atomicAdd(&lcnt[b], 1u), 255u);
+      }
+  }
+  __syncthreads();
+  const uint32_t per = (nb + 1023u) / 1024u;
+  uint32_t local = 0, lmax = 0;
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t b = tid * per + q;
+    const uint32_t c = b < nb ? lcnt[b] : 0u;
+    local += c; lmax = max(lmax, c);
+  }
+  uint32_t inc = local;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(inc, d);
+    if ((int)(tid & 63u) >= d) inc += up;
+  }
+  if ((tid & 63u) == 63u) wave_tot[tid >> 6] = inc;
+  atomicMax(&sh_maxcnt, lmax);
+  __syncthreads();
+  if (sh_maxcnt > LR_BUCKET_MAX) return;                    // clustered depths: network fallback (entry stays unflagged)
+  uint32_t run = inc - local;
+  for (uint32_t w = 0; w < (tid >> 6); w++) run += wave_tot[w];
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t b = tid * per + q;
+    if (b < nb) { const uint32_t c = lcnt[b]; lcnt[b] = run; run += c; }   // lcnt[b] = first list position of bucket b
+  }
+  __syncthreads();
+  // windows of whole buckets: [b0, b1) with start(b1) - start(b0) <= LR_LONG_WIN (a bucket holds <= LR_BUCKET_MAX keys)
+  uint32_t b0 = 0;
+  while (b0 < nb) {
+    const uint32_t w0 = lcnt[b0];
+    uint32_t lo_b = b0 + 1u, hi_b = nb;                    // largest b1 in (b0, nb] with start(b1) <= w0 + WIN
+    while (lo_b < hi_b) {
+      const uint32_t mid = (lo_b + hi_b + 1u) >> 1;
+      const uint32_t st_mid = mid < nb ? lcnt[mid] : L;
+      if (st_mid <= w0 + (uint32_t)LR_LONG_WIN) lo_b = mid; else hi_b = mid - 1u;
+    }
+    const uint32_t b1 = lo_b;                              // window = list positions [start(b0), start(b1))
+    for (uint32_t i = tid; i < L; i += 4096) {             // 4 B per key; the 8-byte key only if it lands in this window
+      uint32_t cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) cc[u] = (i + u * 1024u < L) ? rk[i + u * 1024u] : 0xffffffffu;
+      uint64_t kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {                          // all four key loads in flight before the first is used
+        const uint32_t b = cc[u] >> 8;                       // cc == ~0 (past the end): b = 2^24-1 >= nb
+        kv[u] = (b >= b0 && b < b1) ? k[i + u * 1024u] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t b = cc[u] >> 8;
+        if (b >= b0 && b < b1) win[lcnt[b] + (cc[u] & 255u) - w0] = kv[u];
+      }
+    }
+    __syncthreads();
+    for (uint32_t b = b0 + tid; b < b1; b += 1024)
+      lr_emit_bucket(win - w0, lcnt[b], (b + 1u < nb) ? lcnt[b + 1u] : L, pl);   // win[] holds positions [w0, w1)
+    __syncthreads();
+    b0 = b1;
+  }
+
+  if (tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
+}
+
+static inline size_t lr_long_lds_bytes() {
+  return sizeof(uint32_t) * LR_LONG_NB + sizeof(uint64_t) * (LR_LONG_WIN + LR_BUCKET_MAX);
+}
+
+// Single-block network fallback for long tiles of (LR_LONG_LIST, LR_SORT_BLOCK] keys the bucket sort gave up on.
+__global__ void __launch_bounds__(256)
+lr_sort_long_fallback_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
+                             uint32_t* __restrict__ plist, uint32_t capacity) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t s[];
+  if (state[LR_HDR_NUM] > capacity || blockIdx.x >= state[LR_HDR_NBIG]) return;
+  const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
+  if (entry & LR_LONG_DONE) return;
+  const uint32_t* offsets = state + lr_offsets_off(tiles);
+  const uint32_t beg = offsets[entry], L = offsets[entry + 1] - beg;
+  if (L > LR_SORT_BLOCK) return;                            // hybrid path
+  const uint32_t tid = threadIdx.x;
+  uint32_t P2 = 8;
+  while (P2 < L) P2 <<= 1;
+  for (uint32_t i = tid; i < P2; i += 256) s[lr_phys(i)] = i < L ? keys[beg + i] : ~0ull;
+  __syncthreads();
+  lr_lds_sort<256>(s, P2, tid);
+  for (uint32_t i = tid; i < L; i += 256) plist[beg + i] = (uint32_t)s[lr_phys(i)];
+}
+
 // ---- lists longer than LR_SORT_BLOCK: hybrid network ------------------------------------------------------------
 // The same ascending-only bitonic network over the tile's whole list, split by stride: levels whose stride is
 // >= LR_SORT_BLOCK are single streaming passes over the tile's slice of the key buffer in global memory (one
@@ -136,10 +435,13 @@ struct LrBigTile { uint32_t beg, L, P2; bool ok; };
 LR_DEV LrBigTile lr_big_tile(const uint32_t* __restrict__ state, uint32_t tiles, uint32_t capacity) {
   LrBigTile t{0u, 0u, 0u, false};
   if (state[LR_HDR_NUM] > capacity || blockIdx.x >= state[LR_HDR_NBIG]) return t;
-  const uint32_t tile = state[lr_biglist_off(tiles) + blockIdx.x];
+  const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
+  if (entry & LR_LONG_DONE) return t;  // the depth-bucket sort already produced this tile's list
+  const uint32_t tile = entry;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   t.beg = offsets[tile];
   t.L = offsets[tile + 1] - t.beg;
+  if (t.L <= LR_SORT_BLOCK) return t;  // (LR_LONG_LIST, LR_SORT_BLOCK]: the single-block fallback takes it
   t.P2 = LR_SORT_BLOCK;
   while (t.P2 < t.L) t.P2 <<= 1;
   t.ok = true;
@@ -227,7 +529,7 @@ static inline size_t lr_sort_lds_bytes(uint32_t cap) { return sizeof(uint64_t) *
 
 // max_len: upper bound on the longest tile list known to the HOST (exact count from stage 1, a hint in sync-free
 // operation, or 0 = unknown -> assume `capacity`).  It only decides how many multi-block levels are launched.
-void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
+void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     uint32_t max_len, hipStream_t s) {
   if (tiles == 0) return;
   static bool attr_set = false;
@@ -235,44 +537,83 @@ void lr_launch_sort(const uint32_t* state, uint32_t tiles, uint64_t* keys, uint3
     const int big = (int)lr_sort_lds_bytes(LR_SORT_BLOCK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_rb_kernel<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_fallback_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_bigsort_blocks_kernel<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_bigsort_tail_kernel<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_bucket_kernel<256, 16, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_bucket_lds_bytes(4096));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_bucket_kernel<512, 16, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_bucket_lds_bytes(LR_SORT_BLOCK, false));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_long_lds_bytes());
     attr_set = true;
   }
   if (max_len == 0 || max_len > capacity) max_len = capacity;
-  lr_prof_begin(LRK_SORT_SMALL, s);
-  hipLaunchKernelGGL(lr_sort_rb_kernel<64>, dim3(tiles), dim3(64), lr_sort_lds_bytes(LR_SORT_CAP0), s, state, tiles,
-                     keys, plist, 0u, (uint32_t)LR_SORT_CAP0, capacity);
-  lr_prof_end(LRK_SORT_SMALL, s);
-  if (max_len > LR_SORT_CAP0) {
-    lr_prof_begin(LRK_SORT_LARGE, s);
-    hipLaunchKernelGGL(lr_sort_rb_kernel<256>, dim3(tiles), dim3(256), lr_sort_lds_bytes(LR_SORT_CAP1), s, state, tiles,
-                       keys, plist, (uint32_t)LR_SORT_CAP0, (uint32_t)LR_SORT_CAP1, capacity);
-    if (max_len > LR_SORT_CAP1)
-      hipLaunchKernelGGL(lr_sort_rb_kernel<256>, dim3(tiles), dim3(256), lr_sort_lds_bytes(LR_SORT_CAP2), s, state,
-                         tiles, keys, plist, (uint32_t)LR_SORT_CAP1, (uint32_t)LR_SORT_CAP2, capacity);
-    lr_prof_end(LRK_SORT_LARGE, s);
-  }
-  if (max_len > LR_SORT_BLOCK) {
-    // every big tile holds more than LR_SORT_BLOCK keys, so there are at most capacity / LR_SORT_BLOCK of them
-    const uint32_t nbig = min(tiles, capacity / LR_SORT_BLOCK + 1u);
-    const uint32_t nblk = (max_len + LR_SORT_BLOCK - 1u) / LR_SORT_BLOCK;
-    const uint32_t ypass = min(64u, max(1u, nblk * 4u));  // workgroups per tile for the streaming passes
-    const size_t lds = lr_sort_lds_bytes(LR_SORT_BLOCK);
-    lr_prof_begin(LRK_SORT_HUGE, s);
-    hipLaunchKernelGGL(lr_bigsort_blocks_kernel<512>, dim3(nbig, nblk), dim3(512), lds, s, state, tiles, keys, capacity);
-    for (uint64_t k = 2ull * LR_SORT_BLOCK; (k >> 1) < max_len; k <<= 1) {
-      hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nbig, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
-                         (uint32_t)k, 0u);
-      for (uint64_t j = k >> 2; j >= LR_SORT_BLOCK; j >>= 1)
-        hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nbig, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
-                           (uint32_t)k, (uint32_t)j);
-      hipLaunchKernelGGL(lr_bigsort_tail_kernel<512>, dim3(nbig, nblk), dim3(512), lds, s, state, tiles, keys, capacity,
-                         (uint32_t)k);
+  // LOGRAST_BUCKET_SORT=0: bitonic network only (the reference implementation of the same total order)
+  static const int bucket = lr_env_int("LOGRAST_BUCKET_SORT", 1);
+  // biglist holds the tiles with more than LR_LONG_LIST keys, so there are at most capacity / LR_LONG_LIST of them
+  const uint32_t nlong = min(tiles, capacity / LR_LONG_LIST + 1u);
+  if (bucket) {
+    // network for tiny lists (one wave), depth buckets in LDS up to LR_LONG_LIST keys
+    lr_prof_begin(LRK_SORT_SMALL, s);
+    hipLaunchKernelGGL(lr_sort_rb_kernel<64>, dim3(tiles), dim3(64), lr_sort_lds_bytes(128), s, state, tiles, keys, plist,
+                       0u, 128u, capacity);
+    hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 4, false>), dim3(tiles), dim3(256), lr_bucket_lds_bytes(1024), s, state,
+                       tiles, keys, plist, 128u, capacity);
+    lr_prof_end(LRK_SORT_SMALL, s);
+    if (max_len > 1024u) {
+      lr_prof_begin(LRK_SORT_LARGE, s);
+      hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 16, false>), dim3(tiles), dim3(256), lr_bucket_lds_bytes(LR_LONG_LIST), s,
+                         state, tiles, keys, plist, 1024u, capacity);
+      lr_prof_end(LRK_SORT_LARGE, s);
     }
-    hipLaunchKernelGGL(lr_bigsort_emit_kernel, dim3(nbig, ypass), dim3(256), 0, s, state, tiles, keys, plist, capacity);
+  } else {
+    lr_prof_begin(LRK_SORT_SMALL, s);
+    hipLaunchKernelGGL(lr_sort_rb_kernel<64>, dim3(tiles), dim3(64), lr_sort_lds_bytes(LR_SORT_CAP0), s, state, tiles,
+                       keys, plist, 0u, (uint32_t)LR_SORT_CAP0, capacity);
+    lr_prof_end(LRK_SORT_SMALL, s);
+    if (max_len > LR_SORT_CAP0) {
+      lr_prof_begin(LRK_SORT_LARGE, s);
+      hipLaunchKernelGGL(lr_sort_rb_kernel<256>, dim3(tiles), dim3(256), lr_sort_lds_bytes(LR_SORT_CAP1), s, state, tiles,
+                         keys, plist, (uint32_t)LR_SORT_CAP0, (uint32_t)LR_SORT_CAP1, capacity);
+      if (max_len > LR_SORT_CAP1)
+        hipLaunchKernelGGL(lr_sort_rb_kernel<256>, dim3(tiles), dim3(256), lr_sort_lds_bytes(LR_SORT_CAP2), s, state,
+                           tiles, keys, plist, (uint32_t)LR_SORT_CAP1, (uint32_t)LR_SORT_CAP2, capacity);
+      lr_prof_end(LRK_SORT_LARGE, s);
+    }
+  }
+  if (max_len > LR_LONG_LIST && (bucket || max_len > LR_SORT_BLOCK)) {
+    lr_prof_begin(LRK_SORT_HUGE, s);
+    if (bucket) {
+      // long lists: depth buckets in LDS up to LR_SORT_BLOCK keys (keys held in registers), with the keys in memory
+      // beyond; what they give up on falls through to the networks
+      hipLaunchKernelGGL((lr_sort_bucket_kernel<512, 16, true>), dim3(nlong), dim3(512),
+                         lr_bucket_lds_bytes(LR_SORT_BLOCK, false), s, state, tiles, keys, plist, (uint32_t)LR_LONG_LIST,
+                         capacity);
+      hipLaunchKernelGGL(lr_sort_long_kernel, dim3(nlong), dim3(1024), lr_long_lds_bytes(), s, state, tiles,
+                         keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity);
+      hipLaunchKernelGGL(lr_sort_long_fallback_kernel, dim3(nlong), dim3(256), lr_sort_lds_bytes(LR_SORT_BLOCK), s, state,
+                         tiles, keys, plist, capacity);
+    }
+    if (max_len > LR_SORT_BLOCK) {
+      const uint32_t nblk = (max_len + LR_SORT_BLOCK - 1u) / LR_SORT_BLOCK;
+      const uint32_t ypass = min(64u, max(1u, nblk * 4u));  // workgroups per tile for the streaming passes
+      const size_t lds = lr_sort_lds_bytes(LR_SORT_BLOCK);
+      hipLaunchKernelGGL(lr_bigsort_blocks_kernel<512>, dim3(nlong, nblk), dim3(512), lds, s, state, tiles, keys, capacity);
+      for (uint64_t k = 2ull * LR_SORT_BLOCK; (k >> 1) < max_len; k <<= 1) {
+        hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nlong, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
+                           (uint32_t)k, 0u);
+        for (uint64_t j = k >> 2; j >= LR_SORT_BLOCK; j >>= 1)
+          hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nlong, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
+                             (uint32_t)k, (uint32_t)j);
+        hipLaunchKernelGGL(lr_bigsort_tail_kernel<512>, dim3(nlong, nblk), dim3(512), lds, s, state, tiles, keys, capacity,
+                           (uint32_t)k);
+      }
+      hipLaunchKernelGGL(lr_bigsort_emit_kernel, dim3(nlong, ypass), dim3(256), 0, s, state, tiles, keys, plist, capacity);
+    }
     lr_prof_end(LRK_SORT_HUGE, s);
   }
 }

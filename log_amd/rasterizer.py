@@ -158,7 +158,7 @@ class HipBackend:
                                                      _ptr(opacities), _ptr(colors), _ptr(radii), _ptr(geom),
                                                      _ptr(state), None, None, stream))
                 capacity, max_len = _capacity_hint, _max_len_hint
-            keys = torch.empty(capacity, dtype=torch.int64, device=device)
+            keys = torch.empty(L.lograst_keys_bytes(capacity) // 8, dtype=torch.int64, device=device)
             plist = torch.empty(capacity, **i32)
             image = torch.empty(3, H, W, **f32)
             final_T = torch.empty(H, W, **f32)

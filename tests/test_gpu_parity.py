@@ -38,10 +38,23 @@ def _case(name):
             sc["xyz"][start:start + k] = sc["xyz"][start:start + k] * 0.02 + c
             start += k
         return cam, sc
+    if name.startswith("flat_depth_"):
+        # all Gaussians at (almost) the same view depth, n of them inside one or two tiles: the depth-bucket sorts overflow
+        # their buckets and every size class must fall back to the network (LDS class, long LDS class, hybrid)
+        n = int(name.split("_")[-1])
+        cam, sc = small_case(n=n, W=64, H=64, focal=70.0, seed=11, smax=0.01)
+        sc["xyz"] *= 0.05
+        Wm = np.asarray(cam["world_view_transform"], np.float64)
+        pv = sc["xyz"].astype(np.float64) @ Wm[:3, :3] + Wm[3, :3]
+        levels = np.random.default_rng(12).integers(0, 3, size=n)             # three distinct depths, many ties
+        pv[:, 2] = pv[:, 2].mean() + 1e-3 * levels
+        sc["xyz"] = ((pv - Wm[3, :3]) @ np.linalg.inv(Wm[:3, :3])).astype(np.float32)
+        return cam, sc
     raise KeyError(name)
 
 
-CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "dense_tile", "huge_tiles"]
+CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "dense_tile", "huge_tiles", "flat_depth_3000",
+         "flat_depth_6000", "flat_depth_14000"]
 
 
 @pytest.mark.parametrize("name", CASES)

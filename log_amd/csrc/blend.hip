@@ -361,51 +361,56 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                                 lr_fma2(lr_f2{q01.x, q11.x} * dy2, hdy2, lr_f2{-bdx.x, -bdx.y} * dy2));
       const lr_f2 G2 = lr_exp2(pw2);
       const lr_f2 al2 = lr_f2{op0, op1} * G2;
-      const float dx0 = dx2.x, dx1 = dx2.y, dy0 = dy2.x, dy1 = dy2.y;
       const float power0 = pw2.x, power1 = pw2.y, G0 = G2.x, G1 = G2.y;
       const float alpha0 = fminf(0.99f, al2.x), alpha1 = fminf(0.99f, al2.y);
       const int k0 = hi - 1 - j0, k1 = hi - 1 - j1;  // 0-based positions in the tile list
       const bool hit0 = (k0 < lastc) & !(power0 > 0.f) & !(alpha0 < 1.0f / 255.0f);
       const bool hit1 = has1 & (k1 < lastc) & !(power1 > 0.f) & !(alpha1 < 1.0f / 255.0f);
+      const bool any0 = __builtin_amdgcn_ballot_w64(hit0) != 0, any1 = __builtin_amdgcn_ballot_w64(hit1) != 0;
+      if (!(any0 | any1)) continue;
+      // Both entries of the pair go through ONE 2-wide body (v_pk_* f32: two entries per instruction).  Lanes that do
+      // not contribute run it with alpha = G = 0, which leaves their state untouched exactly (T*1, 0*c + 1*acc) and
+      // makes all nine of their partial sums exact zeros -- no exec masking, no zero-initialised accumulators.  Only T
+      // and the colour behind the current entry (acc <- alpha c + (1-alpha) acc) chain from entry 0 to entry 1.
+      const lr_f2 alpha = {hit0 ? alpha0 : 0.f, hit1 ? alpha1 : 0.f};
+      const lr_f2 G = {hit0 ? G0 : 0.f, hit1 ? G1 : 0.f};
+      const lr_f2 om = 1.f - alpha;
+      lr_f2 rc = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+      rc = lr_fma2(lr_fma2(-om, rc, lr_f2{1.f, 1.f}), rc, rc);  // one Newton step on v_rcp_f32
+      const float Ta = T * rc.x, Tb = Ta * rc.y;                // T in front of entry 0 / entry 1
+      const lr_f2 T2 = {Ta, Tb};
+      T = Tb;
+      const lr_f2 w = alpha * T2;
+      const lr_f2 cr = {q01.z, q11.z}, cg = {q01.w, q11.w}, cbl = {cbl0, cbl1};
+      const float a0r = lr_fma(alpha.x, cr.x, om.x * acc0), a0g = lr_fma(alpha.x, cg.x, om.x * acc1),
+                  a0b = lr_fma(alpha.x, cbl.x, om.x * acc2);   // colour behind entry 1
+      lr_f2 dL_dalpha = lr_fma2(cr - lr_f2{acc0, a0r}, lr_f2{dp0, dp0},
+                                lr_fma2(cg - lr_f2{acc1, a0g}, lr_f2{dp1, dp1}, (cbl - lr_f2{acc2, a0b}) * dp2));
+      dL_dalpha = lr_fma2(dL_dalpha, T2, -(Tf * rc) * bgdot);
+      acc0 = lr_fma(alpha.y, cr.y, om.y * a0r);
+      acc1 = lr_fma(alpha.y, cg.y, om.y * a0g);
+      acc2 = lr_fma(alpha.y, cbl.y, om.y * a0b);
+      const lr_f2 Ar = {q00.z, q10.z}, Br = {q00.w, q10.w}, Cr = {q01.x, q11.x};
+      const lr_f2 dL_dG = lr_f2{op0, op1} * dL_dalpha;
+      const lr_f2 gdx = G * dx2, gdy = G * dy2;
+      const lr_f2 dG_ddx = lr_fma2(-Ar, gdx, -(Br * gdy));     // -gdx*A - gdy*B
+      const lr_f2 dG_ddy = lr_fma2(-Cr, gdy, -(Br * gdx));     // -gdy*C - gdx*B
+      // slot order chosen so that lr_reduce9's rows land on contiguous destinations:
+      //   r0 rows = (s0,s2,s1,s3) = (col r, col g, col b, opacity); r1 rows = (s4,s6,s5,s7) = (mean x, mean y, conic A, conic B); r2 = conic C
+      lr_f2 s2[9];
+      s2[0] = w * dp0; s2[2] = w * dp1; s2[1] = w * dp2; s2[3] = G * dL_dalpha;
+      s2[4] = dL_dG * dG_ddx * sx; s2[6] = dL_dG * dG_ddy * sy;
+      s2[5] = -0.5f * gdx * dx2 * dL_dG; s2[7] = -gdx * dy2 * dL_dG;
+      s2[8] = -0.5f * gdy * dy2 * dL_dG;
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        const bool hit = e ? hit1 : hit0;
-        if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
-        const int j = e ? j1 : j0;
-        const float Ar = e ? q10.z : q00.z, Br = e ? q10.w : q00.w, Cr = e ? q11.x : q01.x, op = e ? op1 : op0;
-        const float dx = e ? dx1 : dx0, dy = e ? dy1 : dy0;
-        const float cr = e ? q11.z : q01.z, cg = e ? q11.w : q01.w, cbl = e ? cbl1 : cbl0;
+        if (!(e ? any1 : any0)) continue;                       // wave-uniform: nothing to commit for this entry
         const int gid = e ? gid1 : gid0;
-        (void)j;
-        // Branch-free body: lanes that do not contribute run it with alpha = G = 0, which leaves their state
-        // untouched exactly (T*1, 0*c + 1*acc) and makes all nine of their partial sums exact zeros -- no exec
-        // masking, no zero-initialised accumulators.  The colour behind the current entry is folded eagerly
-        // (acc <- alpha c + (1-alpha) acc after use), the same operations the lazy form performs one hit later.
-        const float alpha = hit ? (e ? alpha1 : alpha0) : 0.f;
-        const float G = hit ? (e ? G1 : G0) : 0.f;
-        const float om = 1.f - alpha;
-        float rc = __builtin_amdgcn_rcpf(om);
-        rc = lr_fma(lr_fma(-om, rc, 1.f), rc, rc);  // one Newton step on v_rcp_f32
-        T = T * rc;
-        const float w = alpha * T;
-        float dL_dalpha = lr_fma(cr - acc0, dp0, lr_fma(cg - acc1, dp1, (cbl - acc2) * dp2));
-        dL_dalpha = lr_fma(dL_dalpha, T, -(Tf * rc) * bgdot);
-        acc0 = lr_fma(alpha, cr, om * acc0);
-        acc1 = lr_fma(alpha, cg, om * acc1);
-        acc2 = lr_fma(alpha, cbl, om * acc2);
-        const float dL_dG = op * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddx = lr_fma(-Ar, gdx, -(Br * gdy));  // -gdx*A - gdy*B
-        const float dG_ddy = lr_fma(-Cr, gdy, -(Br * gdx));  // -gdy*C - gdx*B
-        // slot order chosen so that lr_reduce9's rows land on contiguous destinations:
-        //   r0 rows = (s0,s2,s1,s3) = (col r, col g, col b, opacity); r1 rows = (s4,s6,s5,s7) = (mean x, mean y, conic A, conic B); r2 = conic C
-        float s[9];
-        s[0] = w * dp0; s[2] = w * dp1; s[1] = w * dp2; s[3] = G * dL_dalpha;
-        s[4] = dL_dG * dG_ddx * sx; s[6] = dL_dG * dG_ddy * sy;
-        s[5] = -0.5f * gdx * dx * dL_dG; s[7] = -gdx * dy * dL_dG;
-        s[8] = -0.5f * gdy * dy * dL_dG;
+        float sv[9];
+#pragma unroll
+        for (int m = 0; m < 9; m++) sv[m] = e ? s2[m].y : s2[m].x;
         float r0, r1, r2;
-        lr_reduce9(s, r0, r1, r2);
+        lr_reduce9(sv, r0, r1, r2);
         if (lead) atomicAdd(base0 + (size_t)gid * mul0, r0);
         if (lead || lane == 1) atomicAdd(base1 + (size_t)gid * mul1, lane == 1 ? r2 : r1);
       }

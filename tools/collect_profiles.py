@@ -56,7 +56,7 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
                 cnt[k] += 1
         return {k: agg[k] / cnt[k] for k in agg}
     f, w = load(fe, "FETCH_SIZE"), load(wr, "WRITE_SIZE")
-    names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_fwd_kernel<true>": "blend_fwd", "lr_project_kernel": "project",
+    names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_fwd_kernel<true>": "blend_fwd", "lr_project_kernel": "project", "lr_project_batched_kernel": "project",
              "lr_fill_kernel": "fill_keys", "lr_project_bwd_kernel<true>": "project_bwd"}
     tj = os.path.join(P, f"{tag}_traffic.json")
     d = json.load(open(tj)) if os.path.exists(tj) else {

@@ -69,7 +69,7 @@ static std::atomic<int> g_tile_cull{-1};
 static uint32_t lr_pick_batch(int32_t n, uint32_t tiles) {
   static const int forced = lr_env_int("LOGRAST_BATCH", -1);
   if (n <= 0 || tiles > LR_BATCH_MAX_TILES || forced == 0) return 0u;
-  if (forced > 0) return (uint32_t)((forced + 1023) / 1024 * 1024);
+  if (forced > 0) return (uint32_t)((forced > 32768 ? 32768 : forced) + 1023) / 1024u * 1024u;  // 16-bit LDS counts
   uint32_t b = ((uint32_t)n / 256u + 1023u) / 1024u * 1024u;
   if (b < 4096u) b = 4096u;
   if (b > 32768u) b = 32768u;

@@ -58,7 +58,7 @@ __host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batche
   return (size_t)lr_basetab_off(tiles) + (size_t)batches * tiles;
 }
 #define LR_BATCH_THREADS 1024
-#define LR_BATCH_MAX_TILES 16384  // 2 x 4 B x tiles of LDS counters must fit one workgroup (128 KB of 160)
+#define LR_BATCH_MAX_TILES 40000  // 4 B x tiles of LDS counters must fit one workgroup (160 KB): up to 3840x2160
 
 // Device-side view (kernel argument, by value).
 struct LrView {

@@ -66,10 +66,10 @@ struct LrGlobalCounters {  // one memory-side atomic per instance (any tile grid
   LR_DEV void count_big(int tile) const { atomicAdd(&big[tile * LR_CTR_STRIDE], 1u); }
 };
 struct LrLdsCounters {  // per-workgroup counters in LDS (batched kernel): 170x the rate of memory-side atomics
-  uint32_t* ranked;
-  uint32_t* big;
-  LR_DEV uint32_t rank(int tile) const { return atomicAdd(&ranked[tile], 1u); }
-  LR_DEV void count_big(int tile) const { atomicAdd(&big[tile], 1u); }
+  uint32_t* ctr;        // one word per tile: ranked count in the low half, big count in the high half (both < 2^16:
+                        // a batch holds at most 32768 Gaussians and a Gaussian enters a tile at most once)
+  LR_DEV uint32_t rank(int tile) const { return atomicAdd(&ctr[tile], 1u) & 0xffffu; }
+  LR_DEV void count_big(int tile) const { atomicAdd(&ctr[tile], 0x10000u); }
 };
 
 // The 56 input bytes of one Gaussian, requested together (five independent loads in flight per lane).
@@ -234,14 +234,12 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
                           const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                           uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
                           uint32_t* __restrict__ basetab, int tile_cull, int B) {
-  extern __shared__ uint32_t lr_lds_ctr[];  // [tiles] ranked counts, [tiles] big counts
+  extern __shared__ uint32_t lr_lds_ctr[];  // [tiles] packed (ranked | big << 16) counts
   const int tiles = v.gx * v.gy;
-  uint32_t* const lranked = lr_lds_ctr;
-  uint32_t* const lbig = lr_lds_ctr + tiles;
-  for (int t = threadIdx.x; t < 2 * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
+  for (int t = threadIdx.x; t < tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
   __syncthreads();
-  const LrLdsCounters ctr{lranked, lbig};
+  const LrLdsCounters ctr{lr_lds_ctr};
   uint32_t rect_instances = 0;
   const int i_begin = blockIdx.x * B, i_end = min(N, i_begin + B);
   // software pipeline: the next Gaussian's inputs are requested before the current one is projected (a workgroup
@@ -268,7 +266,7 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int t = t0 + u * LR_BATCH_THREADS;
-      const uint32_t c = t < tiles ? lranked[t] : 0u, cb = t < tiles ? lbig[t] : 0u;
+      const uint32_t packed = t < tiles ? lr_lds_ctr[t] : 0u, c = packed & 0xffffu, cb = packed >> 16;
       base[u] = c ? atomicAdd(&ranked[t * LR_CTR_STRIDE], c) : 0u;
       if (cb) atomicAdd(&big[t * LR_CTR_STRIDE], cb);
     }
@@ -288,7 +286,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
   lr_prof_begin(LRK_PROJECT, s);
   if (batch > 0) {
     const int tiles = v.gx * v.gy;
-    const size_t lds = sizeof(uint32_t) * 2 * (size_t)tiles;
+    const size_t lds = sizeof(uint32_t) * (size_t)tiles;
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel),

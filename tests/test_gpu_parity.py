@@ -362,10 +362,10 @@ def test_fused_multi_view_accumulation_matches_autograd():
 
 
 @pytest.mark.parametrize("W,H", [(2560, 1440), (3840, 2160), (7680, 4320)],
-                         ids=["1440p_batched_115KB_lds", "4k_scan32", "8k_scan128"])
+                         ids=["1440p_batched", "4k_scan32_batched_130KB_lds", "8k_scan128_unbatched"])
 def test_large_tile_grids(oracle_mod, W, H):
-    """Tile counts beyond 8192 use the wider scan variants (32 / 128 tiles per thread); up to 16384 tiles (1440p) the
-    batched projection still ranks in LDS (more than 64 KB of dynamic LDS), beyond that the unbatched kernel runs."""
+    """Tile counts beyond 8192 use the wider scan variants (32 / 128 tiles per thread); up to 40000 tiles (4K) the
+    batched projection still ranks in LDS (more than 64 KB of dynamic LDS at 4K), beyond that the unbatched kernel runs."""
     import gpu_util as G
     from log_amd import scenes
     cam = scenes.orbit_cameras(1, W=W, H=H, focal=2139.0 * W / 1920.0)[0]

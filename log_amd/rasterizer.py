@@ -345,6 +345,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c,
                                                              scratch_floats=scratch_floats)
         ctx.rs, ctx.flavour, ctx.use_filter = rs, flavour, use_filter
+        ctx.set_materialize_grads(False)   # no zero-filled gradients for radii / the fork maps (4 fill kernels per view)
         ctx.saved = saved
         ctx.sh = (sh, clamped)
         ctx.shapes = (means2D.shape, opacities.shape)
@@ -358,6 +359,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_image, *unused):
         m, s, r = ctx.saved_tensors
+        if grad_image is None:   # only non-differentiable outputs were used downstream
+            return (None,) * 10
         m2_shape, o_shape = ctx.shapes
         sh, clamped = ctx.sh
         sink = _grad_sink

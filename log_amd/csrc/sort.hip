@@ -557,12 +557,10 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   // biglist holds the tiles with more than LR_LONG_LIST keys, so there are at most capacity / LR_LONG_LIST of them
   const uint32_t nlong = min(tiles, capacity / LR_LONG_LIST + 1u);
   if (bucket) {
-    // network for tiny lists (one wave), depth buckets in LDS up to LR_LONG_LIST keys
+    // depth buckets in LDS up to LR_LONG_LIST keys (a separate one-wave network launch for tiny lists costs more than it saves)
     lr_prof_begin(LRK_SORT_SMALL, s);
-    hipLaunchKernelGGL(lr_sort_rb_kernel<64>, dim3(tiles), dim3(64), lr_sort_lds_bytes(128), s, state, tiles, keys, plist,
-                       0u, 128u, capacity);
     hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 4, false>), dim3(tiles), dim3(256), lr_bucket_lds_bytes(1024), s, state,
-                       tiles, keys, plist, 128u, capacity);
+                       tiles, keys, plist, 0u, capacity);
     lr_prof_end(LRK_SORT_SMALL, s);
     if (max_len > 1024u) {
       lr_prof_begin(LRK_SORT_LARGE, s);

@@ -176,7 +176,10 @@ lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64
   if (state[LR_HDR_NUM] > capacity) return;
   if (LONG && blockIdx.x >= state[LR_HDR_NBIG]) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
-  const uint32_t tile = LONG ? (state[lr_biglist_off(tiles) + blockIdx.x] & ~LR_LONG_DONE) : blockIdx.x;
+  // lo > 0: blockIdx.x walks the longest-first dispatch order, so a grid of capacity / lo workgroups reaches every tile
+  // with more than lo keys (each holds more than lo of the capacity) instead of launching one workgroup per tile
+  const uint32_t tile = LONG ? (state[lr_biglist_off(tiles) + blockIdx.x] & ~LR_LONG_DONE)
+                             : (lo ? state[lr_order_off(tiles) + blockIdx.x] : blockIdx.x);
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg;
   if (L <= lo || L > CAP) return;
   const uint32_t tid = threadIdx.x;
@@ -564,8 +567,8 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
     lr_prof_end(LRK_SORT_SMALL, s);
     if (max_len > 1024u) {
       lr_prof_begin(LRK_SORT_LARGE, s);
-      hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 16, false>), dim3(tiles), dim3(256), lr_bucket_lds_bytes(LR_LONG_LIST), s,
-                         state, tiles, keys, plist, 1024u, capacity);
+      hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 16, false>), dim3(min(tiles, capacity / 1024u + 1u)), dim3(256),
+                         lr_bucket_lds_bytes(LR_LONG_LIST), s, state, tiles, keys, plist, 1024u, capacity);
       lr_prof_end(LRK_SORT_LARGE, s);
     }
   } else {

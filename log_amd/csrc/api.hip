@@ -20,7 +20,7 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
                        uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int tile_cull, hipStream_t s);
-void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s);
+void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_off, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s);
 void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
@@ -217,11 +217,15 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
-  // zero header and counters (offsets/cursors are fully rewritten by the scan)
-  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)lr_offsets_off(tiles), s));  // header + ranked + big
+  const uint32_t batch = lr_pick_batch(n, tiles);
+  // Counters: batched projection -> dense (ranked[tiles] | big[tiles] right behind the header), unbatched -> one
+  // counter per 64 B.  Header and counters are zeroed by ONE memset (offsets/cursors are fully rewritten by the scan).
+  const uint32_t cs = batch ? 1u : (uint32_t)LR_CTR_STRIDE;
+  const uint32_t big_off = batch ? lr_ranked_off(tiles) + tiles : lr_big_off(tiles);
+  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)(big_off + tiles * cs), s));
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
-                    st + lr_big_off(tiles), st, st + lr_basetab_off(tiles), (int)lr_pick_batch(n, tiles), lr_tile_cull(), s);
-  lr_launch_scan(st, tiles, s);
+                    st + big_off, st, st + lr_basetab_off(tiles), (int)batch, lr_tile_cull(), s);
+  lr_launch_scan(st, tiles, cs, big_off, s);
   LR_HIP(hipGetLastError());
   if (num_instances_host || max_tile_len_host) {
     uint32_t hdr[LR_HDR_WORDS] = {0};

@@ -267,8 +267,8 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
     for (int u = 0; u < 8; u++) {
       const int t = t0 + u * LR_BATCH_THREADS;
       const uint32_t packed = t < tiles ? lr_lds_ctr[t] : 0u, c = packed & 0xffffu, cb = packed >> 16;
-      base[u] = c ? atomicAdd(&ranked[t * LR_CTR_STRIDE], c) : 0u;
-      if (cb) atomicAdd(&big[t * LR_CTR_STRIDE], cb);
+      base[u] = c ? atomicAdd(&ranked[t], c) : 0u;          // dense counters: see lr_scan_kernel
+      if (cb) atomicAdd(&big[t], cb);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -313,11 +313,11 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
 // line each) and kept in registers: thread t owns tiles [t*CH, (t+1)*CH), CH = ceil(T/1024) <= CHMAX.
 template <int CHMAX>
 __global__ void __launch_bounds__(1024)
-lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
+lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32_t big_off) {
   __shared__ uint32_t part[64];
   __shared__ uint32_t hist[256];
   const uint32_t* ranked = state + lr_ranked_off(tiles);
-  const uint32_t* big = state + lr_big_off(tiles);
+  const uint32_t* big = state + big_off;
   uint32_t* offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   uint32_t* order = state + lr_order_off(tiles);
@@ -333,8 +333,8 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   for (int k = 0; k < CHMAX; k++) {
     const uint32_t t = b + (uint32_t)k;
     const bool in = (uint32_t)k < chunk && t < tiles;
-    nr[k] = in ? ranked[t * LR_CTR_STRIDE] : 0u;
-    tot[k] = nr[k] + (in ? big[t * LR_CTR_STRIDE] : 0u);
+    nr[k] = in ? ranked[t * cs] : 0u;
+    tot[k] = nr[k] + (in ? big[t * cs] : 0u);
     sum += tot[k];
   }
   // inclusive scan of the 1024 per-thread sums: shuffle scan inside each wave, then the 16 wave totals
@@ -405,15 +405,20 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles) {
   }
 }
 
-void lr_launch_scan(uint32_t* state, uint32_t tiles, hipStream_t s) {
+// cs = word stride of the ranked / big counters.  The unbatched projection spreads them 64 B apart (one returning
+// atomic per INSTANCE on random tiles: dense counters share lines and halve the atomic rate); the batched projection
+// reserves per (batch, tile) with consecutive threads on consecutive tiles, where dense counters are what lets the
+// memory side merge a wave's 64 atomics into 4 line operations (project 104 -> 63 us on C2, and this kernel reads
+// 16x fewer lines).
+void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_off, hipStream_t s) {
   lr_prof_begin(LRK_SCAN, s);
   const uint32_t chunk = (tiles + 1023u) / 1024u;
   if (chunk <= 8)
-    hipLaunchKernelGGL(lr_scan_kernel<8>, dim3(1), dim3(1024), 0, s, state, tiles);
+    hipLaunchKernelGGL(lr_scan_kernel<8>, dim3(1), dim3(1024), 0, s, state, tiles, cs, big_off);
   else if (chunk <= 32)
-    hipLaunchKernelGGL(lr_scan_kernel<32>, dim3(1), dim3(1024), 0, s, state, tiles);
+    hipLaunchKernelGGL(lr_scan_kernel<32>, dim3(1), dim3(1024), 0, s, state, tiles, cs, big_off);
   else
-    hipLaunchKernelGGL(lr_scan_kernel<128>, dim3(1), dim3(1024), 0, s, state, tiles);  // up to 131072 tiles (8K x 4K)
+    hipLaunchKernelGGL(lr_scan_kernel<128>, dim3(1), dim3(1024), 0, s, state, tiles, cs, big_off);  // up to 131072 tiles (8K x 4K)
   lr_prof_end(LRK_SCAN, s);
 }
 
@@ -471,7 +476,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 #pragma unroll
     for (int k = 0; k < LR_RANKED_TILES; k++) {
       if (k < nt && slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in lr_project_kernel
-        const int ty = k / w, tx = k - ty * w;
+        const int ty = (w == 1) ? k : ((w == 2 && nt == 4) ? (k >> 1) : 0), tx = k - ty * w;  // as in lr_project_one
         const int t = (y0 + ty) * gx + (x0 + tx);
         keys[offsets[t] + (batch ? bbase[t] : 0u) + slot[k]] = key;
       }

@@ -66,9 +66,9 @@ static std::atomic<int> g_tile_cull{-1};
 // Gaussians per projection batch (project.hip: lr_project_batched_kernel), 0 = unbatched kernel.  One batch per
 // workgroup; big enough that a batch puts several instances into a tile (that is what it saves in memory-side
 // atomics), small enough to leave a few hundred workgroups.  LOGRAST_BATCH overrides (0 disables batching).
-static uint32_t lr_pick_batch(int32_t n, uint32_t tiles) {
+static uint32_t lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t gy) {
   static const int forced = lr_env_int("LOGRAST_BATCH", -1);
-  if (n <= 0 || tiles > LR_BATCH_MAX_TILES || forced == 0) return 0u;
+  if (n <= 0 || tiles > LR_BATCH_MAX_TILES || gx > 8191u || gy > 8191u || forced == 0) return 0u;  // 13-bit tile coordinates in the fill record
   if (forced > 0) return (uint32_t)((forced > 32768 ? 32768 : forced) + 1023) / 1024u * 1024u;  // 16-bit LDS counts
   uint32_t b = ((uint32_t)n / 256u + 1023u) / 1024u * 1024u;
   if (b < 4096u) b = 4096u;
@@ -177,9 +177,11 @@ const char* lograst_last_error(void) { return g_err.c_str(); }
 
 size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
-  return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy)));
+  return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy, gx, gy)));
 }
-size_t lograst_geom_bytes(int32_t n) { return sizeof(float) * LOGRAST_REC_FLOATS * (size_t)(n > 0 ? n : 0); }
+size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection
+  return (sizeof(float) * LOGRAST_REC_FLOATS + 16) * (size_t)(n > 0 ? n : 0);
+}
 size_t lograst_keys_bytes(uint32_t capacity) { return 2 * sizeof(uint64_t) * (size_t)capacity; }  // keys + sort scratch
 size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }
 
@@ -217,7 +219,7 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
-  const uint32_t batch = lr_pick_batch(n, tiles);
+  const uint32_t batch = lr_pick_batch(n, tiles, (uint32_t)v.gx, (uint32_t)v.gy);
   // Counters: batched projection -> dense (ranked[tiles] | big[tiles] right behind the header), unbatched -> one
   // counter per 64 B.  Header and counters are zeroed by ONE memset (offsets/cursors are fully rewritten by the scan).
   const uint32_t cs = batch ? 1u : (uint32_t)LR_CTR_STRIDE;

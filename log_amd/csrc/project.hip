@@ -255,7 +255,27 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
     lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
     radii[i] = rad;
     float4* rec = geom + LR_REC_QUADS * (size_t)i;
-    rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;
+    rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;     // q3 is not read in this mode: written to complete the 64-byte line
+    // Fill record (16 B, its own coalesced array behind the records): everything lr_fill_kernel needs, so that it
+    // does not fetch half of every 64-byte record again.  x = depth bits; y = x0 | y0<<13 | (w-1)<<26 | (h-1)<<28 |
+    // big<<30 (all ones = nothing to fill); ranked: z,w = four 16-bit ranks inside the batch (0xffff = tile dropped
+    // by the support cull); big: z = x1 | y1<<16.
+    uint4 fr = {__float_as_uint(g2.y), 0xffffffffu, 0u, 0u};
+    if (rad > 0) {
+      const uint32_t r0 = __float_as_uint(g2.z), r1 = __float_as_uint(g2.w);
+      const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = r1 & 0xffffu, y1 = r1 >> 16, w = x1 - x0, h = y1 - y0;
+      if (w * h <= LR_RANKED_TILES) {
+        const uint32_t s0 = __float_as_uint(g3.x), s1 = __float_as_uint(g3.y), s2 = __float_as_uint(g3.z),
+                       s3 = __float_as_uint(g3.w);
+        fr.y = x0 | (y0 << 13) | ((w - 1u) << 26) | ((h - 1u) << 28);
+        fr.z = (s0 & 0xffffu) | (s1 << 16);                  // 0xffffffff -> 0xffff; ranks are < 32768
+        fr.w = (s2 & 0xffffu) | (s3 << 16);
+      } else {
+        fr.y = x0 | (y0 << 13) | (1u << 30);
+        fr.z = x1 | (y1 << 16);
+      }
+    }
+    reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N)[i] = fr;
   }
   __syncthreads();
   // reservations: eight tiles per thread per round, all eight returning atomics in flight before the first result
@@ -458,24 +478,42 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       batch ? state + lr_basetab_off(tiles) + (size_t)((uint32_t)i / batch) * tiles : nullptr;
   int lane = threadIdx.x & 63;
   bool vis = (i < N);
-  uint32_t r0 = 0, r1 = 0, dbits = 0;
-  if (vis) {
-    float4 g2 = geom[LR_REC_QUADS * (size_t)i + 2];
+  uint32_t dbits = 0;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  uint32_t slot[LR_RANKED_TILES] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  if (vis && batch) {
+    // batched projection: the 16-byte fill record (see lr_project_batched_kernel)
+    const uint4 fr = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N)[i];
+    dbits = fr.x;
+    if (fr.y != 0xffffffffu) {
+      x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
+      if (fr.y & (1u << 30)) {
+        x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
+      } else {
+        x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
+        const uint32_t h0 = fr.z & 0xffffu, h1 = fr.z >> 16, h2 = fr.w & 0xffffu, h3 = fr.w >> 16;
+        slot[0] = h0 == 0xffffu ? 0xffffffffu : h0; slot[1] = h1 == 0xffffu ? 0xffffffffu : h1;
+        slot[2] = h2 == 0xffffu ? 0xffffffffu : h2; slot[3] = h3 == 0xffffu ? 0xffffffffu : h3;
+      }
+    }
+  } else if (vis) {
+    const float4 g2 = geom[LR_REC_QUADS * (size_t)i + 2];
     dbits = __float_as_uint(g2.y);
-    r0 = __float_as_uint(g2.z);
-    r1 = __float_as_uint(g2.w);
+    const uint32_t r0 = __float_as_uint(g2.z), r1 = __float_as_uint(g2.w);
+    x0 = (int)(r0 & 0xffff); y0 = (int)(r0 >> 16); x1 = (int)(r1 & 0xffff); y1 = (int)(r1 >> 16);
+    if ((x1 - x0) * (y1 - y0) <= LR_RANKED_TILES && (x1 - x0) * (y1 - y0) > 0) {
+      const float4 g3 = geom[LR_REC_QUADS * (size_t)i + 3];
+      slot[0] = __float_as_uint(g3.x); slot[1] = __float_as_uint(g3.y);
+      slot[2] = __float_as_uint(g3.z); slot[3] = __float_as_uint(g3.w);
+    }
   }
-  int x0 = r0 & 0xffff, y0 = r0 >> 16, x1 = r1 & 0xffff, y1 = r1 >> 16;
   int w = x1 - x0, h = y1 - y0;
   int nt = vis ? w * h : 0;
   uint64_t key = ((uint64_t)dbits << 32) | (uint32_t)i;
   if (nt > 0 && nt <= LR_RANKED_TILES) {
-    const float4 g3 = geom[LR_REC_QUADS * (size_t)i + 3];
-    const uint32_t slot[LR_RANKED_TILES] = {__float_as_uint(g3.x), __float_as_uint(g3.y), __float_as_uint(g3.z),
-                                            __float_as_uint(g3.w)};
 #pragma unroll
     for (int k = 0; k < LR_RANKED_TILES; k++) {
-      if (k < nt && slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in lr_project_kernel
+      if (k < nt && slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in the projection kernel
         const int ty = (w == 1) ? k : ((w == 2 && nt == 4) ? (k >> 1) : 0), tx = k - ty * w;  // as in lr_project_one
         const int t = (y0 + ty) * gx + (x0 + tx);
         keys[offsets[t] + (batch ? bbase[t] : 0u) + slot[k]] = key;

@@ -144,7 +144,7 @@ class HipBackend:
         i32 = dict(dtype=torch.int32, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         radii = torch.empty(N, **i32)
-        geom = torch.empty(N * _lib.REC_FLOATS, **f32)
+        geom = torch.empty(L.lograst_geom_bytes(N) // 4, **f32)
         state = torch.empty(L.lograst_tile_state_bytes(W, H, N) // 4, **i32)
         with torch.cuda.device(device):
             if _capacity_hint is None:

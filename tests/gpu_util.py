@@ -31,7 +31,7 @@ def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", 
     offs = R.tile_offsets_of(saved, W, H).cpu().numpy().astype(np.uint32)
     I = int(offs[-1])
     out = dict(image=image.cpu().numpy(), radii=radii.cpu().numpy(),
-               rec=saved["geom"].cpu().numpy().reshape(-1, 16)[:, :12], tile_offsets=offs,
+               rec=saved["geom"][:16 * len(radii)].cpu().numpy().reshape(-1, 16)[:, :12], tile_offsets=offs,
                point_list=saved["plist"].cpu().numpy().astype(np.uint32)[:I], I=I,
                final_T=saved["final_T"].cpu().numpy(), n_contrib=saved["n_contrib"].cpu().numpy())
     if pid is not None:

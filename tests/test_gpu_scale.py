@@ -26,7 +26,7 @@ def _tile_sorted_ok(saved, W, H, dev):
     if I == 0:
         return True, 0
     plist = saved["plist"][:I].to(torch.int64)
-    depth = saved["geom"].view(-1, 16)[:, 9].view(torch.int32).to(torch.int64)   # positive floats: bits are monotone
+    depth = saved["geom"][:16 * saved["radii"].numel()].view(-1, 16)[:, 9].view(torch.int32).to(torch.int64)   # positive floats: bits are monotone
     key = depth[plist] * (1 << 32) + plist
     tile_of = torch.repeat_interleave(torch.arange(len(offs) - 1, device=dev), offs[1:] - offs[:-1])
     same = tile_of[1:] == tile_of[:-1]
@@ -35,7 +35,7 @@ def _tile_sorted_ok(saved, W, H, dev):
 
 
 def _rects_total(saved):
-    g = saved["geom"].view(-1, 16)
+    g = saved["geom"][:16 * saved["radii"].numel()].view(-1, 16)
     r0 = g[:, 10].view(torch.int32)
     r1 = g[:, 11].view(torch.int32)
     w = (r1 & 0xffff) - (r0 & 0xffff)

@@ -11,7 +11,7 @@ t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
 m, s, r, o, c = t(sc["xyz"]), t(sc["scaling"]), t(sc["rotation"]), t(sc["opacity"]).reshape(-1), t(sc["colors"])
 B = R._backend; L = B.require(dev)
 view, keep = B.make_view(rs, R.WODILATE, True, dev)
-radii = torch.empty(N, dtype=torch.int32, device=dev); geom = torch.empty(N*16, device=dev)
+radii = torch.empty(N, dtype=torch.int32, device=dev); geom = torch.empty(L.lograst_geom_bytes(N)//4, device=dev)
 state = torch.empty(L.lograst_tile_state_bytes(1920,1080,N)//4, dtype=torch.int32, device=dev)
 _lib.profile_reset(); _lib.profile_enable(True)
 for _ in range(10):

@@ -246,6 +246,10 @@ def main():
         alg = algorithmic_bytes(N, V, I, Px)
         total_alg = 184 * N + 116 * V + 108 * I + 48 * Px
         result["algorithmic_GBs_whole_view"] = total_alg / (elapsed / (args.steps * args.views)) / 1e9
+        # the same box's device-copy bandwidth (the measured roof next to the 8 TB/s spec figure)
+        copy_gbs = measured_copy_bandwidth(dev)
+        result["measured_copy_GBs"] = copy_gbs
+        result["algorithmic_frac_of_measured_copy"] = result["algorithmic_GBs_whole_view"] / copy_gbs
         if timing:
             def roof(prof):
                 kern = {}
@@ -287,6 +291,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_copy_bandwidth(dev, mib=1024, reps=5):
+    """Device-to-device copy of `mib` MiB (read + write counted), best of `reps`: GB/s."""
+    a = torch.empty(mib * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del a, b
+    return 2 * mib * 1024 * 1024 / (best * 1e-3) / 1e9
 
 
 def pmc_traffic(kernel, N, W, H, field="traffic_bytes"):

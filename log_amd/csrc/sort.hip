@@ -411,19 +411,23 @@ __global__ void __launch_bounds__(256)
 lr_sort_long_fallback_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                              uint32_t* __restrict__ plist, uint32_t capacity) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (state[LR_HDR_NUM] > capacity || blockIdx.x >= state[LR_HDR_NBIG]) return;
-  const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
-  if (entry & LR_LONG_DONE) return;
+  if (state[LR_HDR_NUM] > capacity) return;
+  const uint32_t nbig = state[LR_HDR_NBIG];
   const uint32_t* offsets = state + lr_offsets_off(tiles);
-  const uint32_t beg = offsets[entry], L = offsets[entry + 1] - beg;
-  if (L > LR_SORT_BLOCK) return;                            // hybrid path
-  const uint32_t tid = threadIdx.x;
-  uint32_t P2 = 8;
-  while (P2 < L) P2 <<= 1;
-  for (uint32_t i = tid; i < P2; i += 256) s[lr_phys(i)] = i < L ? keys[beg + i] : ~0ull;
-  __syncthreads();
-  lr_lds_sort<256>(s, P2, tid);
-  for (uint32_t i = tid; i < L; i += 256) plist[beg + i] = (uint32_t)s[lr_phys(i)];
+  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
+    const uint32_t entry = state[lr_biglist_off(tiles) + e];
+    if (entry & LR_LONG_DONE) continue;
+    const uint32_t beg = offsets[entry], L = offsets[entry + 1] - beg;
+    if (L > LR_SORT_BLOCK) continue;                        // hybrid path
+    const uint32_t tid = threadIdx.x;
+    uint32_t P2 = 8;
+    while (P2 < L) P2 <<= 1;
+    for (uint32_t i = tid; i < P2; i += 256) s[lr_phys(i)] = i < L ? keys[beg + i] : ~0ull;
+    __syncthreads();
+    lr_lds_sort<256>(s, P2, tid);
+    for (uint32_t i = tid; i < L; i += 256) plist[beg + i] = (uint32_t)s[lr_phys(i)];
+    __syncthreads();
+  }
 }
 
 // ---- lists longer than LR_SORT_BLOCK: hybrid network ------------------------------------------------------------
@@ -435,10 +439,12 @@ lr_sort_long_fallback_kernel(const uint32_t* __restrict__ state, uint32_t tiles,
 // (measured before: 27 ms per view at 30 M Gaussians).  Launches are ordered by the stream; tiles that do not take
 // part in a level (list too short) exit at once.  blockIdx.x indexes the big-tile list written by the scan kernel.
 struct LrBigTile { uint32_t beg, L, P2; bool ok; };
-LR_DEV LrBigTile lr_big_tile(const uint32_t* __restrict__ state, uint32_t tiles, uint32_t capacity) {
+// The network-fallback kernels below walk biglist[] with a SMALL grid (entry e = blockIdx.x, += gridDim.x): normally
+// every entry is already flagged done by the depth-bucket sort, and a launch of thousands of idle workgroups (each
+// with its LDS allocation) costs 15-30 us where a few dozen that skim the flags cost 3.
+LR_DEV LrBigTile lr_big_tile(const uint32_t* __restrict__ state, uint32_t tiles, uint32_t e) {
   LrBigTile t{0u, 0u, 0u, false};
-  if (state[LR_HDR_NUM] > capacity || blockIdx.x >= state[LR_HDR_NBIG]) return t;
-  const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
+  const uint32_t entry = state[lr_biglist_off(tiles) + e];
   if (entry & LR_LONG_DONE) return t;  // the depth-bucket sort already produced this tile's list
   const uint32_t tile = entry;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -457,40 +463,48 @@ __global__ void __launch_bounds__(NT)
 lr_bigsort_blocks_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
                          uint32_t capacity) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  const LrBigTile t = lr_big_tile(state, tiles, capacity);
-  if (!t.ok) return;
-  const uint32_t b0 = blockIdx.y * LR_SORT_BLOCK;
-  if (b0 >= t.L) return;
-  const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, t.L - b0), tid = threadIdx.x;
-  uint32_t P2 = 8;
-  while (P2 < cnt) P2 <<= 1;
-  uint64_t* k = keys + t.beg + b0;
-  for (uint32_t i = tid; i < P2; i += NT) s[lr_phys(i)] = i < cnt ? k[i] : ~0ull;
-  __syncthreads();
-  lr_lds_sort<NT>(s, P2, tid);
-  for (uint32_t i = tid; i < cnt; i += NT) k[i] = s[lr_phys(i)];
+  if (state[LR_HDR_NUM] > capacity) return;
+  const uint32_t nbig = state[LR_HDR_NBIG];
+  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
+    const LrBigTile t = lr_big_tile(state, tiles, e);
+    const uint32_t b0 = blockIdx.y * LR_SORT_BLOCK;
+    if (!t.ok || b0 >= t.L) continue;
+    const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, t.L - b0), tid = threadIdx.x;
+    uint32_t P2 = 8;
+    while (P2 < cnt) P2 <<= 1;
+    uint64_t* k = keys + t.beg + b0;
+    for (uint32_t i = tid; i < P2; i += NT) s[lr_phys(i)] = i < cnt ? k[i] : ~0ull;
+    __syncthreads();
+    lr_lds_sort<NT>(s, P2, tid);
+    for (uint32_t i = tid; i < cnt; i += NT) k[i] = s[lr_phys(i)];
+    __syncthreads();
+  }
 }
 
 // One global level of phase k: the flip level (j == 0) or the half-cleaner with stride j >= LR_SORT_BLOCK.
 __global__ void __launch_bounds__(256)
 lr_bigsort_global_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
                          uint32_t capacity, uint32_t k, uint32_t j) {
-  const LrBigTile t = lr_big_tile(state, tiles, capacity);
-  if (!t.ok || (k >> 1) >= t.L) return;  // phase k only merges something when the list reaches past k/2
-  uint64_t* a = keys + t.beg;
-  const uint32_t pairs = t.P2 >> 1;
-  for (uint32_t p = blockIdx.y * 256 + threadIdx.x; p < pairs; p += gridDim.y * 256) {
-    uint32_t i, l;
-    if (j == 0) {
-      const uint32_t half = k >> 1, off = p & (half - 1u), blk = (p - off) << 1;
-      i = blk + off; l = blk + (k - 1u - off);
-    } else {
-      const uint32_t low = p & (j - 1u);
-      i = ((p - low) << 1) | low; l = i + j;
-    }
-    if (l < t.L) {
-      const uint64_t x = a[i], y = a[l];
-      if (x > y) { a[i] = y; a[l] = x; }
+  if (state[LR_HDR_NUM] > capacity) return;
+  const uint32_t nbig = state[LR_HDR_NBIG];
+  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
+    const LrBigTile t = lr_big_tile(state, tiles, e);
+    if (!t.ok || (k >> 1) >= t.L) continue;  // phase k only merges something when the list reaches past k/2
+    uint64_t* a = keys + t.beg;
+    const uint32_t pairs = t.P2 >> 1;
+    for (uint32_t p = blockIdx.y * 256 + threadIdx.x; p < pairs; p += gridDim.y * 256) {
+      uint32_t i, l;
+      if (j == 0) {
+        const uint32_t half = k >> 1, off = p & (half - 1u), blk = (p - off) << 1;
+        i = blk + off; l = blk + (k - 1u - off);
+      } else {
+        const uint32_t low = p & (j - 1u);
+        i = ((p - low) << 1) | low; l = i + j;
+      }
+      if (l < t.L) {
+        const uint64_t x = a[i], y = a[l];
+        if (x > y) { a[i] = y; a[l] = x; }
+      }
     }
   }
 }
@@ -501,25 +515,33 @@ __global__ void __launch_bounds__(NT)
 lr_bigsort_tail_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
                        uint32_t capacity, uint32_t k) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  const LrBigTile t = lr_big_tile(state, tiles, capacity);
-  if (!t.ok || (k >> 1) >= t.L) return;
-  const uint32_t b0 = blockIdx.y * LR_SORT_BLOCK;
-  if (b0 >= t.L) return;
-  const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, t.L - b0), tid = threadIdx.x;
-  uint64_t* kk = keys + t.beg + b0;
-  for (uint32_t i = tid; i < LR_SORT_BLOCK; i += NT) s[lr_phys(i)] = i < cnt ? kk[i] : ~0ull;
-  __syncthreads();
-  lr_lds_halfcleaners<NT>(s, LR_SORT_BLOCK >> 3, tid, 12);  // strides 4096 ... 1  (LR_SORT_BLOCK == 8192)
-  for (uint32_t i = tid; i < cnt; i += NT) kk[i] = s[lr_phys(i)];
+  if (state[LR_HDR_NUM] > capacity) return;
+  const uint32_t nbig = state[LR_HDR_NBIG];
+  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
+    const LrBigTile t = lr_big_tile(state, tiles, e);
+    const uint32_t b0 = blockIdx.y * LR_SORT_BLOCK;
+    if (!t.ok || (k >> 1) >= t.L || b0 >= t.L) continue;
+    const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, t.L - b0), tid = threadIdx.x;
+    uint64_t* kk = keys + t.beg + b0;
+    for (uint32_t i = tid; i < LR_SORT_BLOCK; i += NT) s[lr_phys(i)] = i < cnt ? kk[i] : ~0ull;
+    __syncthreads();
+    lr_lds_halfcleaners<NT>(s, LR_SORT_BLOCK >> 3, tid, 12);  // strides 4096 ... 1  (LR_SORT_BLOCK == 8192)
+    for (uint32_t i = tid; i < cnt; i += NT) kk[i] = s[lr_phys(i)];
+    __syncthreads();
+  }
 }
 
 __global__ void __launch_bounds__(256)
 lr_bigsort_emit_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                        uint32_t* __restrict__ plist, uint32_t capacity) {
-  const LrBigTile t = lr_big_tile(state, tiles, capacity);
-  if (!t.ok) return;
-  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < t.L; i += gridDim.y * 256)
-    plist[t.beg + i] = (uint32_t)keys[t.beg + i];
+  if (state[LR_HDR_NUM] > capacity) return;
+  const uint32_t nbig = state[LR_HDR_NBIG];
+  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
+    const LrBigTile t = lr_big_tile(state, tiles, e);
+    if (!t.ok) continue;
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < t.L; i += gridDim.y * 256)
+      plist[t.beg + i] = (uint32_t)keys[t.beg + i];
+  }
 }
 
 // Size classes: the LDS footprint (9 B/key with padding) sets how many workgroups a CU can hold, so small
@@ -559,6 +581,7 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   static const int bucket = lr_env_int("LOGRAST_BUCKET_SORT", 1);
   // biglist holds the tiles with more than LR_LONG_LIST keys, so there are at most capacity / LR_LONG_LIST of them
   const uint32_t nlong = min(tiles, capacity / LR_LONG_LIST + 1u);
+  const uint32_t nfb = bucket ? min(nlong, 256u) : nlong;  // network fallback kernels: a chip-sized grid that walks biglist[]
   if (bucket) {
     // depth buckets in LDS up to LR_LONG_LIST keys (a separate one-wave network launch for tiny lists costs more than it saves)
     lr_prof_begin(LRK_SORT_SMALL, s);
@@ -596,24 +619,24 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
                          capacity);
       hipLaunchKernelGGL(lr_sort_long_kernel, dim3(nlong), dim3(1024), lr_long_lds_bytes(), s, state, tiles,
                          keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity);
-      hipLaunchKernelGGL(lr_sort_long_fallback_kernel, dim3(nlong), dim3(256), lr_sort_lds_bytes(LR_SORT_BLOCK), s, state,
+      hipLaunchKernelGGL(lr_sort_long_fallback_kernel, dim3(nfb), dim3(256), lr_sort_lds_bytes(LR_SORT_BLOCK), s, state,
                          tiles, keys, plist, capacity);
     }
     if (max_len > LR_SORT_BLOCK) {
       const uint32_t nblk = (max_len + LR_SORT_BLOCK - 1u) / LR_SORT_BLOCK;
       const uint32_t ypass = min(64u, max(1u, nblk * 4u));  // workgroups per tile for the streaming passes
       const size_t lds = lr_sort_lds_bytes(LR_SORT_BLOCK);
-      hipLaunchKernelGGL(lr_bigsort_blocks_kernel<512>, dim3(nlong, nblk), dim3(512), lds, s, state, tiles, keys, capacity);
+      hipLaunchKernelGGL(lr_bigsort_blocks_kernel<512>, dim3(nfb, nblk), dim3(512), lds, s, state, tiles, keys, capacity);
       for (uint64_t k = 2ull * LR_SORT_BLOCK; (k >> 1) < max_len; k <<= 1) {
-        hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nlong, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
+        hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nfb, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
                            (uint32_t)k, 0u);
         for (uint64_t j = k >> 2; j >= LR_SORT_BLOCK; j >>= 1)
-          hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nlong, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
+          hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nfb, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
                              (uint32_t)k, (uint32_t)j);
-        hipLaunchKernelGGL(lr_bigsort_tail_kernel<512>, dim3(nlong, nblk), dim3(512), lds, s, state, tiles, keys, capacity,
+        hipLaunchKernelGGL(lr_bigsort_tail_kernel<512>, dim3(nfb, nblk), dim3(512), lds, s, state, tiles, keys, capacity,
                            (uint32_t)k);
       }
-      hipLaunchKernelGGL(lr_bigsort_emit_kernel, dim3(nlong, ypass), dim3(256), 0, s, state, tiles, keys, plist, capacity);
+      hipLaunchKernelGGL(lr_bigsort_emit_kernel, dim3(nfb, ypass), dim3(256), 0, s, state, tiles, keys, plist, capacity);
     }
     lr_prof_end(LRK_SORT_HUGE, s);
   }

@@ -85,7 +85,9 @@ int lograst_compute_radius(int32_t p, const float* means3d, const float* scales,
  * tile_state (per-tile counts/offsets).  The total number of tile instances is left in
  * tile_state and, if num_instances_host != NULL (pinned or pageable host memory), also copied there
  * after a stream synchronise so the caller can size the key/list buffers exactly; max_tile_len_host (optional)
- * receives the longest tile list, which stage 2 uses to launch only the sort levels that are needed. */
+ * receives the longest tile list, which stage 2 uses to launch only the sort levels that are needed.
+ * geom must hold lograst_geom_bytes(n) and tile_state lograst_tile_state_bytes(width, height, n) bytes for THIS n
+ * (both grow with n: per-Gaussian fill records, per-batch slot reservations). */
 int lograst_forward_project(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                             const float* rotations, const float* opacities, const float* colors,
                             int32_t* radii, void* geom, void* tile_state, uint32_t* num_instances_host,

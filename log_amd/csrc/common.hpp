@@ -98,7 +98,8 @@ LR_DEV float lr_exp(float x) {
   return __uint_as_float(__float_as_uint(p) + ((uint32_t)ni << 23));
 }
 
-// power = -0.5 (A dx^2 + C dy^2) - B dx dy with hA = -0.5 A, hC = -0.5 C, nB = -B (exact scalings).
+// power = -0.5 (A dx^2 + C dy^2) - B dx dy with hA = -0.5 A, hC = -0.5 C, nB = -B (exact scalings): the reference op
+// sequence shared with oracle/lograst_oracle.c:ora_power.
 LR_DEV float lr_power(float hA, float nB, float hC, float dx, float dy) {
   return lr_fma(hA * dx, dx, lr_fma(hC * dy, dy, (nB * dx) * dy));
 }
@@ -111,9 +112,8 @@ typedef float lr_f2 __attribute__((ext_vector_type(2)));
 typedef int lr_i2 __attribute__((ext_vector_type(2)));
 typedef unsigned int lr_u2 __attribute__((ext_vector_type(2)));
 LR_DEV lr_f2 lr_fma2(lr_f2 a, lr_f2 b, lr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
-LR_DEV lr_f2 lr_power2(lr_f2 hA, lr_f2 nB, lr_f2 hC, lr_f2 dx, lr_f2 dy) {
-  return lr_fma2(hA * dx, dx, lr_fma2(hC * dy, dy, (nB * dx) * dy));
-}
+// (the blend kernels evaluate lr_power with the conic straight from the record and the -0.5 / sign scalings moved to
+// the pixel side -- fma(A*dx, -0.5*dx, .) rounds the same real number as fma((-0.5*A)*dx, dx, .) -- see blend.hip)
 LR_DEV lr_f2 lr_exp2(lr_f2 x) {
   lr_f2 t = x * 1.44269504088896341f;
   t = lr_f2{fmaxf(t.x, -125.0f), fmaxf(t.y, -125.0f)};

@@ -285,7 +285,7 @@ def main():
                                                   "the timed region (inside it %d views are in flight and kernels "
                                                   "time-share the chip: see roofline_timed_region)" % S)
                 result["kernels_timed_region"], result["roofline_timed_region"] = roof(prof_timed)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: the host cores are shared by all ranks
             result["cpu_baseline"] = cpu_baseline(sc, cams, wloss.cpu().numpy(), N)
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -64,7 +64,7 @@ const char* lograst_last_error(void);
 /* bytes of the per-tile state block for a WxH image and n Gaussians (header, counters, offsets, cursors, dispatch
  * order, and the per-batch slot reservations of the projection stage, which grow with n) */
 size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n);
-/* bytes of the projected-record array for N Gaussians (64-byte records followed by two arrays of 16-byte fill records) */
+/* bytes of the projected-record array for N Gaussians (64-byte records followed by 16-byte fill records) */
 size_t lograst_geom_bytes(int32_t n);
 /* bytes of the (depth,id) key buffer (keys + an equally large scratch half used by the long-list sort) / of the
  * sorted id list, for `capacity` tile instances */

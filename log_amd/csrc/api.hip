@@ -179,8 +179,8 @@ size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
   return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy, gx, gy)));
 }
-size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + two arrays of 16-byte fill records (batched projection)
-  return (sizeof(float) * LOGRAST_REC_FLOATS + 32) * (size_t)(n > 0 ? n : 0);
+size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection
+  return (sizeof(float) * LOGRAST_REC_FLOATS + 16) * (size_t)(n > 0 ? n : 0);
 }
 size_t lograst_keys_bytes(uint32_t capacity) { return 2 * sizeof(uint64_t) * (size_t)capacity; }  // keys + sort scratch
 size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }

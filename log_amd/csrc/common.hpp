@@ -32,7 +32,6 @@
 #define LR_CTR_STRIDE 16
 #endif
 #define LR_RANKED_TILES 4
-#define LR_RANKED_BATCHED 10  // batched projection: rects up to this many tiles are ranked (ranks live in the fill records)
 #define LR_HDR_WORDS 16
 #define LR_HDR_NUM 0
 #define LR_HDR_OVERFLOW 1

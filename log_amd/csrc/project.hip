@@ -60,14 +60,12 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
 // sorted and walked.  radii[] keeps the reference meaning (rect non-empty).
 // Counter policies: where the per-tile counters that rank / count the tile instances live.
 struct LrGlobalCounters {  // one memory-side atomic per instance (any tile grid)
-  static constexpr int kRanked = LR_RANKED_TILES;   // slots kept in the record's q3
   uint32_t* ranked;
   uint32_t* big;
   LR_DEV uint32_t rank(int tile) const { return atomicAdd(&ranked[tile * LR_CTR_STRIDE], 1u); }
   LR_DEV void count_big(int tile) const { atomicAdd(&big[tile * LR_CTR_STRIDE], 1u); }
 };
 struct LrLdsCounters {  // per-workgroup counters in LDS (batched kernel): 170x the rate of memory-side atomics
-  static constexpr int kRanked = LR_RANKED_BATCHED;  // 16-bit ranks kept in the fill records (covers 2x3 ... 3x3, 2x5 rects)
   uint32_t* ctr;        // one word per tile: ranked count in the low half, big count in the high half (both < 2^16:
                         // a batch holds at most 32768 Gaussians and a Gaussian enters a tile at most once)
   LR_DEV uint32_t rank(int tile) const { return atomicAdd(&ctr[tile], 1u) & 0xffffu; }
@@ -96,17 +94,13 @@ LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const flo
 // record quads, the integer radius (0 = culled) and the rect-rule instance count.
 template <typename Counters>
 LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, const Counters& ctr, float4& g0,
-                           float4& g1, float4& g2, uint32_t (&slot)[Counters::kRanked], int& rad,
-                           uint32_t& rect_instances) {
-  constexpr int RK = Counters::kRanked;
+                           float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances) {
   const float* __restrict__ V = v.view;
   const float* __restrict__ Pm = v.proj;
   rad = 0;
   g0 = float4{0.f, 0.f, 0.f, 0.f};
-  g1 = g0;
-  g2 = g0;  // culled: empty rect
-#pragma unroll
-  for (int k = 0; k < RK; k++) slot[k] = 0xffffffffu;
+  g1 = g0; g3 = g0;
+  g2 = g0;  // culled: empty rect (the fill kernel reads only q2)
   const float p[3] = {in.p[0], in.p[1], in.p[2]};
   float tz = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
   if (!(tz > 0.2f)) return;
@@ -143,17 +137,20 @@ LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, c
   const int w = x1 - x0, nt = w * (y1 - y0);
   rect_instances += (uint32_t)nt;
   const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, g1.y);
-  if (nt <= RK) {
-    int tx = 0, ty = 0;   // row-major walk over the rect without integer division
+  if (nt <= LR_RANKED_TILES) {
+    uint32_t slot[LR_RANKED_TILES] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < RK; k++) {
+    for (int k = 0; k < LR_RANKED_TILES; k++) {
       if (k < nt) {
+        // nt <= 4: the rect is one row (w >= nt), one column (w == 1) or 2x2 -- no integer division
+        const int ty = (w == 1) ? k : ((w == 2 && nt == 4) ? (k >> 1) : 0), tx = k - ty * w;
         // a single-tile rect holds the centre's neighbourhood: testing it would almost never drop it
         const bool keep = !tile_cull || nt == 1 || lr_support_tile(sup, x0 + tx, y0 + ty);
-        if (keep) slot[k] = ctr.rank((y0 + ty) * v.gx + (x0 + tx));
-        if (++tx == w) { tx = 0; ty++; }
+        slot[k] = keep ? ctr.rank((y0 + ty) * v.gx + (x0 + tx)) : 0xffffffffu;
       }
     }
+    g3 = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]),
+                __uint_as_float(slot[3])};
   } else {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++)
@@ -202,10 +199,8 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
     if (i < N) {
       int rad;
-      uint32_t slot[LR_RANKED_TILES];
       const LrInputs in = lr_load_inputs(i, means, scales, rots, opac, colors);
-      lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, slot, rad, rect_instances);
-      g3 = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]), __uint_as_float(slot[3])};
+      lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
       radii[i] = rad;
     }
     wstage[lane * LR_REC_QUADS + 0] = g0;
@@ -255,30 +250,32 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   for (; i < i_end; i += LR_BATCH_THREADS) {
     const LrInputs in = nxt;
     if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors);
-    float4 g0, g1, g2;
+    float4 g0, g1, g2, g3;
     int rad;
-    uint32_t rk[LR_RANKED_BATCHED];
-    lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, rk, rad, rect_instances);
+    lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
     radii[i] = rad;
     float4* rec = geom + LR_REC_QUADS * (size_t)i;
-    rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g2;     // q3 is not read in this mode: written to complete the 64-byte line
-    // Fill records (two coalesced arrays of 16 B behind the records): everything lr_fill_kernel needs, so that it does
-    // not fetch half of every 64-byte record again.  A = (depth bits, x0 | y0<<13 | big<<30 -- all ones = nothing to
-    // fill --, x1 | y1<<16, ranks 0,1); B = ranks 2..9 (written only for rects of 3..10 tiles).  Ranks are 16-bit
-    // positions inside the batch's reservation, 0xffff = tile dropped by the support cull.
-    uint4 fa = {__float_as_uint(g2.y), 0xffffffffu, 0u, 0u};
+    rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;     // q3 is not read in this mode: written to complete the 64-byte line
+    // Fill record (16 B, its own coalesced array behind the records): everything lr_fill_kernel needs, so that it
+    // does not fetch half of every 64-byte record again.  x = depth bits; y = x0 | y0<<13 | (w-1)<<26 | (h-1)<<28 |
+    // big<<30 (all ones = nothing to fill); ranked: z,w = four 16-bit ranks inside the batch (0xffff = tile dropped
+    // by the support cull); big: z = x1 | y1<<16.
+    uint4 fr = {__float_as_uint(g2.y), 0xffffffffu, 0u, 0u};
     if (rad > 0) {
       const uint32_t r0 = __float_as_uint(g2.z), r1 = __float_as_uint(g2.w);
-      const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, nt = ((r1 & 0xffffu) - x0) * ((r1 >> 16) - y0);
-      fa.y = x0 | (y0 << 13) | (nt > LR_RANKED_BATCHED ? (1u << 30) : 0u);
-      fa.z = r1;
-      fa.w = (rk[0] & 0xffffu) | (rk[1] << 16);              // 0xffffffff -> 0xffff; ranks are < 32768
-      if (nt > 2u && nt <= LR_RANKED_BATCHED)
-        reinterpret_cast<uint4*>(geom + (LR_REC_QUADS + 1) * (size_t)N)[i] =
-            uint4{(rk[2] & 0xffffu) | (rk[3] << 16), (rk[4] & 0xffffu) | (rk[5] << 16), (rk[6] & 0xffffu) | (rk[7] << 16),
-                  (rk[8] & 0xffffu) | (rk[9] << 16)};
+      const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = r1 & 0xffffu, y1 = r1 >> 16, w = x1 - x0, h = y1 - y0;
+      if (w * h <= LR_RANKED_TILES) {
+        const uint32_t s0 = __float_as_uint(g3.x), s1 = __float_as_uint(g3.y), s2 = __float_as_uint(g3.z),
+                       s3 = __float_as_uint(g3.w);
+        fr.y = x0 | (y0 << 13) | ((w - 1u) << 26) | ((h - 1u) << 28);
+        fr.z = (s0 & 0xffffu) | (s1 << 16);                  // 0xffffffff -> 0xffff; ranks are < 32768
+        fr.w = (s2 & 0xffffu) | (s3 << 16);
+      } else {
+        fr.y = x0 | (y0 << 13) | (1u << 30);
+        fr.z = x1 | (y1 << 16);
+      }
     }
-    reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N)[i] = fa;
+    reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N)[i] = fr;
   }
   __syncthreads();
   // reservations: eight tiles per thread per round, all eight returning atomics in flight before the first result
@@ -484,29 +481,20 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   bool vis = (i < N);
   uint32_t dbits = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  uint32_t slot[LR_RANKED_BATCHED];
-#pragma unroll
-  for (int k = 0; k < LR_RANKED_BATCHED; k++) slot[k] = 0xffffffffu;
-  const int ranked_max = batch ? LR_RANKED_BATCHED : LR_RANKED_TILES;
+  uint32_t slot[LR_RANKED_TILES] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   if (vis && batch) {
-    // batched projection: the 16-byte fill records (see lr_project_batched_kernel)
-    const uint4 fa = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N)[i];
-    dbits = fa.x;
-    if (fa.y != 0xffffffffu) {
-      x0 = (int)(fa.y & 0x1fffu); y0 = (int)((fa.y >> 13) & 0x1fffu);
-      x1 = (int)(fa.z & 0xffffu); y1 = (int)(fa.z >> 16);
-      if (!(fa.y & (1u << 30))) {
-        uint32_t h[LR_RANKED_BATCHED];
-        h[0] = fa.w & 0xffffu; h[1] = fa.w >> 16;
-#pragma unroll
-        for (int k = 2; k < LR_RANKED_BATCHED; k++) h[k] = 0xffffu;
-        if ((x1 - x0) * (y1 - y0) > 2) {
-          const uint4 fb = reinterpret_cast<const uint4*>(geom + (LR_REC_QUADS + 1) * (size_t)N)[i];
-          h[2] = fb.x & 0xffffu; h[3] = fb.x >> 16; h[4] = fb.y & 0xffffu; h[5] = fb.y >> 16;
-          h[6] = fb.z & 0xffffu; h[7] = fb.z >> 16; h[8] = fb.w & 0xffffu; h[9] = fb.w >> 16;
-        }
-#pragma unroll
-        for (int k = 0; k < LR_RANKED_BATCHED; k++) slot[k] = h[k] == 0xffffu ? 0xffffffffu : h[k];
+    // batched projection: the 16-byte fill record (see lr_project_batched_kernel)
+    const uint4 fr = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N)[i];
+    dbits = fr.x;
+    if (fr.y != 0xffffffffu) {
+      x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
+      if (fr.y & (1u << 30)) {
+        x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
+      } else {
+        x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
+        const uint32_t h0 = fr.z & 0xffffu, h1 = fr.z >> 16, h2 = fr.w & 0xffffu, h3 = fr.w >> 16;
+        slot[0] = h0 == 0xffffu ? 0xffffffffu : h0; slot[1] = h1 == 0xffffu ? 0xffffffffu : h1;
+        slot[2] = h2 == 0xffffu ? 0xffffffffu : h2; slot[3] = h3 == 0xffffu ? 0xffffffffu : h3;
       }
     }
   } else if (vis) {
@@ -523,27 +511,24 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   int w = x1 - x0, h = y1 - y0;
   int nt = vis ? w * h : 0;
   uint64_t key = ((uint64_t)dbits << 32) | (uint32_t)i;
-  if (nt > 0 && nt <= ranked_max) {
-    int tx = 0, ty = 0;
+  if (nt > 0 && nt <= LR_RANKED_TILES) {
 #pragma unroll
-    for (int k = 0; k < LR_RANKED_BATCHED; k++) {
-      if (k < nt) {
-        if (slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in the projection kernel
-          const int t = (y0 + ty) * gx + (x0 + tx);
-          keys[offsets[t] + (batch ? bbase[t] : 0u) + slot[k]] = key;
-        }
-        if (++tx == w) { tx = 0; ty++; }
+    for (int k = 0; k < LR_RANKED_TILES; k++) {
+      if (k < nt && slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in the projection kernel
+        const int ty = (w == 1) ? k : ((w == 2 && nt == 4) ? (k >> 1) : 0), tx = k - ty * w;  // as in lr_project_one
+        const int t = (y0 + ty) * gx + (x0 + tx);
+        keys[offsets[t] + (batch ? bbase[t] : 0u) + slot[k]] = key;
       }
     }
   }
   // Larger rects were only counted; repeat the projection kernel's support test (same record, same code) so the
   // same tiles are filled.
   LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};  // mode 1: every tile of the rect
-  if (nt > ranked_max && tile_cull) {
+  if (nt > LR_RANKED_TILES && tile_cull) {
     const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
     sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
   }
-  if (nt > ranked_max && nt <= LR_COOP_TILES) {
+  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES) {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++)
         if (lr_support_tile(sup, x, y)) {

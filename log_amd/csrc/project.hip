@@ -384,7 +384,7 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
     const uint32_t t = b + (uint32_t)k;
     if ((uint32_t)k < chunk && t < tiles) {
       offsets[t] = run;
-      cursor[t * cs] = run + nr[k];  // big instances go behind the ranked ones (dense like the counters in batched mode)
+      cursor[t * LR_CTR_STRIDE] = run + nr[k];  // big instances go behind the ranked ones (64 B apart: the fill's atomics hit random tiles)
       run += tot[k];
       atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u);
       lmax = max(lmax, tot[k]);
@@ -471,7 +471,6 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   }
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
-  const uint32_t ccs = state[LR_HDR_BATCH] ? 1u : (uint32_t)LR_CTR_STRIDE;   // cursor stride: as written by the scan
   int i = blockIdx.x * 256 + threadIdx.x;
   // batched projection: a ranked instance's slot is relative to its batch's reservation in the tile
   const uint32_t batch = state[LR_HDR_BATCH];
@@ -532,7 +531,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++)
         if (lr_support_tile(sup, x, y)) {
-          uint32_t pos = atomicAdd(&cursor[(y * gx + x) * ccs], 1u);
+          uint32_t pos = atomicAdd(&cursor[(y * gx + x) * LR_CTR_STRIDE], 1u);
           keys[pos] = key;
         }
   }
@@ -554,7 +553,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     for (int t = lane; t < bn; t += 64) {
       int ty = t / bw, tx = t - ty * bw;
       if (lr_support_tile(bs, bx0 + tx, by0 + ty)) {
-        uint32_t pos = atomicAdd(&cursor[((by0 + ty) * gx + (bx0 + tx)) * ccs], 1u);
+        uint32_t pos = atomicAdd(&cursor[((by0 + ty) * gx + (bx0 + tx)) * LR_CTR_STRIDE], 1u);
         keys[pos] = bkey;
       }
     }

@@ -353,6 +353,9 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       const float4* __restrict__ rr1 = geom + LR_REC_QUADS * (size_t)(uint32_t)gid1;
       const float4 q00 = rr0[0], q01 = rr0[1], q10 = rr1[0], q11 = rr1[1];
       const float cbl0 = reinterpret_cast<const float*>(rr0)[8], cbl1 = reinterpret_cast<const float*>(rr1)[8];
+      // keep the colour loads in this first batch of scalar loads: left alone the compiler sinks them below the hit
+      // test, i.e. a second, fully exposed scalar-cache round trip in every contributing iteration
+      asm volatile("" : : "s"(q01.z), "s"(q01.w), "s"(cbl0), "s"(q11.z), "s"(q11.w), "s"(cbl1));
       const float op0 = q01.y, op1 = q11.y;
       const lr_f2 dx2 = lr_f2{q00.x, q10.x} - pxf, dy2 = lr_f2{q00.y, q10.y} - pyf;
       const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;

@@ -156,6 +156,9 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       const float4* __restrict__ r1 = geom + LR_REC_QUADS * (size_t)(uint32_t)gid1;
       const float4 q00 = r0[0], q01 = r0[1], q10 = r1[0], q11 = r1[1];
       const float cbl0 = reinterpret_cast<const float*>(r0)[8], cbl1 = reinterpret_cast<const float*>(r1)[8];
+      // keep the colour loads in this one batch of scalar loads (left alone the compiler sinks them below the hit test:
+      // a second, exposed scalar-cache round trip in every contributing iteration)
+      asm volatile("" : : "s"(q01.z), "s"(q01.w), "s"(cbl0), "s"(q11.z), "s"(q11.w), "s"(cbl1));
       const float op0 = q01.y, op1 = q11.y;
       const lr_f2 dx2 = lr_f2{q00.x, q10.x} - pxf, dy2 = lr_f2{q00.y, q10.y} - pyf;
       const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
@@ -183,7 +186,9 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       T = acc1 ? test1 : T;
       last = acc1 ? pos0 + j1 + 1 : last;
       done = done | stop1;
-      const bool hit0 = __builtin_amdgcn_ballot_w64(acc0) != 0, hit1 = __builtin_amdgcn_ballot_w64(acc1) != 0;
+      // an accumulating lane has w > 0 (alpha >= 1/255, T > 1e-4): testing the VGPR gives the wave-level predicate in one
+      // v_cmp, where a ballot of the lane-mask predicate costs a v_cndmask + v_cmp
+      const bool hit0 = __builtin_amdgcn_ballot_w64(w0 > 0.f) != 0, hit1 = __builtin_amdgcn_ballot_w64(w1 > 0.f) != 0;
       if (hit0) {
         const float cr = q01.z, cg = q01.w, cbl = cbl0;
         const int gid = gid0;
@@ -369,13 +374,14 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       const int k0 = hi - 1 - j0, k1 = hi - 1 - j1;  // 0-based positions in the tile list
       const bool hit0 = (k0 < lastc) & !(power0 > 0.f) & !(alpha0 < 1.0f / 255.0f);
       const bool hit1 = has1 & (k1 < lastc) & !(power1 > 0.f) & !(alpha1 < 1.0f / 255.0f);
-      const bool any0 = __builtin_amdgcn_ballot_w64(hit0) != 0, any1 = __builtin_amdgcn_ballot_w64(hit1) != 0;
+      const lr_f2 alpha = {hit0 ? alpha0 : 0.f, hit1 ? alpha1 : 0.f};
+      // (a contributing lane has alpha >= 1/255: testing the VGPR is one v_cmp, a ballot of the lane-mask predicate two ops)
+      const bool any0 = __builtin_amdgcn_ballot_w64(alpha.x > 0.f) != 0, any1 = __builtin_amdgcn_ballot_w64(alpha.y > 0.f) != 0;
       if (!(any0 | any1)) continue;
       // Both entries of the pair go through ONE 2-wide body (v_pk_* f32: two entries per instruction).  Lanes that do
       // not contribute run it with alpha = G = 0, which leaves their state untouched exactly (T*1, 0*c + 1*acc) and
       // makes all nine of their partial sums exact zeros -- no exec masking, no zero-initialised accumulators.  Only T
       // and the colour behind the current entry (acc <- alpha c + (1-alpha) acc) chain from entry 0 to entry 1.
-      const lr_f2 alpha = {hit0 ? alpha0 : 0.f, hit1 ? alpha1 : 0.f};
       const lr_f2 G = {hit0 ? G0 : 0.f, hit1 ? G1 : 0.f};
       const lr_f2 om = 1.f - alpha;
       lr_f2 rc = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};

@@ -378,27 +378,27 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
   __syncthreads();
   inc += (tid >> 6) ? part[32 + (tid >> 6) - 1] : 0u;
   const uint32_t grand = part[32 + 15];
-  uint32_t run = inc - sum;  // exclusive prefix of this thread's chunk
+  const uint32_t run0 = inc - sum;  // exclusive prefix of this thread's chunk
+  // Where the per-tile stores go (measured): for the wide variants (4K / 8K grids, 32 / 128 tiles per thread) after
+  // the last barrier -- a barrier waits for the workgroup's outstanding global stores (4K: 174 -> 108 us) --, for
+  // 1080p here, where they overlap the LDS phases below (25 vs 28 us).
+  constexpr bool LATE = CHMAX > 8;
+  uint32_t run = run0;
 #pragma unroll
   for (int k = 0; k < CHMAX; k++) {
     const uint32_t t = b + (uint32_t)k;
     if ((uint32_t)k < chunk && t < tiles) {
-      offsets[t] = run;
-      cursor[t * LR_CTR_STRIDE] = run + nr[k];  // big instances go behind the ranked ones (64 B apart: the fill's atomics hit random tiles)
-      run += tot[k];
       atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u);
       lmax = max(lmax, tot[k]);
-      if (tot[k] > LR_LONG_LIST) biglist[atomicAdd(&state[LR_HDR_NBIG], 1u)] = t;  // long-list sort paths
+      if (!LATE) {
+        offsets[t] = run;
+        cursor[t * LR_CTR_STRIDE] = run + nr[k];  // big instances go behind the ranked ones (64 B apart: the fill's atomics hit random tiles)
+        run += tot[k];
+      }
     }
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d));
-  if ((tid & 63u) == 0u && lmax) atomicMax(&state[LR_HDR_MAXLEN], lmax);
-  if (tid == 1023) {
-    offsets[tiles] = grand;
-    state[LR_HDR_NUM] = grand;
-    state[LR_HDR_OVERFLOW] = 0u;
-  }
   // Longest-processing-time-first dispatch order for the blend kernels: a tile's list is walked serially by
   // its waves, so the longest lists must start first or they become the tail of the launch.  Counting sort
   // of the tiles into 256 length buckets (16 entries wide), longest bucket first.
@@ -418,10 +418,25 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
     for (int i = 0; i < 4; i++) { hist[255 - (4 * (int)tid + i)] = start; start += c[i]; }
   }
   __syncthreads();
+  run = run0;
 #pragma unroll
   for (int k = 0; k < CHMAX; k++) {
     const uint32_t t = b + (uint32_t)k;
-    if ((uint32_t)k < chunk && t < tiles) order[atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u)] = t;
+    if ((uint32_t)k < chunk && t < tiles) {
+      order[atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u)] = t;
+      if (LATE) {
+        offsets[t] = run;
+        cursor[t * LR_CTR_STRIDE] = run + nr[k];
+        run += tot[k];
+      }
+      if (tot[k] > LR_LONG_LIST) biglist[atomicAdd(&state[LR_HDR_NBIG], 1u)] = t;  // long-list sort paths
+    }
+  }
+  if ((tid & 63u) == 0u && lmax) atomicMax(&state[LR_HDR_MAXLEN], lmax);
+  if (tid == 1023) {
+    offsets[tiles] = grand;
+    state[LR_HDR_NUM] = grand;
+    state[LR_HDR_OVERFLOW] = 0u;
   }
 }
 

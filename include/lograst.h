@@ -180,11 +180,79 @@ int lograst_sh_backward(int32_t n, int32_t degree, int32_t max_coeffs, const flo
  * Pointers into a tile_state block (device): offsets has tiles+1 entries. */
 const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height);
 
+/* ---- "next" row N3: level-of-detail selection ------------------------------------------------------------
+ * Replaces TensorTree.traverse + TensorTree._query_tree_torch (/root/reference/LoG/model/tensor_tree.py:131-185;
+ * caller LoG.prepare, LoG/model/level_of_gaussian.py:241) together with the Gaussian.compute_radius it calls per
+ * level (level_of_gaussian.py:65-88: gather, exp / normalize activations, compute_radius_module.compute_radius).
+ * Inputs are the tree buffers as TensorTree keeps them (node_index i32[num_points], -1 = leaf; tree
+ * i32[num_nodes, max_child], -1 = removed child), the RAW model parameters (xyz[P,3], log-scales[P,3],
+ * unnormalised quaternions[P,4]), the roots to start from (i64[num_roots]) and the camera of
+ * lograst_compute_radius.  `levels` = number of levels to expand below the roots = min(tree.max_level, max_depth)
+ * of the reference call (values beyond the tree's depth cost only empty launches).
+ * out_index (i64, capacity out_capacity >= num_points is always enough: a point is selected at most once)
+ * receives, in the reference's order, [roots kept | children kept at level 1 | ... | frontier left at the depth
+ * limit], keep = (radius < min_resolution_pixel) | is_leaf.  The count stays on the device; read it with
+ * lograst_lod_read (one stream synchronise -- the only one; the reference synchronises several times per level).
+ * scratch: lograst_lod_scratch_bytes(num_roots, num_nodes, max_child) bytes. */
+size_t lograst_lod_scratch_bytes(int32_t num_roots, int32_t num_nodes, int32_t max_child);
+int lograst_lod_traverse(int32_t num_points, int32_t num_nodes, int32_t max_child, const int32_t* node_index,
+                         const int32_t* tree, const float* xyz, const float* scaling, const float* rotation,
+                         const int64_t* root_index, int32_t num_roots, const float* projmatrix,
+                         const float* viewmatrix, float focal_x, float focal_y, float tanfovx, float tanfovy,
+                         float min_resolution_pixel, int32_t levels, int64_t* out_index, uint32_t out_capacity,
+                         void* scratch, size_t scratch_bytes, void* stream);
+/* count_host / overflow_host: host words.  overflow != 0 means the tree buffers were inconsistent (a point
+ * reachable twice) and out_index is incomplete. */
+int lograst_lod_read(const void* scratch, uint32_t* count_host, uint32_t* overflow_host, void* stream);
+
+/* ---- "next" row N4: what LoG does with the rasterizer's outputs after every view ----------------------------
+ * (a) lograst_id_histogram replaces `torch.unique(point_id_pixel, sorted=True, return_counts=True)` + dropping the
+ *     leading -1 (/root/reference/LoG/render/renderer.py:156-159): ids_out (i32) = the distinct ids >= 0 in
+ *     ascending order, counts_out (i64) = pixels each one wins; both need capacity min(n, num_pixels), n = number
+ *     of Gaussians handed to the rasterizer (ids are < n).  The number of distinct ids stays on the device:
+ *     lograst_id_histogram_read synchronises the stream and returns it.
+ *     scratch: lograst_id_histogram_scratch_bytes(n). */
+size_t lograst_id_histogram_scratch_bytes(int32_t n);
+int lograst_id_histogram(int32_t n, const int32_t* point_id_pixel, int32_t num_pixels, int32_t* ids_out,
+                         int64_t* counts_out, void* scratch, size_t scratch_bytes, void* stream);
+int lograst_id_histogram_read(const void* scratch, uint32_t* count_host, void* stream);
+
+/* (b) lograst_counter_update replaces Counter.update_by_output for ONE view
+ *     (/root/reference/LoG/model/counter.py:36-68; caller LoG.update_by_output, level_of_gaussian.py:364-365).
+ *     visible_index i64[nv] (no duplicates) maps the view's submitted Gaussians to model rows; grad_means2d
+ *     f32[nv,3] is viewspace_points.grad; radii i32[nv]; point_weight f32[nv]; point_id i32[k] / point_count i64[k]
+ *     the lists of (a).  The eight Counter buffers (length num_points, dtypes as registered at counter.py:7-19)
+ *     are updated in place.  flag_vis_out (u8[nv], optional) receives radii > 0 (counter.py:48,50). */
+int lograst_counter_update(int32_t nv, const int64_t* visible_index, const float* grad_means2d, const int32_t* radii,
+                           const float* point_weight, int32_t k, const int32_t* point_id, const int64_t* point_count,
+                           int32_t num_points, float* weights_max, float* weights_sum, float* grad_sum,
+                           int16_t* radii_max, int16_t* visible_count, int32_t* radii_max_max, int32_t* area_sum,
+                           int32_t* create_steps, uint8_t* flag_vis_out, void* stream);
+
+/* (c) lograst_sparse_adam replaces SparseOptimizer.step + _single_tensor_adam
+ *     (/root/reference/LoG/model/sparse_optimizer.py:41-78,163-196; caller LoG.step, level_of_gaussian.py:379-390):
+ *     for every r < m with flag_vis[r] != 0 and every key, Adam on model row index[r] starting from the gathered
+ *     parameter row r, with the reference's scalars: step_size = lr / (1 - beta1^step), bias_correction2_sqrt =
+ *     sqrt(1 - beta2^step), eps; amsgrad when max_exp_avg_sq != NULL.  All keys go in one launch (num_keys <= 8). */
+typedef struct lograst_adam_key {
+  void* model_param;        /* f32 [num_points, width]: rows index[flag_vis] are rewritten */
+  const void* param;        /* f32 [m, width]: params[key].data */
+  const void* grad;         /* f32 [m, width]: params[key].grad */
+  void* exp_avg;            /* f32 [num_points, width] */
+  void* exp_avg_sq;         /* f32 [num_points, width] */
+  void* max_exp_avg_sq;     /* f32 [num_points, width] or NULL */
+  int32_t width;            /* floats per row */
+  float step_size;          /* lr / bias_correction1 */
+} lograst_adam_key;
+int lograst_sparse_adam(int32_t m, int32_t num_points, const int64_t* index, const uint8_t* flag_vis,
+                        int32_t num_keys, const lograst_adam_key* keys, double beta1, double beta2,
+                        double bias_correction2_sqrt, double eps, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream (used by bench.py) -----------------
  * When enabled every kernel launch is bracketed by hipEventRecord on its stream.  read() synchronises
  * the recorded events and returns, for kernel slot i < LOGRAST_NUM_KERNELS, accumulated milliseconds
  * and launch counts since the last reset. */
-#define LOGRAST_NUM_KERNELS 12
+#define LOGRAST_NUM_KERNELS 16
 void lograst_profile_enable(int on);
 void lograst_profile_reset(void);
 int lograst_profile_read(double* ms_out, int64_t* count_out);

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblogra
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
 REC_FLOATS = 16
-NUM_KERNELS = 12
+NUM_KERNELS = 16
 
 c_void_p, c_int32, c_uint32, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
                                                   ctypes.c_float, ctypes.c_size_t)
@@ -23,6 +23,12 @@ class LograstView(ctypes.Structure):
         ("filter_mode", c_int32), ("ndc_cull", c_int32), ("extras", c_int32),
         ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("bg", c_void_p),
     ]
+
+
+class LograstAdamKey(ctypes.Structure):
+    """struct lograst_adam_key (include/lograst.h)."""
+    _fields_ = [("model_param", c_void_p), ("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p),
+                ("exp_avg_sq", c_void_p), ("max_exp_avg_sq", c_void_p), ("width", c_int32), ("step_size", c_float)]
 
 
 class LograstError(RuntimeError):
@@ -56,6 +62,19 @@ _SIGNATURES = {
     "lograst_sh_backward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p]),
     "lograst_knn_scratch_bytes": (c_size_t, [c_int32]),
     "lograst_knn_mean_dist2": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lograst_lod_scratch_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "lograst_lod_traverse": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 6 + [c_int32, c_void_p, c_void_p,
+                                            c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p, c_uint32,
+                                            c_void_p, c_size_t, c_void_p]),
+    "lograst_lod_read": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_id_histogram_scratch_bytes": (c_size_t, [c_int32]),
+    "lograst_id_histogram": (ctypes.c_int, [c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lograst_id_histogram_read": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_counter_update": (ctypes.c_int, [c_int32] + [c_void_p] * 4 + [c_int32, c_void_p, c_void_p, c_int32]
+                               + [c_void_p] * 10),
+    "lograst_sparse_adam": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                           ctypes.POINTER(LograstAdamKey), ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double, c_void_p]),
     "lograst_profile_enable": (None, [ctypes.c_int]),
     "lograst_profile_reset": (None, []),
     "lograst_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

@@ -45,6 +45,22 @@ void lr_launch_sh_bwd(int N, int deg, int M, const float* means, const float* ca
                       const uint8_t* clamped, const float* g_colors, float* g_shs, float* g_means, bool accumulate,
                       hipStream_t s);
 
+size_t lr_lod_scratch_bytes(int num_roots, int num_nodes, int max_child);
+hipError_t lr_launch_lod(int num_points, int num_nodes, int max_child, const int32_t* node_index, const int32_t* tree,
+                         const float* xyz, const float* scaling, const float* rotation, const int64_t* root_index,
+                         int num_roots, const float* proj, const float* view, float fx, float fy, float tanfovx,
+                         float tanfovy, float min_px, int levels, int64_t* out, uint32_t out_capacity, void* scratch,
+                         hipStream_t s);
+int lr_lod_max_levels();
+uint32_t lr_lod_total_word();
+uint32_t lr_lod_overflow_word();
+
+size_t lr_hist_scratch_bytes(int n);
+hipError_t lr_launch_id_histogram(int n, const int32_t* pid, int npix, int32_t* ids, int64_t* counts, void* scratch,
+                                  hipStream_t s);
+hipError_t lr_launch_counter(const CounterArgs& a, hipStream_t s);
+hipError_t lr_launch_sparse_adam(const AdamArgs& a, int num_keys, hipStream_t s);
+
 static thread_local std::string g_err;
 static int lr_fail(int code, const std::string& msg) {
   g_err = msg;
@@ -89,7 +105,8 @@ static int lr_tile_cull() {
 // ---- profiling ------------------------------------------------------------------------------------------
 static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
     "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
-    "blend_fwd", "blend_bwd", "project_bwd", "knn3", "reserved"};
+    "blend_fwd", "blend_bwd", "project_bwd", "knn3", "lod_traverse", "counter_update", "sparse_adam",
+    "id_histogram", "reserved"};
 struct ProfRec { int slot; hipEvent_t a, b; bool own_a; };
 // Consecutive launches inside one entry point share an event: the end of kernel k is the begin of kernel k+1 (N+1
 // events for a chain of N kernels instead of 2N; every recorded event costs ~1.4 us of stream time).
@@ -352,6 +369,114 @@ int lograst_knn_mean_dist2(int32_t p, const float* points, float* out, void* scr
   if (!points || !out || !scratch) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   if (scratch_bytes < lr_knn_scratch_bytes(p)) return lr_fail(LOGRAST_ERR_ARG, "knn scratch too small");
   LR_HIP(lr_launch_knn(p, points, out, scratch, scratch_bytes, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+size_t lograst_lod_scratch_bytes(int32_t num_roots, int32_t num_nodes, int32_t max_child) {
+  return lr_lod_scratch_bytes(num_roots, num_nodes, max_child > 0 ? max_child : 1);
+}
+
+int lograst_lod_traverse(int32_t num_points, int32_t num_nodes, int32_t max_child, const int32_t* node_index,
+                         const int32_t* tree, const float* xyz, const float* scaling, const float* rotation,
+                         const int64_t* root_index, int32_t num_roots, const float* projmatrix,
+                         const float* viewmatrix, float focal_x, float focal_y, float tanfovx, float tanfovy,
+                         float min_resolution_pixel, int32_t levels, int64_t* out_index, uint32_t out_capacity,
+                         void* scratch, size_t scratch_bytes, void* stream) {
+  if (num_points < 0 || num_nodes < 0 || num_roots < 0) return lr_fail(LOGRAST_ERR_ARG, "negative count");
+  if (max_child < 1) return lr_fail(LOGRAST_ERR_ARG, "max_child must be >= 1");
+  if ((uint64_t)num_nodes * (uint64_t)max_child > 0x7fffffffull) return lr_fail(LOGRAST_ERR_ARG, "tree too large");
+  if (!scratch || scratch_bytes < lr_lod_scratch_bytes(num_roots, num_nodes, max_child))
+    return lr_fail(LOGRAST_ERR_ARG, "lod scratch too small");
+  if (num_roots > 0 && (!root_index || !node_index || !xyz || !scaling || !rotation || !projmatrix || !viewmatrix || !out_index))
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (num_nodes > 0 && !tree) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (levels < 0) levels = 0;
+  if (levels > lr_lod_max_levels()) levels = lr_lod_max_levels();
+  g_prof_call++;
+  LR_HIP(lr_launch_lod(num_points, num_nodes, max_child, node_index, tree, xyz, scaling, rotation, root_index, num_roots,
+                       projmatrix, viewmatrix, focal_x, focal_y, tanfovx, tanfovy, min_resolution_pixel, levels,
+                       out_index, out_capacity, scratch, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+int lograst_lod_read(const void* scratch, uint32_t* count_host, uint32_t* overflow_host, void* stream) {
+  if (!scratch || !count_host) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  uint32_t w[2] = {0, 0};
+  LR_HIP(hipMemcpyAsync(w, reinterpret_cast<const uint32_t*>(scratch) + lr_lod_total_word(), sizeof(w),
+                        hipMemcpyDeviceToHost, (hipStream_t)stream));
+  LR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  *count_host = w[0];
+  if (overflow_host) *overflow_host = w[1];
+  return LOGRAST_OK;
+}
+
+size_t lograst_id_histogram_scratch_bytes(int32_t n) { return lr_hist_scratch_bytes(n); }
+
+int lograst_id_histogram(int32_t n, const int32_t* point_id_pixel, int32_t num_pixels, int32_t* ids_out,
+                         int64_t* counts_out, void* scratch, size_t scratch_bytes, void* stream) {
+  if (n < 0 || num_pixels < 0) return lr_fail(LOGRAST_ERR_ARG, "negative count");
+  if (!scratch || scratch_bytes < lr_hist_scratch_bytes(n)) return lr_fail(LOGRAST_ERR_ARG, "histogram scratch too small");
+  if (n > 0 && num_pixels > 0 && (!point_id_pixel || !ids_out || !counts_out)) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  g_prof_call++;
+  LR_HIP(lr_launch_id_histogram(n, point_id_pixel, num_pixels, ids_out, counts_out, scratch, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+int lograst_id_histogram_read(const void* scratch, uint32_t* count_host, void* stream) {
+  if (!scratch || !count_host) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  LR_HIP(hipMemcpyAsync(count_host, scratch, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  LR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+int lograst_counter_update(int32_t nv, const int64_t* visible_index, const float* grad_means2d, const int32_t* radii,
+                           const float* point_weight, int32_t k, const int32_t* point_id, const int64_t* point_count,
+                           int32_t num_points, float* weights_max, float* weights_sum, float* grad_sum,
+                           int16_t* radii_max, int16_t* visible_count, int32_t* radii_max_max, int32_t* area_sum,
+                           int32_t* create_steps, uint8_t* flag_vis_out, void* stream) {
+  if (nv < 0 || k < 0 || num_points < 0) return lr_fail(LOGRAST_ERR_ARG, "negative count");
+  if (nv == 0) return LOGRAST_OK;
+  if (!visible_index || !grad_means2d || !radii || !point_weight || (k > 0 && (!point_id || !point_count)))
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (!weights_max || !weights_sum || !grad_sum || !radii_max || !visible_count || !radii_max_max || !area_sum || !create_steps)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL counter buffer");
+  CounterArgs a;
+  a.visible_index = visible_index; a.grad = grad_means2d; a.radii = radii; a.weight = point_weight;
+  a.point_id = point_id; a.point_count = point_count;
+  a.weights_max = weights_max; a.weights_sum = weights_sum; a.grad_sum = grad_sum;
+  a.radii_max = radii_max; a.visible_count = visible_count;
+  a.radii_max_max = radii_max_max; a.area_sum = area_sum; a.create_steps = create_steps;
+  a.flag_vis = flag_vis_out;
+  a.nv = nv; a.k = k; a.num_points = num_points;
+  g_prof_call++;
+  LR_HIP(lr_launch_counter(a, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+int lograst_sparse_adam(int32_t m, int32_t num_points, const int64_t* index, const uint8_t* flag_vis,
+                        int32_t num_keys, const lograst_adam_key* keys, double beta1, double beta2,
+                        double bias_correction2_sqrt, double eps, void* stream) {
+  if (m < 0 || num_points < 0) return lr_fail(LOGRAST_ERR_ARG, "negative count");
+  if (num_keys < 0 || num_keys > ADAM_MAX_KEYS) return lr_fail(LOGRAST_ERR_ARG, "at most 8 keys per call");
+  if (m == 0 || num_keys == 0) return LOGRAST_OK;
+  if (!index || !flag_vis || !keys) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  AdamArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < num_keys; i++) {
+    const lograst_adam_key& k = keys[i];
+    if (!k.model_param || !k.param || !k.grad || !k.exp_avg || !k.exp_avg_sq) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer in key");
+    if (k.width < 1) return lr_fail(LOGRAST_ERR_ARG, "key width must be >= 1");
+    a.key[i].model = (float*)k.model_param; a.key[i].param = (const float*)k.param; a.key[i].grad = (const float*)k.grad;
+    a.key[i].exp_avg = (float*)k.exp_avg; a.key[i].exp_avg_sq = (float*)k.exp_avg_sq;
+    a.key[i].max_exp_avg_sq = (float*)k.max_exp_avg_sq;
+    a.key[i].width = k.width; a.key[i].neg_step_size = -k.step_size;
+  }
+  a.index = index; a.flag_vis = flag_vis; a.m = m; a.num_points = num_points;
+  // the reference's Python scalars are doubles that torch narrows to fp32 when they meet an fp32 tensor
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+  a.bc2_sqrt = (float)bias_correction2_sqrt; a.eps = (float)eps;
+  g_prof_call++;
+  LR_HIP(lr_launch_sparse_adam(a, num_keys, (hipStream_t)stream));
   return LOGRAST_OK;
 }
 

@@ -207,6 +207,53 @@ LR_DEV float lr_radius_from_cov(float a, float c, float det) {
   return 3.f * sqrtf(fmaxf(l1, l2));
 }
 
+// A0 for one Gaussian: the body of compute_radius_cuda (/root/reference/LoG/cuda/compute_radius_kernel.cu:107-156)
+// -- float radius (no ceil), |ndc| > 1.3 cull only, fork low-pass max(., 0.3), det == 0 -> 0.  Shared by
+// lr_radius_kernel (project.hip) and the level-of-detail traversal (lod.hip).
+LR_DEV float lr_radius_one(const float p[3], const float s[3], const float q[4], const float* __restrict__ proj,
+                           const float* __restrict__ view, float fx, float fy, float tanfovx, float tanfovy) {
+  float hx = lr_dot3p(proj[0], proj[4], proj[8], p[0], p[1], p[2], proj[12]);
+  float hy = lr_dot3p(proj[1], proj[5], proj[9], p[0], p[1], p[2], proj[13]);
+  float hw = lr_dot3p(proj[3], proj[7], proj[11], p[0], p[1], p[2], proj[15]);
+  float pw = 1.0f / (hw + 0.0000001f);
+  float nx = hx * pw, ny = hy * pw;
+  float out = 0.f;
+  if (!(nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) {
+    float R[9], Sg[6];
+    lr_cov3d(s, q, R, Sg);
+    LrEwa e;
+    lr_ewa(p, Sg, view, fx, fy, tanfovx, tanfovy, LOGRAST_FILTER_CLAMP, e);
+    float det = e.a * e.c - e.b * e.b;
+    if (det != 0.0f) out = lr_radius_from_cov(e.a, e.c, det);
+  }
+  return out;
+}
+
+// exp(x) for either sign: lr_exp's op sequence with the exponent also clamped from above (lr_exp itself stays as
+// it is: the blend kernels only call it with x <= 0).  Shared with oracle/lograst_oracle.c:ora_exp_any.
+LR_DEV float lr_exp_any(float x) {
+  float t = x * 1.44269504088896341f;
+  t = fminf(fmaxf(t, -125.0f), 125.0f);
+  float n = rintf(t);
+  float f = t - n;
+  float p = 0x1.5c08e4p-10f;
+  p = lr_fma(p, f, 0x1.3d0c52p-7f);
+  p = lr_fma(p, f, 0x1.c6b6e4p-5f);
+  p = lr_fma(p, f, 0x1.ebf918p-3f);
+  p = lr_fma(p, f, 0x1.62e428p-1f);
+  p = lr_fma(p, f, 0x1.000002p+0f);
+  int ni = (int)n;
+  return __uint_as_float(__float_as_uint(p) + ((uint32_t)ni << 23));
+}
+
+// torch.nn.functional.normalize on one quaternion (LoG/model/activation.py:17): q / max(|q|, 1e-12), as a fixed
+// op sequence (oracle: ora_normalize4).
+LR_DEV void lr_normalize4(float q[4]) {
+  const float n2 = lr_fma(q[0], q[0], lr_fma(q[1], q[1], lr_fma(q[2], q[2], q[3] * q[3])));
+  const float d = fmaxf(sqrtf(n2), 1e-12f);
+  q[0] = q[0] / d; q[1] = q[1] / d; q[2] = q[2] / d; q[3] = q[3] / d;
+}
+
 // ---- alpha-support test against a pixel box, prepared once per Gaussian ------------------------------
 // Can the Gaussian reach alpha >= 1/255 anywhere in the pixel box [x0,x1]x[y0,y1]?  Same conservative rule as
 // blend.hip:lr_support_hits (level set 0.5 d^T Q d <= 1.01 ln(255 opacity) + 0.01, "yes" whenever the fp32
@@ -283,10 +330,42 @@ LR_DEV uint32_t lr_wave_umax_to63(uint32_t v) {
   return v;
 }
 
+// ---- N4 kernel arguments (counter.hip; filled in by api.hip) ------------------------------------------
+struct CounterArgs {
+  const int64_t* visible_index;
+  const float* grad;       // dL/dmeans2D [nv, 3]
+  const int32_t* radii;
+  const float* weight;     // point_weight [nv]
+  const int32_t* point_id;
+  const int64_t* point_count;
+  float* weights_max; float* weights_sum; float* grad_sum;
+  int16_t* radii_max; int16_t* visible_count;
+  int32_t* radii_max_max; int32_t* area_sum; int32_t* create_steps;
+  uint8_t* flag_vis;
+  int32_t nv, k, num_points;
+};
+
+#define ADAM_MAX_KEYS 8
+struct AdamKey {
+  float* model;        // [num_points, width]: rows `index` are rewritten
+  const float* param;  // [m, width]: the gathered parameter the step starts from (params[key].data)
+  const float* grad;   // [m, width]
+  float* exp_avg; float* exp_avg_sq; float* max_exp_avg_sq;  // [num_points, width]; max_exp_avg_sq may be NULL
+  int32_t width;
+  float neg_step_size;
+};
+struct AdamArgs {
+  AdamKey key[ADAM_MAX_KEYS];
+  const int64_t* index;
+  const uint8_t* flag_vis;
+  int32_t m, num_points;
+  float beta1, beta2, omb1, omb2, bc2_sqrt, eps;
+};
+
 // ---- host-side launch bookkeeping (api.hip) ------------------------------------------------------
 enum LrKernelSlot {
   LRK_RADIUS = 0, LRK_PROJECT, LRK_SCAN, LRK_FILL, LRK_SORT_SMALL, LRK_SORT_LARGE, LRK_SORT_HUGE,
-  LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_RESERVED
+  LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_LOD, LRK_COUNTER, LRK_ADAM, LRK_HIST, LRK_RESERVED
 };
 void lr_prof_begin(int slot, hipStream_t s);
 void lr_prof_end(int slot, hipStream_t s);

@@ -18,21 +18,8 @@ lr_radius_kernel(int P, const float* __restrict__ means, const float* __restrict
   float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
   float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
   const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
-  float hx = lr_dot3p(proj[0], proj[4], proj[8], p[0], p[1], p[2], proj[12]);
-  float hy = lr_dot3p(proj[1], proj[5], proj[9], p[0], p[1], p[2], proj[13]);
-  float hw = lr_dot3p(proj[3], proj[7], proj[11], p[0], p[1], p[2], proj[15]);
-  float pw = 1.0f / (hw + 0.0000001f);
-  float nx = hx * pw, ny = hy * pw;
-  float out = 0.f;
-  if (!(nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) {
-    float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    float R[9], Sg[6];
-    lr_cov3d(s, q, R, Sg);
-    LrEwa e;
-    lr_ewa(p, Sg, view, fx, fy, tanfovx, tanfovy, LOGRAST_FILTER_CLAMP, e);
-    float det = e.a * e.c - e.b * e.b;
-    if (det != 0.0f) out = lr_radius_from_cov(e.a, e.c, det);
-  }
+  const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+  const float out = lr_radius_one(p, s, q, proj, view, fx, fy, tanfovx, tanfovy);
   radii[i] = out;
 }
 

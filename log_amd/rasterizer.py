@@ -274,6 +274,118 @@ class HipBackend:
         return out
 
 
+    def lod_traverse(self, node_index, tree, xyz, scaling, rotation, root_index, projmatrix, viewmatrix, fx, fy,
+                     tanfovx, tanfovy, min_resolution_pixel, levels):
+        """N3 (log_amd/lod.py): -> int64 indices selected for this camera, in the reference's order."""
+        device = xyz.device
+        L = self.require(device)
+        P = int(xyz.shape[0])
+        ni = node_index.detach().to(device=device, dtype=torch.int32).contiguous()
+        tr = tree.detach().to(device=device, dtype=torch.int32).contiguous()
+        num_nodes, max_child = (int(tr.shape[0]), int(tr.shape[1])) if tr.dim() == 2 else (0, 1)
+        roots = root_index.detach().to(device=device, dtype=torch.int64).contiguous()
+        x, s, r = _dev_f32(xyz, device), _dev_f32(scaling, device), _dev_f32(rotation, device)
+        pm, vm = _dev_f32(projmatrix, device), _dev_f32(viewmatrix, device)
+        out = torch.empty(max(P, 1), dtype=torch.int64, device=device)
+        nbytes = L.lograst_lod_scratch_bytes(int(roots.numel()), num_nodes, max_child)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        count, overflow = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_lod_traverse(P, num_nodes, max_child, _ptr(ni), _ptr(tr), _ptr(x), _ptr(s), _ptr(r),
+                                              _ptr(roots), int(roots.numel()), _ptr(pm), _ptr(vm), float(fx),
+                                              float(fy), float(tanfovx), float(tanfovy), float(min_resolution_pixel),
+                                              int(levels), _ptr(out), int(out.numel()), _ptr(scratch), nbytes,
+                                              _stream_ptr(device)))
+            _lib.check(L.lograst_lod_read(_ptr(scratch), ctypes.byref(count), ctypes.byref(overflow),
+                                          _stream_ptr(device)))
+        if overflow.value:
+            raise _lib.LograstError("lod_traverse: inconsistent tree buffers (a point is reachable more than once)")
+        return out[:count.value]
+
+
+    def id_histogram(self, point_id_pixel, n):
+        """N4a (log_amd/counter.py): sorted distinct ids >= 0 of the per-pixel id map and their pixel counts."""
+        device = point_id_pixel.device
+        L = self.require(device)
+        pid = point_id_pixel.detach().to(torch.int32).contiguous()
+        npix = int(pid.numel())
+        cap = max(1, min(n, npix))
+        ids = torch.empty(cap, dtype=torch.int32, device=device)
+        counts = torch.empty(cap, dtype=torch.int64, device=device)
+        nbytes = L.lograst_id_histogram_scratch_bytes(n)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        k = ctypes.c_uint32(0)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_id_histogram(n, _ptr(pid), npix, _ptr(ids), _ptr(counts), _ptr(scratch), nbytes,
+                                              _stream_ptr(device)))
+            _lib.check(L.lograst_id_histogram_read(_ptr(scratch), ctypes.byref(k), _stream_ptr(device)))
+        return ids[:k.value], counts[:k.value]
+
+    def counter_update(self, buffers, visible_index, grad, radii, point_weight, point_id, point_count):
+        """N4b (log_amd/counter.py): Counter.update_by_output for one view; -> flag_vis (bool[nv])."""
+        device = radii.device
+        L = self.require(device)
+        want = {"weights_max": torch.float32, "weights_sum": torch.float32, "grad_sum": torch.float32,
+                "radii_max": torch.int16, "visible_count": torch.int16, "radii_max_max": torch.int32,
+                "area_sum": torch.int32, "create_steps": torch.int32}
+        for name, dt in want.items():
+            b = buffers[name]
+            if b.dtype != dt or b.device != device or not b.is_contiguous():
+                raise ValueError(f"counter buffer {name}: expected a contiguous {dt} tensor on {device}")
+        num_points = int(buffers["weights_max"].shape[0])
+        vi = visible_index.detach().to(device=device, dtype=torch.int64).contiguous()
+        nv = int(vi.numel())
+        g = _dev_f32(grad, device)
+        if g.shape != (nv, 3):
+            raise ValueError("viewspace gradient must be [nv, 3]")
+        r = radii.detach().to(torch.int32).contiguous()
+        w = _dev_f32(point_weight, device).reshape(-1)
+        pid = point_id.detach().to(device=device, dtype=torch.int32).contiguous()
+        pc = point_count.detach().to(device=device, dtype=torch.int64).contiguous()
+        flag = torch.empty(nv, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_counter_update(
+                nv, _ptr(vi), _ptr(g), _ptr(r), _ptr(w), int(pid.numel()), _ptr(pid), _ptr(pc), num_points,
+                *[_ptr(buffers[name]) for name in want], _ptr(flag), _stream_ptr(device)))
+        return flag.view(torch.bool)
+
+    def sparse_adam(self, index, flag_vis, entries, beta1, beta2, bias_correction2_sqrt, eps):
+        """N4c (log_amd/sparse_optimizer.py).  entries: (model_param, param, grad, exp_avg, exp_avg_sq,
+        max_exp_avg_sq | None, step_size) per key."""
+        device = index.device
+        L = self.require(device)
+        idx = index.detach().to(torch.int64).contiguous()
+        m = int(idx.numel())
+        fv = flag_vis.detach().to(device=device).contiguous()
+        fv = fv.view(torch.uint8) if fv.dtype == torch.bool else fv.to(torch.uint8)
+        if int(fv.numel()) != m:
+            raise ValueError("flag_vis and index must have the same length")
+        keep = []
+        with torch.cuda.device(device):
+            for first in range(0, len(entries), 8):
+                chunk = entries[first:first + 8]
+                keys = (_lib.LograstAdamKey * len(chunk))()
+                for slot, (model_p, param, grad, m1, m2, mmax, step_size) in zip(keys, chunk):
+                    num_points = int(model_p.shape[0])
+                    width = int(model_p[0].numel()) if num_points else 1
+                    for t in (model_p, m1, m2) + ((mmax,) if mmax is not None else ()):
+                        if t.device != device or t.dtype != torch.float32 or not t.is_contiguous() or t.shape != model_p.shape:
+                            raise NotImplementedError("parameters and Adam moments must be contiguous fp32 tensors on "
+                                                      "the parameter's device (CPU-resident optimizer state is not supported)")
+                    p, g = _dev_f32(param, device), _dev_f32(grad, device)
+                    if int(p.numel()) != m * width or int(g.numel()) != m * width:
+                        raise ValueError("param / grad rows do not match index")
+                    keep += [p, g]
+                    slot.model_param, slot.param, slot.grad = model_p.data_ptr(), p.data_ptr(), g.data_ptr()
+                    slot.exp_avg, slot.exp_avg_sq = m1.data_ptr(), m2.data_ptr()
+                    slot.max_exp_avg_sq = mmax.data_ptr() if mmax is not None else None
+                    slot.width, slot.step_size = width, float(step_size)
+                _lib.check(L.lograst_sparse_adam(m, num_points, _ptr(idx), _ptr(fv), len(chunk), keys, float(beta1),
+                                                 float(beta2), float(bias_correction2_sqrt), float(eps),
+                                                 _stream_ptr(device)))
+        del keep
+
+
 _backend = HipBackend()
 
 

@@ -1,0 +1,65 @@
+"""Drop-in for ``SparseOptimizer.step`` (/root/reference/LoG/model/sparse_optimizer.py:163-196 with
+``_single_tensor_adam`` :41-78 and the state gather / scatter :198-249) -- SURVEY 8f row N4.
+
+The reference compacts ``index[flag_vis]``, copies it to the host, gathers both Adam moments of every key, runs
+~10 elementwise kernels per key and scatters parameters and moments back.  Here all keys are updated in ONE kernel
+launch that skips rows with ``flag_vis == False`` itself (include/lograst.h: lograst_sparse_adam); the only host
+work is the learning-rate schedule.  ``global_steps`` stays a device buffer (it is part of the state dict) and is
+mirrored by a host-side counter so that the step does not synchronise.
+
+Install with ``log_amd.sparse_optimizer.install()`` (= ``SparseOptimizer.step = step``)."""
+import math
+
+import torch
+
+from . import rasterizer as _r
+
+BETA1, BETA2, EPS = 0.9, 0.999, 1e-15      # _single_tensor_adam defaults / the eps passed at sparse_optimizer.py:190
+
+
+def _host_steps(opt):
+    n = getattr(opt, "_lograst_steps", None)
+    if n is None:
+        n = int(opt.global_steps.item())    # once (and again after load_state_dict)
+    return n
+
+
+def step(self, model, index, params, flag_vis):
+    """Same signature and effects as SparseOptimizer.step: rows ``index[flag_vis]`` of every ``getattr(model, key)``
+    with a gradient, and of its Adam moments, are updated; ``self.xyz_lr`` and ``self.global_steps`` advance."""
+    steps = _host_steps(self) + 1            # read (first call only) BEFORE the device-side increment
+    self.global_steps += 1
+    self._lograst_steps = steps
+    bc1 = 1 - BETA1 ** steps
+    bc2 = 1 - BETA2 ** steps
+    entries = []
+    for key, param in params.items():
+        if param.grad is None:
+            continue
+        if key == "xyz":
+            lr = self.xyz_scheduler_args(steps)
+            self.xyz_lr = lr
+        elif key == "scaling":
+            lr = self.scaling_scheduler_args(steps)
+        else:
+            lr = self.lr_dict[key]
+        entries.append((getattr(model, key).data, param.data, param.grad, self.exp_avg[key], self.exp_avg_sq[key],
+                        self.max_exp_avg_sq[key] if self.use_amsgrad else None, lr / bc1))
+    if entries:
+        with torch.no_grad():
+            _r._backend.sparse_adam(index, flag_vis, entries, BETA1, BETA2, math.sqrt(bc2), EPS)
+
+
+def _load_state_dict(self, state_dict):
+    self._lograst_steps = None
+    return self._lograst_load_state_dict(state_dict)
+
+
+def install():
+    """Patch the reference class in place (needs LoG importable)."""
+    from LoG.model.sparse_optimizer import SparseOptimizer
+    if not hasattr(SparseOptimizer, "_lograst_load_state_dict"):
+        SparseOptimizer._lograst_load_state_dict = SparseOptimizer.load_state_dict
+        SparseOptimizer.load_state_dict = _load_state_dict
+    SparseOptimizer.step = step
+    return SparseOptimizer

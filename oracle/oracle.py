@@ -87,6 +87,52 @@ def compute_radius(means, scales, rots, proj, viewm, fx, fy, tanfovx, tanfovy):
     return out
 
 
+def lod_radius(idx, xyz, scaling, rotation, proj, viewm, fx, fy, tanfovx, tanfovy):
+    """Gaussian.compute_radius for TensorTree.traverse (LoG/model/level_of_gaussian.py:65-88) on RAW parameters:
+    gather `idx`, exp / normalize, A0."""
+    idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
+    xyz, scaling, rotation = _f32(xyz), _f32(scaling), _f32(rotation)
+    proj, viewm = _f32(proj).reshape(-1), _f32(viewm).reshape(-1)
+    out = np.zeros(idx.shape[0], np.float32)
+    lib().ora_lod_radius(ctypes.c_int32(idx.shape[0]), _p(idx), _p(xyz), _p(scaling), _p(rotation), _p(proj),
+                         _p(viewm), ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_float(tanfovx),
+                         ctypes.c_float(tanfovy), _p(out))
+    return out
+
+
+def lod_traverse(node_index, tree, xyz, scaling, rotation, root_index, proj, viewm, fx, fy, tanfovx, tanfovy,
+                 min_resolution_pixel, max_level, max_depth=1000):
+    """N3 -- TensorTree.traverse + _query_tree_torch, LoG/model/tensor_tree.py:131-185, restated with numpy.
+    Returns the selected point indices (int64) in the reference's order."""
+    node_index = np.asarray(node_index, dtype=np.int64)
+    tree = np.asarray(tree, dtype=np.int64).reshape(-1, tree.shape[-1] if np.ndim(tree) == 2 else 1)
+    root_index = np.asarray(root_index, dtype=np.int64)
+    min_px = np.float32(min_resolution_pixel)
+
+    def radius(idx):
+        return lod_radius(idx, xyz, scaling, rotation, proj, viewm, fx, fy, tanfovx, tanfovy)
+
+    # tensor_tree.py:167-174
+    keep = (radius(root_index) < min_px) | (node_index[root_index] == -1)
+    out = [root_index[keep]]
+    index = root_index[~keep]
+    # tensor_tree.py:131-165
+    level = 1
+    while True:
+        if level > max_level or level > max_depth:
+            out.append(index)
+            break
+        child = tree[node_index[index]].reshape(-1)
+        child = child[child != -1]
+        keep = (radius(child) < min_px) | (node_index[child] == -1)
+        out.append(child[keep])
+        if not (~keep).any():
+            break
+        index = child[~keep]
+        level += 1
+    return np.concatenate(out).astype(np.int64)
+
+
 def forward(view, means, scales, rots, opac, colors, extras=True):
     """Full forward.  Returns a dict with every intermediate the HIP path is compared against."""
     means, scales, rots = _f32(means), _f32(scales), _f32(rots)
@@ -190,3 +236,55 @@ def sh_backward(means, campos, shs, degree, clamped, g_colors):
     lib().ora_sh_bwd(ctypes.c_int32(N), ctypes.c_int32(degree), ctypes.c_int32(M), _p(means), _p(campos), _p(shs),
                      _p(cl), _p(g_colors), _p(g_shs), _p(g_means))
     return g_shs[:N], g_means[:N]
+
+
+def id_histogram(point_id_pixel):
+    """N4a -- LoG/render/renderer.py:156-159: sorted distinct ids (without -1) and how many pixels each one wins."""
+    ids, counts = np.unique(np.asarray(point_id_pixel).reshape(-1), return_counts=True)
+    if ids.size and ids[0] == -1:
+        ids, counts = ids[1:], counts[1:]
+    return ids.astype(np.int32), counts.astype(np.int64)
+
+
+COUNTER_FIELDS = (("weights_max", np.float32), ("weights_sum", np.float32), ("grad_sum", np.float32),
+                  ("radii_max", np.int16), ("visible_count", np.int16), ("radii_max_max", np.int32),
+                  ("area_sum", np.int32), ("create_steps", np.int32))
+
+
+def counter_update(state, visible_index, grad, radii, point_weight, point_id, point_count):
+    """N4b -- Counter.update_by_output for one view (LoG/model/counter.py:36-68).  `state`: dict of the eight
+    Counter buffers (COUNTER_FIELDS), updated IN PLACE (arrays must be contiguous, of the registered dtypes).
+    Returns flag_vis (bool[nv])."""
+    vi = np.ascontiguousarray(np.asarray(visible_index, np.int64))
+    g = _f32(grad)
+    r = np.ascontiguousarray(np.asarray(radii, np.int32))
+    w = _f32(point_weight)
+    pid = np.ascontiguousarray(np.asarray(point_id, np.int32))
+    pc = np.ascontiguousarray(np.asarray(point_count, np.int64))
+    for name, dt in COUNTER_FIELDS:
+        assert state[name].dtype == dt and state[name].flags["C_CONTIGUOUS"], name
+    flag = np.zeros(vi.shape[0], np.uint8)
+    lib().ora_counter_update(ctypes.c_int32(vi.shape[0]), _p(vi), _p(g), _p(r), _p(w), ctypes.c_int32(pid.shape[0]),
+                             _p(pid), _p(pc), *[_p(state[name]) for name, _ in COUNTER_FIELDS], _p(flag))
+    return flag.astype(bool)
+
+
+def sparse_adam(model, param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, index, flag_vis, lr, step, beta1=0.9,
+                beta2=0.999, eps=1e-15):
+    """N4c -- one key of SparseOptimizer.step (LoG/model/sparse_optimizer.py:41-78,163-196).  model / exp_avg /
+    exp_avg_sq / max_exp_avg_sq ([P, ...] fp32, contiguous) are updated IN PLACE; the Python-side scalars follow
+    sparse_optimizer.py:62-71."""
+    import math
+    idx = np.ascontiguousarray(np.asarray(index, np.int64))
+    fv = np.ascontiguousarray(np.asarray(flag_vis, np.uint8))
+    param, grad = _f32(param), _f32(grad)
+    width = int(np.prod(param.shape[1:])) if param.ndim > 1 else 1
+    bc1 = 1 - beta1 ** int(step)
+    bc2 = 1 - beta2 ** int(step)
+    for a in (model, exp_avg, exp_avg_sq):
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    lib().ora_sparse_adam(ctypes.c_int32(idx.shape[0]), _p(idx), _p(fv), ctypes.c_int32(width), _p(model), _p(param),
+                          _p(grad), _p(exp_avg), _p(exp_avg_sq),
+                          _p(max_exp_avg_sq) if max_exp_avg_sq is not None else ctypes.c_void_p(0),
+                          ctypes.c_double(lr / bc1), ctypes.c_double(beta1), ctypes.c_double(beta2),
+                          ctypes.c_double(math.sqrt(bc2)), ctypes.c_double(eps))

@@ -52,3 +52,40 @@ class OracleBackend:
                                         clamped.numpy(), g_colors.numpy())
         g_means3D += torch.from_numpy(g_m.copy())
         return torch.from_numpy(g_shs.copy())
+
+    def lod_traverse(self, node_index, tree, xyz, scaling, rotation, root_index, projmatrix, viewmatrix, fx, fy,
+                     tanfovx, tanfovy, min_resolution_pixel, levels):
+        n = lambda a: a.detach().cpu().numpy()
+        tr = n(tree)
+        idx = oracle.lod_traverse(n(node_index), tr.reshape(-1, tr.shape[-1]) if tr.ndim == 2 else tr.reshape(0, 1),
+                                  n(xyz), n(scaling), n(rotation), n(root_index), n(projmatrix), n(viewmatrix),
+                                  float(fx), float(fy), float(tanfovx), float(tanfovy), float(min_resolution_pixel),
+                                  max_level=int(levels), max_depth=int(levels))
+        return torch.from_numpy(idx)
+
+    def id_histogram(self, point_id_pixel, n):
+        ids, counts = oracle.id_histogram(point_id_pixel.detach().cpu().numpy())
+        return torch.from_numpy(ids), torch.from_numpy(counts)
+
+    def counter_update(self, buffers, visible_index, grad, radii, point_weight, point_id, point_count):
+        n = lambda a: a.detach().cpu().numpy()
+        state = {k: buffers[k].numpy() for k, _ in oracle.COUNTER_FIELDS}      # shares memory: updated in place
+        flag = oracle.counter_update(state, n(visible_index), n(grad), n(radii), n(point_weight), n(point_id),
+                                     n(point_count))
+        return torch.from_numpy(flag)
+
+    def sparse_adam(self, index, flag_vis, entries, beta1, beta2, bias_correction2_sqrt, eps):
+        import ctypes
+        n = lambda a: a.detach().cpu().numpy()
+        idx = np.ascontiguousarray(n(index).astype(np.int64))
+        fv = np.ascontiguousarray(n(flag_vis).astype(np.uint8))
+        for model_p, param, grad, m1, m2, mmax, step_size in entries:
+            width = int(model_p[0].numel())
+            p, g = np.ascontiguousarray(n(param), np.float32), np.ascontiguousarray(n(grad), np.float32)
+            ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            oracle.lib().ora_sparse_adam(
+                ctypes.c_int32(idx.shape[0]), ptr(idx), ptr(fv), ctypes.c_int32(width), ptr(model_p.numpy()), ptr(p),
+                ptr(g), ptr(m1.numpy()), ptr(m2.numpy()),
+                ptr(mmax.numpy()) if mmax is not None else ctypes.c_void_p(0), ctypes.c_double(step_size),
+                ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(bias_correction2_sqrt),
+                ctypes.c_double(eps))

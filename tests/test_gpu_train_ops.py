@@ -1,0 +1,150 @@
+"""N4 on the GPU: lograst_id_histogram / lograst_counter_update / lograst_sparse_adam through the drop-ins
+(log_amd/counter.py, log_amd/sparse_optimizer.py) against results of the reference's own Counter / SparseOptimizer /
+torch.unique (tests/golden/*.npz) and against the oracle (same fp32 op sequence: compared bit for bit)."""
+import numpy as np
+import pytest
+import torch
+
+import train_util as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_id_histogram_matches_reference_lists():
+    from log_amd import counter
+    g = U.load("counter_a.npz")
+    for v in range(int(g["n_views"])):
+        ids, counts = counter.unique_ids(torch.from_numpy(g[f"v{v}_pid_map"]).to(DEV), int(g[f"v{v}_radii"].shape[0]))
+        assert ids.dtype == torch.int32 and counts.dtype == torch.int64
+        np.testing.assert_array_equal(ids.cpu().numpy(), g[f"v{v}_point_id"])
+        np.testing.assert_array_equal(counts.cpu().numpy(), g[f"v{v}_point_count"])
+
+
+@pytest.mark.parametrize("n,shape", [(1000000, (1080, 1920)), (5, (7, 13)), (70000, (100, 100))])
+def test_id_histogram_matches_torch_unique(n, shape):
+    from log_amd import counter
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    # runs of equal ids along rows (what a splat produces), -1 holes, ids spread over [0, n)
+    base = torch.randint(0, n, (shape[0], (shape[1] + 4) // 5), generator=gen, device=DEV, dtype=torch.int32)
+    pid = base.repeat_interleave(5, dim=1)[:, :shape[1]].contiguous()
+    pid[torch.rand(shape, generator=gen, device=DEV) < 0.2] = -1
+    ids, counts = counter.unique_ids(pid, n)
+    want_ids, want_counts = torch.unique(pid, sorted=True, return_counts=True)
+    if want_ids[0] == -1:
+        want_ids, want_counts = want_ids[1:], want_counts[1:]
+    assert torch.equal(ids, want_ids) and torch.equal(counts, want_counts)
+    # nothing hit at all
+    ids, counts = counter.unique_ids(torch.full(shape, -1, dtype=torch.int32, device=DEV), n)
+    assert ids.numel() == 0 and counts.numel() == 0
+
+
+def test_counter_matches_reference_counter_and_oracle(oracle_mod):
+    from log_amd import counter
+    g = U.load("counter_a.npz")
+    P = int(g["P"])
+    c = U.fresh_counter(P, DEV)
+    out = U.counter_output(g, DEV)
+    counter.update_by_output(c, out, fix_parent=True)
+    U.check_counter(c, g)                                            # the reference's own class, run on CPU
+    state = {k: np.zeros(P, dt) for k, dt in oracle_mod.COUNTER_FIELDS}
+    for v in range(int(g["n_views"])):
+        flag = oracle_mod.counter_update(state, g[f"v{v}_visible_index"], g[f"v{v}_grad"], g[f"v{v}_radii"],
+                                         g[f"v{v}_point_weight"], g[f"v{v}_point_id"], g[f"v{v}_point_count"])
+        np.testing.assert_array_equal(out["visibility_flag"][v]["flag_vis"].cpu().numpy(), flag)
+        np.testing.assert_array_equal(out["visibility_flag"][v]["index_vis"].cpu().numpy(), np.nonzero(flag)[0])
+    for k, _ in oracle_mod.COUNTER_FIELDS:
+        np.testing.assert_array_equal(getattr(c, k).cpu().numpy(), state[k], err_msg=k)     # bit for bit
+
+
+def test_counter_on_rasterizer_outputs():
+    """End to end on the device: render a view with the drop-in rasterizer, histogram its id map, update a counter;
+    check the invariants LoG's densification relies on."""
+    import math
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
+    from log_amd import counter, scenes
+    N, W, H = 20000, 320, 240
+    sc = scenes.random_scene(N, seed=4, opacity=None, smax=0.03)
+    cam = scenes.orbit_cameras(1, W=W, H=H, focal=300.0)[0]
+    t = lambda a: torch.tensor(a, device=DEV)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam["FoVx"] * 0.5), tanfovy=math.tan(cam["FoVy"] * 0.5),
+        bg=torch.ones(3, device=DEV), scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]),
+        projmatrix=t(cam["full_proj_transform"]), sh_degree=0, campos=t(cam["camera_center"]), prefiltered=False,
+        debug=False)
+    means2D = torch.zeros(N, 3, device=DEV, requires_grad=True)
+    xyz = t(sc["xyz"]).requires_grad_(True)
+    image, radii, pid, pwp, pw = GaussianRasterizer(raster_settings=rs)(
+        means3D=xyz, means2D=means2D, shs=None, colors_precomp=t(sc["colors"]), opacities=t(sc["opacity"]),
+        scales=t(sc["scaling"]), rotations=t(sc["rotation"]), cov3D_precomp=None)
+    image.sum().backward()
+    ids, counts = counter.unique_ids(pid, N)
+    wi, wc = torch.unique(pid, sorted=True, return_counts=True)
+    assert torch.equal(ids, wi[1:] if wi[0] == -1 else wi) and torch.equal(counts, wc[1:] if wi[0] == -1 else wc)
+    P = 3 * N
+    c = U.fresh_counter(P, DEV)
+    vis_index = torch.randperm(P, device=DEV)[:N]
+    out = {"render": [image], "visibility_flag": [{"index": vis_index}],
+           "viewspace_points": [means2D], "radii": [radii], "point_weight": [pw], "point_id": [ids],
+           "point_count": [counts]}
+    counter.update_by_output(c, out)
+    assert int(c.area_sum.sum()) == int((pid >= 0).sum())
+    assert int(c.visible_count.sum()) == int((radii > 0).sum()) == int(c.create_steps.sum())
+    assert torch.equal(c.weights_max[vis_index], torch.where(radii > 0, pw, torch.zeros_like(pw)))
+    assert torch.equal(c.radii_max[vis_index].int(), radii.clamp(min=0))
+    gn = torch.norm(means2D.grad[:, :2], dim=-1)
+    want = torch.zeros(P, device=DEV)
+    want[vis_index[ids.long()]] = gn[ids.long()] * counts
+    torch.testing.assert_close(c.grad_sum, want, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", ["adam_a.npz", "adam_ams.npz"])
+def test_sparse_adam_matches_reference_optimizer_and_oracle(name, oracle_mod):
+    from log_amd import sparse_optimizer, rasterizer as R
+    from oracle_backend import OracleBackend
+    g = U.load(name)
+    model, opt = U.run_adam(g, DEV, sparse_optimizer.step)
+    U.check_adam(model, opt, g)                                      # the reference's own class, run on CPU
+    old = R._set_backend_for_tests(OracleBackend())
+    try:
+        m_o, o_o = U.run_adam(g, "cpu", sparse_optimizer.step)       # same host logic, oracle arithmetic
+    finally:
+        R._set_backend_for_tests(None if isinstance(old, R.HipBackend) else old)
+    for k in U.ADAM_KEYS:
+        np.testing.assert_array_equal(getattr(model, k).cpu().numpy(), getattr(m_o, k).numpy(), err_msg=k)
+        np.testing.assert_array_equal(opt.exp_avg[k].cpu().numpy(), o_o.exp_avg[k].numpy(), err_msg=k)
+        np.testing.assert_array_equal(opt.exp_avg_sq[k].cpu().numpy(), o_o.exp_avg_sq[k].numpy(), err_msg=k)
+
+
+def test_sparse_adam_many_rows_and_untouched_rows():
+    """1 M rows: rows outside index[flag_vis] keep parameters and moments bit for bit."""
+    from log_amd import sparse_optimizer
+    import types
+    P, m = 1000000, 400000
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    model = types.SimpleNamespace(xyz=torch.randn(P, 3, device=DEV, generator=gen),
+                                  shs=torch.randn(P, 15, 3, device=DEV, generator=gen))
+    before = {k: getattr(model, k).clone() for k in ("xyz", "shs")}
+    zeros = lambda: {k: torch.zeros_like(getattr(model, k)) for k in ("xyz", "shs")}
+    opt = types.SimpleNamespace(global_steps=torch.tensor(0., device=DEV), lr_dict={"shs": 1e-3}, exp_avg=zeros(),
+                                exp_avg_sq=zeros(), use_amsgrad=False, xyz_lr=None,
+                                xyz_scheduler_args=lambda step: 1e-2, scaling_scheduler_args=lambda step: 5e-3)
+    index = torch.randperm(P, device=DEV, generator=gen)[:m]
+    flag_vis = torch.rand(m, device=DEV, generator=gen) < 0.7
+    params = {}
+    for k in ("xyz", "shs"):
+        p = torch.nn.Parameter(getattr(model, k)[index].clone())
+        p.grad = torch.randn(p.shape, device=DEV, generator=gen)
+        params[k] = p
+    sparse_optimizer.step(opt, model, index, params, flag_vis)
+    touched = torch.zeros(P, dtype=torch.bool, device=DEV)
+    touched[index[flag_vis]] = True
+    for k in ("xyz", "shs"):
+        now = getattr(model, k)
+        assert torch.equal(now[~touched], before[k][~touched])
+        assert bool((opt.exp_avg[k][~touched] == 0).all())
+        # first Adam step moves every touched element by lr * sign(g) (m / sqrt(v) = +-1 after bias correction)
+        lr = 1e-2 if k == "xyz" else 1e-3
+        sel = index[flag_vis]
+        torch.testing.assert_close(now[sel] - before[k][sel], -lr * torch.sign(params[k].grad[flag_vis]), rtol=1e-3, atol=1e-6)
+    assert float(opt.global_steps) == 1.0

@@ -26,5 +26,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLE
 timeout 300 python tools/bench_knn.py > $D/knn_bench.log 2>&1
 timeout 300 python tools/bench_radius.py 10000000 > $D/radius_10M.log 2>&1
 timeout 300 python tools/bench_sh.py 10000000 3 8 > $D/sh_10M.log 2>&1
+timeout 300 python tools/bench_lod.py > $D/lod_bench.log 2>&1
+timeout 300 python tools/bench_train_ops.py > $D/train_ops_bench.log 2>&1
 tail -n 3 $D/pytest.log
 grep -h '^{' $D/b_default.log | cut -c1-400

@@ -123,3 +123,127 @@ def test_reference_lod_compute_radius_call_site(log_env, oracle_mod):
     # fork-only method used at level_of_gaussian.py:59
     r2 = rast.compute_radius(g.xyz, torch.tensor(sc["scaling"]), g.rotation)
     np.testing.assert_allclose(r2.numpy()[::2], ref, rtol=1e-5, atol=1e-5)
+
+
+class _Cfg(dict):
+    """Attribute + item access, like the reference's yacs-style config nodes."""
+    __getattr__ = dict.__getitem__
+
+
+def _log_model(seed, n):
+    """The reference's LoG model (level_of_gaussian.py:174-196) on a synthetic cloud, with a two-level tree grown
+    through its own densification plumbing (tree.split_and_remove + Splitter, as update_depth_stage :510-515 does)."""
+    from LoG.model.level_of_gaussian import LoG
+    from log_amd import scenes
+    sc = scenes.random_scene(n, seed=seed, smax=0.08)
+    cfg_opt = _Cfg(optimize_keys=["xyz", "colors", "scaling", "opacity", "rotation", "shs"], opt_all_levels=True,
+                   lr_dict={"xyz": 0.00016, "xyz_final": 0.0000016, "colors": 0.0025, "shs": 0.000125, "scaling": 0.005,
+                            "opacity": 0.05, "rotation": 0.001, "max_steps": 300})
+    torch.manual_seed(seed)
+    model = LoG(gaussian=_Cfg(init_ply=dict(filename={"xyz": sc["xyz"], "colors": sc["colors"]}, scale3d=1.0,
+                                            init_opacity=0.3), sh_degree=1, xyz_scale=1.0),
+                tree=_Cfg(max_child=4, max_level=30), optimizer=cfg_opt, densify_and_remove=_Cfg())
+    model.base_iter = 1
+    model.set_stage("tree")
+    model.training_setup()
+    model.upgrade_tree()
+    gen = torch.Generator().manual_seed(seed + 1)
+    for level in range(2):
+        leaf = (model.tree.node_index == -1) & (model.tree.depth == level)
+        flag_split = leaf & (torch.rand(leaf.shape[0], generator=gen) < 0.5)
+        flag_remove = torch.zeros_like(flag_split)
+        flag_split, flag_remove = model.tree.split_and_remove(flag_split, flag_remove)
+        model.splitter.split_and_remove(model.gaussian, model.optimizer, flag_split, flag_remove, remove_split=False)
+        model.splitter.split_and_remove_other(model.counter, ["create_steps", "radius3d_min", "radius3d_max"],
+                                              flag_split, flag_remove, remove_split=False)
+        model.counter.reset(model.num_points)
+    model.counter.radius3d_max.fill_(10.0)
+    model.counter.radius3d_min.fill_(1e-4)
+    model.train()
+    return model
+
+
+def _run_steps(model, steps, W, H):
+    """trainer.py:144-160 (training_step): render -> loss.backward -> update_by_output -> step."""
+    from LoG.render.renderer import NaiveRendererAndLoss
+    from log_amd import scenes
+    renderer = NaiveRendererAndLoss(split="train", use_origin_render=False, background=[1., 1., 1.])
+    cams = scenes.orbit_cameras(steps, W=W, H=H, focal=1.1 * W, radius=2.2)
+    torch.manual_seed(11)
+    selected = []
+    for it in range(steps):
+        batch = _batch([cams[it]])
+        batch["image"] = torch.rand(1, H, W, 3)
+        output = renderer(batch, model)
+        selected.append(torch.cat([output["visibility_flag"][0]["index"], output["visibility_flag"][0]["index_node"]]).clone())
+        output["loss"].backward()
+        model.update_by_output(output)
+        model.step()
+    return selected
+
+
+@pytest.fixture()
+def cpu_cuda_shims(log_env):
+    """create_from_point (LoG/utils/file.py:88-91) calls distCUDA2(xyz.cuda()): on the CPU-only machine `.cuda()` is
+    made the identity and the 3-NN distance comes from scipy (TEST DOUBLES for host-only plumbing)."""
+    from scipy.spatial import cKDTree
+
+    def dist2(points):
+        p = points.detach().cpu().numpy().astype(np.float64)
+        d, _ = cKDTree(p).query(p, k=4)
+        return torch.from_numpy((d[:, 1:] ** 2).mean(axis=1).astype(np.float32))
+
+    mod = types.ModuleType("simple_knn._C")
+    mod.distCUDA2 = dist2
+    old_mod, old_cuda = sys.modules.get("simple_knn._C"), torch.Tensor.cuda
+    sys.modules["simple_knn._C"] = mod
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    yield
+    torch.Tensor.cuda = old_cuda
+    if old_mod is not None:
+        sys.modules["simple_knn._C"] = old_mod
+    else:
+        sys.modules.pop("simple_knn._C", None)
+
+
+def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
+    """The reference's own LoG model, tree, counter, optimizer and renderer run three training steps twice: as they
+    are, and with the N3/N4 drop-ins installed on their classes (log_amd.{lod,counter,sparse_optimizer}.install()).
+    Same selected points in the same order, same integer counters, parameters and Adam moments within fp32
+    round-off (the arithmetic below the boundary is the oracle's in both runs)."""
+    from LoG.model.tensor_tree import TensorTree
+    from LoG.model.counter import Counter
+    from LoG.model.sparse_optimizer import SparseOptimizer
+    from log_amd import lod, counter, sparse_optimizer
+    saved = (TensorTree.traverse, Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict)
+    W, H = 96, 72
+    try:
+        ref = _log_model(0, 400)
+        assert ref.tree.num_nodes > 50 and int(ref.tree.depth.max()) == 2
+        sel_ref = _run_steps(ref, 3, W, H)
+        lod.install()
+        counter.install()
+        sparse_optimizer.install()
+        new = _log_model(0, 400)
+        sel_new = _run_steps(new, 3, W, H)
+    finally:
+        TensorTree.traverse, Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict = saved
+        if hasattr(SparseOptimizer, "_lograst_load_state_dict"):
+            del SparseOptimizer._lograst_load_state_dict
+    for a, b in zip(sel_ref, sel_new):
+        assert a.numel() > 100 and torch.equal(a, b)
+    for k in ("radii_max", "visible_count", "radii_max_max", "area_sum", "create_steps"):
+        assert torch.equal(getattr(ref.counter, k), getattr(new.counter, k)), k
+    assert int(ref.counter.area_sum.sum()) > 0 and int(ref.counter.visible_count.max()) >= 2
+    for k in ("weights_max", "weights_sum", "grad_sum"):
+        torch.testing.assert_close(getattr(new.counter, k), getattr(ref.counter, k), rtol=1e-4, atol=1e-6)
+    assert float(new.optimizer.global_steps) == float(ref.optimizer.global_steps) == 3.0
+    moved = 0.0
+    for k in ("xyz", "colors", "scaling", "opacity", "rotation", "shs"):
+        p, q = getattr(new.gaussian, k), getattr(ref.gaussian, k)
+        # rel-L2: Adam turns a round-off-sized gradient (m / sqrt(v) = +-1 whatever its magnitude) into a full step
+        assert float((p - q).norm() / q.norm()) < 1e-5, k
+        a, b = new.optimizer.exp_avg[k], ref.optimizer.exp_avg[k]       # sums of gradients: compared in rel-L2
+        assert float((a - b).norm() / b.norm()) < 2e-3, k   # three chained steps: step 1 round-off feeds steps 2 and 3
+        moved += float(ref.optimizer.exp_avg[k].abs().sum())
+    assert moved > 0

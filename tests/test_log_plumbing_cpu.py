@@ -159,6 +159,7 @@ def _log_model(seed, n):
         model.counter.reset(model.num_points)
     model.counter.radius3d_max.fill_(10.0)
     model.counter.radius3d_min.fill_(1e-4)
+    model.gaussian.active_sh_degree = 1          # exercise the shs key (activation.py:27-34)
     model.train()
     return model
 
@@ -239,11 +240,17 @@ def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
         torch.testing.assert_close(getattr(new.counter, k), getattr(ref.counter, k), rtol=1e-4, atol=1e-6)
     assert float(new.optimizer.global_steps) == float(ref.optimizer.global_steps) == 3.0
     moved = 0.0
+    cfg_lr = {"colors": 0.0025, "shs": 0.000125, "opacity": 0.05, "rotation": 0.001}
     for k in ("xyz", "colors", "scaling", "opacity", "rotation", "shs"):
         p, q = getattr(new.gaussian, k), getattr(ref.gaussian, k)
-        # rel-L2: Adam turns a round-off-sized gradient (m / sqrt(v) = +-1 whatever its magnitude) into a full step
-        assert float((p - q).norm() / q.norm()) < 1e-5, k
+        # Adam turns a round-off-sized gradient into a full +-lr step (m / sqrt(v) = +-1 whatever the magnitude; e.g.
+        # the real part of the identity quaternions here, whose analytic gradient is 0), so a handful of elements
+        # may differ by up to 2 * lr per step; everything else agrees to fp32 round-off.
+        lr = {"xyz": 0.00016, "scaling": 0.005}.get(k, cfg_lr.get(k))
+        d = (p - q).abs()
+        assert float((d > 1e-5 * (1 + q.abs())).float().mean()) < 0.02, k
+        assert float(d.max()) <= 2.5 * lr * 3, k
         a, b = new.optimizer.exp_avg[k], ref.optimizer.exp_avg[k]       # sums of gradients: compared in rel-L2
-        assert float((a - b).norm() / b.norm()) < 2e-3, k   # three chained steps: step 1 round-off feeds steps 2 and 3
+        assert float(b.norm()) > 0 and float((a - b).norm() / b.norm()) < 2e-3, k   # three chained steps: step 1 round-off feeds steps 2 and 3
         moved += float(ref.optimizer.exp_avg[k].abs().sum())
     assert moved > 0

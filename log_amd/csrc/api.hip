@@ -86,7 +86,13 @@ static uint32_t lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t g
   static const int forced = lr_env_int("LOGRAST_BATCH", -1);
   if (n <= 0 || tiles > LR_BATCH_MAX_TILES || gx > 8191u || gy > 8191u || forced == 0) return 0u;  // 13-bit tile coordinates in the fill record
   if (forced > 0) return (uint32_t)((forced > 32768 ? 32768 : forced) + 1023) / 1024u * 1024u;  // 16-bit LDS counts
-  uint32_t b = ((uint32_t)n / 256u + 1023u) / 1024u * 1024u;
+  // One batch = one 1024-thread workgroup, and the kernel's 82 VGPRs allow one such workgroup per CU: 256 run at a
+  // time.  Size the batches so that their number fills whole rounds of 256 (10 M Gaussians: 306 batches of 32768
+  // = 1.2 rounds ran as long as 2; 489 batches of 20480 = 1.9 rounds do the same work in the same 2).
+  static const uint32_t slots = (uint32_t)lr_env_int("LOGRAST_BATCH_SLOTS", 256);
+  const uint32_t rounds = ((uint32_t)n + slots * 32768u - 1u) / (slots * 32768u);
+  const uint32_t want = slots * rounds;                                   // batches
+  uint32_t b = (((uint32_t)n + want - 1u) / want + 1023u) / 1024u * 1024u;
   if (b < 4096u) b = 4096u;
   if (b > 32768u) b = 32768u;
   return b;

@@ -215,6 +215,8 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
 // in that tile, and its start goes to basetab[b][tile].  An instance's slot is basetab[batch][tile] + its rank
 // inside the batch (stored in q3 as before) -- the fill kernel adds the two.  With B >> tiles / (instances per
 // Gaussian) the memory-side atomics shrink by the average number of instances a batch puts into a tile.
+// 82 VGPRs: one 1024-thread workgroup per CU.  Forcing two (amdgpu_waves_per_eu(8): 64 VGPRs, 19 spilled) is slower
+// at every size (1 M: 62 -> 81 us, 30 M: 1.06 -> 1.68 ms).
 __global__ void __launch_bounds__(LR_BATCH_THREADS)
 lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                           const float* __restrict__ rots, const float* __restrict__ opac,
@@ -455,11 +457,19 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_o
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity, float* __restrict__ zero_n,
-               float* __restrict__ zero_block, int zero_block_floats) {
+               float* __restrict__ zero_block, int zero_block_floats, int xcd_order) {
   // Per-Gaussian buffers that later kernels accumulate into with atomics (point_weight; the backward scratch)
   // are cleared here, in a kernel that already has one thread per Gaussian, instead of by separate memsets.
+  // XCD-contiguous block order (speed only): blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
+  // observed, MI355X_MICROARCH.md), each with its own non-coherent L2.  In dispatch order the 8-byte key writes of one
+  // (batch, tile) segment -- adjacent in memory, written by Gaussians of the same batch -- would be spread over all
+  // eight L2s and leave each of them as a partial line (a read-modify-write at HBM: 30 M Gaussians, 44 M keys took
+  // 1.1 ms = 128 B of traffic per key).  With XCD x walking Gaussians [x N/8, (x+1) N/8) the segments of consecutive
+  // batches complete their lines inside one L2 before they are evicted.
+  const uint32_t per_xcd = gridDim.x >> 3;                       // grid is a multiple of 8
+  const uint32_t vblock = xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   {
-    const int zi = blockIdx.x * 256 + threadIdx.x;
+    const int zi = (int)(vblock * 256u + threadIdx.x);
     if (zi < N) {
       if (zero_n) zero_n[zi] = 0.f;
       for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + zi] = 0.f;
@@ -473,7 +483,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   }
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
-  int i = blockIdx.x * 256 + threadIdx.x;
+  int i = (int)(vblock * 256u + threadIdx.x);
   // batched projection: a ranked instance's slot is relative to its batch's reservation in the tile
   const uint32_t batch = state[LR_HDR_BATCH];
   const uint32_t* __restrict__ bbase =
@@ -566,8 +576,10 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
                     uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
-  hipLaunchKernelGGL(lr_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, gx,
+  static const int xcd_order = lr_env_int("LOGRAST_FILL_XCD_ORDER", 1);
+  const int blocks = ((N + 255) / 256 + 7) & ~7;
+  hipLaunchKernelGGL(lr_fill_kernel, dim3(blocks), dim3(256), 0, s, N, gx,
                      reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, zero_n, zero_block,
-                     zero_block_floats);
+                     zero_block_floats, xcd_order);
   lr_prof_end(LRK_FILL, s);
 }

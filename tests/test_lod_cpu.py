@@ -79,3 +79,47 @@ def test_product_path_refuses_cpu_tensors():
     tree, model, cam = _tree_and_model(g)
     with pytest.raises(_lib.LograstError):
         lod.traverse(tree, model, torch.from_numpy(g["root_index"]), cam)
+
+
+REF = os.environ.get("LOG_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "LoG")), reason="reference tree not present")
+@pytest.mark.parametrize("seed", range(8))
+def test_oracle_and_dropin_follow_reference_on_random_trees(seed, oracle_mod):
+    """Fresh trees grown and pruned by the reference's TensorTree (different arity, depth, removal rate per seed), a
+    random camera and threshold: the reference's traverse, the oracle and the drop-in (through the test double)
+    return the same list."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden_lod as G
+    from log_amd import lod, rasterizer as R
+    rng = np.random.default_rng(seed)
+    G.reference_env()                                     # installs the oracle test double + LoG.cuda stand-in
+    try:
+        mc = int(rng.choice([2, 3, 4, 8]))
+        tree, xyz, scaling, rotation = G.build_case(100 + seed, int(rng.integers(50, 400)), int(rng.integers(1, 5)), mc,
+                                                    split_prob=float(rng.uniform(0.3, 0.95)),
+                                                    remove_prob=float(rng.uniform(0.0, 0.3)))
+        cam, rast = G.camera_and_rasterizer(320, 240, float(rng.uniform(150, 500)), theta=float(rng.integers(0, 8) * 45))
+        roots = tree.root_index.long()
+        roots = roots[torch.from_numpy(rng.random(roots.shape[0]) < 0.85)]
+        for _ in range(3):
+            min_px = float(rng.choice([0.5, 2.0, 3.0, 6.0, 20.0]))
+            max_depth = int(rng.choice([0, 1, 2, 3, 1000]))
+            want = G.reference_traverse(tree, xyz, scaling, rotation, roots, rast, min_px, max_depth).numpy()
+            rs = rast.raster_settings
+            fx, fy = rs.image_width / (2 * rs.tanfovx), rs.image_height / (2 * rs.tanfovy)
+            got = oracle_mod.lod_traverse(tree.node_index.numpy(), tree.tree.numpy(), xyz.numpy(), scaling.numpy(),
+                                          rotation.numpy(), roots.numpy(), rs.projmatrix.numpy(), rs.viewmatrix.numpy(),
+                                          fx, fy, rs.tanfovx, rs.tanfovy, min_px, tree.max_level, max_depth)
+            np.testing.assert_array_equal(got, want)
+            g = types.SimpleNamespace(xyz=xyz, scaling=scaling, rotation=rotation,
+                                      activation=types.SimpleNamespace(scaling_activation=torch.exp,
+                                                                       rotation_activation=torch.nn.functional.normalize))
+            tree.min_resolution_pixel = min_px
+            np.testing.assert_array_equal(lod.traverse(tree, g, roots, rast, max_depth=max_depth).numpy(), want)
+    finally:
+        R._set_backend_for_tests(None)
+        for k in ("LoG.cuda.compute_radius",):
+            sys.modules.pop(k, None)

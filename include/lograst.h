@@ -248,11 +248,35 @@ int lograst_sparse_adam(int32_t m, int32_t num_points, const int64_t* index, con
                         int32_t num_keys, const lograst_adam_key* keys, double beta1, double beta2,
                         double bias_correction2_sqrt, double eps, void* stream);
 
+/* ---- rows N2 / N3: LoG.get_all + Activation.activate_root_return, fused ---------------------------------------
+ * Replaces the per-key gathers of LoG.get_all (/root/reference/LoG/model/level_of_gaussian.py:262-296) and the
+ * activations of Activation.activate_root_return / colors_activation (/root/reference/LoG/model/activation.py:27-44;
+ * SH polynomial /root/reference/LoG/model/sh_utils.py:31-72).  For every r < n, row index[r] of the model buffers
+ * (xyz[P,3], scaling[P,3] log-scales, opacity[P,1] logits, rotation[P,4], colors[P,3] SH DC term, shs[P,K,3] higher
+ * coefficients, K = 0 allowed with shs = NULL) is copied to the raw_* outputs [n, ...] (the step's parameters) and
+ * activated: act_scaling = exp, act_opacity = sigmoid, act_rotation = q / max(|q|, 1e-12), act_colors =
+ * 0.28209479 * colors + 0.5 (+ eval_sh_wobase(normalize(xyz - camera_center), shs, active_degree) when
+ * active_degree > 0; degrees 1..3, camera_center = 3 floats on the device).  xyz is passed through (raw_xyz). */
+int lograst_gather_activate(int32_t n, int32_t num_points, const int64_t* index, const float* xyz,
+                            const float* scaling, const float* opacity, const float* rotation, const float* colors,
+                            const float* shs, int32_t sh_coeffs, int32_t active_degree, const float* camera_center,
+                            float* raw_xyz, float* raw_scaling, float* raw_opacity, float* raw_rotation,
+                            float* raw_colors, float* raw_shs, float* act_scaling, float* act_opacity,
+                            float* act_rotation, float* act_colors, void* stream);
+/* Backward of the activations for the first n rows (the rows that are parameters): from dL/d(act_*) to
+ * dL/d(raw_*).  dl_dshs (may be NULL) is [n, sh_coeffs, 3]; coefficients above active_degree get 0.  The direction
+ * is detached in the reference (activation.py:30), so xyz receives no gradient from the colours. */
+int lograst_activate_backward(int32_t n, const float* raw_xyz, const float* raw_scaling, const float* raw_opacity,
+                              const float* raw_rotation, int32_t sh_coeffs, int32_t active_degree,
+                              const float* camera_center, const float* dl_dact_scaling, const float* dl_dact_opacity,
+                              const float* dl_dact_rotation, const float* dl_dact_colors, float* dl_dscaling,
+                              float* dl_dopacity, float* dl_drotation, float* dl_dcolors, float* dl_dshs, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream (used by bench.py) -----------------
  * When enabled every kernel launch is bracketed by hipEventRecord on its stream.  read() synchronises
  * the recorded events and returns, for kernel slot i < LOGRAST_NUM_KERNELS, accumulated milliseconds
  * and launch counts since the last reset. */
-#define LOGRAST_NUM_KERNELS 16
+#define LOGRAST_NUM_KERNELS 18
 void lograst_profile_enable(int on);
 void lograst_profile_reset(void);
 int lograst_profile_read(double* ms_out, int64_t* count_out);

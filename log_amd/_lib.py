@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblogra
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
 REC_FLOATS = 16
-NUM_KERNELS = 16
+NUM_KERNELS = 18
 
 c_void_p, c_int32, c_uint32, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
                                                   ctypes.c_float, ctypes.c_size_t)
@@ -75,6 +75,8 @@ _SIGNATURES = {
     "lograst_sparse_adam": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                            ctypes.POINTER(LograstAdamKey), ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, c_void_p]),
+    "lograst_gather_activate": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_int32] + [c_void_p] * 12),
+    "lograst_activate_backward": (ctypes.c_int, [c_int32] + [c_void_p] * 4 + [c_int32, c_int32] + [c_void_p] * 11),
     "lograst_profile_enable": (None, [ctypes.c_int]),
     "lograst_profile_reset": (None, []),
     "lograst_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

@@ -61,6 +61,9 @@ hipError_t lr_launch_id_histogram(int n, const int32_t* pid, int npix, int32_t* 
 hipError_t lr_launch_counter(const CounterArgs& a, hipStream_t s);
 hipError_t lr_launch_sparse_adam(const AdamArgs& a, int num_keys, hipStream_t s);
 
+hipError_t lr_launch_gather_activate(const GatherArgs& a, hipStream_t s);
+hipError_t lr_launch_activate_bwd(const ActBwdArgs& a, hipStream_t s);
+
 static thread_local std::string g_err;
 static int lr_fail(int code, const std::string& msg) {
   g_err = msg;
@@ -112,7 +115,7 @@ static int lr_tile_cull() {
 static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
     "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
     "blend_fwd", "blend_bwd", "project_bwd", "knn3", "lod_traverse", "counter_update", "sparse_adam",
-    "id_histogram", "reserved"};
+    "id_histogram", "gather_activate", "activate_bwd", "reserved"};
 struct ProfRec { int slot; hipEvent_t a, b; bool own_a; };
 // Consecutive launches inside one entry point share an event: the end of kernel k is the begin of kernel k+1 (N+1
 // events for a chain of N kernels instead of 2N; every recorded event costs ~1.4 us of stream time).
@@ -483,6 +486,66 @@ int lograst_sparse_adam(int32_t m, int32_t num_points, const int64_t* index, con
   a.bc2_sqrt = (float)bias_correction2_sqrt; a.eps = (float)eps;
   g_prof_call++;
   LR_HIP(lr_launch_sparse_adam(a, num_keys, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+static int lr_ga_check(int32_t n, int32_t sh_coeffs, int32_t active_degree, const float* camera_center) {
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative row count");
+  if (sh_coeffs < 0 || sh_coeffs > 15) return lr_fail(LOGRAST_ERR_ARG, "sh_coeffs must be 0..15 (degree <= 3)");
+  if (active_degree < 0 || active_degree > 3) return lr_fail(LOGRAST_ERR_ARG, "active SH degree must be 0..3");
+  if (active_degree > 0 && (active_degree + 1) * (active_degree + 1) - 1 > sh_coeffs)
+    return lr_fail(LOGRAST_ERR_ARG, "shs holds fewer coefficients than the active degree needs");
+  if (active_degree > 0 && !camera_center) return lr_fail(LOGRAST_ERR_ARG, "camera_center is NULL");
+  return LOGRAST_OK;
+}
+
+int lograst_gather_activate(int32_t n, int32_t num_points, const int64_t* index, const float* xyz,
+                            const float* scaling, const float* opacity, const float* rotation, const float* colors,
+                            const float* shs, int32_t sh_coeffs, int32_t active_degree, const float* camera_center,
+                            float* raw_xyz, float* raw_scaling, float* raw_opacity, float* raw_rotation,
+                            float* raw_colors, float* raw_shs, float* act_scaling, float* act_opacity,
+                            float* act_rotation, float* act_colors, void* stream) {
+  int rc = lr_ga_check(n, sh_coeffs, active_degree, camera_center);
+  if (rc) return rc;
+  if (n == 0) return LOGRAST_OK;
+  if (num_points <= 0) return lr_fail(LOGRAST_ERR_ARG, "rows requested from an empty model");
+  if (!index || !xyz || !scaling || !opacity || !rotation || !colors || !raw_xyz || !raw_scaling || !raw_opacity ||
+      !raw_rotation || !raw_colors || !act_scaling || !act_opacity || !act_rotation || !act_colors)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (sh_coeffs > 0 && (!shs || !raw_shs)) return lr_fail(LOGRAST_ERR_ARG, "NULL shs pointer");
+  GatherArgs a;
+  a.index = index; a.xyz = xyz; a.scaling = scaling; a.opacity = opacity; a.rotation = rotation; a.colors = colors;
+  a.shs = shs; a.campos = camera_center;
+  a.r_xyz = raw_xyz; a.r_scaling = raw_scaling; a.r_opacity = raw_opacity; a.r_rotation = raw_rotation;
+  a.r_colors = raw_colors; a.r_shs = raw_shs;
+  a.a_scaling = act_scaling; a.a_opacity = act_opacity; a.a_rotation = act_rotation; a.a_colors = act_colors;
+  a.n = n; a.num_points = num_points; a.K = sh_coeffs; a.deg = active_degree;
+  g_prof_call++;
+  LR_HIP(lr_launch_gather_activate(a, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+int lograst_activate_backward(int32_t n, const float* raw_xyz, const float* raw_scaling, const float* raw_opacity,
+                              const float* raw_rotation, int32_t sh_coeffs, int32_t active_degree,
+                              const float* camera_center, const float* dl_dact_scaling, const float* dl_dact_opacity,
+                              const float* dl_dact_rotation, const float* dl_dact_colors, float* dl_dscaling,
+                              float* dl_dopacity, float* dl_drotation, float* dl_dcolors, float* dl_dshs, void* stream) {
+  int rc = lr_ga_check(n, sh_coeffs, active_degree, camera_center);
+  if (rc) return rc;
+  if (n == 0) return LOGRAST_OK;
+  if (!raw_xyz || !raw_scaling || !raw_opacity || !raw_rotation || !dl_dact_scaling || !dl_dact_opacity ||
+      !dl_dact_rotation || !dl_dact_colors || !dl_dscaling || !dl_dopacity || !dl_drotation || !dl_dcolors)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  ActBwdArgs a;
+  a.r_xyz = raw_xyz; a.r_scaling = raw_scaling; a.r_opacity = raw_opacity; a.r_rotation = raw_rotation;
+  a.campos = camera_center;
+  a.g_a_scaling = dl_dact_scaling; a.g_a_opacity = dl_dact_opacity; a.g_a_rotation = dl_dact_rotation;
+  a.g_a_colors = dl_dact_colors;
+  a.g_scaling = dl_dscaling; a.g_opacity = dl_dopacity; a.g_rotation = dl_drotation; a.g_colors = dl_dcolors;
+  a.g_shs = dl_dshs;
+  a.n = n; a.K = sh_coeffs; a.deg = active_degree;
+  g_prof_call++;
+  LR_HIP(lr_launch_activate_bwd(a, (hipStream_t)stream));
   return LOGRAST_OK;
 }
 

@@ -362,10 +362,28 @@ struct AdamArgs {
   float beta1, beta2, omb1, omb2, bc2_sqrt, eps;
 };
 
+// ---- fused get_all (sh.hip: ga_fwd_kernel / ga_bwd_kernel) ---------------------------------------------
+struct GatherArgs {
+  const int64_t* index;
+  const float *xyz, *scaling, *opacity, *rotation, *colors, *shs;   // model buffers [num_points, ...]
+  const float* campos;
+  float *r_xyz, *r_scaling, *r_opacity, *r_rotation, *r_colors, *r_shs;  // gathered raw rows [n, ...]
+  float *a_scaling, *a_opacity, *a_rotation, *a_colors;                  // activated [n, ...]
+  int n, num_points, K, deg;
+};
+
+struct ActBwdArgs {
+  const float *r_xyz, *r_scaling, *r_opacity, *r_rotation;    // the gathered raw rows (the Parameters' data)
+  const float* campos;
+  const float *g_a_scaling, *g_a_opacity, *g_a_rotation, *g_a_colors;   // dL/d(activated), rows [0, n) are used
+  float *g_scaling, *g_opacity, *g_rotation, *g_colors, *g_shs;           // dL/d(raw) [n, ...]; g_shs may be NULL
+  int n, K, deg;
+};
+
 // ---- host-side launch bookkeeping (api.hip) ------------------------------------------------------
 enum LrKernelSlot {
   LRK_RADIUS = 0, LRK_PROJECT, LRK_SCAN, LRK_FILL, LRK_SORT_SMALL, LRK_SORT_LARGE, LRK_SORT_HUGE,
-  LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_LOD, LRK_COUNTER, LRK_ADAM, LRK_HIST, LRK_RESERVED
+  LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_LOD, LRK_COUNTER, LRK_ADAM, LRK_HIST, LRK_GATHER, LRK_GATHER_BWD, LRK_RESERVED
 };
 void lr_prof_begin(int slot, hipStream_t s);
 void lr_prof_end(int slot, hipStream_t s);

@@ -183,3 +183,167 @@ void lr_launch_sh_bwd(int N, int deg, int M, const float* means, const float* ca
     hipLaunchKernelGGL(lr_sh_bwd_kernel<false>, dim3((N + 255) / 256), dim3(256), lds, s, N, deg, M, means, campos, shs,
                        clamped, g_colors, g_shs, g_means);
 }
+
+// ---- LoG.get_all + Activation.activate_root_return, fused -------------------------------------
+// /root/reference/LoG/model/level_of_gaussian.py:262-296 gathers every model buffer at the selected rows (one
+// indexing kernel per key, a cat with the node rows) and /root/reference/LoG/model/activation.py:27-44 activates them
+// with ~25 elementwise kernels: exp (scales), sigmoid (opacity), normalize (quaternions), SH2RGB(colors) +
+// eval_sh_wobase(dir, shs) (/root/reference/LoG/model/sh_utils.py:31-72).  Here: one kernel gathers the rows, writes
+// the raw copies (they become the step's nn.Parameters) and the activated tensors the rasterizer consumes; one kernel
+// turns the rasterizer's input gradients into the gradients of the raw copies.
+// LoG's SH layout: colors[P,3] is the DC term, shs[P,K,3] the K = (max_degree+1)^2 - 1 higher coefficients, no clamp.
+
+LR_DEV float ga_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+ga_fwd_kernel(GatherArgs a) {
+  extern __shared__ float lr_sh_lds[];  // 4 waves x (64 rows x (L+1) floats)
+  __shared__ int64_t rowid[4][64];
+  const int L = 3 * a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (i0 >= a.n) return;
+  const int rows = min(64, a.n - i0);
+  const int i = i0 + lane;
+  const bool ok = i < a.n;
+  int64_t row = ok ? a.index[i] : 0;
+  if (row < 0 || row >= a.num_points) row = 0;   // an invalid index reads row 0 instead of faulting
+  rowid[wave][lane] = row;
+  float p[3] = {0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f};
+  if (ok) {
+    float s[3], q[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      p[k] = a.xyz[3 * row + k]; s[k] = a.scaling[3 * row + k]; c[k] = a.colors[3 * row + k];
+    }
+    const float4 q4 = reinterpret_cast<const float4*>(a.rotation)[row];
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    const float o = a.opacity[row];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      a.r_xyz[3 * (size_t)i + k] = p[k]; a.r_scaling[3 * (size_t)i + k] = s[k]; a.r_colors[3 * (size_t)i + k] = c[k];
+      a.a_scaling[3 * (size_t)i + k] = expf(s[k]);
+    }
+    reinterpret_cast<float4*>(a.r_rotation)[i] = q4;
+    a.r_opacity[i] = o;
+    a.a_opacity[i] = ga_sigmoid(o);
+    const float nrm = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+    reinterpret_cast<float4*>(a.a_rotation)[i] = float4{q[0] / nrm, q[1] / nrm, q[2] / nrm, q[3] / nrm};
+  }
+  float col[3] = {lr_fma(c[0], SH_C0, 0.5f), lr_fma(c[1], SH_C0, 0.5f), lr_fma(c[2], SH_C0, 0.5f)};   // SH2RGB
+  if (L > 0) {
+    float* const wl = lr_sh_lds + wave * 64 * (L + 1);
+    lr_sh_wave_sync();                                      // rowid[] written by this wave
+    const uint32_t magic = 0xffffffffu / (uint32_t)L + 1u;  // e / L for e < 65536
+    float* const out = a.r_shs + (size_t)i0 * L;
+    for (int e = lane; e < rows * L; e += 64) {             // lanes walk the rows' coefficients contiguously
+      const int g = (int)__umulhi((uint32_t)e, magic), j = e - g * L;
+      const float v = a.shs[(size_t)rowid[wave][g] * L + j];
+      out[e] = v;                                           // the raw copy is contiguous in e
+      wl[g * (L + 1) + j] = v;
+    }
+    lr_sh_wave_sync();
+    if (ok && a.deg > 0) {
+      const float vx = p[0] - a.campos[0], vy = p[1] - a.campos[1], vz = p[2] - a.campos[2];
+      const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+      float b[16], bx[16], by[16], bz[16];
+      lr_sh_basis(a.deg, vx / nrm, vy / nrm, vz / nrm, b, bx, by, bz);
+      const int nk = (a.deg + 1) * (a.deg + 1);
+      const float* sh = wl + lane * (L + 1);
+#pragma unroll
+      for (int k = 1; k < 16; k++) {
+        if (k < nk && k - 1 < a.K) {
+          col[0] = lr_fma(b[k], sh[3 * (k - 1)], col[0]); col[1] = lr_fma(b[k], sh[3 * (k - 1) + 1], col[1]);
+          col[2] = lr_fma(b[k], sh[3 * (k - 1) + 2], col[2]);
+        }
+      }
+    }
+  }
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) a.a_colors[3 * (size_t)i + k] = col[k];
+  }
+}
+
+
+__global__ void __launch_bounds__(256)
+ga_bwd_kernel(ActBwdArgs a) {
+  extern __shared__ float lr_sh_lds[];
+  const int L = 3 * a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (i0 >= a.n) return;
+  const int rows = min(64, a.n - i0);
+  const int i = i0 + lane;
+  const bool ok = i < a.n;
+  float gc[3] = {0.f, 0.f, 0.f};
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      gc[k] = a.g_a_colors[3 * (size_t)i + k];
+      a.g_colors[3 * (size_t)i + k] = gc[k] * SH_C0;
+      a.g_scaling[3 * (size_t)i + k] = a.g_a_scaling[3 * (size_t)i + k] * expf(a.r_scaling[3 * (size_t)i + k]);
+    }
+    const float sg = ga_sigmoid(a.r_opacity[i]);
+    a.g_opacity[i] = a.g_a_opacity[i] * (sg * (1.f - sg));
+    const float4 q = reinterpret_cast<const float4*>(a.r_rotation)[i], gy = reinterpret_cast<const float4*>(a.g_a_rotation)[i];
+    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, nrm = sqrtf(n2);
+    float4 gq = float4{0.f, 0.f, 0.f, 0.f};
+    if (nrm > 1e-12f) {   // y = q / |q|: dL/dq = (g - y (y . g)) / |q|; below eps the clamp makes y = q / eps
+      const float ix = 1.f / nrm, yx = q.x * ix, yy = q.y * ix, yz = q.z * ix, yw = q.w * ix;
+      const float dot = yx * gy.x + yy * gy.y + yz * gy.z + yw * gy.w;
+      gq = float4{(gy.x - yx * dot) * ix, (gy.y - yy * dot) * ix, (gy.z - yz * dot) * ix, (gy.w - yw * dot) * ix};
+    } else {
+      gq = float4{gy.x * 1e12f, gy.y * 1e12f, gy.z * 1e12f, gy.w * 1e12f};
+    }
+    reinterpret_cast<float4*>(a.g_rotation)[i] = gq;
+  }
+  if (L > 0 && a.g_shs) {
+    float* const wl = lr_sh_lds + wave * 64 * (L + 1);
+    if (ok) {
+      float b[16], bx[16], by[16], bz[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) b[k] = 0.f;
+      if (a.deg > 0) {
+        const float vx = a.r_xyz[3 * (size_t)i] - a.campos[0], vy = a.r_xyz[3 * (size_t)i + 1] - a.campos[1],
+                    vz = a.r_xyz[3 * (size_t)i + 2] - a.campos[2];
+        const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+        lr_sh_basis(a.deg, vx / nrm, vy / nrm, vz / nrm, b, bx, by, bz);
+      }
+      const int nk = (a.deg + 1) * (a.deg + 1);
+      float* rowp = wl + lane * (L + 1);
+      for (int k = 0; k < a.K; k++) {
+        const float w = (k + 1 < nk && k + 1 < 16) ? b[k + 1] : 0.f;   // coefficients above the active degree: zero gradient
+        rowp[3 * k] = w * gc[0]; rowp[3 * k + 1] = w * gc[1]; rowp[3 * k + 2] = w * gc[2];
+      }
+    }
+    lr_sh_wave_sync();
+    lr_sh_wave_copy<false, false>(wl, a.g_shs + (size_t)i0 * L, L, rows * L, lane);
+  }
+}
+
+hipError_t lr_launch_gather_activate(const GatherArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  const size_t lds = sizeof(float) * 4 * 64 * (size_t)(3 * a.K + 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ga_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ga_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  lr_prof_begin(LRK_GATHER, s);
+  hipLaunchKernelGGL(ga_fwd_kernel, dim3((a.n + 255) / 256), dim3(256), a.K > 0 ? lds : 0, s, a);
+  lr_prof_end(LRK_GATHER, s);
+  return hipGetLastError();
+}
+hipError_t lr_launch_activate_bwd(const ActBwdArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  const size_t lds = sizeof(float) * 4 * 64 * (size_t)(3 * a.K + 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ga_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  lr_prof_begin(LRK_GATHER_BWD, s);
+  hipLaunchKernelGGL(ga_bwd_kernel, dim3((a.n + 255) / 256), dim3(256), (a.K > 0 && a.g_shs) ? lds : 0, s, a);
+  lr_prof_end(LRK_GATHER_BWD, s);
+  return hipGetLastError();
+}

@@ -1,0 +1,77 @@
+"""Drop-in for ``LoG.get_all`` (/root/reference/LoG/model/level_of_gaussian.py:262-296) together with the
+``Activation.activate_root_return`` it ends with (/root/reference/LoG/model/activation.py:27-44; SH polynomial
+/root/reference/LoG/model/sh_utils.py:31-72) -- SURVEY 8f rows N2 ("fused activation + SH-eval (+ its backward)
+feeding colors_precomp") and N3 ("fuse get_all gathers").
+
+The reference gathers every model buffer at the selected rows (an indexing kernel per key, a ``cat`` with the node
+rows), wraps the leaf rows in ``nn.Parameter`` and runs ~25 elementwise kernels (and as many again in backward)
+for exp / sigmoid / normalize / SH2RGB + eval_sh_wobase.  Here one kernel gathers + activates
+(include/lograst.h: lograst_gather_activate) and one kernel is the whole backward (lograst_activate_backward).
+Same return value (dict xyz / scaling / opacity / rotation / colors), same side effect
+(``visibility_flag['params']`` = the step's parameters, keyed and ordered like ``gaussian.keys``).
+
+Install with ``log_amd.get_all.install()`` (= ``LoG.get_all = get_all``)."""
+import torch
+import torch.nn as nn
+
+from . import rasterizer as _r
+
+_KNOWN = ("xyz", "scaling", "opacity", "rotation", "colors", "shs")
+
+
+class _Activate(torch.autograd.Function):
+    """Connects the activated tensors (already computed by the gather kernel) to the step's parameters."""
+
+    @staticmethod
+    def forward(ctx, pack, *params):
+        ctx.pack = pack
+        act = pack["act"]
+        return act["xyz"], act["scaling"], act["opacity"], act["rotation"], act["colors"]
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_scaling, g_opacity, g_rotation, g_colors):
+        pack = ctx.pack
+        n = pack["n_param"]
+        g = _r._backend.activate_backward(pack["raw"], n, pack["degree"], pack["campos"], g_scaling, g_opacity,
+                                          g_rotation, g_colors)
+        g["xyz"] = g_xyz[:n]
+        return (None,) + tuple(g.get(k) for k in pack["param_keys"])
+
+
+def get_all(self, camera, rasterizer):
+    """``self``: the LoG model (``gaussian``, ``fix_parent``, ``training``)."""
+    gaussian = self.gaussian
+    flags = gaussian.visibility_flag
+    index = flags["index"]
+    n_leaf = int(index.shape[0])
+    if "index_node" in flags:
+        index = torch.cat([index, flags["index_node"]])
+    n_param = n_leaf if self.fix_parent else int(index.shape[0])
+    bufs = dict(gaussian.items())
+    if any(k not in _KNOWN for k in bufs) or any(k not in bufs for k in _KNOWN[:5]):
+        raise NotImplementedError(f"log_amd.get_all fuses the keys {_KNOWN}; this model has {list(bufs)}")
+    degree = int(gaussian.active_sh_degree) if camera is not None else 0
+    if degree > 0 and "shs" not in bufs:
+        raise ValueError("active_sh_degree > 0 but the model has no shs buffer")
+    campos = camera["camera_center"] if degree > 0 else None
+    with torch.no_grad():
+        raw, act = _r._backend.gather_activate(index, {k: v.detach() for k, v in bufs.items()}, degree, campos)
+    # visibility_flag['params']: the rows that are optimised, in gaussian.keys order (level_of_gaussian.py:267-272, :288-293)
+    params = {}
+    for key in bufs:
+        rows = raw[key][:n_param]
+        params[key] = nn.Parameter(rows) if self.training else rows
+    flags["params"] = params
+    if not self.training:
+        return {k: act[k] for k in ("xyz", "scaling", "opacity", "rotation", "colors")}
+    param_keys = [k for k in bufs if k != "shs" or degree > 0]   # unused shs: no gradient, like the reference
+    pack = {"raw": raw, "act": act, "n_param": n_param, "degree": degree, "campos": campos, "param_keys": param_keys}
+    xyz, scaling, opacity, rotation, colors = _Activate.apply(pack, *[params[k] for k in param_keys])
+    return {"xyz": xyz, "scaling": scaling, "opacity": opacity, "rotation": rotation, "colors": colors}
+
+
+def install():
+    """Patch the reference class in place (needs LoG importable)."""
+    from LoG.model.level_of_gaussian import LoG
+    LoG.get_all = get_all
+    return LoG

@@ -386,6 +386,50 @@ class HipBackend:
         del keep
 
 
+    def gather_activate(self, index, bufs, degree, campos):
+        """Rows N2/N3 (log_amd/get_all.py): gather rows `index` of the model buffers, -> (raw dict, activated dict)."""
+        device = bufs["xyz"].device
+        L = self.require(device)
+        idx = index.detach().to(device=device, dtype=torch.int64).contiguous()
+        n, P = int(idx.numel()), int(bufs["xyz"].shape[0])
+        src = {k: _dev_f32(v, device) for k, v in bufs.items()}
+        K = int(src["shs"].shape[1]) if "shs" in src else 0
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+        raw = {"xyz": new(n, 3), "scaling": new(n, 3), "opacity": new(n, 1), "rotation": new(n, 4), "colors": new(n, 3)}
+        if K:
+            raw["shs"] = new(n, K, 3)
+        act = {"scaling": new(n, 3), "opacity": new(n, 1), "rotation": new(n, 4), "colors": new(n, 3)}
+        cp = _dev_f32(campos, device).reshape(-1) if campos is not None else None
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_gather_activate(
+                n, P, _ptr(idx), _ptr(src["xyz"]), _ptr(src["scaling"]), _ptr(src["opacity"]), _ptr(src["rotation"]),
+                _ptr(src["colors"]), _ptr(src.get("shs")), K, int(degree), _ptr(cp), _ptr(raw["xyz"]),
+                _ptr(raw["scaling"]), _ptr(raw["opacity"]), _ptr(raw["rotation"]), _ptr(raw["colors"]),
+                _ptr(raw.get("shs")), _ptr(act["scaling"]), _ptr(act["opacity"]), _ptr(act["rotation"]),
+                _ptr(act["colors"]), _stream_ptr(device)))
+        act["xyz"] = raw["xyz"]
+        return raw, act
+
+    def activate_backward(self, raw, n, degree, campos, g_scaling, g_opacity, g_rotation, g_colors):
+        """-> dict of dL/d(raw rows [0, n)) for scaling / opacity / rotation / colors (/ shs when degree > 0)."""
+        device = raw["xyz"].device
+        L = self.require(device)
+        K = int(raw["shs"].shape[1]) if "shs" in raw else 0
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+        g = {"scaling": new(n, 3), "opacity": new(n, 1), "rotation": new(n, 4), "colors": new(n, 3)}
+        if K and degree > 0:
+            g["shs"] = new(n, K, 3)
+        ups = [_dev_f32(t, device) for t in (g_scaling, g_opacity, g_rotation, g_colors)]
+        cp = _dev_f32(campos, device).reshape(-1) if campos is not None else None
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_activate_backward(
+                int(n), _ptr(raw["xyz"]), _ptr(raw["scaling"]), _ptr(raw["opacity"]), _ptr(raw["rotation"]), K,
+                int(degree), _ptr(cp), _ptr(ups[0]), _ptr(ups[1]), _ptr(ups[2]), _ptr(ups[3]), _ptr(g["scaling"]),
+                _ptr(g["opacity"]), _ptr(g["rotation"]), _ptr(g["colors"]), _ptr(g.get("shs")), _stream_ptr(device)))
+        del ups
+        return g
+
+
 _backend = HipBackend()
 
 

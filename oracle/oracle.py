@@ -288,3 +288,45 @@ def sparse_adam(model, param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, index, 
                           _p(max_exp_avg_sq) if max_exp_avg_sq is not None else ctypes.c_void_p(0),
                           ctypes.c_double(lr / bc1), ctypes.c_double(beta1), ctypes.c_double(beta2),
                           ctypes.c_double(math.sqrt(bc2)), ctypes.c_double(eps))
+
+
+def gather_activate(index, xyz, scaling, opacity, rotation, colors, shs, degree, campos):
+    """Rows N2/N3 -- LoG.get_all + Activation.activate_root_return (LoG/model/level_of_gaussian.py:262-296,
+    LoG/model/activation.py:27-44).  shs: [P,K,3] or None.  -> (raw dict, activated dict)."""
+    idx = np.ascontiguousarray(np.asarray(index, np.int64))
+    n = idx.shape[0]
+    xyz, scaling, opacity, rotation, colors = (_f32(a) for a in (xyz, scaling, opacity, rotation, colors))
+    K = 0 if shs is None else int(shs.shape[1])
+    shs_c = _f32(shs) if K else np.zeros((1, 1, 3), np.float32)
+    cp = _f32(campos if campos is not None else np.zeros(3)).reshape(-1)
+    raw = {"xyz": np.zeros((n, 3), np.float32), "scaling": np.zeros((n, 3), np.float32),
+           "opacity": np.zeros((n, 1), np.float32), "rotation": np.zeros((n, 4), np.float32),
+           "colors": np.zeros((n, 3), np.float32), "shs": np.zeros((n, K, 3), np.float32)}
+    act = {"scaling": np.zeros((n, 3), np.float32), "opacity": np.zeros((n, 1), np.float32),
+           "rotation": np.zeros((n, 4), np.float32), "colors": np.zeros((n, 3), np.float32)}
+    lib().ora_gather_activate(ctypes.c_int32(n), _p(idx), _p(xyz), _p(scaling), _p(opacity), _p(rotation), _p(colors),
+                              _p(shs_c), ctypes.c_int32(K), ctypes.c_int32(int(degree)), _p(cp), _p(raw["xyz"]),
+                              _p(raw["scaling"]), _p(raw["opacity"]), _p(raw["rotation"]), _p(raw["colors"]),
+                              _p(raw["shs"]), _p(act["scaling"]), _p(act["opacity"]), _p(act["rotation"]),
+                              _p(act["colors"]))
+    act["xyz"] = raw["xyz"]
+    if not K:
+        del raw["shs"]
+    return raw, act
+
+
+def activate_backward(raw, degree, campos, g_scaling, g_opacity, g_rotation, g_colors):
+    """Gradients of the raw rows from the gradients of the activated tensors (same row count)."""
+    n = raw["xyz"].shape[0]
+    K = int(raw["shs"].shape[1]) if "shs" in raw else 0
+    cp = _f32(campos if campos is not None else np.zeros(3)).reshape(-1)
+    g = {"scaling": np.zeros((n, 3), np.float32), "opacity": np.zeros((n, 1), np.float32),
+         "rotation": np.zeros((n, 4), np.float32), "colors": np.zeros((n, 3), np.float32)}
+    if K:
+        g["shs"] = np.zeros((n, K, 3), np.float32)
+    lib().ora_activate_backward(ctypes.c_int32(n), _p(_f32(raw["xyz"])), _p(_f32(raw["scaling"])),
+                                _p(_f32(raw["opacity"])), _p(_f32(raw["rotation"])), ctypes.c_int32(K),
+                                ctypes.c_int32(int(degree)), _p(cp), _p(_f32(g_scaling)), _p(_f32(g_opacity)),
+                                _p(_f32(g_rotation)), _p(_f32(g_colors)), _p(g["scaling"]), _p(g["opacity"]),
+                                _p(g["rotation"]), _p(g["colors"]), _p(g["shs"]) if K else ctypes.c_void_p(0))
+    return g

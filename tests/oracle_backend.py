@@ -89,3 +89,22 @@ class OracleBackend:
                 ptr(mmax.numpy()) if mmax is not None else ctypes.c_void_p(0), ctypes.c_double(step_size),
                 ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(bias_correction2_sqrt),
                 ctypes.c_double(eps))
+
+    def gather_activate(self, index, bufs, degree, campos):
+        n = lambda a: a.detach().cpu().numpy()
+        raw, act = oracle.gather_activate(n(index), n(bufs["xyz"]), n(bufs["scaling"]), n(bufs["opacity"]),
+                                          n(bufs["rotation"]), n(bufs["colors"]), n(bufs["shs"]) if "shs" in bufs else None,
+                                          int(degree), n(campos) if campos is not None else None)
+        t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+        raw, act = t(raw), t(act)
+        act["xyz"] = raw["xyz"]
+        return raw, act
+
+    def activate_backward(self, raw, n, degree, campos, g_scaling, g_opacity, g_rotation, g_colors):
+        a = lambda x: x.detach().cpu().numpy()
+        sub = {k: a(v)[:n] for k, v in raw.items()}
+        g = oracle.activate_backward(sub, int(degree), a(campos) if campos is not None else None, a(g_scaling)[:n],
+                                     a(g_opacity)[:n], a(g_rotation)[:n], a(g_colors)[:n])
+        if degree <= 0:
+            g.pop("shs", None)
+        return {k: torch.from_numpy(v) for k, v in g.items()}

@@ -1,0 +1,68 @@
+"""Rows N2/N3: the fused LoG.get_all + activate_root_return drop-in.  CPU side: host logic and the
+oracle's restatement (through the test double) against activations and autograd gradients produced by the
+reference's own Activation class (tests/golden/make_golden_getall.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import getall_util as U
+
+
+@pytest.fixture()
+def double(oracle_mod):
+    from log_amd import rasterizer as R
+    from oracle_backend import OracleBackend
+    old = R._set_backend_for_tests(OracleBackend())
+    yield
+    R._set_backend_for_tests(None if isinstance(old, R.HipBackend) else old)
+
+
+@pytest.mark.parametrize("path", U.GOLDEN, ids=[os.path.basename(p) for p in U.GOLDEN])
+def test_get_all_matches_reference_activation_and_autograd(path, double):
+    from log_amd import get_all
+    g = np.load(path)
+    model, camera = U.log_like(g, "cpu")
+    U.check(g, model, camera, get_all.get_all)
+
+
+def test_eval_mode_and_unfixed_parent(double):
+    from log_amd import get_all
+    g = np.load(U.GOLDEN[1])
+    model, camera = U.log_like(g, "cpu", training=False)
+    ret = get_all.get_all(model, camera, None)
+    params = model.gaussian.visibility_flag["params"]
+    assert not any(isinstance(p, torch.nn.Parameter) for p in params.values())
+    assert not any(v.requires_grad for v in ret.values())
+    np.testing.assert_allclose(ret["colors"].numpy(), g["act_colors"], rtol=3e-6, atol=1e-6)
+    # fix_parent=False: node rows are parameters too (level_of_gaussian.py:282-293)
+    model, camera = U.log_like(g, "cpu", fix_parent=False)
+    ret = get_all.get_all(model, camera, None)
+    n_all = g["index"].shape[0] + g["index_node"].shape[0]
+    assert all(p.shape[0] == n_all for p in model.gaussian.visibility_flag["params"].values())
+    ret["scaling"].sum().backward()
+    gs = model.gaussian.visibility_flag["params"]["scaling"].grad
+    np.testing.assert_allclose(gs.numpy(), ret["scaling"].detach().numpy(), rtol=1e-6)      # d exp = exp
+
+
+def test_nothing_selected_and_bad_models(double):
+    from log_amd import get_all
+    g = np.load(U.GOLDEN[0])
+    model, camera = U.log_like(g, "cpu")
+    model.gaussian.visibility_flag = {"index": torch.zeros(0, dtype=torch.int64)}
+    ret = get_all.get_all(model, camera, None)
+    assert ret["xyz"].shape == (0, 3) and ret["opacity"].shape == (0, 1)
+    model, camera = U.log_like(g, "cpu")
+    model.gaussian.keys.append("extra")
+    model.gaussian.extra = torch.zeros(3)
+    with pytest.raises(NotImplementedError):
+        get_all.get_all(model, camera, None)
+
+
+def test_product_path_refuses_cpu_tensors():
+    from log_amd import get_all, _lib
+    g = np.load(U.GOLDEN[0])
+    model, camera = U.log_like(g, "cpu")
+    with pytest.raises(_lib.LograstError):
+        get_all.get_all(model, camera, None)

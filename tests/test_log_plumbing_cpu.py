@@ -209,14 +209,16 @@ def cpu_cuda_shims(log_env):
 
 def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
     """The reference's own LoG model, tree, counter, optimizer and renderer run three training steps twice: as they
-    are, and with the N3/N4 drop-ins installed on their classes (log_amd.{lod,counter,sparse_optimizer}.install()).
+    are, and with the N2/N3/N4 drop-ins installed on their classes (log_amd.{lod,counter,sparse_optimizer,get_all}.install()).
     Same selected points in the same order, same integer counters, parameters and Adam moments within fp32
     round-off (the arithmetic below the boundary is the oracle's in both runs)."""
     from LoG.model.tensor_tree import TensorTree
     from LoG.model.counter import Counter
     from LoG.model.sparse_optimizer import SparseOptimizer
-    from log_amd import lod, counter, sparse_optimizer
+    from LoG.model.level_of_gaussian import LoG
+    from log_amd import lod, counter, sparse_optimizer, get_all
     saved = (TensorTree.traverse, Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict)
+    saved_get_all = LoG.get_all
     W, H = 96, 72
     try:
         ref = _log_model(0, 400)
@@ -225,10 +227,12 @@ def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
         lod.install()
         counter.install()
         sparse_optimizer.install()
+        get_all.install()
         new = _log_model(0, 400)
         sel_new = _run_steps(new, 3, W, H)
     finally:
         TensorTree.traverse, Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict = saved
+        LoG.get_all = saved_get_all
         if hasattr(SparseOptimizer, "_lograst_load_state_dict"):
             del SparseOptimizer._lograst_load_state_dict
     for a, b in zip(sel_ref, sel_new):

@@ -77,7 +77,7 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
 for n, out in (("knn_bench.log", "knn_bench.json"), ("radius_10M.log", "radius_10000000.json"),
                ("sh_10M.log", "sh3_10M.json"), ("lod_bench.log", "lod_bench.json"),
                ("train_ops_bench.log", "train_ops_bench.json"), ("get_all_deg3.log", "get_all_deg3.json"),
-               ("get_all_deg1.log", "get_all_deg1.json")):
+               ("get_all_deg1.log", "get_all_deg1.json"), ("log_step.log", "log_step.json")):
     f = os.path.join(G, n)
     if os.path.exists(f) and any(l.startswith("{") for l in open(f)):
         json.dump(json.loads([l for l in open(f) if l.startswith("{")][-1]), open(os.path.join(P, f"{tag}_{out}"), "w"), indent=1)

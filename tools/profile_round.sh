@@ -30,5 +30,6 @@ timeout 300 python tools/bench_lod.py > $D/lod_bench.log 2>&1
 timeout 300 python tools/bench_train_ops.py > $D/train_ops_bench.log 2>&1
 timeout 300 python tools/bench_get_all.py 1000000 3 > $D/get_all_deg3.log 2>&1
 timeout 300 python tools/bench_get_all.py 1000000 1 > $D/get_all_deg1.log 2>&1
+timeout 400 python tools/bench_log_step.py > $D/log_step.log 2>&1
 tail -n 3 $D/pytest.log
 grep -h '^{' $D/b_default.log | cut -c1-400

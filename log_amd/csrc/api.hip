@@ -115,7 +115,7 @@ static int lr_tile_cull() {
 static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
     "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
     "blend_fwd", "blend_bwd", "project_bwd", "knn3", "lod_traverse", "counter_update", "sparse_adam",
-    "id_histogram", "gather_activate", "activate_bwd", "reserved"};
+    "id_histogram", "gather_activate", "activate_bwd", "count_huge"};
 struct ProfRec { int slot; hipEvent_t a, b; bool own_a; };
 // Consecutive launches inside one entry point share an event: the end of kernel k is the begin of kernel k+1 (N+1
 // events for a chain of N kernels instead of 2N; every recorded event costs ~1.4 us of stream time).

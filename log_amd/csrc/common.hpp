@@ -54,9 +54,16 @@ __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cur
 __host__ __device__ inline uint32_t lr_biglist_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
 // then basetab[batches][T]: start of every projection batch's reservation inside each tile's ranked range
 __host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_biglist_off(tiles) + lr_tpad(tiles); }
-__host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batches) {
+// then hugecount[batches]: how many Gaussians of the batch left their (more than LR_COOP_TILES tile) rect to
+// lr_count_huge_kernel
+__host__ __device__ inline size_t lr_hugecount_off(uint32_t tiles, uint32_t batches) {
   return (size_t)lr_basetab_off(tiles) + (size_t)batches * tiles;
 }
+__host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batches) {
+  return lr_hugecount_off(tiles, batches) + ((batches + 15u) & ~15u);
+}
+#define LR_COOP_TILES 16   // rects above this many tiles are expanded by a whole wave (lanes = tiles), not by their lane
+#define LR_HUGE_CHUNK 2048 // Gaussians per workgroup of lr_count_huge_kernel
 #define LR_BATCH_THREADS 1024
 #define LR_BATCH_MAX_TILES 40000  // 4 B x tiles of LDS counters must fit one workgroup (160 KB): up to 3840x2160
 

@@ -79,9 +79,14 @@ LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const flo
 
 // Projection of one Gaussian (A1) + counting / ranking of its tile instances (A2) against `ctr`.  Outputs the four
 // record quads, the integer radius (0 = culled) and the rect-rule instance count.
-template <typename Counters>
+// DEFER_HUGE: rects of more than `defer_tiles` tiles are not counted here (`huge` is raised instead and
+// lr_count_huge_kernel counts them, one wave per rect) -- a lane walking an 81-tile rect with a 50-instruction support
+// test per tile holds up its whole wave, and in level-of-detail order the big splats sit together in a few batches.
+template <bool DEFER_HUGE, typename Counters>
 LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, const Counters& ctr, float4& g0,
-                           float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances) {
+                           float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances, bool& huge,
+                           int defer_tiles = LR_COOP_TILES) {
+  huge = false;
   const float* __restrict__ V = v.view;
   const float* __restrict__ Pm = v.proj;
   rad = 0;
@@ -138,6 +143,8 @@ LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, c
     }
     g3 = float4{__uint_as_float(slot[0]), __uint_as_float(slot[1]), __uint_as_float(slot[2]),
                 __uint_as_float(slot[3])};
+  } else if (DEFER_HUGE && nt > defer_tiles) {
+    huge = true;
   } else {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++)
@@ -187,7 +194,8 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
     if (i < N) {
       int rad;
       const LrInputs in = lr_load_inputs(i, means, scales, rots, opac, colors);
-      lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
+      bool huge;
+      lr_project_one<false>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge);
       radii[i] = rad;
     }
     wstage[lane * LR_REC_QUADS + 0] = g0;
@@ -222,10 +230,13 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
                           const float* __restrict__ rots, const float* __restrict__ opac,
                           const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                           uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
-                          uint32_t* __restrict__ basetab, int tile_cull, int B) {
+                          uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugecount, int tile_cull, int B,
+                          int defer_tiles) {
   extern __shared__ uint32_t lr_lds_ctr[];  // [tiles] packed (ranked | big << 16) counts
+  __shared__ uint32_t lr_huge_cnt;
   const int tiles = v.gx * v.gy;
   for (int t = threadIdx.x; t < tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
+  if (threadIdx.x == 0) lr_huge_cnt = 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
   __syncthreads();
   const LrLdsCounters ctr{lr_lds_ctr};
@@ -241,7 +252,9 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
     if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors);
     float4 g0, g1, g2, g3;
     int rad;
-    lr_project_one(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances);
+    bool huge;
+    lr_project_one<true>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
+    if (huge) atomicAdd(&lr_huge_cnt, 1u);
     radii[i] = rad;
     float4* rec = geom + LR_REC_QUADS * (size_t)i;
     rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;     // q3 is not read in this mode: written to complete the 64-byte line
@@ -285,7 +298,66 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       if (t < tiles) mybase[t] = base[u];
     }
   }
+  if (threadIdx.x == 0) hugecount[blockIdx.x] = lr_huge_cnt;   // complete: the barrier after the Gaussian loop
   lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
+}
+
+// Rects of more than `defer_tiles` tiles, left out by lr_project_batched_kernel: one wave per rect, lanes = tiles, so
+// the support tests of a rect run 64 at a time and the LDS atomics never collide; counts go through per-workgroup
+// LDS counters (one memory-side atomic per touched tile and workgroup).  A workgroup owns `chunk` Gaussians and
+// returns at once when its batches left nothing (the common case: small splats only).
+__global__ void __launch_bounds__(256)
+lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,
+                     const uint32_t* __restrict__ hugecount, int B, int tile_cull, int defer_tiles, int chunk) {
+  extern __shared__ uint32_t lr_lds_ctr[];
+  const int base = blockIdx.x * chunk;
+  const int b0 = base / B, b1 = min(N - 1, base + chunk - 1) / B;
+  uint32_t any = 0;
+  for (int b = b0; b <= b1; b++) any |= hugecount[b];
+  if (!any) return;
+  for (int t = threadIdx.x; t < tiles; t += 256) lr_lds_ctr[t] = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint4* __restrict__ fill = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
+  for (int k = 0; k < chunk / 256; k++) {
+    const int i = base + k * 256 + (int)threadIdx.x;
+    int x0 = 0, y0 = 0, w = 0, nt = 0;
+    LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};
+    if (i < N) {
+      const uint4 fr = fill[i];
+      if (fr.y != 0xffffffffu && (fr.y & (1u << 30))) {
+        x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
+        w = (int)(fr.z & 0xffffu) - x0;
+        nt = w * ((int)(fr.z >> 16) - y0);
+        if (nt > defer_tiles && tile_cull) {
+          const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
+          sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
+        }
+      }
+    }
+    uint64_t m = __ballot(nt > defer_tiles);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const int bx0 = lr_readlane_i(x0, src), by0 = lr_readlane_i(y0, src), bw = lr_readlane_i(w, src),
+                bn = lr_readlane_i(nt, src);
+      LrSupport bs;
+      bs.mx = lr_readlane_f(sup.mx, src); bs.my = lr_readlane_f(sup.my, src);
+      bs.A = lr_readlane_f(sup.A, src); bs.B = lr_readlane_f(sup.B, src); bs.C = lr_readlane_f(sup.C, src);
+      bs.tau = lr_readlane_f(sup.tau, src); bs.ex = lr_readlane_f(sup.ex, src); bs.ey = lr_readlane_f(sup.ey, src);
+      bs.iA = lr_readlane_f(sup.iA, src); bs.iC = lr_readlane_f(sup.iC, src);
+      bs.mode = lr_readlane_i(sup.mode, src);
+      for (int t = lane; t < bn; t += 64) {
+        const int ty = t / bw, tx = t - ty * bw;
+        if (lr_support_tile(bs, bx0 + tx, by0 + ty)) atomicAdd(&lr_lds_ctr[(by0 + ty) * gx + (bx0 + tx)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < tiles; t += 256) {
+    const uint32_t c = lr_lds_ctr[t];
+    if (c) atomicAdd(&big[t], c);   // dense counters in batched mode
+  }
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
@@ -299,12 +371,25 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 128);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_count_huge_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 128);
       attr_set = true;
     }
-    hipLaunchKernelGGL(lr_project_batched_kernel, dim3((N + batch - 1) / batch), dim3(LR_BATCH_THREADS), lds, s, v, N,
+    static const int defer_tiles = lr_env_int("LOGRAST_DEFER_TILES", LR_COOP_TILES);
+    static const int chunk = lr_env_int("LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK) / 256 * 256;
+    const int batches = (N + batch - 1) / batch;
+    uint32_t* hugecount = basetab + (size_t)batches * tiles;
+    hipLaunchKernelGGL(lr_project_batched_kernel, dim3(batches), dim3(LR_BATCH_THREADS), lds, s, v, N,
                        means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                       basetab, tile_cull, batch);
+                       basetab, hugecount, tile_cull, batch, defer_tiles);
+    lr_prof_end(LRK_PROJECT, s);
+    lr_prof_begin(LRK_RESERVED, s);
+    hipLaunchKernelGGL(lr_count_huge_kernel, dim3((N + chunk - 1) / chunk), dim3(256), lds, s, N, v.gx,
+                       tiles, reinterpret_cast<const float4*>(geom), big, (const uint32_t*)hugecount, batch, tile_cull,
+                       defer_tiles, chunk);
+    lr_prof_end(LRK_RESERVED, s);
+    return;
   } else {
     static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 512);  // 2 workgroups per CU: measured optimum
     int blocks = (N + 255) / 256;
@@ -453,7 +538,6 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_o
 // rects take positions from the per-tile cursor; up to LR_COOP_TILES tiles a lane expands its own rect,
 // beyond that the whole wave expands it (ballot over the lanes that hold one, record broadcast with
 // readlane) so that a single screen-filling Gaussian does not serialise its wave.
-#define LR_COOP_TILES 16
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity, float* __restrict__ zero_n,

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
-from log_amd import lod, get_all, counter, sparse_optimizer, scenes  # noqa: E402
+from log_amd import lod, get_all, counter, sparse_optimizer, scenes, _lib, rasterizer as R  # noqa: E402
 from log_amd.compute_radius import compute_radius_module  # noqa: E402
 from lod_util import synth_tree  # noqa: E402
 
@@ -243,7 +243,13 @@ def run(fused, staged):
 
 tot_f, _, info, st_f = run(True, False)
 tot_t, _, _, st_t = run(False, False)
+_lib.profile_enable(True)
+_lib.profile_reset()
 _, stg_f, _, _ = run(True, True)
+prof = _lib.profile_read()
+_lib.profile_enable(False)
+kern = {k: round(v[0] / (V + 1) * 1e3, 1) for k, v in prof.items()}       # us per view (V timed views + the warm-up)
+inst = R.last_state_info()
 _, stg_t, _, _ = run(False, True)
 same = {k: float((st_f.bufs[k] - st_t.bufs[k]).norm() / st_t.bufs[k].norm()) for k in keys}
 print(json.dumps({
@@ -251,4 +257,5 @@ print(json.dumps({
     "sh_degree": D, "views": V, "root_scale": RS, "selected_per_view": float(np.mean([i[0] for i in info])),
     "distinct_winners_per_view": float(np.mean([i[1] for i in info])),
     "ms_per_view_fused": tot_f, "ms_per_view_torch": tot_t, "speedup": tot_t / tot_f,
-    "stages_ms_fused": stg_f, "stages_ms_torch": stg_t, "model_rel_l2_fused_vs_torch_after_views": same}))
+    "stages_ms_fused": stg_f, "kernels_us_per_view_fused": kern,
+    "last_view_tile_instances": int(inst[0]), "last_view_longest_tile_list": int(inst[2]), "stages_ms_torch": stg_t, "model_rel_l2_fused_vs_torch_after_views": same}))

@@ -394,11 +394,16 @@ class HipBackend:
         n, P = int(idx.numel()), int(bufs["xyz"].shape[0])
         src = {k: _dev_f32(v, device) for k, v in bufs.items()}
         K = int(src["shs"].shape[1]) if "shs" in src else 0
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
-        raw = {"xyz": new(n, 3), "scaling": new(n, 3), "opacity": new(n, 1), "rotation": new(n, 4), "colors": new(n, 3)}
-        if K:
-            raw["shs"] = new(n, K, 3)
-        act = {"scaling": new(n, 3), "opacity": new(n, 1), "rotation": new(n, 4), "colors": new(n, 3)}
+        # one allocation for all outputs (the quaternion blocks first: their rows are read and written as float4)
+        widths = [("raw", "rotation", 4), ("act", "rotation", 4), ("raw", "xyz", 3), ("raw", "scaling", 3),
+                  ("raw", "colors", 3), ("act", "scaling", 3), ("act", "colors", 3), ("raw", "opacity", 1),
+                  ("act", "opacity", 1)] + ([("raw", "shs", 3 * K)] if K else [])
+        flat = torch.empty(n * sum(w for _, _, w in widths), dtype=torch.float32, device=device)
+        raw, act, off = {}, {}, 0
+        for kind, key, w in widths:
+            view = flat[off:off + n * w].view((n, K, 3) if key == "shs" else (n, w))
+            (raw if kind == "raw" else act)[key] = view
+            off += n * w
         cp = _dev_f32(campos, device).reshape(-1) if campos is not None else None
         with torch.cuda.device(device):
             _lib.check(L.lograst_gather_activate(
@@ -415,10 +420,13 @@ class HipBackend:
         device = raw["xyz"].device
         L = self.require(device)
         K = int(raw["shs"].shape[1]) if "shs" in raw else 0
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
-        g = {"scaling": new(n, 3), "opacity": new(n, 1), "rotation": new(n, 4), "colors": new(n, 3)}
-        if K and degree > 0:
-            g["shs"] = new(n, K, 3)
+        # one allocation; 16-byte aligned blocks first (quaternion rows and, for 3K % 4 == 0, the SH rows go out as float4)
+        widths = [("rotation", 4)] + ([("shs", 3 * K)] if K and degree > 0 else []) + [("scaling", 3), ("colors", 3), ("opacity", 1)]
+        flat = torch.empty(n * sum(w for _, w in widths), dtype=torch.float32, device=device)
+        g, off = {}, 0
+        for key, w in widths:
+            g[key] = flat[off:off + n * w].view((n, K, 3) if key == "shs" else (n, w))
+            off += n * w
         ups = [_dev_f32(t, device) for t in (g_scaling, g_opacity, g_rotation, g_colors)]
         cp = _dev_f32(campos, device).reshape(-1) if campos is not None else None
         with torch.cuda.device(device):

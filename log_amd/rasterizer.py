@@ -107,6 +107,12 @@ def _dev_f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+# Blocks carved out of one allocation are read / written in lock step by one kernel; starting them at multiples of
+# n floats apart puts all streams on the same HBM channels (measured: the activation backward 0.12 -> 0.17 ms for
+# n = 1 M).  Each block is followed by this many floats (4352 B: keeps 16-byte alignment, breaks the stride).
+_BLOCK_SKEW = 1088
+
+
 class HipBackend:
     """Drives the kernels.  All buffers come from torch's caching allocator."""
 
@@ -398,12 +404,12 @@ class HipBackend:
         widths = [("raw", "rotation", 4), ("act", "rotation", 4), ("raw", "xyz", 3), ("raw", "scaling", 3),
                   ("raw", "colors", 3), ("act", "scaling", 3), ("act", "colors", 3), ("raw", "opacity", 1),
                   ("act", "opacity", 1)] + ([("raw", "shs", 3 * K)] if K else [])
-        flat = torch.empty(n * sum(w for _, _, w in widths), dtype=torch.float32, device=device)
+        flat = torch.empty(sum(n * w + _BLOCK_SKEW for _, _, w in widths), dtype=torch.float32, device=device)
         raw, act, off = {}, {}, 0
         for kind, key, w in widths:
             view = flat[off:off + n * w].view((n, K, 3) if key == "shs" else (n, w))
             (raw if kind == "raw" else act)[key] = view
-            off += n * w
+            off += n * w + _BLOCK_SKEW
         cp = _dev_f32(campos, device).reshape(-1) if campos is not None else None
         with torch.cuda.device(device):
             _lib.check(L.lograst_gather_activate(
@@ -422,11 +428,11 @@ class HipBackend:
         K = int(raw["shs"].shape[1]) if "shs" in raw else 0
         # one allocation; 16-byte aligned blocks first (quaternion rows and, for 3K % 4 == 0, the SH rows go out as float4)
         widths = [("rotation", 4)] + ([("shs", 3 * K)] if K and degree > 0 else []) + [("scaling", 3), ("colors", 3), ("opacity", 1)]
-        flat = torch.empty(n * sum(w for _, w in widths), dtype=torch.float32, device=device)
+        flat = torch.empty(sum(n * w + _BLOCK_SKEW for _, w in widths), dtype=torch.float32, device=device)
         g, off = {}, 0
         for key, w in widths:
             g[key] = flat[off:off + n * w].view((n, K, 3) if key == "shs" else (n, w))
-            off += n * w
+            off += n * w + _BLOCK_SKEW
         ups = [_dev_f32(t, device) for t in (g_scaling, g_opacity, g_rotation, g_colors)]
         cp = _dev_f32(campos, device).reshape(-1) if campos is not None else None
         with torch.cuda.device(device):

@@ -201,9 +201,13 @@ int lograst_lod_traverse(int32_t num_points, int32_t num_nodes, int32_t max_chil
                          const float* viewmatrix, float focal_x, float focal_y, float tanfovx, float tanfovy,
                          float min_resolution_pixel, int32_t levels, int64_t* out_index, uint32_t out_capacity,
                          void* scratch, size_t scratch_bytes, void* stream);
-/* count_host / overflow_host: host words.  overflow != 0 means the tree buffers were inconsistent (a point
- * reachable twice) and out_index is incomplete. */
-int lograst_lod_read(const void* scratch, uint32_t* count_host, uint32_t* overflow_host, void* stream);
+/* count_host / overflow_host / frontier_left_host: host words (the last two optional).  overflow != 0 means the
+ * tree buffers were inconsistent (a point reachable twice) and out_index is incomplete.  frontier_left = how many of
+ * the selected points are nodes that were still waiting to be expanded when `levels` ran out (0 whenever `levels`
+ * reached the bottom of the tree): a caller that passes a cached tree depth as `levels` re-runs with the full value
+ * if this is not 0. */
+int lograst_lod_read(const void* scratch, uint32_t* count_host, uint32_t* overflow_host, uint32_t* frontier_left_host,
+                     void* stream);
 
 /* ---- "next" row N4: what LoG does with the rasterizer's outputs after every view ----------------------------
  * (a) lograst_id_histogram replaces `torch.unique(point_id_pixel, sorted=True, return_counts=True)` + dropping the

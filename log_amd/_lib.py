@@ -66,7 +66,8 @@ _SIGNATURES = {
     "lograst_lod_traverse": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 6 + [c_int32, c_void_p, c_void_p,
                                             c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p, c_uint32,
                                             c_void_p, c_size_t, c_void_p]),
-    "lograst_lod_read": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_lod_read": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),
+                                        ctypes.POINTER(c_uint32), c_void_p]),
     "lograst_id_histogram_scratch_bytes": (c_size_t, [c_int32]),
     "lograst_id_histogram": (ctypes.c_int, [c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lograst_id_histogram_read": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), c_void_p]),

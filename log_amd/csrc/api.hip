@@ -408,14 +408,16 @@ int lograst_lod_traverse(int32_t num_points, int32_t num_nodes, int32_t max_chil
   return LOGRAST_OK;
 }
 
-int lograst_lod_read(const void* scratch, uint32_t* count_host, uint32_t* overflow_host, void* stream) {
+int lograst_lod_read(const void* scratch, uint32_t* count_host, uint32_t* overflow_host, uint32_t* frontier_left_host,
+                     void* stream) {
   if (!scratch || !count_host) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
-  uint32_t w[2] = {0, 0};
+  uint32_t w[3] = {0, 0, 0};
   LR_HIP(hipMemcpyAsync(w, reinterpret_cast<const uint32_t*>(scratch) + lr_lod_total_word(), sizeof(w),
                         hipMemcpyDeviceToHost, (hipStream_t)stream));
   LR_HIP(hipStreamSynchronize((hipStream_t)stream));
   *count_host = w[0];
   if (overflow_host) *overflow_host = w[1];
+  if (frontier_left_host) *frontier_left_host = w[2];
   return LOGRAST_OK;
 }
 

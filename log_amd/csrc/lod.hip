@@ -17,6 +17,7 @@
 #define LOD_HDR_OUT (LOD_MAX_LEVELS + 4)         // [l] output cursor before level l's keeps
 #define LOD_HDR_TOTAL (2 * (LOD_MAX_LEVELS + 4))
 #define LOD_HDR_OVERFLOW (LOD_HDR_TOTAL + 1)
+#define LOD_HDR_LEFT (LOD_HDR_TOTAL + 2)       // size of the frontier that was appended unexpanded at the depth limit
 #define LOD_HDR_WORDS (LOD_HDR_TOTAL + 8)
 #define LOD_CHUNK 1024u
 #define LOD_NONE 0xFFFFFFFFu
@@ -202,7 +203,7 @@ lod_finish_kernel(LodArgs a, int level, const uint32_t* __restrict__ frontier) {
     if (base + i < a.out_capacity) a.out[base + i] = (int64_t)frontier[i];
     else a.hdr[LOD_HDR_OVERFLOW] = 1u;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.hdr[LOD_HDR_TOTAL] = base + n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.hdr[LOD_HDR_TOTAL] = base + n; a.hdr[LOD_HDR_LEFT] = n; }
 }
 
 hipError_t lr_launch_lod(int num_points, int num_nodes, int max_child, const int32_t* node_index, const int32_t* tree,

@@ -35,7 +35,27 @@ def traverse(self, model, root_index, camera, max_depth=1000):
     with torch.no_grad():
         return _r._backend.lod_traverse(self.node_index, self.tree, model.xyz.detach(), model.scaling.detach(),
                                         model.rotation.detach(), root_index, rs.projmatrix, rs.viewmatrix, fx, fy,
-                                        rs.tanfovx, rs.tanfovy, float(self.min_resolution_pixel), levels)
+                                        rs.tanfovx, rs.tanfovy, float(self.min_resolution_pixel), levels,
+                                        depth_hint=_tree_depth(self))
+
+
+def _tree_depth(tree):
+    """Depth of the tree, cached on the tree object and keyed on its `depth` buffer (TensorTree replaces the buffer
+    whenever it splits or removes, tensor_tree.py:57-119).  Only a hint: LoG passes max_depth = 20 / 1000 for trees
+    a handful of levels deep, and every level costs three launches; a stale value is detected on the device
+    (lograst_lod_read: frontier_left) and the selection repeated with the full depth."""
+    depth = getattr(tree, "depth", None)
+    if depth is None or depth.numel() == 0:
+        return None
+    key = (depth.data_ptr(), int(depth.numel()))
+    cached = getattr(tree, "_lograst_depth", None)
+    if cached is None or cached[0] != key:
+        cached = (key, int(depth.max()))
+        try:
+            tree._lograst_depth = cached
+        except Exception:      # an object that refuses new attributes: no caching
+            pass
+    return cached[1]
 
 
 def install():

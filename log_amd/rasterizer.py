@@ -281,8 +281,10 @@ class HipBackend:
 
 
     def lod_traverse(self, node_index, tree, xyz, scaling, rotation, root_index, projmatrix, viewmatrix, fx, fy,
-                     tanfovx, tanfovy, min_resolution_pixel, levels):
-        """N3 (log_amd/lod.py): -> int64 indices selected for this camera, in the reference's order."""
+                     tanfovx, tanfovy, min_resolution_pixel, levels, depth_hint=None):
+        """N3 (log_amd/lod.py): -> int64 indices selected for this camera, in the reference's order.  depth_hint: a
+        (possibly stale) guess of the tree's depth; fewer levels are launched, and the call repeats itself with the
+        full `levels` if the device reports that the guess cut the descent short."""
         device = xyz.device
         L = self.require(device)
         P = int(xyz.shape[0])
@@ -295,15 +297,19 @@ class HipBackend:
         out = torch.empty(max(P, 1), dtype=torch.int64, device=device)
         nbytes = L.lograst_lod_scratch_bytes(int(roots.numel()), num_nodes, max_child)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        count, overflow = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        count, overflow, left = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+        tries = [int(levels)] if depth_hint is None or depth_hint >= levels else [int(depth_hint), int(levels)]
         with torch.cuda.device(device):
-            _lib.check(L.lograst_lod_traverse(P, num_nodes, max_child, _ptr(ni), _ptr(tr), _ptr(x), _ptr(s), _ptr(r),
-                                              _ptr(roots), int(roots.numel()), _ptr(pm), _ptr(vm), float(fx),
-                                              float(fy), float(tanfovx), float(tanfovy), float(min_resolution_pixel),
-                                              int(levels), _ptr(out), int(out.numel()), _ptr(scratch), nbytes,
-                                              _stream_ptr(device)))
-            _lib.check(L.lograst_lod_read(_ptr(scratch), ctypes.byref(count), ctypes.byref(overflow),
-                                          _stream_ptr(device)))
+            for lv in tries:
+                _lib.check(L.lograst_lod_traverse(P, num_nodes, max_child, _ptr(ni), _ptr(tr), _ptr(x), _ptr(s), _ptr(r),
+                                                  _ptr(roots), int(roots.numel()), _ptr(pm), _ptr(vm), float(fx),
+                                                  float(fy), float(tanfovx), float(tanfovy), float(min_resolution_pixel),
+                                                  lv, _ptr(out), int(out.numel()), _ptr(scratch), nbytes,
+                                                  _stream_ptr(device)))
+                _lib.check(L.lograst_lod_read(_ptr(scratch), ctypes.byref(count), ctypes.byref(overflow),
+                                              ctypes.byref(left), _stream_ptr(device)))
+                if left.value == 0:
+                    break
         if overflow.value:
             raise _lib.LograstError("lod_traverse: inconsistent tree buffers (a point is reachable more than once)")
         return out[:count.value]

@@ -54,7 +54,7 @@ class OracleBackend:
         return torch.from_numpy(g_shs.copy())
 
     def lod_traverse(self, node_index, tree, xyz, scaling, rotation, root_index, projmatrix, viewmatrix, fx, fy,
-                     tanfovx, tanfovy, min_resolution_pixel, levels):
+                     tanfovx, tanfovy, min_resolution_pixel, levels, depth_hint=None):
         n = lambda a: a.detach().cpu().numpy()
         tr = n(tree)
         idx = oracle.lod_traverse(n(node_index), tr.reshape(-1, tr.shape[-1]) if tr.ndim == 2 else tr.reshape(0, 1),

@@ -93,3 +93,32 @@ def test_traverse_edge_cases(oracle_mod):
                                    np.arange(0, 500, 2), cam["full_proj_transform"], cam["world_view_transform"],
                                    640 / (2 * tfx), 480 / (2 * tfy), tfx, tfy, 3.0, 30, 1000)
     np.testing.assert_array_equal(got, want)
+
+
+def test_cached_tree_depth_hint_and_stale_hint(oracle_mod):
+    """lod.traverse launches only as many levels as the tree is deep (cached on the tree object); a stale cache is
+    noticed on the device (frontier left at the hinted depth) and the selection repeated with the full depth."""
+    from log_amd import lod, scenes
+    from lod_util import synth_tree
+    cam = scenes.orbit_cameras(1, W=640, H=480, focal=500.0)[0]
+    tfx, tfy = math.tan(cam["FoVx"] * 0.5), math.tan(cam["FoVy"] * 0.5)
+    s = synth_tree(2000, 5, 4, seed=11)
+    tree, model, rast = _objects(s["node_index"], s["tree"], s["xyz"], s["scaling"], s["rotation"], 640, 480, tfx, tfy,
+                                 cam["world_view_transform"], cam["full_proj_transform"])
+    tree.depth = torch.from_numpy(s["depth"]).cuda()
+    roots = torch.from_numpy(s["root_index"]).cuda()
+    want = oracle_mod.lod_traverse(s["node_index"], s["tree"], s["xyz"], s["scaling"], s["rotation"], s["root_index"],
+                                   cam["full_proj_transform"], cam["world_view_transform"], 640 / (2 * tfx),
+                                   480 / (2 * tfy), tfx, tfy, 3.0, 30, 1000)
+    got = lod.traverse(tree, model, roots, rast)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert tree._lograst_depth[1] == int(s["depth"].max())
+    tree._lograst_depth = (tree._lograst_depth[0], 1)          # pretend the cache is stale
+    got = lod.traverse(tree, model, roots, rast)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    # an explicit depth limit below the tree's depth is not a stale hint: the frontier is part of the answer
+    want2 = oracle_mod.lod_traverse(s["node_index"], s["tree"], s["xyz"], s["scaling"], s["rotation"], s["root_index"],
+                                    cam["full_proj_transform"], cam["world_view_transform"], 640 / (2 * tfx),
+                                    480 / (2 * tfy), tfx, tfy, 3.0, 30, 2)
+    tree._lograst_depth = None
+    np.testing.assert_array_equal(lod.traverse(tree, model, roots, rast, max_depth=2).cpu().numpy(), want2)

@@ -52,8 +52,7 @@ hipError_t lr_launch_lod(int num_points, int num_nodes, int max_child, const int
                          float tanfovy, float min_px, int levels, int64_t* out, uint32_t out_capacity, void* scratch,
                          hipStream_t s);
 int lr_lod_max_levels();
-uint32_t lr_lod_total_word();
-uint32_t lr_lod_overflow_word();
+uint32_t lr_lod_total_word();   // header words TOTAL, OVERFLOW, LEFT are consecutive
 
 size_t lr_hist_scratch_bytes(int n);
 hipError_t lr_launch_id_histogram(int n, const int32_t* pid, int npix, int32_t* ids, int64_t* counts, void* scratch,

@@ -250,4 +250,3 @@ hipError_t lr_launch_lod(int num_points, int num_nodes, int max_child, const int
 
 int lr_lod_max_levels() { return LOD_MAX_LEVELS; }
 uint32_t lr_lod_total_word() { return LOD_HDR_TOTAL; }
-uint32_t lr_lod_overflow_word() { return LOD_HDR_OVERFLOW; }

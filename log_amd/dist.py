@@ -52,7 +52,6 @@ class GradientBucket:
         if self.world <= 1 or not dist.is_initialized():
             return self.flat
         shard = self.flat.numel() // self.world
-        rank = dist.get_rank(group)
         mine = torch.empty(shard, dtype=self.flat.dtype, device=self.flat.device)
         if dist.get_backend(group) == "gloo":
             # gloo has no reduce_scatter_tensor: same result via all_reduce (CPU tests only)
@@ -60,5 +59,4 @@ class GradientBucket:
             return self.flat
         dist.reduce_scatter_tensor(mine, self.flat, op=dist.ReduceOp.SUM, group=group)
         dist.all_gather_into_tensor(self.flat, mine, group=group)
-        del rank
         return self.flat

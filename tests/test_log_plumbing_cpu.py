@@ -224,10 +224,9 @@ def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
         ref = _log_model(0, 400)
         assert ref.tree.num_nodes > 50 and int(ref.tree.depth.max()) == 2
         sel_ref = _run_steps(ref, 3, W, H)
-        lod.install()
-        counter.install()
-        sparse_optimizer.install()
-        get_all.install()
+        import log_amd
+        patched = log_amd.install_all()                 # = the four install() calls of INTEGRATION.md 3b
+        assert [c.__name__ for c in patched] == ["LoG", "TensorTree", "Counter", "SparseOptimizer"]
         new = _log_model(0, 400)
         sel_new = _run_steps(new, 3, W, H)
     finally:

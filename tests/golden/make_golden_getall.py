@@ -53,6 +53,7 @@ def case(seed, P, n_leaf, n_node, K, degree):
 def main():
     for name, kw in (("deg0", dict(seed=1, P=2500, n_leaf=900, n_node=200, K=3, degree=0)),
                      ("deg1", dict(seed=2, P=2500, n_leaf=1000, n_node=130, K=3, degree=1)),
+                     ("deg2", dict(seed=5, P=900, n_leaf=333, n_node=41, K=8, degree=2)),
                      ("deg3", dict(seed=3, P=1500, n_leaf=700, n_node=0, K=15, degree=3)),
                      ("nosh", dict(seed=4, P=800, n_leaf=300, n_node=50, K=0, degree=0))):
         f = os.path.join(HERE, f"getall_{name}.npz")

@@ -137,3 +137,93 @@ def test_installed_on_reference_classes_side_by_side(double):
         Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict = ref_update, ref_step, ref_load
         if hasattr(SparseOptimizer, "_lograst_load_state_dict"):
             del SparseOptimizer._lograst_load_state_dict
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "LoG")), reason="reference tree not present")
+@pytest.mark.parametrize("seed", range(6))
+def test_random_views_and_steps_against_reference_classes(seed, double):
+    """Random sizes, random subsets of keys without gradient, amsgrad on/off, several views / steps: the reference's
+    Counter and SparseOptimizer (unpatched, torch CPU) and the drop-in functions see identical inputs."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import types
+    from LoG.model.counter import Counter
+    from LoG.model.sparse_optimizer import SparseOptimizer
+    from log_amd import counter, sparse_optimizer
+    rng = np.random.default_rng(100 + seed)
+    g = torch.Generator().manual_seed(seed)
+    P = int(rng.integers(50, 3000))
+    # ---- counter: views with random visible sets, radii (some 0 = culled), id lists over the visible ones
+    views = []
+    for _ in range(int(rng.integers(1, 4))):
+        nv = int(rng.integers(1, P + 1))
+        vis = rng.permutation(P)[:nv]
+        n_leaf = int(rng.integers(0, nv + 1))
+        radii = rng.integers(0, 40000, nv).astype(np.int32) * (rng.random(nv) < 0.8)       # > int16 range too (.short() wraps)
+        k = int(rng.integers(0, nv + 1))
+        pid = np.sort(rng.permutation(nv)[:k]).astype(np.int32)
+        views.append(dict(index=vis[:n_leaf], index_node=vis[n_leaf:], grad=rng.standard_normal((nv, 3)).astype(np.float32),
+                          radii=radii.astype(np.int32), pw=rng.random(nv).astype(np.float32), pid=pid,
+                          pc=rng.integers(1, 5000, k).astype(np.int64)))
+
+    def output():
+        t = torch.from_numpy
+        return {"render": [None] * len(views),
+                "visibility_flag": [{"index": t(v["index"]), "index_node": t(v["index_node"])} for v in views],
+                "viewspace_points": [types.SimpleNamespace(grad=t(v["grad"])) for v in views],
+                "radii": [t(v["radii"]) for v in views], "point_weight": [t(v["pw"]) for v in views],
+                "point_id": [t(v["pid"]) for v in views], "point_count": [t(v["pc"]) for v in views]}
+
+    c_ref, c_new = Counter(num_points=P), Counter(num_points=P)
+    o_ref, o_new = output(), output()
+    c_ref.update_by_output(o_ref, fix_parent=True)
+    counter.update_by_output(c_new, o_new, fix_parent=True)
+    for k in U.COUNTER_DTYPES:
+        a, b = getattr(c_new, k).numpy(), getattr(c_ref, k).numpy()
+        if a.dtype.kind == "f":
+            np.testing.assert_allclose(a, b, rtol=3e-6, atol=1e-12, err_msg=k)
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=k)
+    for v in range(len(views)):
+        assert torch.equal(o_new["visibility_flag"][v]["flag_vis"], o_ref["visibility_flag"][v]["flag_vis"])
+        assert torch.equal(o_new["visibility_flag"][v]["index_vis"], o_ref["visibility_flag"][v]["index_vis"])
+    # ---- sparse Adam
+    amsgrad = bool(seed % 2)
+    shapes = {"xyz": (3,), "colors": (3,), "scaling": (3,), "opacity": (1,), "rotation": (4,), "shs": (int(rng.integers(1, 16)), 3)}
+    lr = {"xyz": 0.00016, "xyz_final": 0.0000016, "colors": 0.0025, "shs": 0.000125, "scaling": 0.005, "opacity": 0.05,
+          "rotation": 0.001, "max_steps": 30000}
+
+    def make():
+        gg = torch.Generator().manual_seed(seed)
+        model = types.SimpleNamespace(**{k: torch.randn(P, *s, generator=gg) for k, s in shapes.items()})
+        opt = SparseOptimizer(list(shapes), dict(lr), model, device=torch.device("cpu"), xyz_scale=1.0, use_amsgrad=amsgrad)
+        opt.global_steps += int(seed * 7)
+        return model, opt
+
+    (m_ref, op_ref), (m_new, op_new) = make(), make()
+    for _ in range(int(rng.integers(1, 4))):
+        m = int(rng.integers(1, P + 1))
+        index = torch.randperm(P, generator=g)[:m]
+        flag_vis = torch.rand(m, generator=g) < 0.7
+        no_grad = {k for k in shapes if rng.random() < 0.25}
+        grads = {k: torch.randn(m, *s, generator=g) * 10.0 ** float(rng.integers(-6, 1)) for k, s in shapes.items()}
+
+        def params(model):
+            out = {}
+            for k in shapes:
+                p = torch.nn.Parameter(getattr(model, k)[index].clone())
+                if k not in no_grad:
+                    p.grad = grads[k].clone()
+                out[k] = p
+            return out
+
+        op_ref.step(m_ref, index, params(m_ref), flag_vis)
+        sparse_optimizer.step(op_new, m_new, index, params(m_new), flag_vis)
+    assert float(op_ref.global_steps) == float(op_new.global_steps)
+    for k in shapes:
+        np.testing.assert_allclose(getattr(m_new, k).numpy(), getattr(m_ref, k).numpy(), rtol=3e-6, atol=2e-8, err_msg=k)
+        np.testing.assert_allclose(op_new.exp_avg[k].numpy(), op_ref.exp_avg[k].numpy(), rtol=3e-6, atol=1e-12, err_msg=k)
+        np.testing.assert_allclose(op_new.exp_avg_sq[k].numpy(), op_ref.exp_avg_sq[k].numpy(), rtol=3e-6, atol=1e-20, err_msg=k)
+        if amsgrad:
+            np.testing.assert_allclose(op_new.max_exp_avg_sq[k].numpy(), op_ref.max_exp_avg_sq[k].numpy(), rtol=3e-6,
+                                       atol=1e-20, err_msg=k)

@@ -50,14 +50,17 @@ def _batch(cams):
     return {"camera": cam}
 
 
-def test_reference_renderer_runs_unchanged_on_dropin(log_env, oracle_mod):
+@pytest.mark.parametrize("n,W,focal,smax", [(1500, 96, 110.0, 0.06), (50000, 400, 445.0, None)],
+                         ids=["small", "C1_50k_400x400_2views"])
+def test_reference_renderer_runs_unchanged_on_dropin(log_env, oracle_mod, n, W, focal, smax):
+    """ids[1] is BASELINE.json configs[0] (C1, "plumbing, no GPU"): 50 000 Gaussians, 400x400, 2 views, through
+    NaiveRendererAndLoss + BaseGaussian.create_from_record."""
     from LoG.render.renderer import NaiveRendererAndLoss          # reference code, unmodified
     from LoG.model.base_gaussian import BaseGaussian              # reference code, unmodified
     from log_amd import scenes
-    W = H = 96
-    n = 1500
-    cams = scenes.orbit_cameras(2, W=W, H=H, focal=110.0)
-    sc = scenes.random_scene(n, seed=0, opacity=None, smax=0.06)
+    H = W
+    cams = scenes.orbit_cameras(2, W=W, H=H, focal=focal)
+    sc = scenes.random_scene(n, seed=0, opacity=None, smax=smax)
     sc["opacity"] = np.clip(sc["opacity"], 0.05, 0.95)
     model = BaseGaussian.create_from_record({k: v for k, v in sc.items()})
     renderer = NaiveRendererAndLoss(split="train", use_origin_render=False, background=[1., 1., 1.])

@@ -77,3 +77,17 @@ def test_reference_error_strings():
         r(means3D=z(2, 3), means2D=z(2, 3), opacities=z(2, 1), scales=z(2, 3), rotations=z(2, 4))
     with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
         r(means3D=z(2, 3), means2D=z(2, 3), opacities=z(2, 1), colors_precomp=z(2, 3))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lograst.h is the drop-in boundary for hosts that are not Python: it must compile as C99 on its own."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "lograst.h"\nint main(void) { lograst_view v; lograst_adam_key k; (void)v; (void)k; return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])

@@ -55,6 +55,11 @@ typedef struct lograst_view {
   const float* viewmatrix; /* device, 16 floats */
   const float* projmatrix; /* device, 16 floats */
   const float* bg;         /* device, 3 floats */
+  /* Image split across GPUs ("per-GPU tile ownership"; new design, the reference is single-GPU): only
+   * the tile rows [tile_row_begin, tile_row_end) are rendered -- every Gaussian's rect is clipped to them, so lists,
+   * image rows, gradients and point_weight cover this band only, radii is 0 for Gaussians that do not reach it, and
+   * pixels outside the band come out as background.  Both 0 = the whole image. */
+  int32_t tile_row_begin, tile_row_end;
 } lograst_view;
 
 int lograst_version(void);

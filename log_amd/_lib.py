@@ -22,6 +22,7 @@ class LograstView(ctypes.Structure):
         ("scale_modifier", c_float),
         ("filter_mode", c_int32), ("ndc_cull", c_int32), ("extras", c_int32),
         ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("bg", c_void_p),
+        ("tile_row_begin", c_int32), ("tile_row_end", c_int32),
     ]
 
 

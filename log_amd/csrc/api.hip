@@ -186,6 +186,12 @@ static int lr_make_view(const lograst_view* in, LrView* out) {
   out->W = in->width; out->H = in->height;
   out->gx = (in->width + LOGRAST_TILE - 1) / LOGRAST_TILE;
   out->gy = (in->height + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  out->ty0 = 0; out->ty1 = out->gy;
+  if (in->tile_row_begin != 0 || in->tile_row_end != 0) {
+    if (in->tile_row_begin < 0 || in->tile_row_end <= in->tile_row_begin || in->tile_row_end > out->gy)
+      return lr_fail(LOGRAST_ERR_ARG, "tile_row_begin / tile_row_end outside the tile grid");
+    out->ty0 = in->tile_row_begin; out->ty1 = in->tile_row_end;
+  }
   out->tanfovx = in->tanfovx; out->tanfovy = in->tanfovy;
   out->fx = (float)in->width / (2.0f * in->tanfovx);
   out->fy = (float)in->height / (2.0f * in->tanfovy);

@@ -70,6 +70,7 @@ __host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batche
 // Device-side view (kernel argument, by value).
 struct LrView {
   int W, H, gx, gy;
+  int ty0, ty1;   // tile rows this call owns (image split across GPUs): rects are clipped to [ty0, ty1)
   float tanfovx, tanfovy, fx, fy, scale_modifier;
   int filter_mode, ndc_cull, extras;
   const float* view;

@@ -119,7 +119,7 @@ LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, c
   int x0 = (int)((mx - rf) / 16.f), y0 = (int)((my - rf) / 16.f);
   int x1 = (int)(((mx + rf) + 15.f) / 16.f), y1 = (int)(((my + rf) + 15.f) / 16.f);
   x0 = min(v.gx, max(0, x0)); x1 = min(v.gx, max(0, x1));
-  y0 = min(v.gy, max(0, y0)); y1 = min(v.gy, max(0, y1));
+  y0 = min(v.ty1, max(v.ty0, y0)); y1 = min(v.ty1, max(v.ty0, y1));   // [ty0, ty1) = [0, gy) unless the image is split
   if ((x1 - x0) * (y1 - y0) <= 0) return;
   rad = (int)rf;
   g0 = float4{mx, my, cA, cB};

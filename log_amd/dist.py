@@ -60,3 +60,41 @@ class GradientBucket:
         dist.reduce_scatter_tensor(mine, self.flat, op=dist.ReduceOp.SUM, group=group)
         dist.all_gather_into_tensor(self.flat, mine, group=group)
         return self.flat
+
+
+# ---- second axis: the image split into bands of tile rows, one band per rank ----------------------
+# Every rank keeps all Gaussians and renders only its rows (log_amd.rasterizer.tile_rows clips every rect to the band
+# in the projection kernel, so a rank bins, sorts and composites only what reaches its rows); no compositing across
+# ranks is needed.  Exchange per view: an all-gather of the bands (3 * H * W * 4 bytes in total) and the same gradient
+# sum as above.
+TILE = 16
+
+
+def band_rows(rank, world, height):
+    """Tile rows [begin, end) owned by `rank`: contiguous, sizes differing by at most one row of tiles."""
+    gy = (int(height) + TILE - 1) // TILE
+    return rank * gy // world, (rank + 1) * gy // world
+
+
+def band_pixels(rank, world, height):
+    b, e = band_rows(rank, world, height)
+    return b * TILE, min(e * TILE, int(height))
+
+
+def gather_bands(image, rank, world, group=None):
+    """image: [C, H, W] with this rank's band rendered (other rows: anything).  Returns the full image on every rank.
+    Bands are padded to a common height for the collective (all_gather needs equal shapes)."""
+    C, H, W = image.shape
+    if world <= 1 or not dist.is_initialized():
+        return image
+    rows = [band_pixels(r, world, H) for r in range(world)]
+    hmax = max(e - b for b, e in rows)
+    b, e = rows[rank]
+    mine = torch.zeros(C, hmax, W, dtype=image.dtype, device=image.device)
+    mine[:, :e - b] = image[:, b:e]
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    out = torch.empty_like(image)
+    for (rb, re), part in zip(rows, parts):
+        out[:, rb:re] = part[:, :re - rb]
+    return out

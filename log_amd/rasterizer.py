@@ -18,6 +18,7 @@ All arithmetic runs in hand-written HIP kernels (log_amd/csrc) through the C ABI
 (include/lograst.h).  Tensors must live on the MI355X; there is no CPU fallback.
 """
 import ctypes
+import threading
 from typing import NamedTuple
 
 import torch
@@ -113,6 +114,41 @@ def _dev_f32(t, device):
 _BLOCK_SKEW = 1088
 
 
+class _TileRows:
+    """The band of tile rows rendered by the calls inside a ``tile_rows(begin, end)`` block (image split across GPUs:
+    log_amd/dist.py).  (0, 0) = the whole image."""
+
+    def __init__(self):
+        self._local = threading.local()
+
+    def get(self):
+        return getattr(self._local, "rows", (0, 0))
+
+    def set(self, rows):
+        self._local.rows = rows
+
+
+_tile_rows = _TileRows()
+
+
+class tile_rows:
+    """``with tile_rows(begin, end): image, ... = rasterizer(...); loss.backward()`` renders (and differentiates) only
+    the tile rows [begin, end) -- pixel rows [16*begin, 16*end) -- of every view set up inside the block; the backward
+    of a view uses the band its forward used.  New design, not part of the reference's API."""
+
+    def __init__(self, begin, end):
+        self.rows = (int(begin), int(end))
+
+    def __enter__(self):
+        self.prev = _tile_rows.get()
+        _tile_rows.set(self.rows)
+        return self
+
+    def __exit__(self, *exc):
+        _tile_rows.set(self.prev)
+        return False
+
+
 class HipBackend:
     """Drives the kernels.  All buffers come from torch's caching allocator."""
 
@@ -135,6 +171,7 @@ class HipBackend:
         v.filter_mode = flavour.filter_mode if use_filter else _lib.FILTER_NONE
         v.ndc_cull, v.extras = flavour.ndc_cull, flavour.extras
         v.viewmatrix, v.projmatrix, v.bg = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+        v.tile_row_begin, v.tile_row_end = _tile_rows.get()
         return v, keep
 
     def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0):

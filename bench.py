@@ -176,6 +176,7 @@ def main():
     # from here on: no host sync inside forward(); the longest tile list (it picks the sort's multi-block levels)
     # comes from the same measurement, with the same margin
     R.set_instance_capacity(cap, max_tile_len=int(max(s[2] for s in stats) * 1.02) + 64)
+    R.overflow_since_reset(dev)         # clear the status block: from here on every forward is recorded in it
 
     for _ in range(args.warmup):
         step()
@@ -214,8 +215,9 @@ def main():
             torch.cuda.synchronize()
             _lib.profile_enable(False)
             prof_serial = _lib.profile_read()
-    n_inst, over = R.last_overflow()
-    assert not over and n_inst <= cap, "tile-instance capacity overflow inside the timed region: result invalid"
+    chk = R.overflow_since_reset(dev)   # every forward since the capacity was set, on all streams
+    assert not chk["overflowed"] and chk["max_instances"] <= cap, \
+        "tile-instance capacity overflow inside the timed region: result invalid (%r)" % (chk,)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -36,6 +36,17 @@ extern "C" {
 #define LOGRAST_FILTER_DILATE 1 /* upstream package: cov.xx += 0.3 (LoG/model/geometry.py:87-88) */
 #define LOGRAST_FILTER_CLAMP 2  /* `wodilate` fork: cov.xx = max(cov.xx, 0.3) (LoG/cuda/compute_radius_kernel.cu:100-104) */
 
+/* Caller-owned status block of the forward (device words; see lograst_forward_render) */
+#define LOGRAST_STATUS_WORDS 8
+#define LOGRAST_STATUS_OVERFLOW 0        /* sticky: bit 0 set by every forward that overflowed */
+#define LOGRAST_STATUS_LAST_INSTANCES 1  /* the most recent forward: tile instances, ... */
+#define LOGRAST_STATUS_LAST_OVERFLOW 2   /* ... whether it overflowed, ... */
+#define LOGRAST_STATUS_LAST_MAX_LEN 3    /* ... its longest tile list, ... */
+#define LOGRAST_STATUS_LAST_RECT 4       /* ... and its rect-rule instance count */
+#define LOGRAST_STATUS_MAX_INSTANCES 5   /* running maxima over all forwards since the caller cleared the block */
+#define LOGRAST_STATUS_MAX_MAX_LEN 6
+#define LOGRAST_STATUS_FORWARDS 7        /* forwards recorded since then */
+
 /* error codes */
 #define LOGRAST_OK 0
 #define LOGRAST_ERR_ARG -1
@@ -112,12 +123,29 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
  * bwd_scratch (optional, NULL/0 = none): a block of bwd_scratch_floats * n fp32 that this call zero-fills (inside
  * a kernel it launches anyway) for a caller that will run lograst_backward on this view: carve dL_dmeans2d[n,3],
  * dL_dconic[n,4] (7 floats per Gaussian) and, without LOGRAST_BWD_ACCUMULATE, dL_dopacities[n], dL_dcolors[n,3]
- * (11) out of it and pass LOGRAST_BWD_SCRATCH_ZEROED -- no separate memset launches. */
+ * (11) out of it and pass LOGRAST_BWD_SCRATCH_ZEROED -- no separate memset launches.
+ * max_tile_len is also CHECKED on the device: when the real longest list exceeds a non-zero max_tile_len (or the
+ * instance count exceeds capacity) nothing is sorted or composited and the overflow flag of tile_state is raised; the
+ * outputs of such a call are undefined.  status (optional): LOGRAST_STATUS_WORDS device words owned by the caller
+ * (zeroed once), into which every forward records itself -- see LOGRAST_STATUS_* -- so that a caller running many
+ * sync-free forwards, on any number of streams, checks all of them with one read-back.
+ * bwd_scratch must be 16-byte aligned. */
 int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
                            uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
                            float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
                            float* point_weight_pixel, float* point_weight, float* bwd_scratch,
-                           int32_t bwd_scratch_floats, void* stream);
+                           int32_t bwd_scratch_floats, uint32_t* status, void* stream);
+
+/* ---- forward in ONE call (sync-free operation) ---------------------------------------------------------------
+ * lograst_forward_project + lograst_forward_render back to back for a caller that already knows a capacity (and a
+ * max_tile_len, or 0): one boundary crossing and no host decision between the stages -- what GaussianRasterizer.forward
+ * (LoG/render/renderer.py:153) costs the host is then one call.  Arguments as in the two stage calls. */
+int lograst_forward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                    const float* rotations, const float* opacities, const float* colors, int32_t* radii, void* geom,
+                    void* tile_state, uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
+                    float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
+                    float* point_weight_pixel, float* point_weight, float* bwd_scratch, int32_t bwd_scratch_floats,
+                    uint32_t* status, void* stream);
 
 /* Copies {num_instances, overflow_flag, longest tile list, rect instances} of a tile_state to host (synchronises
  * the stream; any pointer may be NULL).  rect_instances = what the plain rect rule of the reference would have
@@ -136,7 +164,8 @@ int lograst_set_tile_cull(int enabled);
  * (LoG/utils/trainer.py:158).  dL_dimage[3,H,W] in; all gradient outputs are overwritten:
  *   dL_dmeans2d[n,3]  (x,y = d/d ndc, z = 0; consumed at LoG/model/counter.py:40,46)
  *   dL_dmeans3d[n,3], dL_dscales[n,3], dL_drotations[n,4], dL_dopacities[n], dL_dcolors[n,3]
- * dL_dconic[n,4] is scratch.  flags:
+ * dL_dconic[n,4] is scratch and, like rotations / dl_drotations, must be 16-byte aligned (read and written as one
+ * 16-byte access per Gaussian).  flags:
  *   LOGRAST_BWD_SCRATCH_ZEROED  the caller already zeroed dl_dmeans2d / dl_dconic (and, unless accumulating,
  *                               dl_dopacities / dl_dcolors) -- e.g. one memset over a block holding all of them;
  *   LOGRAST_BWD_ACCUMULATE      multi-view accumulation (new, not in the reference): dl_dopacities, dl_dcolors,

@@ -53,7 +53,9 @@ _SIGNATURES = {
                                                ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
     "lograst_forward_render": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+                                              c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "lograst_forward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10 + [c_uint32, c_uint32]
+                        + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p]),
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),
                                           ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
     "lograst_set_tile_cull": (ctypes.c_int, [ctypes.c_int]),

@@ -3,6 +3,7 @@
 // the header says so.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,10 +20,12 @@ void lr_launch_radius(int P, const float* means, const float* scales, const floa
                       hipStream_t s);
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
-                       uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int tile_cull, hipStream_t s);
+                       uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int planes, int tile_cull,
+                       hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_off, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
-                    uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s);
+                    uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
+                    int zero_block_floats, hipStream_t s);
 void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
@@ -81,23 +84,39 @@ int lr_env_int(const char* name, int dflt) {
 }
 // Support cull in the binning kernels (project.hip): on unless LOGRAST_TILE_CULL=0 or lograst_set_tile_cull(0).
 static std::atomic<int> g_tile_cull{-1};
-// Gaussians per projection batch (project.hip: lr_project_batched_kernel), 0 = unbatched kernel.  One batch per
-// workgroup; big enough that a batch puts several instances into a tile (that is what it saves in memory-side
-// atomics), small enough to leave a few hundred workgroups.  LOGRAST_BATCH overrides (0 disables batching).
-static uint32_t lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t gy) {
+// Gaussians per projection batch (project.hip: lr_project_batched_kernel), 0 = unbatched kernel, and the number of
+// consecutive batches one workgroup owns (`planes`: one plane of LDS tile counters each).  A batch is big enough that it
+// puts several instances into a tile (that is what it saves in memory-side atomics) and at most 32768 Gaussians (16-bit
+// ranks); a workgroup takes as many batches as its LDS holds (up to 4), which makes the runs it reserves in a tile
+// adjacent (longer contiguous key writes in the fill) and leaves one workgroup per CU per round.
+// LOGRAST_BATCH overrides the batch size (0 disables batching), LOGRAST_BATCH_PLANES caps the planes.
+struct LrBatching { uint32_t batch, planes; };
+static LrBatching lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t gy) {
   static const int forced = lr_env_int("LOGRAST_BATCH", -1);
-  if (n <= 0 || tiles > LR_BATCH_MAX_TILES || gx > 8191u || gy > 8191u || forced == 0) return 0u;  // 13-bit tile coordinates in the fill record
-  if (forced > 0) return (uint32_t)((forced > 32768 ? 32768 : forced) + 1023) / 1024u * 1024u;  // 16-bit LDS counts
-  // One batch = one 1024-thread workgroup, and the kernel's 82 VGPRs allow one such workgroup per CU: 256 run at a
-  // time.  Size the batches so that their number fills whole rounds of 256 (10 M Gaussians: 306 batches of 32768
-  // = 1.2 rounds ran as long as 2; 489 batches of 20480 = 1.9 rounds do the same work in the same 2).
+  static const uint32_t max_planes = (uint32_t)lr_env_int("LOGRAST_BATCH_PLANES", 4);
+  if (n <= 0 || tiles > LR_BATCH_MAX_TILES || gx > 8191u || gy > 8191u || forced == 0) return {0u, 1u};  // 13-bit tile coordinates in the fill record
+  uint32_t smax = (uint32_t)(LR_BATCH_LDS_BYTES / (sizeof(uint32_t) * (size_t)tiles));
+  if (smax > max_planes) smax = max_planes;
+  if (smax > 4u) smax = 4u;
+  if (smax < 1u) smax = 1u;
+  if (forced > 0) {
+    const uint32_t b = (uint32_t)((forced > 32768 ? 32768 : forced) + 1023) / 1024u * 1024u;  // 16-bit LDS counts
+    return {b, smax};
+  }
+  // One workgroup of 1024 threads per CU (82 VGPRs): 256 run at a time.  Size the work so that the workgroups fill
+  // whole rounds of 256 (10 M Gaussians: 306 batches of 32768 = 1.2 rounds ran as long as 2).
   static const uint32_t slots = (uint32_t)lr_env_int("LOGRAST_BATCH_SLOTS", 256);
-  const uint32_t rounds = ((uint32_t)n + slots * 32768u - 1u) / (slots * 32768u);
-  const uint32_t want = slots * rounds;                                   // batches
-  uint32_t b = (((uint32_t)n + want - 1u) / want + 1023u) / 1024u * 1024u;
+  const uint64_t per_round = (uint64_t)slots * 32768u * smax;
+  const uint32_t rounds = (uint32_t)(((uint64_t)n + per_round - 1u) / per_round);
+  const uint32_t groups = slots * rounds;                                  // workgroups
+  const uint32_t g = ((uint32_t)n + groups - 1u) / groups;                 // Gaussians per workgroup
+  uint32_t planes = (g + 32767u) / 32768u;
+  if (planes < 1u) planes = 1u;
+  if (planes > smax) planes = smax;
+  uint32_t b = ((g + planes - 1u) / planes + 1023u) / 1024u * 1024u;
   if (b < 4096u) b = 4096u;
   if (b > 32768u) b = 32768u;
-  return b;
+  return {b, planes};
 }
 static uint32_t lr_batches(int32_t n, uint32_t batch) { return batch ? ((uint32_t)n + batch - 1u) / batch : 0u; }
 
@@ -208,7 +227,7 @@ const char* lograst_last_error(void) { return g_err.c_str(); }
 
 size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
-  return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy, gx, gy)));
+  return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy, gx, gy).batch));
 }
 size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection
   return (sizeof(float) * LOGRAST_REC_FLOATS + 16) * (size_t)(n > 0 ? n : 0);
@@ -235,6 +254,68 @@ int lograst_compute_radius(int32_t p, const float* means3d, const float* scales,
   return LOGRAST_OK;
 }
 
+// stage 1 launches: memset of header + counters, projection (+ counting / ranking), tile scan
+static int lr_stage1(const LrView& v, int32_t n, const float* means3d, const float* scales, const float* rotations,
+                     const float* opacities, const float* colors, int32_t* radii, void* geom, uint32_t* st,
+                     hipStream_t s) {
+  const uint32_t tiles = (uint32_t)(v.gx * v.gy);
+  const LrBatching bt = lr_pick_batch(n, tiles, (uint32_t)v.gx, (uint32_t)v.gy);
+  // Counters: batched projection -> dense (ranked[tiles] | big[tiles] right behind the header), unbatched -> one
+  // counter per 64 B.  Header and counters are zeroed by ONE memset (offsets/cursors are fully rewritten by the scan).
+  const uint32_t cs = bt.batch ? 1u : (uint32_t)LR_CTR_STRIDE;
+  const uint32_t big_off = bt.batch ? lr_ranked_off(tiles) + tiles : lr_big_off(tiles);
+  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)(big_off + tiles * cs), s));
+  lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
+                    st + big_off, st, st + lr_basetab_off(tiles), (int)bt.batch, (int)bt.planes, lr_tile_cull(), s);
+  lr_launch_scan(st, tiles, cs, big_off, s);
+  return LOGRAST_OK;
+}
+
+// stage 2 launches: bucket fill (+ zero-fills), per-tile sort, compositing
+static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st, uint64_t* keys, uint32_t* point_list,
+                     uint32_t capacity, uint32_t max_tile_len, float* image, float* final_t, int32_t* n_contrib,
+                     int32_t* point_id_pixel, float* point_weight_pixel, float* point_weight, float* bwd_scratch,
+                     int32_t bwd_scratch_floats, uint32_t* status, hipStream_t s) {
+  const uint32_t tiles = (uint32_t)(v.gx * v.gy);
+  if (n == 0 && status)   // no fill kernel runs: this forward's entries of the status block
+    LR_HIP(hipMemsetAsync(status + LOGRAST_STATUS_LAST_INSTANCES, 0, 4 * sizeof(uint32_t), s));
+  // point_weight (atomicMax target) and the optional backward scratch are cleared by the fill kernel
+  lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, max_tile_len, status,
+                 v.extras ? point_weight : nullptr, bwd_scratch_floats > 0 ? bwd_scratch : nullptr, bwd_scratch_floats, s);
+  lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
+  lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
+                      point_weight_pixel, point_weight, s);
+  return LOGRAST_OK;
+}
+
+static int lr_check_stage1_args(int32_t n, const float* means3d, const float* scales, const float* rotations,
+                                const float* opacities, const float* colors, const int32_t* radii, const void* geom,
+                                const void* tile_state) {
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
+  if (n > 0 && (!means3d || !scales || !rotations || !opacities || !colors || !radii || !geom))
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(geom)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "rotations / geom must be 16-byte aligned");
+  return LOGRAST_OK;
+}
+
+static int lr_check_stage2_args(const LrView& v, int32_t n, const void* tile_state, const uint64_t* keys,
+                                const uint32_t* point_list, uint32_t capacity, const float* image, const float* final_t,
+                                const int32_t* n_contrib, const int32_t* point_id_pixel, const float* point_weight_pixel,
+                                const float* point_weight, const float* bwd_scratch, int32_t bwd_scratch_floats) {
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (!tile_state || !image || !final_t || !n_contrib) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (capacity > 0 && (!keys || !point_list)) return lr_fail(LOGRAST_ERR_ARG, "keys/point_list NULL with capacity > 0");
+  if (v.extras && (!point_id_pixel || !point_weight_pixel || (n > 0 && !point_weight)))
+    return lr_fail(LOGRAST_ERR_ARG, "extras requested but output pointers are NULL");
+  if (bwd_scratch_floats < 0 || bwd_scratch_floats > 16 || (bwd_scratch_floats > 0 && n > 0 && !bwd_scratch))
+    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch: 0..16 floats per Gaussian and a non-NULL block");
+  if (bwd_scratch_floats > 0 && (reinterpret_cast<uintptr_t>(bwd_scratch) & 15u))
+    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch must be 16-byte aligned");
+  return LOGRAST_OK;
+}
+
 int lograst_forward_project(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                             const float* rotations, const float* opacities, const float* colors,
                             int32_t* radii, void* geom, void* tile_state, uint32_t* num_instances_host,
@@ -243,22 +324,12 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
-  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
-  if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
-  if (n > 0 && (!means3d || !scales || !rotations || !opacities || !colors || !radii || !geom))
-    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  rc = lr_check_stage1_args(n, means3d, scales, rotations, opacities, colors, radii, geom, tile_state);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  uint32_t tiles = (uint32_t)(v.gx * v.gy);
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
-  const uint32_t batch = lr_pick_batch(n, tiles, (uint32_t)v.gx, (uint32_t)v.gy);
-  // Counters: batched projection -> dense (ranked[tiles] | big[tiles] right behind the header), unbatched -> one
-  // counter per 64 B.  Header and counters are zeroed by ONE memset (offsets/cursors are fully rewritten by the scan).
-  const uint32_t cs = batch ? 1u : (uint32_t)LR_CTR_STRIDE;
-  const uint32_t big_off = batch ? lr_ranked_off(tiles) + tiles : lr_big_off(tiles);
-  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)(big_off + tiles * cs), s));
-  lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
-                    st + big_off, st, st + lr_basetab_off(tiles), (int)batch, lr_tile_cull(), s);
-  lr_launch_scan(st, tiles, cs, big_off, s);
+  rc = lr_stage1(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st, s);
+  if (rc) return rc;
   LR_HIP(hipGetLastError());
   if (num_instances_host || max_tile_len_host) {
     uint32_t hdr[LR_HDR_WORDS] = {0};
@@ -274,27 +345,44 @@ int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom
                            uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
                            float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
                            float* point_weight_pixel, float* point_weight, float* bwd_scratch,
-                           int32_t bwd_scratch_floats, void* stream) {
+                           int32_t bwd_scratch_floats, uint32_t* status, void* stream) {
   g_prof_call++;
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
-  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
-  if (!tile_state || !image || !final_t || !n_contrib) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
-  if (capacity > 0 && (!keys || !point_list)) return lr_fail(LOGRAST_ERR_ARG, "keys/point_list NULL with capacity > 0");
-  if (v.extras && (!point_id_pixel || !point_weight_pixel || (n > 0 && !point_weight)))
-    return lr_fail(LOGRAST_ERR_ARG, "extras requested but output pointers are NULL");
+  rc = lr_check_stage2_args(v, n, tile_state, keys, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
+                            point_weight_pixel, point_weight, bwd_scratch, bwd_scratch_floats);
+  if (rc) return rc;
+  rc = lr_stage2(v, n, geom, reinterpret_cast<uint32_t*>(tile_state), keys, point_list, capacity, max_tile_len, image,
+                 final_t, n_contrib, point_id_pixel, point_weight_pixel, point_weight, bwd_scratch, bwd_scratch_floats,
+                 status, (hipStream_t)stream);
+  if (rc) return rc;
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+int lograst_forward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                    const float* rotations, const float* opacities, const float* colors, int32_t* radii, void* geom,
+                    void* tile_state, uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
+                    float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
+                    float* point_weight_pixel, float* point_weight, float* bwd_scratch, int32_t bwd_scratch_floats,
+                    uint32_t* status, void* stream) {
+  g_prof_call++;
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  rc = lr_check_stage1_args(n, means3d, scales, rotations, opacities, colors, radii, geom, tile_state);
+  if (rc) return rc;
+  rc = lr_check_stage2_args(v, n, tile_state, keys, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
+                            point_weight_pixel, point_weight, bwd_scratch, bwd_scratch_floats);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  uint32_t tiles = (uint32_t)(v.gx * v.gy);
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
-  if (bwd_scratch_floats < 0 || bwd_scratch_floats > 16 || (bwd_scratch_floats > 0 && n > 0 && !bwd_scratch))
-    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch: 0..16 floats per Gaussian and a non-NULL block");
-  // point_weight (atomicMax target) and the optional backward scratch are cleared by the fill kernel
-  lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, v.extras ? point_weight : nullptr,
-                 bwd_scratch_floats > 0 ? bwd_scratch : nullptr, bwd_scratch_floats, s);
-  lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
-  lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
-                      point_weight_pixel, point_weight, s);
+  rc = lr_stage1(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st, s);
+  if (rc) return rc;
+  rc = lr_stage2(v, n, geom, st, keys, point_list, capacity, max_tile_len, image, final_t, n_contrib, point_id_pixel,
+                 point_weight_pixel, point_weight, bwd_scratch, bwd_scratch_floats, status, s);
+  if (rc) return rc;
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
@@ -334,6 +422,9 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   if (!means3d || !scales || !rotations || !radii || !geom || !tile_state || !final_t || !n_contrib || !dl_dimage ||
       !dl_dmeans2d || !dl_dconic || !dl_dopacities || !dl_dcolors || !dl_dmeans3d || !dl_dscales || !dl_drotations)
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(dl_dconic) | reinterpret_cast<uintptr_t>(rotations) |
+       reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   const uint32_t* st = reinterpret_cast<const uint32_t*>(tile_state);
@@ -368,6 +459,9 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
   if (!means3d || !scales || !rotations || !radii || !dl_dmeans2d || !dl_dconic || !dl_dmeans3d || !dl_dscales ||
       !dl_drotations)
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(dl_dconic) | reinterpret_cast<uintptr_t>(rotations) |
+       reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
                         dl_drotations, false, (hipStream_t)stream);
   LR_HIP(hipGetLastError());

@@ -99,7 +99,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw, int xcd_mode,
                     int cull) {
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -284,7 +284,7 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
                     float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
                     int xcd_mode, int cull) {
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);

@@ -66,6 +66,7 @@ __host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batche
 #define LR_HUGE_CHUNK 512  // Gaussians per workgroup of lr_count_huge_kernel (2048: a chunk full of 81-tile rects ran 0.36 ms)
 #define LR_BATCH_THREADS 1024
 #define LR_BATCH_MAX_TILES 40000  // 4 B x tiles of LDS counters must fit one workgroup (160 KB): up to 3840x2160
+#define LR_BATCH_LDS_BYTES (160 * 1024 - 512)  // dynamic LDS a projection workgroup may use (counter planes)
 
 // Device-side view (kernel argument, by value).
 struct LrView {
@@ -312,6 +313,12 @@ LR_DEV bool lr_support_box(const LrSupport& s, float x0, float x1, float y0, flo
 LR_DEV bool lr_support_tile(const LrSupport& s, int tx, int ty) {
   const float x0 = (float)(tx * LR_TILE), y0 = (float)(ty * LR_TILE);
   return lr_support_box(s, x0, x0 + (float)(LR_TILE - 1), y0, y0 + (float)(LR_TILE - 1));
+}
+
+// Every kernel behind the fill checks this first: nothing is sorted or composited when the caller's buffers were too
+// small (capacity) or its longest-list hint too low (the fill kernel raises LR_HDR_OVERFLOW for both).
+LR_DEV bool lr_bail(const uint32_t* __restrict__ state, uint32_t capacity) {
+  return state[LR_HDR_NUM] > capacity || state[LR_HDR_OVERFLOW] != 0u;
 }
 
 // ---- wave64 helpers ------------------------------------------------------------------------------

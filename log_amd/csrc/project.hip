@@ -217,31 +217,36 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
   lr_commit_rect_count<4>(rect_instances, hdr);
 }
 
-// Batched kernel (tile grids whose counters fit in LDS): workgroup b owns Gaussians [b*B, (b+1)*B).  Its instances
+// Batched kernel (tile grids whose counters fit in LDS): batch b owns Gaussians [b*B, (b+1)*B).  Its instances
 // are counted and ranked in LDS counters (integer LDS atomics run at ~4 T/s chip-wide, memory-side atomics at
-// 0.025 T/s); afterwards ONE memory-side atomic per non-empty (batch, tile) reserves the batch's range of slots
-// in that tile, and its start goes to basetab[b][tile].  An instance's slot is basetab[batch][tile] + its rank
-// inside the batch (stored in q3 as before) -- the fill kernel adds the two.  With B >> tiles / (instances per
-// Gaussian) the memory-side atomics shrink by the average number of instances a batch puts into a tile.
+// 0.025 T/s); afterwards ONE memory-side atomic per non-empty tile reserves a range of slots in that tile, and the
+// batch's start inside it goes to basetab[b][tile].  An instance's slot is basetab[batch][tile] + its rank inside the
+// batch (kept in the fill record) -- the fill kernel adds the two.  With B >> tiles / (instances per Gaussian) the
+// memory-side atomics shrink by the average number of instances a batch puts into a tile.
+// A workgroup owns S CONSECUTIVE batches (one plane of LDS counters each, S <= 4: 4 x 8160 words at 1080p) and reserves
+// for all of them with one atomic per tile, so their S runs are adjacent in the tile's list: at 30 M Gaussians a
+// (batch, tile) run is ~19 keys = 152 B, which the fill kernel's scattered 8-byte stores left as partial lines
+// (0.89 GB of write traffic for 0.35 GB of keys); four adjacent runs are 608 B, written by neighbouring workgroups of
+// one XCD within microseconds of each other.  It also divides the reservation atomics by S.
 // 82 VGPRs: one 1024-thread workgroup per CU.  Forcing two (amdgpu_waves_per_eu(8): 64 VGPRs, 19 spilled) is slower
 // at every size (1 M: 62 -> 81 us, 30 M: 1.06 -> 1.68 ms).
+#define LR_MAX_PLANES 4
 __global__ void __launch_bounds__(LR_BATCH_THREADS)
 lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                           const float* __restrict__ rots, const float* __restrict__ opac,
                           const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                           uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
                           uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugecount, int tile_cull, int B,
-                          int defer_tiles) {
-  extern __shared__ uint32_t lr_lds_ctr[];  // [tiles] packed (ranked | big << 16) counts
-  __shared__ uint32_t lr_huge_cnt;
+                          int S, int defer_tiles) {
+  extern __shared__ uint32_t lr_lds_ctr[];  // [S][tiles] packed (ranked | big << 16) counts, one plane per batch
+  __shared__ uint32_t lr_huge_cnt[LR_MAX_PLANES];
   const int tiles = v.gx * v.gy;
-  for (int t = threadIdx.x; t < tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
-  if (threadIdx.x == 0) lr_huge_cnt = 0u;
+  for (int t = threadIdx.x; t < S * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
+  if (threadIdx.x < LR_MAX_PLANES) lr_huge_cnt[threadIdx.x] = 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
   __syncthreads();
-  const LrLdsCounters ctr{lr_lds_ctr};
   uint32_t rect_instances = 0;
-  const int i_begin = blockIdx.x * B, i_end = min(N, i_begin + B);
+  const int i_begin = blockIdx.x * (S * B), i_end = min(N, i_begin + S * B);
   // software pipeline: the next Gaussian's inputs are requested before the current one is projected (a workgroup
   // is 16 waves on one CU, so there is little other work to hide the loads behind)
   int i = i_begin + (int)threadIdx.x;
@@ -250,11 +255,13 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   for (; i < i_end; i += LR_BATCH_THREADS) {
     const LrInputs in = nxt;
     if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors);
+    const int plane = (i - i_begin) / B;                    // B is a multiple of the workgroup size: uniform per iteration
+    const LrLdsCounters ctr{lr_lds_ctr + plane * tiles};
     float4 g0, g1, g2, g3;
     int rad;
     bool huge;
     lr_project_one<true>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
-    if (huge) atomicAdd(&lr_huge_cnt, 1u);
+    if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
     radii[i] = rad;
     float4* rec = geom + LR_REC_QUADS * (size_t)i;
     rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;     // q3 is not read in this mode: written to complete the 64-byte line
@@ -281,24 +288,30 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   }
   __syncthreads();
   // reservations: eight tiles per thread per round, all eight returning atomics in flight before the first result
-  // is stored (one memory round trip per round, not eight)
-  uint32_t* const mybase = basetab + (size_t)blockIdx.x * tiles;
+  // is stored (one memory round trip per round, not eight); one atomic covers the workgroup's S batches
+  const int nplanes = min(S, (i_end - i_begin + B - 1) / B);   // batches this workgroup really holds
+  uint32_t* const mybase = basetab + (size_t)blockIdx.x * S * tiles;
   for (int t0 = threadIdx.x; t0 < tiles; t0 += 8 * LR_BATCH_THREADS) {
     uint32_t base[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int t = t0 + u * LR_BATCH_THREADS;
-      const uint32_t packed = t < tiles ? lr_lds_ctr[t] : 0u, c = packed & 0xffffu, cb = packed >> 16;
+      uint32_t c = 0u, cb = 0u;
+      if (t < tiles)
+        for (int pl = 0; pl < nplanes; pl++) { const uint32_t packed = lr_lds_ctr[pl * tiles + t]; c += packed & 0xffffu; cb += packed >> 16; }
       base[u] = c ? atomicAdd(&ranked[t], c) : 0u;          // dense counters: see lr_scan_kernel
       if (cb) atomicAdd(&big[t], cb);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int t = t0 + u * LR_BATCH_THREADS;
-      if (t < tiles) mybase[t] = base[u];
+      if (t < tiles) {
+        uint32_t run = base[u];
+        for (int pl = 0; pl < nplanes; pl++) { mybase[(size_t)pl * tiles + t] = run; run += lr_lds_ctr[pl * tiles + t] & 0xffffu; }
+      }
     }
   }
-  if (threadIdx.x == 0) hugecount[blockIdx.x] = lr_huge_cnt;   // complete: the barrier after the Gaussian loop
+  if ((int)threadIdx.x < nplanes) hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];   // complete: the barrier after the Gaussian loop
   lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
 }
 
@@ -362,7 +375,8 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
-                       uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int tile_cull, hipStream_t s) {
+                       uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int planes, int tile_cull,
+                       hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_PROJECT, s);
   if (batch > 0) {
@@ -371,18 +385,19 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 128);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_count_huge_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 128);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
       attr_set = true;
     }
     static const int defer_tiles = lr_env_int("LOGRAST_DEFER_TILES", LR_COOP_TILES);
     static const int chunk = lr_env_int("LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK) / 256 * 256;
     const int batches = (N + batch - 1) / batch;
+    const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
     uint32_t* hugecount = basetab + (size_t)batches * tiles;
-    hipLaunchKernelGGL(lr_project_batched_kernel, dim3(batches), dim3(LR_BATCH_THREADS), lds, s, v, N,
+    hipLaunchKernelGGL(lr_project_batched_kernel, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                        means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                       basetab, hugecount, tile_cull, batch, defer_tiles);
+                       basetab, hugecount, tile_cull, batch, planes, defer_tiles);
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
     hipLaunchKernelGGL(lr_count_huge_kernel, dim3((N + chunk - 1) / chunk), dim3(256), lds, s, N, v.gx,
@@ -540,8 +555,8 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_o
 // readlane) so that a single screen-filling Gaussian does not serialise its wave.
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
-               uint64_t* __restrict__ keys, uint32_t capacity, float* __restrict__ zero_n,
-               float* __restrict__ zero_block, int zero_block_floats, int xcd_order) {
+               uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
+               float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order, int stream_nt) {
   // Per-Gaussian buffers that later kernels accumulate into with atomics (point_weight; the backward scratch)
   // are cleared here, in a kernel that already has one thread per Gaussian, instead of by separate memsets.
   // XCD-contiguous block order (speed only): blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
@@ -553,18 +568,41 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   const uint32_t per_xcd = gridDim.x >> 3;                       // grid is a multiple of 8
   const uint32_t vblock = xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   {
+    // (streaming stores: non-temporal, so that they do not push the partially written key lines of this kernel out
+    // of the XCD's L2 before their neighbours arrive)
     const int zi = (int)(vblock * 256u + threadIdx.x);
     if (zi < N) {
-      if (zero_n) zero_n[zi] = 0.f;
-      for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + zi] = 0.f;
+      if (stream_nt) {
+        if (zero_n) __builtin_nontemporal_store(0.f, &zero_n[zi]);
+        for (int k = 0; k < zero_block_floats; k++) __builtin_nontemporal_store(0.f, &zero_block[(size_t)k * N + zi]);
+      } else {
+        if (zero_n) zero_n[zi] = 0.f;
+        for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + zi] = 0.f;
+      }
     }
   }
   const bool tile_cull = state[LR_HDR_CULL] != 0u;
-  uint32_t total = state[LR_HDR_NUM];
-  if (total > capacity) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) state[LR_HDR_OVERFLOW] = 1u;
-    return;
+  // The caller's buffers hold `capacity` instances and it launched the sort levels for lists of up to `max_len_hint`
+  // keys (0 = no hint: the levels for `capacity`): if either is exceeded nothing may be sorted or composited.  Every
+  // workgroup reaches the same verdict from the scan's header; the flag makes the later kernels return at once
+  // (lr_bail), and the caller's status block (optional, include/lograst.h: LOGRAST_STATUS_*) records this forward and
+  // the running maxima / sticky overflow bit across forwards.
+  const uint32_t total = state[LR_HDR_NUM], maxlen = state[LR_HDR_MAXLEN];
+  const bool over = total > capacity || (max_len_hint != 0u && maxlen > max_len_hint);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (over) state[LR_HDR_OVERFLOW] = 1u;
+    if (status) {
+      status[LOGRAST_STATUS_LAST_INSTANCES] = total;
+      status[LOGRAST_STATUS_LAST_OVERFLOW] = over ? 1u : 0u;
+      status[LOGRAST_STATUS_LAST_MAX_LEN] = maxlen;
+      status[LOGRAST_STATUS_LAST_RECT] = state[LR_HDR_RECT];
+      atomicMax(&status[LOGRAST_STATUS_MAX_INSTANCES], total);
+      atomicMax(&status[LOGRAST_STATUS_MAX_MAX_LEN], maxlen);
+      atomicAdd(&status[LOGRAST_STATUS_FORWARDS], 1u);
+      if (over) atomicOr(&status[LOGRAST_STATUS_OVERFLOW], 1u);
+    }
   }
+  if (over) return;
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   int i = (int)(vblock * 256u + threadIdx.x);
@@ -579,7 +617,15 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   uint32_t slot[LR_RANKED_TILES] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   if (vis && batch) {
     // batched projection: the 16-byte fill record (see lr_project_batched_kernel)
-    const uint4 fr = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N)[i];
+    const uint4* frp = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N) + i;
+    uint4 fr;
+    if (stream_nt) {
+      typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
+      const lr_u4v t4 = __builtin_nontemporal_load(reinterpret_cast<const lr_u4v*>(frp));
+      fr = uint4{t4.x, t4.y, t4.z, t4.w};
+    } else {
+      fr = *frp;
+    }
     dbits = fr.x;
     if (fr.y != 0xffffffffu) {
       x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
@@ -657,13 +703,15 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 }
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
-                    uint32_t capacity, float* zero_n, float* zero_block, int zero_block_floats, hipStream_t s) {
+                    uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
+                    int zero_block_floats, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   static const int xcd_order = lr_env_int("LOGRAST_FILL_XCD_ORDER", 1);
+  static const int fill_nt = lr_env_int("LOGRAST_FILL_NT", 1);
   const int blocks = ((N + 255) / 256 + 7) & ~7;
   hipLaunchKernelGGL(lr_fill_kernel, dim3(blocks), dim3(256), 0, s, N, gx,
-                     reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, zero_n, zero_block,
-                     zero_block_floats, xcd_order);
+                     reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, max_len_hint, status, zero_n,
+                     zero_block, zero_block_floats, xcd_order, fill_nt);
   lr_prof_end(LRK_FILL, s);
 }

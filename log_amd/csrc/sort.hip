@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(NT)
 lr_sort_rb_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                   uint32_t* __restrict__ plist, uint32_t lo, uint32_t hi, uint32_t capacity) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t tile = blockIdx.x;
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg;
@@ -139,10 +139,18 @@ lr_sort_rb_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint
 #define LR_BUCKET_MAX 32
 // Final order inside buckets, one thread per BUCKET: consecutive threads read consecutive LDS addresses (every key
 // once, no bank conflicts -- ranking every key against its bucket read each key ~6 times from random banks and was
-// LDS-bandwidth bound), sort up to 8 keys in registers with the network's 8-key kernel, and write the ids in order.
-// Larger buckets (rare: the mean is 2-5 keys) are ranked by the same thread key by key.
-LR_DEV void lr_emit_bucket(const uint64_t* __restrict__ bk, uint32_t st, uint32_t en, uint32_t* __restrict__ out) {
-  const uint32_t n = en - st;   // bk[] and out[] are indexed by list position
+// LDS-bandwidth bound), sort up to 8 keys in registers with the network's 8-key kernel (eight independent LDS loads:
+// one round trip), and write the ids in order.
+// Buckets of 9..LR_BUCKET_MAX keys (a few per cent at the usual mean of 2-5 keys, so nearly every wave meets one) are
+// ranked by the WHOLE WAVE, one bucket at a time: lane l loads key l of the bucket (one round trip), every lane counts
+// the smaller keys through readlane broadcasts (no further LDS access), and writes its id.  What this replaces -- the
+// owning thread ranking the bucket key by key, n^2 DEPENDENT LDS reads at ~150 ns each under load -- cost 20-30 us per
+// 12 K-key window (wall_clock64 per phase), i.e. most of the long-list sort; one thread per KEY, each counting the
+// smaller keys of its own bucket (~20 dependent round trips per key), measured 37 us.
+// Call with the whole wave converged; `valid` = this lane owns a bucket.  bk[] and out[] are indexed by list position.
+LR_DEV void lr_emit_bucket(const uint64_t* __restrict__ bk, uint32_t st, uint32_t en, bool valid,
+                           uint32_t* __restrict__ out) {
+  const uint32_t n = valid ? en - st : 0u;
   if (n <= 8u) {
     uint64_t r[8];
 #pragma unroll
@@ -151,13 +159,22 @@ LR_DEV void lr_emit_bucket(const uint64_t* __restrict__ bk, uint32_t st, uint32_
 #pragma unroll
     for (int m = 0; m < 8; m++)
       if ((uint32_t)m < n) out[st + m] = (uint32_t)r[m];
-  } else {
-    for (uint32_t a = st; a < en; a++) {
-      const uint64_t key = bk[a];
-      uint32_t smaller = 0;
-      for (uint32_t j = st; j < en; j++) smaller += bk[j] < key ? 1u : 0u;
-      out[st + smaller] = (uint32_t)key;
+  }
+  uint64_t big = __ballot(n > 8u);
+  const uint32_t lane = threadIdx.x & 63u;
+  while (big) {
+    const int src = __builtin_ctzll(big);
+    big &= big - 1;
+    const uint32_t bst = (uint32_t)lr_readlane_i((int)st, src);
+    const uint32_t bn = min((uint32_t)lr_readlane_i((int)n, src), 64u);   // <= LR_BUCKET_MAX by the callers' check
+    const uint64_t key = lane < bn ? bk[bst + lane] : ~0ull;
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    uint32_t smaller = 0;
+    for (uint32_t j = 0; j < bn; j++) {
+      const uint64_t kj = ((uint64_t)(uint32_t)lr_readlane_i((int)khi, (int)j) << 32) | (uint32_t)lr_readlane_i((int)klo, (int)j);
+      smaller += kj < key ? 1u : 0u;
     }
+    if (lane < bn) out[bst + smaller] = klo;
   }
 }
 // LONG = false: blockIdx.x is the tile; the keys are also staged in network layout so that the workgroup can fall
@@ -173,7 +190,7 @@ lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64
   uint64_t* const Bk = LONG ? s : s + (CAP + (CAP >> 3));
   uint32_t* const cnt = reinterpret_cast<uint32_t*>(Bk + CAP);
   __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[NT / 64];
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   if (LONG && blockIdx.x >= state[LR_HDR_NBIG]) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   // lo > 0: blockIdx.x walks the longest-first dispatch order, so a grid of capacity / lo workgroups reaches every tile
@@ -282,6 +299,10 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
 //           into the window (known from its code: 4 B re-read per key and window, cache-resident) is fetched and
 //           dropped into an LDS copy of that window, ranked inside its bucket there, and its id written to its final
 //           list position.
+// (Measured alternative, removed: one 1024-thread workgroup per tile holding the depth bits of all its keys in VGPRs --
+// 24 per thread, keys read from memory once -- needs all 128 VGPRs, i.e. ONE workgroup per CU, and every phase of this
+// sort is a short chain of LDS round trips at ~150 ns each: 60 us per 20 K-key tile against 2 x 57 us here with two
+// workgroups per CU overlapping, the same 0.66 ms per 30 M-Gaussian view.)
 // Nothing is scattered through memory except the final ids inside one window at a time (an earlier version scattered
 // the keys into a bucket-ordered scratch copy: 8-byte stores all over a 160 KB region from 512 concurrent workgroups
 // cost more HBM traffic than the whole network sort).  O(L) work instead of n log^2 n; a tile whose depths are too
@@ -295,9 +316,9 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
   uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
   __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[16];
-  if (state[LR_HDR_NUM] > capacity || blockIdx.x >= state[LR_HDR_NBIG]) return;
+  if (lr_bail(state, capacity) || blockIdx.x >= state[LR_HDR_NBIG]) return;
   const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
-  if (entry & LR_LONG_DONE) return;                        // (LR_LONG_LIST, LR_SORT_BLOCK]: done in LDS
+  if (entry & LR_LONG_DONE) return;                        // done in LDS / registers by an earlier launch
   const uint32_t tile = entry;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg, tid = threadIdx.x;
@@ -393,8 +414,11 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
       }
     }
     __syncthreads();
-    for (uint32_t b = b0 + tid; b < b1; b += 1024)
-      lr_emit_bucket(win - w0, lcnt[b], (b + 1u < nb) ? lcnt[b + 1u] : L, pl);   // win[] holds positions [w0, w1)
+    for (uint32_t bb = b0; bb < b1; bb += 1024u) {           // (uniform trip count: the emit needs whole waves)
+      const uint32_t b = bb + tid;
+      const bool valid = b < b1;
+      lr_emit_bucket(win - w0, valid ? lcnt[b] : 0u, valid ? ((b + 1u < nb) ? lcnt[b + 1u] : L) : 0u, valid, pl);   // win[] holds positions [w0, w1)
+    }
     __syncthreads();
     b0 = b1;
   }
@@ -411,7 +435,7 @@ __global__ void __launch_bounds__(256)
 lr_sort_long_fallback_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                              uint32_t* __restrict__ plist, uint32_t capacity) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t nbig = state[LR_HDR_NBIG];
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
@@ -463,7 +487,7 @@ __global__ void __launch_bounds__(NT)
 lr_bigsort_blocks_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
                          uint32_t capacity) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t nbig = state[LR_HDR_NBIG];
   for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
     const LrBigTile t = lr_big_tile(state, tiles, e);
@@ -485,7 +509,7 @@ lr_bigsort_blocks_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uin
 __global__ void __launch_bounds__(256)
 lr_bigsort_global_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
                          uint32_t capacity, uint32_t k, uint32_t j) {
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t nbig = state[LR_HDR_NBIG];
   for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
     const LrBigTile t = lr_big_tile(state, tiles, e);
@@ -515,7 +539,7 @@ __global__ void __launch_bounds__(NT)
 lr_bigsort_tail_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
                        uint32_t capacity, uint32_t k) {
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t nbig = state[LR_HDR_NBIG];
   for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
     const LrBigTile t = lr_big_tile(state, tiles, e);
@@ -534,7 +558,7 @@ lr_bigsort_tail_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint6
 __global__ void __launch_bounds__(256)
 lr_bigsort_emit_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                        uint32_t* __restrict__ plist, uint32_t capacity) {
-  if (state[LR_HDR_NUM] > capacity) return;
+  if (lr_bail(state, capacity)) return;
   const uint32_t nbig = state[LR_HDR_NBIG];
   for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
     const LrBigTile t = lr_big_tile(state, tiles, e);

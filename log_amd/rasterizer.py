@@ -56,26 +56,64 @@ WODILATE = Flavour("diff_gaussian_rasterization_wodilate", _lib.FILTER_CLAMP, 1,
 # ---- instance-capacity policy ----------------------------------------------------------------------
 # Default (None): exact -- stage 1 reports the number of tile instances to the host (one 4-byte
 # read-back, as the third-party package does for `num_rendered`) and the buffers are sized exactly.
-# With a hint, no host synchronisation happens in forward(); the kernels refuse to write past the
-# capacity and raise the overflow flag, which `last_overflow()` / bench.py check afterwards.
+# With a hint, no host synchronisation happens in forward() (one C-ABI call per forward); the kernels refuse to
+# write past the capacity, or to sort a list longer than the max_tile_len hint, and record the overflow in the
+# process's status block (include/lograst.h: LOGRAST_STATUS_*), which `overflow_since_reset()` / bench.py read.
 _capacity_hint = None
 _max_len_hint = 0
-_last_state = None
+_status = {}          # device -> int32[8] status block (sticky across forwards, all streams)
+_debug_keep = False   # tests: keep dL/dconic of the last backward (HipBackend.last_conic_grad)
 
 
 def set_instance_capacity(n, max_tile_len=0):
     """n = int: sync-free forward with room for n tile instances; None: exact sizing (default).
     max_tile_len: upper bound on the longest per-tile list in sync-free mode (0 = unknown: the sort then launches
-    every multi-block level the capacity allows; only lists longer than 8192 entries care)."""
+    every multi-block level the capacity allows; only lists longer than 8192 entries care).  A forward whose real
+    numbers exceed either renders nothing and raises the overflow bit of the status block."""
     global _capacity_hint, _max_len_hint
     _capacity_hint = None if n is None else int(n)
     _max_len_hint = int(max_tile_len) if n is not None else 0
 
 
-def last_overflow():
-    """(num_instances, overflowed) of the most recent forward on this process (synchronises)."""
-    n, o = last_state_info()[:2]
+def _status_block(device):
+    st = _status.get(device)
+    if st is None:
+        st = torch.zeros(8, dtype=torch.int32, device=device)
+        _status[device] = st
+    return st
+
+
+def _current_device():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def last_state_info(device=None):
+    """(num_instances, overflowed, longest_tile_list, rect_instances) of the most recent forward on `device`
+    (synchronises).  rect_instances = instances of the reference's plain rect rule (>= num_instances when the
+    support cull is on)."""
+    st = _status.get(device if device is not None else _current_device())
+    if st is None:
+        return 0, False, 0, 0
+    w = st.cpu().tolist()
+    return int(w[1]), bool(w[2]), int(w[3]), int(w[4])
+
+
+def last_overflow(device=None):
+    """(num_instances, overflowed) of the most recent forward (synchronises)."""
+    n, o = last_state_info(device)[:2]
     return n, o
+
+
+def overflow_since_reset(device=None, reset=True):
+    """dict(overflowed, max_instances, max_tile_len, forwards) over EVERY forward on `device` (all streams) since the
+    last reset -- what a caller of the sync-free mode checks after a batch of views (synchronises)."""
+    st = _status.get(device if device is not None else _current_device())
+    if st is None:
+        return dict(overflowed=False, max_instances=0, max_tile_len=0, forwards=0)
+    w = st.cpu().tolist()
+    if reset:
+        st.zero_()
+    return dict(overflowed=bool(w[0]), max_instances=int(w[5]), max_tile_len=int(w[6]), forwards=int(w[7]))
 
 
 def set_tile_cull(enabled):
@@ -83,17 +121,6 @@ def set_tile_cull(enabled):
     alpha >= 1/255 are not binned.  Result-preserving; off = the reference's exact rect lists.  Returns the
     previous setting."""
     return bool(_lib.lib().lograst_set_tile_cull(1 if enabled else 0))
-
-
-def last_state_info():
-    """(num_instances, overflowed, longest_tile_list, rect_instances) of the most recent forward (synchronises).
-    rect_instances = instances of the reference's plain rect rule (>= num_instances when the support cull is on)."""
-    if _last_state is None:
-        return 0, False, 0, 0
-    n, o, m, r = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
-    _lib.check(_lib.lib().lograst_read_state(_last_state.data_ptr(), ctypes.byref(n), ctypes.byref(o),
-                                             ctypes.byref(m), ctypes.byref(r), _stream_ptr(_last_state.device)))
-    return int(n.value), bool(o.value), int(m.value), int(r.value)
 
 
 def _stream_ptr(device):
@@ -112,6 +139,7 @@ def _dev_f32(t, device):
 # n floats apart puts all streams on the same HBM channels (measured: the activation backward 0.12 -> 0.17 ms for
 # n = 1 M).  Each block is followed by this many floats (4352 B: keeps 16-byte alignment, breaks the stride).
 _BLOCK_SKEW = 1088
+_ITEMSIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8}
 
 
 class _TileRows:
@@ -174,54 +202,71 @@ class HipBackend:
         v.tile_row_begin, v.tile_row_end = _tile_rows.get()
         return v, keep
 
+    @staticmethod
+    def _carve(device, parts):
+        """One allocation for several buffers: parts = [(name, dtype, shape)], every buffer 256-byte aligned inside it
+        (one caching-allocator call instead of one per buffer: the host side of a forward is mostly such calls)."""
+        spans, total = [], 0
+        for _, dt, shape in parts:
+            n = _ITEMSIZE[dt]
+            for d in shape:
+                n *= int(d)
+            spans.append((total, n))
+            total += (n + 255) // 256 * 256
+        arena = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
+        return {name: arena[off:off + n].view(dt).view(shape) for (name, dt, shape), (off, n) in zip(parts, spans)}
+
     def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0):
         """scratch_floats: 0, or the fp32 words per Gaussian of backward scratch to allocate and have the forward
         zero-fill (7 with a gradient sink, 11 without): saved as `bwd_scratch` and consumed by the first backward."""
-        global _last_state
         device = means3D.device
         L = self.require(device)
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
         view, keep = self.make_view(rs, flavour, use_filter, device)
         stream = _stream_ptr(device)
-        i32 = dict(dtype=torch.int32, device=device)
-        f32 = dict(dtype=torch.float32, device=device)
-        radii = torch.empty(N, **i32)
-        geom = torch.empty(L.lograst_geom_bytes(N) // 4, **f32)
-        state = torch.empty(L.lograst_tile_state_bytes(W, H, N) // 4, **i32)
+        status = _status_block(device)
+        i32, f32, u8 = torch.int32, torch.float32, torch.uint8
+        # what the caller gets (image, radii, the fork's maps) / what backward needs / what dies with this call
+        outs = [("image", f32, (3, H, W)), ("radii", i32, (N,))]
+        if flavour.extras:
+            outs += [("pid", i32, (H, W)), ("pwp", f32, (H, W)), ("pw", f32, (N,))]
+        o = self._carve(device, outs)
+        kept = [("geom", u8, (L.lograst_geom_bytes(N),)), ("state", u8, (L.lograst_tile_state_bytes(W, H, N),)),
+                ("final_T", f32, (H, W)), ("n_contrib", i32, (H, W))]
+        if scratch_floats and N:
+            kept.append(("bwd_scratch", f32, (N * scratch_floats,)))
         with torch.cuda.device(device):
             if _capacity_hint is None:
+                k = self._carve(device, kept)
                 n_host, m_host = ctypes.c_uint32(0), ctypes.c_uint32(0)
                 _lib.check(L.lograst_forward_project(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
-                                                     _ptr(opacities), _ptr(colors), _ptr(radii), _ptr(geom),
-                                                     _ptr(state), ctypes.byref(n_host), ctypes.byref(m_host), stream))
+                                                     _ptr(opacities), _ptr(colors), _ptr(o["radii"]), _ptr(k["geom"]),
+                                                     _ptr(k["state"]), ctypes.byref(n_host), ctypes.byref(m_host), stream))
                 capacity, max_len = int(n_host.value), max(int(m_host.value), 1)
+                plist = torch.empty(capacity, dtype=i32, device=device)
+                keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                _lib.check(L.lograst_forward_render(
+                    ctypes.byref(view), N, _ptr(k["geom"]), _ptr(k["state"]), _ptr(keys), _ptr(plist), capacity, max_len,
+                    _ptr(o["image"]), _ptr(k["final_T"]), _ptr(k["n_contrib"]), _ptr(o.get("pid")), _ptr(o.get("pwp")),
+                    _ptr(o.get("pw")), _ptr(k.get("bwd_scratch")), scratch_floats if "bwd_scratch" in k else 0,
+                    _ptr(status), stream))
             else:
-                _lib.check(L.lograst_forward_project(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
-                                                     _ptr(opacities), _ptr(colors), _ptr(radii), _ptr(geom),
-                                                     _ptr(state), None, None, stream))
                 capacity, max_len = _capacity_hint, _max_len_hint
-            keys = torch.empty(L.lograst_keys_bytes(capacity) // 8, dtype=torch.int64, device=device)
-            plist = torch.empty(capacity, **i32)
-            image = torch.empty(3, H, W, **f32)
-            final_T = torch.empty(H, W, **f32)
-            n_contrib = torch.empty(H, W, **i32)
-            if flavour.extras:
-                pid = torch.empty(H, W, **i32)
-                pwp = torch.empty(H, W, **f32)
-                pw = torch.empty(N, **f32)
-            else:
-                pid = pwp = pw = None
-            scratch = torch.empty(N * scratch_floats, **f32) if scratch_floats and N else None
-            _lib.check(L.lograst_forward_render(ctypes.byref(view), N, _ptr(geom), _ptr(state), _ptr(keys), _ptr(plist),
-                                                capacity, max_len, _ptr(image), _ptr(final_T), _ptr(n_contrib), _ptr(pid),
-                                                _ptr(pwp), _ptr(pw), _ptr(scratch),
-                                                scratch_floats if scratch is not None else 0, stream))
+                k = self._carve(device, kept + [("plist", i32, (capacity,))])
+                plist = k["plist"]
+                keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                _lib.check(L.lograst_forward(
+                    ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(colors),
+                    _ptr(o["radii"]), _ptr(k["geom"]), _ptr(k["state"]), _ptr(keys), _ptr(plist), capacity, max_len,
+                    _ptr(o["image"]), _ptr(k["final_T"]), _ptr(k["n_contrib"]), _ptr(o.get("pid")), _ptr(o.get("pwp")),
+                    _ptr(o.get("pw")), _ptr(k.get("bwd_scratch")), scratch_floats if "bwd_scratch" in k else 0,
+                    _ptr(status), stream))
         del keys, keep
-        _last_state = state
-        saved = dict(radii=radii, geom=geom, state=state, plist=plist, final_T=final_T, n_contrib=n_contrib,
-                     bwd_scratch=scratch)
-        return image, radii, pid, pwp, pw, saved
+        saved = dict(radii=o["radii"], geom=k["geom"].view(f32), state=k["state"].view(i32), plist=plist,
+                     final_T=k["final_T"], n_contrib=k["n_contrib"], bwd_scratch=k.get("bwd_scratch"),
+                     tile_rows=(view.tile_row_begin, view.tile_row_end))
+        return o["image"], o["radii"], o.get("pid"), o.get("pwp"), o.get("pw"), saved
 
     def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None):
         """sink: optional dict of running-sum tensors (means3D, scales, rotations, opacities, colors) that this call
@@ -230,25 +275,29 @@ class HipBackend:
         L = self.require(device)
         N = means3D.shape[0]
         view, keep = self.make_view(rs, flavour, use_filter, device)
+        view.tile_row_begin, view.tile_row_end = saved.get("tile_rows", (0, 0))   # the band the forward rendered
         f32 = dict(dtype=torch.float32, device=device)
         grad_image = grad_image.to(torch.float32).contiguous()
         need = 11 if sink is None else 7
         # The accumulators the reverse walk adds into come from ONE zeroed block: the one the forward already
-        # cleared for this purpose (first backward of this forward), else a fresh torch.zeros.
+        # cleared for this purpose (first backward of this forward), else a fresh torch.zeros.  Layout: the 16-byte
+        # rows first (dL/dconic [N,4], read as one access per Gaussian), then dL/dmeans2D [N,3] (, opacity, colours).
         acc = saved.pop("bwd_scratch", None)
         if acc is None or acc.numel() < need * N:
             acc = torch.zeros(N * need, **f32)
+        g_conic = acc[:4 * N].view(N, 4)
+        g_means2D = acc[4 * N:7 * N].view(N, 3)
         if sink is None:
             g_opac = acc[7 * N:8 * N]
             g_colors = acc[8 * N:11 * N].view(N, 3)
-            g_means3D, g_scales, g_rot = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 4, **f32)
+            g = self._carve(device, [("rot", torch.float32, (N, 4)), ("means3D", torch.float32, (N, 3)),
+                                     ("scales", torch.float32, (N, 3))])
+            g_means3D, g_scales, g_rot = g["means3D"], g["scales"], g["rot"]
             flags = 1
         else:
             g_opac, g_colors = sink["opacities"], sink["colors"]
             g_means3D, g_scales, g_rot = sink["means3D"], sink["scales"], sink["rotations"]
             flags = 1 | 2
-        g_means2D = acc[:3 * N].view(N, 3)
-        g_conic = acc[3 * N:7 * N].view(N, 4)
         with torch.cuda.device(device):
             _lib.check(L.lograst_backward(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
                                           _ptr(saved["radii"]), _ptr(saved["geom"]), _ptr(saved["state"]),
@@ -257,7 +306,7 @@ class HipBackend:
                                           _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot),
                                           flags, _stream_ptr(device)))
         del keep
-        self.last_conic_grad = g_conic  # test/debug introspection only
+        self.last_conic_grad = g_conic if _debug_keep else None   # test introspection only (pins the whole block)
         if sink is not None:
             return None, g_means2D, None, None, None, None
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
@@ -389,6 +438,8 @@ class HipBackend:
             raise ValueError("viewspace gradient must be [nv, 3]")
         r = radii.detach().to(torch.int32).contiguous()
         w = _dev_f32(point_weight, device).reshape(-1)
+        if int(r.numel()) != nv or int(w.numel()) != nv:
+            raise ValueError("radii and point_weight must have one entry per visible_index row")
         pid = point_id.detach().to(device=device, dtype=torch.int32).contiguous()
         pc = point_count.detach().to(device=device, dtype=torch.int64).contiguous()
         flag = torch.empty(nv, dtype=torch.uint8, device=device)
@@ -488,15 +539,6 @@ class HipBackend:
 
 
 _backend = HipBackend()
-
-
-def _set_backend_for_tests(backend):
-    """TEST HOOK.  tests/ install a CPU double here to drive LoG's unmodified Python on machines without a
-    GPU (plumbing only).  Nothing in the product path calls this; the default is always HipBackend."""
-    global _backend
-    old = _backend
-    _backend = backend if backend is not None else HipBackend()
-    return old
 
 
 # ---- multi-view gradient accumulation (new design, SURVEY 8e; not part of the reference's API) ---------------

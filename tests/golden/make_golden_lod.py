@@ -29,13 +29,14 @@ def reference_env():
     """Stubs for host-only deps + the LoG.cuda drop-in backed by the oracle (CPU)."""
     from log_amd import rasterizer as R
     from log_amd.compute_radius import compute_radius_module
+    import oracle_backend
     from oracle_backend import OracleBackend
     if "cv2" not in sys.modules:
         sys.modules["cv2"] = types.ModuleType("cv2")
     drop = types.ModuleType("LoG.cuda.compute_radius")
     drop.compute_radius_module = compute_radius_module
     sys.modules["LoG.cuda.compute_radius"] = drop
-    R._set_backend_for_tests(OracleBackend())
+    oracle_backend.install(OracleBackend())
 
 
 def build_case(seed, n_roots, n_levels, max_child, split_prob=0.7, remove_prob=0.04, extent=1.0):

@@ -8,6 +8,8 @@ import torch
 from log_amd import _lib, rasterizer as R
 from util import cam_tan
 
+R._debug_keep = True   # keep dL/dconic of the last backward for the comparisons below
+
 
 def settings(cam, bg, dev, scale_modifier=1.0):
     tfx, tfy = cam_tan(cam)

@@ -1,7 +1,7 @@
 """TEST DOUBLE: a CPU backend for log_amd.rasterizer built on the oracle, so that the reference's unmodified
 Python (LoG/render/renderer.py, LoG/model/*) can be driven end-to-end on a machine without a GPU
-(BASELINE config C1, "plumbing").  Installed only by tests through rasterizer._set_backend_for_tests; the
-product path never imports this file."""
+(BASELINE config C1, "plumbing").  Installed only by tests, through install() below (it swaps the module attribute
+log_amd.rasterizer._backend; the product module has no hook for this); the product path never imports this file."""
 import math
 
 import numpy as np
@@ -9,6 +9,14 @@ import torch
 
 from oracle import oracle
 from log_amd import _lib
+
+
+def install(backend):
+    """Swap log_amd.rasterizer's backend object (None = a fresh HipBackend); returns the previous one."""
+    from log_amd import rasterizer as R
+    old = R._backend
+    R._backend = backend if backend is not None else R.HipBackend()
+    return old
 
 
 class OracleBackend:

@@ -13,10 +13,11 @@ import getall_util as U
 @pytest.fixture()
 def double(oracle_mod):
     from log_amd import rasterizer as R
+    import oracle_backend
     from oracle_backend import OracleBackend
-    old = R._set_backend_for_tests(OracleBackend())
+    old = oracle_backend.install(OracleBackend())
     yield
-    R._set_backend_for_tests(None if isinstance(old, R.HipBackend) else old)
+    oracle_backend.install(None if isinstance(old, R.HipBackend) else old)
 
 
 @pytest.mark.parametrize("path", U.GOLDEN, ids=[os.path.basename(p) for p in U.GOLDEN])

@@ -101,15 +101,16 @@ def test_counter_on_rasterizer_outputs():
 @pytest.mark.parametrize("name", ["adam_a.npz", "adam_ams.npz"])
 def test_sparse_adam_matches_reference_optimizer_and_oracle(name, oracle_mod):
     from log_amd import sparse_optimizer, rasterizer as R
+    import oracle_backend
     from oracle_backend import OracleBackend
     g = U.load(name)
     model, opt = U.run_adam(g, DEV, sparse_optimizer.step)
     U.check_adam(model, opt, g)                                      # the reference's own class, run on CPU
-    old = R._set_backend_for_tests(OracleBackend())
+    old = oracle_backend.install(OracleBackend())
     try:
         m_o, o_o = U.run_adam(g, "cpu", sparse_optimizer.step)       # same host logic, oracle arithmetic
     finally:
-        R._set_backend_for_tests(None if isinstance(old, R.HipBackend) else old)
+        oracle_backend.install(None if isinstance(old, R.HipBackend) else old)
     for k in U.ADAM_KEYS:
         np.testing.assert_array_equal(getattr(model, k).cpu().numpy(), getattr(m_o, k).numpy(), err_msg=k)
         np.testing.assert_array_equal(opt.exp_avg[k].cpu().numpy(), o_o.exp_avg[k].numpy(), err_msg=k)

@@ -53,10 +53,11 @@ def _tree_and_model(g):
 
 def test_dropin_host_logic_with_test_double(oracle_mod):
     from log_amd import lod, rasterizer as R
+    import oracle_backend
     from oracle_backend import OracleBackend
     g = np.load(GOLDEN[-1])
     tree, model, cam = _tree_and_model(g)
-    old = R._set_backend_for_tests(OracleBackend())
+    old = oracle_backend.install(OracleBackend())
     try:
         for qi, (min_px, max_depth) in enumerate(g["queries"]):
             tree.min_resolution_pixel = float(min_px)
@@ -70,7 +71,7 @@ def test_dropin_host_logic_with_test_double(oracle_mod):
         with pytest.raises(NotImplementedError):
             lod.traverse(tree, model, torch.from_numpy(g["root_index"]), cam)
     finally:
-        R._set_backend_for_tests(None if isinstance(old, R.HipBackend) else old)
+        oracle_backend.install(None if isinstance(old, R.HipBackend) else old)
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -93,6 +94,7 @@ def test_oracle_and_dropin_follow_reference_on_random_trees(seed, oracle_mod):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     import make_golden_lod as G
+    import oracle_backend
     from log_amd import lod, rasterizer as R
     rng = np.random.default_rng(seed)
     G.reference_env()                                     # installs the oracle test double + LoG.cuda stand-in
@@ -120,6 +122,6 @@ def test_oracle_and_dropin_follow_reference_on_random_trees(seed, oracle_mod):
             tree.min_resolution_pixel = min_px
             np.testing.assert_array_equal(lod.traverse(tree, g, roots, rast, max_depth=max_depth).numpy(), want)
     finally:
-        R._set_backend_for_tests(None)
+        oracle_backend.install(None)
         for k in ("LoG.cuda.compute_radius",):
             sys.modules.pop(k, None)

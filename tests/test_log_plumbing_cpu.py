@@ -21,6 +21,7 @@ def log_env(oracle_mod):
     """sys.path + stubs for the reference's host-only deps that are absent here (cv2) + the LoG.cuda drop-in."""
     from log_amd import rasterizer as R
     from log_amd.compute_radius import compute_radius_module
+    import oracle_backend
     from oracle_backend import OracleBackend
     added = []
     if REF not in sys.path:
@@ -33,9 +34,9 @@ def log_env(oracle_mod):
     drop.compute_radius_module = compute_radius_module
     stubs["LoG.cuda.compute_radius"] = drop
     sys.modules.update(stubs)
-    old = R._set_backend_for_tests(OracleBackend())
+    old = oracle_backend.install(OracleBackend())
     yield
-    R._set_backend_for_tests(None if isinstance(old, R.HipBackend) else old)
+    oracle_backend.install(None if isinstance(old, R.HipBackend) else old)
     for k in stubs:
         sys.modules.pop(k, None)
     for p in added:

@@ -17,10 +17,11 @@ REF = os.environ.get("LOG_REFERENCE", "/root/reference")
 @pytest.fixture()
 def double(oracle_mod):
     from log_amd import rasterizer as R
+    import oracle_backend
     from oracle_backend import OracleBackend
-    old = R._set_backend_for_tests(OracleBackend())
+    old = oracle_backend.install(OracleBackend())
     yield
-    R._set_backend_for_tests(None if isinstance(old, R.HipBackend) else old)
+    oracle_backend.install(None if isinstance(old, R.HipBackend) else old)
 
 
 def test_oracle_id_histogram_matches_torch_unique(oracle_mod):

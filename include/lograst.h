@@ -121,9 +121,11 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
  * Outputs: image[3,H,W], final_T[H,W], n_contrib[H,W] (both kept for backward), and when
  * view->extras: point_id_pixel[H,W] (i32, -1 = none), point_weight_pixel[H,W], point_weight[n].
  * bwd_scratch (optional, NULL/0 = none): a block of bwd_scratch_floats * n fp32 that this call zero-fills (inside
- * a kernel it launches anyway) for a caller that will run lograst_backward on this view: carve dL_dmeans2d[n,3],
- * dL_dconic[n,4] (7 floats per Gaussian) and, without LOGRAST_BWD_ACCUMULATE, dL_dopacities[n], dL_dcolors[n,3]
- * (11) out of it and pass LOGRAST_BWD_SCRATCH_ZEROED -- no separate memset launches.
+ * a kernel it launches anyway) for a caller that will run lograst_backward on this view: carve dL_dconic[n,4],
+ * dL_dmeans2d[n,3] (7 floats per Gaussian, in this order) and, without LOGRAST_BWD_ACCUMULATE, dL_dopacities[n],
+ * dL_dcolors[n,3] (11) out of it and pass LOGRAST_BWD_SCRATCH_ZEROED -- no separate memset launches.  With
+ * view->extras the leading dL_dconic block is cleared only in the rows of Gaussians that contributed to a pixel
+ * (point_weight > 0): pass point_weight and LOGRAST_BWD_CONIC_TOUCHED_ONLY to lograst_backward.
  * max_tile_len is also CHECKED on the device: when the real longest list exceeds a non-zero max_tile_len (or the
  * instance count exceeds capacity) nothing is sorted or composited and the overflow flag of tile_state is raised; the
  * outputs of such a call are undefined.  status (optional): LOGRAST_STATUS_WORDS device words owned by the caller
@@ -171,15 +173,23 @@ int lograst_set_tile_cull(int enabled);
  *   LOGRAST_BWD_ACCUMULATE      multi-view accumulation (new, not in the reference): dl_dopacities, dl_dcolors,
  *                               dl_dmeans3d, dl_dscales, dl_drotations are running sums that this call ADDS to
  *                               (the reverse walk's atomics and the chain-rule kernel write straight into the
- *                               caller's per-step gradient bucket; no separate accumulate pass). */
+ *                               caller's per-step gradient bucket; no separate accumulate pass).
+ *   LOGRAST_BWD_CONIC_TOUCHED_ONLY  dl_dconic is zeroed only in the rows of Gaussians with point_weight > 0 (what a
+ *                               forward with extras and a bwd_scratch leaves: see below); needs point_weight.
+ * point_weight (optional, NULL = none): the forward's per-Gaussian maximum blend weight.  A Gaussian with weight 0
+ * contributed to no pixel, so its dL/dmean2D and dL/dconic are exactly zero: the chain rule skips it (its gradients
+ * are written as 0, or left alone when accumulating) without reading its inputs -- in an opaque scene that is most of
+ * the Gaussians.
+ * bwd_scratch of the forward: [dL_dconic n x 4 | dL_dmeans2d n x 3 | (dL_dopacities n | dL_dcolors n x 3)]. */
 #define LOGRAST_BWD_SCRATCH_ZEROED 1
 #define LOGRAST_BWD_ACCUMULATE 2
+#define LOGRAST_BWD_CONIC_TOUCHED_ONLY 4
 int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                      const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
                      const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
-                     int32_t flags, void* stream);
+                     const float* point_weight, int32_t flags, void* stream);
 
 /* Stage A6b alone: the per-Gaussian chain rule, given dL/d(ndc mean) [n,3] and dL/d(conic) [n,4] (as left
  * by the reverse walk).  Writes dl_dmeans3d/dl_dscales/dl_drotations.  lograst_backward = reverse walk +
@@ -314,7 +324,7 @@ int lograst_activate_backward(int32_t n, const float* raw_xyz, const float* raw_
  * When enabled every kernel launch is bracketed by hipEventRecord on its stream.  read() synchronises
  * the recorded events and returns, for kernel slot i < LOGRAST_NUM_KERNELS, accumulated milliseconds
  * and launch counts since the last reset. */
-#define LOGRAST_NUM_KERNELS 18
+#define LOGRAST_NUM_KERNELS 20
 void lograst_profile_enable(int on);
 void lograst_profile_reset(void);
 int lograst_profile_read(double* ms_out, int64_t* count_out);

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblogra
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
 REC_FLOATS = 16
-NUM_KERNELS = 18
+NUM_KERNELS = 20
 
 c_void_p, c_int32, c_uint32, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
                                                   ctypes.c_float, ctypes.c_size_t)
@@ -59,7 +59,7 @@ _SIGNATURES = {
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),
                                           ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
     "lograst_set_tile_cull": (ctypes.c_int, [ctypes.c_int]),
-    "lograst_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 17 + [c_int32, c_void_p]),
+    "lograst_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 18 + [c_int32, c_void_p]),
     "lograst_project_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10),
     "lograst_sh_forward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 6),
     "lograst_sh_backward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p]),

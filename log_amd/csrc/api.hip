@@ -23,9 +23,10 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int planes, int tile_cull,
                        hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_off, hipStream_t s);
+void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, hipStream_t s);
+                    int zero_block_floats, int rebased, hipStream_t s);
 void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
@@ -36,8 +37,9 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
                          hipStream_t s);
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
-                           const int* radii, const float* g_mean2d, const float* g_conic, float* g_means3d,
-                           float* g_scales, float* g_rots, bool accumulate, hipStream_t s);
+                           const int* radii, const float* g_mean2d, const float* g_conic, const float* pw,
+                           float* g_means3d, float* g_scales, float* g_rots, bool accumulate, hipStream_t s);
+void lr_launch_zero_touched(int N, const float* pw, float* conic, hipStream_t s);
 
 size_t lr_knn_scratch_bytes(int P);
 hipError_t lr_launch_knn(int P, const float* pts, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
@@ -119,6 +121,13 @@ static LrBatching lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t
   return {b, planes};
 }
 static uint32_t lr_batches(int32_t n, uint32_t batch) { return batch ? ((uint32_t)n + batch - 1u) / batch : 0u; }
+// Two helper passes pay for their launch only on large inputs (each is ~10 us at 1 M Gaussians, where the work they
+// save is smaller than that): lr_rebase_kernel (absolute slot table for the fill) and the touched-only clearing of
+// dL/dconic.  Both stages of a forward evaluate this with the same n.
+static bool lr_big_input(int32_t n) {
+  static const int min_n = lr_env_int("LOGRAST_HELPER_MIN_N", 4000000);
+  return n >= min_n;
+}
 
 static int lr_tile_cull() {
   int c = g_tile_cull.load(std::memory_order_relaxed);
@@ -133,7 +142,7 @@ static int lr_tile_cull() {
 static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
     "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
     "blend_fwd", "blend_bwd", "project_bwd", "knn3", "lod_traverse", "counter_update", "sparse_adam",
-    "id_histogram", "gather_activate", "activate_bwd", "count_huge"};
+    "id_histogram", "gather_activate", "activate_bwd", "count_huge", "rebase_slots", "zero_touched"};
 struct ProfRec { int slot; hipEvent_t a, b; bool own_a; };
 // Consecutive launches inside one entry point share an event: the end of kernel k is the begin of kernel k+1 (N+1
 // events for a chain of N kernels instead of 2N; every recorded event costs ~1.4 us of stream time).
@@ -268,7 +277,7 @@ static int lr_stage1(const LrView& v, int32_t n, const float* means3d, const flo
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
                     st + big_off, st, st + lr_basetab_off(tiles), (int)bt.batch, (int)bt.planes, lr_tile_cull(), s);
   lr_launch_scan(st, tiles, cs, big_off, s);
-  return LOGRAST_OK;
+  if (lr_big_input(n)) lr_launch_rebase(st, tiles, lr_batches(n, bt.batch), s);  return LOGRAST_OK;
 }
 
 // stage 2 launches: bucket fill (+ zero-fills), per-tile sort, compositing
@@ -279,12 +288,22 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   const uint32_t tiles = (uint32_t)(v.gx * v.gy);
   if (n == 0 && status)   // no fill kernel runs: this forward's entries of the status block
     LR_HIP(hipMemsetAsync(status + LOGRAST_STATUS_LAST_INSTANCES, 0, 4 * sizeof(uint32_t), s));
-  // point_weight (atomicMax target) and the optional backward scratch are cleared by the fill kernel
+  // point_weight (atomicMax target) and the optional backward scratch are cleared by the fill kernel -- except, in
+  // the 5-tuple flavour, the scratch's leading dL/dconic block [n,4]: only the rows of Gaussians that contributed to
+  // a pixel (point_weight > 0, known after compositing) will ever be read, and they are cleared below
+  const bool touched_only = v.extras && bwd_scratch_floats >= 4 && lr_big_input(n);
+  float* zero_block = bwd_scratch_floats > 0 ? bwd_scratch : nullptr;
+  int zero_floats = bwd_scratch_floats;
+  if (touched_only) { zero_block += 4 * (size_t)n; zero_floats -= 4; }
   lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, max_tile_len, status,
-                 v.extras ? point_weight : nullptr, bwd_scratch_floats > 0 ? bwd_scratch : nullptr, bwd_scratch_floats, s);
+                 v.extras ? point_weight : nullptr, zero_floats > 0 ? zero_block : nullptr, zero_floats,
+                 lr_big_input(n) ? 1 : 0, s);
+  static const int stop_after_fill = lr_env_int("LOGRAST_STOP_AFTER_FILL", 0);   // timing experiments (tools/) only
+  if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
                       point_weight_pixel, point_weight, s);
+  if (touched_only) lr_launch_zero_touched(n, point_weight, bwd_scratch, s);
   return LOGRAST_OK;
 }
 
@@ -412,7 +431,7 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
                      const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
-                     int32_t flags, void* stream) {
+                     const float* point_weight, int32_t flags, void* stream) {
   g_prof_call++;
   LrView v;
   int rc = lr_make_view(view, &v);
@@ -429,6 +448,8 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   const uint32_t* st = reinterpret_cast<const uint32_t*>(tile_state);
   const bool accumulate = (flags & LOGRAST_BWD_ACCUMULATE) != 0;
+  if ((flags & LOGRAST_BWD_CONIC_TOUCHED_ONLY) && !point_weight)
+    return lr_fail(LOGRAST_ERR_ARG, "LOGRAST_BWD_CONIC_TOUCHED_ONLY needs point_weight");
   if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED)) {
     LR_HIP(hipMemsetAsync(dl_dmeans2d, 0, sizeof(float) * 3 * (size_t)n, s));
     LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * 4 * (size_t)n, s));
@@ -440,8 +461,8 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   // capacity check is a forward concern: a list that rendered is by construction within capacity
   lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dmeans2d,
                       dl_dconic, dl_dopacities, dl_dcolors, s);
-  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
-                        dl_drotations, accumulate, s);
+  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, point_weight, dl_dmeans3d,
+                        dl_dscales, dl_drotations, accumulate, s);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
@@ -462,8 +483,8 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
   if ((reinterpret_cast<uintptr_t>(dl_dconic) | reinterpret_cast<uintptr_t>(rotations) |
        reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");
-  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, dl_dmeans3d, dl_dscales,
-                        dl_drotations, false, (hipStream_t)stream);
+  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, nullptr, dl_dmeans3d,
+                        dl_dscales, dl_drotations, false, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

@@ -546,6 +546,25 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_o
   lr_prof_end(LRK_SCAN, s);
 }
 
+// ---- batched mode: absolute slots ---------------------------------------------------------------------------
+// basetab[b][t] (start of batch b's run inside tile t's list) + offsets[t] (start of the tile's list), once per
+// (batch, tile) here instead of once per INSTANCE in the fill kernel, whose cost is the number of scattered accesses it
+// issues (30 M Gaussians: three per instance -- two table reads and the key store -- cost 0.5 ms of address
+// processing; this pass moves 66 MB, coalesced).
+__global__ void __launch_bounds__(256)
+lr_rebase_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t batches) {
+  const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
+  uint32_t* __restrict__ row = state + lr_basetab_off(tiles) + (size_t)blockIdx.y * tiles;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t < tiles) row[t] += offsets[t];
+}
+void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, hipStream_t s) {
+  if (!batches) return;
+  lr_prof_begin(LRK_REBASE, s);
+  hipLaunchKernelGGL(lr_rebase_kernel, dim3((tiles + 255u) / 256u, batches), dim3(256), 0, s, state, tiles, batches);
+  lr_prof_end(LRK_REBASE, s);
+}
+
 // ---- A3: per-tile bucket fill ---------------------------------------------------------------------------
 // key = (fp32 bits of view depth) << 32 | Gaussian index; depth > 0.2 so the bit pattern is monotone.
 // (Also clears point_weight[N] and the caller's backward scratch: see the top of the kernel.)
@@ -556,7 +575,8 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_o
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
-               float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order, int stream_nt) {
+               float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order, int stream_nt,
+               int ablate, int rebased) {
   // Per-Gaussian buffers that later kernels accumulate into with atomics (point_weight; the backward scratch)
   // are cleared here, in a kernel that already has one thread per Gaussian, instead of by separate memsets.
   // XCD-contiguous block order (speed only): blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
@@ -571,7 +591,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     // (streaming stores: non-temporal, so that they do not push the partially written key lines of this kernel out
     // of the XCD's L2 before their neighbours arrive)
     const int zi = (int)(vblock * 256u + threadIdx.x);
-    if (zi < N) {
+    if (zi < N && !(ablate & 1)) {
       if (stream_nt) {
         if (zero_n) __builtin_nontemporal_store(0.f, &zero_n[zi]);
         for (int k = 0; k < zero_block_floats; k++) __builtin_nontemporal_store(0.f, &zero_block[(size_t)k * N + zi]);
@@ -658,7 +678,9 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       if (k < nt && slot[k] != 0xffffffffu) {  // 0xffffffff: dropped by the support cull in the projection kernel
         const int ty = (w == 1) ? k : ((w == 2 && nt == 4) ? (k >> 1) : 0), tx = k - ty * w;  // as in lr_project_one
         const int t = (y0 + ty) * gx + (x0 + tx);
-        keys[offsets[t] + (batch ? bbase[t] : 0u) + slot[k]] = key;
+        // batched: slot relative to the batch's run in the tile; lr_rebase_kernel (large inputs) made the table absolute
+        const uint32_t pos = (batch ? (rebased ? bbase[t] : offsets[t] + bbase[t]) : offsets[t]) + slot[k];
+        if (!(ablate & 2) || pos == 0xffffffffu) keys[pos] = key;
       }
     }
   }
@@ -704,14 +726,30 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, hipStream_t s) {
+                    int zero_block_floats, int rebased, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   static const int xcd_order = lr_env_int("LOGRAST_FILL_XCD_ORDER", 1);
   static const int fill_nt = lr_env_int("LOGRAST_FILL_NT", 1);
+  static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores
   const int blocks = ((N + 255) / 256 + 7) & ~7;
   hipLaunchKernelGGL(lr_fill_kernel, dim3(blocks), dim3(256), 0, s, N, gx,
                      reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, max_len_hint, status, zero_n,
-                     zero_block, zero_block_floats, xcd_order, fill_nt);
+                     zero_block, zero_block_floats, xcd_order, fill_nt, ablate, rebased);
   lr_prof_end(LRK_FILL, s);
+}
+
+// After compositing (5-tuple flavour, training forward): clear dL/dconic [N,4] for the Gaussians that contributed to a
+// pixel (point_weight > 0).  The rows of all the others are never read (lr_project_bwd_kernel<., true>), so the
+// forward does not spend 16 B per Gaussian zero-filling them.
+__global__ void __launch_bounds__(256)
+lr_zero_touched_kernel(int N, const float* __restrict__ pw, float4* __restrict__ conic) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N && pw[i] > 0.f) conic[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+void lr_launch_zero_touched(int N, const float* pw, float* conic, hipStream_t s) {
+  if (N <= 0) return;
+  lr_prof_begin(LRK_ZERO_TOUCHED, s);
+  hipLaunchKernelGGL(lr_zero_touched_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, pw, reinterpret_cast<float4*>(conic));
+  lr_prof_end(LRK_ZERO_TOUCHED, s);
 }

@@ -310,6 +310,7 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
 // its biglist entry so that they skip it.
 #define LR_LONG_NB 4096     // bucket counters in LDS
 #define LR_LONG_WIN 6144    // list positions ranked in LDS at a time
+#define LR_LONG_UNR 8       // independent loads in flight per thread in the streaming passes
 __global__ void __launch_bounds__(1024)
 lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity) {
@@ -331,43 +332,58 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   if (tid == 0) { sh_min = 0xffffffffu; sh_max = 0u; sh_maxcnt = 0u; }
   for (uint32_t b = tid; b < nb; b += 1024) lcnt[b] = 0u;
   uint32_t dmin = 0xffffffffu, dmax = 0u;
-  // (the streaming loops are unrolled by hand: four independent loads in flight per thread)
-  for (uint32_t i = tid; i < L; i += 4096) {
-    uint64_t kk[4];
+  // (the streaming loops are unrolled by hand: LR_LONG_UNR independent loads in flight per thread -- every pass is a
+  // latency chain per workgroup, 1024 threads x 8 loads x 8 B = 64 KB in flight)
+  // Depth range from the first eighth of the list (the keys arrive in no particular order, so this is a random
+  // sample): the range only has to spread the keys over the buckets, keys outside it clamp into the first / last
+  // bucket, and a bucket that overflows sends the tile to the fallback as before.
+  const uint32_t Ls = min(L, max(L >> 3, 4096u));
+  for (uint32_t i = tid; i < Ls; i += LR_LONG_UNR * 1024u) {
+    uint64_t kk[LR_LONG_UNR];
 #pragma unroll
-    for (int u = 0; u < 4; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
+    for (int u = 0; u < LR_LONG_UNR; u++) kk[u] = (i + u * 1024u < Ls) ? k[i + u * 1024u] : 0ull;
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (i + u * 1024u < L) { const uint32_t d = (uint32_t)(kk[u] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
+    for (int u = 0; u < LR_LONG_UNR; u++)
+      if (i + u * 1024u < Ls) { const uint32_t d = (uint32_t)(kk[u] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d));
+    dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d));
   }
   __syncthreads();
-  atomicMin(&sh_min, dmin);
-  atomicMax(&sh_max, dmax);
+  if ((tid & 63u) == 0u) { atomicMin(&sh_min, dmin); atomicMax(&sh_max, dmax); }
   __syncthreads();
   const float fmin = __uint_as_float(sh_min), range = __uint_as_float(sh_max) - fmin;
   const float scale = (float)nb / range;
   auto bucket_of = [&](uint64_t key) -> uint32_t {
     const float rel = (__uint_as_float((uint32_t)(key >> 32)) - fmin) * scale;
-    return rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;  // NaN (range == 0) -> bucket 0
+    return rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;  // below the sampled range / NaN (range == 0) -> bucket 0
   };
-  for (uint32_t i = tid; i < L; i += 4096) {               // rank inside the bucket
-    uint64_t kk[4];
+  for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // rank inside the bucket
+    uint64_t kk[LR_LONG_UNR];
 #pragma unroll
-    for (int u = 0; u < 4; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
+    for (int u = 0; u < LR_LONG_UNR; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
+    uint32_t cd[LR_LONG_UNR];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (i + u * 1024u < L) {                             // (bucket, rank) code: all a window pass needs to skip a key
-        const uint32_t b = bucket_of(kk[u]);
-        rk[i + u * 1024u] = (b << 8) | min(atomicAdd(&lcnt[b], 1u), 255u);
-      }
+    for (int u = 0; u < LR_LONG_UNR; u++) {                  // (bucket, rank) code: all a window pass needs to skip a key
+      const uint32_t b = bucket_of(kk[u]);
+      cd[u] = (i + u * 1024u < L) ? ((b << 8) | min(atomicAdd(&lcnt[b], 1u), 255u)) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < LR_LONG_UNR; u++)
+      if (i + u * 1024u < L) rk[i + u * 1024u] = cd[u];
   }
   __syncthreads();
-  const uint32_t per = (nb + 1023u) / 1024u;
+  // exclusive scan of the nb counts: thread t owns counters [t * per, (t + 1) * per); every wave scans the 16 wave totals
+  const uint32_t per = (nb + 1023u) / 1024u;               // <= LR_LONG_NB / 1024
+  uint32_t cown[LR_LONG_NB / 1024];
   uint32_t local = 0, lmax = 0;
-  for (uint32_t q = 0; q < per; q++) {
+#pragma unroll
+  for (uint32_t q = 0; q < LR_LONG_NB / 1024; q++) {
     const uint32_t b = tid * per + q;
-    const uint32_t c = b < nb ? lcnt[b] : 0u;
-    local += c; lmax = max(lmax, c);
+    cown[q] = (q < per && b < nb) ? lcnt[b] : 0u;
+    local += cown[q]; lmax = max(lmax, cown[q]);
   }
   uint32_t inc = local;
 #pragma unroll
@@ -375,15 +391,25 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
     const uint32_t up = __shfl_up(inc, d);
     if ((int)(tid & 63u) >= d) inc += up;
   }
-  if ((tid & 63u) == 63u) wave_tot[tid >> 6] = inc;
-  atomicMax(&sh_maxcnt, lmax);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d));
+  if ((tid & 63u) == 63u) { wave_tot[tid >> 6] = inc; atomicMax(&sh_maxcnt, lmax); }
   __syncthreads();
   if (sh_maxcnt > LR_BUCKET_MAX) return;                    // clustered depths: network fallback (entry stays unflagged)
-  uint32_t run = inc - local;
-  for (uint32_t w = 0; w < (tid >> 6); w++) run += wave_tot[w];
-  for (uint32_t q = 0; q < per; q++) {
-    const uint32_t b = tid * per + q;
-    if (b < nb) { const uint32_t c = lcnt[b]; lcnt[b] = run; run += c; }   // lcnt[b] = first list position of bucket b
+  {
+    const uint32_t wt = (tid & 63u) < 16u ? wave_tot[tid & 63u] : 0u;
+    uint32_t winc = wt;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t up = __shfl_up(winc, d);
+      if ((int)(tid & 63u) >= d) winc += up;
+    }
+    uint32_t run = (uint32_t)__shfl((int)(winc - wt), (int)(tid >> 6)) + inc - local;   // waves in front of mine + lanes in front of me
+#pragma unroll
+    for (uint32_t q = 0; q < LR_LONG_NB / 1024; q++) {
+      const uint32_t b = tid * per + q;
+      if (q < per && b < nb) { lcnt[b] = run; run += cown[q]; }   // lcnt[b] = first list position of bucket b
+    }
   }
   __syncthreads();
   // windows of whole buckets: [b0, b1) with start(b1) - start(b0) <= LR_LONG_WIN (a bucket holds <= LR_BUCKET_MAX keys)
@@ -397,20 +423,23 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
       if (st_mid <= w0 + (uint32_t)LR_LONG_WIN) lo_b = mid; else hi_b = mid - 1u;
     }
     const uint32_t b1 = lo_b;                              // window = list positions [start(b0), start(b1))
-    for (uint32_t i = tid; i < L; i += 4096) {             // 4 B per key; the 8-byte key only if it lands in this window
-      uint32_t cc[4];
+    for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // 4 B per key; the 8-byte key only if it lands in this window
+      uint32_t cc[LR_LONG_UNR];
 #pragma unroll
-      for (int u = 0; u < 4; u++) cc[u] = (i + u * 1024u < L) ? rk[i + u * 1024u] : 0xffffffffu;
-      uint64_t kv[4];
+      for (int u = 0; u < LR_LONG_UNR; u++) cc[u] = (i + u * 1024u < L) ? rk[i + u * 1024u] : 0xffffffffu;
+      uint64_t kv[LR_LONG_UNR];
+      uint32_t st[LR_LONG_UNR];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {                          // all four key loads in flight before the first is used
+      for (int u = 0; u < LR_LONG_UNR; u++) {                // all key loads and bucket starts requested before the first is used
         const uint32_t b = cc[u] >> 8;                       // cc == ~0 (past the end): b = 2^24-1 >= nb
-        kv[u] = (b >= b0 && b < b1) ? k[i + u * 1024u] : 0ull;
+        const bool in = b >= b0 && b < b1;
+        kv[u] = in ? k[i + u * 1024u] : 0ull;
+        st[u] = lcnt[in ? b : b0];
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < LR_LONG_UNR; u++) {
         const uint32_t b = cc[u] >> 8;
-        if (b >= b0 && b < b1) win[lcnt[b] + (cc[u] & 255u) - w0] = kv[u];
+        if (b >= b0 && b < b1) win[st[u] + (cc[u] & 255u) - w0] = kv[u];
       }
     }
     __syncthreads();

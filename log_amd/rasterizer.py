@@ -265,7 +265,7 @@ class HipBackend:
         del keys, keep
         saved = dict(radii=o["radii"], geom=k["geom"].view(f32), state=k["state"].view(i32), plist=plist,
                      final_T=k["final_T"], n_contrib=k["n_contrib"], bwd_scratch=k.get("bwd_scratch"),
-                     tile_rows=(view.tile_row_begin, view.tile_row_end))
+                     point_weight=o.get("pw"), tile_rows=(view.tile_row_begin, view.tile_row_end))
         return o["image"], o["radii"], o.get("pid"), o.get("pwp"), o.get("pw"), saved
 
     def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None):
@@ -282,9 +282,15 @@ class HipBackend:
         # The accumulators the reverse walk adds into come from ONE zeroed block: the one the forward already
         # cleared for this purpose (first backward of this forward), else a fresh torch.zeros.  Layout: the 16-byte
         # rows first (dL/dconic [N,4], read as one access per Gaussian), then dL/dmeans2D [N,3] (, opacity, colours).
+        # In the 5-tuple flavour the forward cleared the dL/dconic rows of the contributing Gaussians only
+        # (point_weight > 0); the chain rule skips all the others (LOGRAST_BWD_CONIC_TOUCHED_ONLY).
         acc = saved.pop("bwd_scratch", None)
+        pw = saved.get("point_weight")
+        flags = 1
         if acc is None or acc.numel() < need * N:
             acc = torch.zeros(N * need, **f32)
+        elif pw is not None:
+            flags |= 4
         g_conic = acc[:4 * N].view(N, 4)
         g_means2D = acc[4 * N:7 * N].view(N, 3)
         if sink is None:
@@ -293,17 +299,16 @@ class HipBackend:
             g = self._carve(device, [("rot", torch.float32, (N, 4)), ("means3D", torch.float32, (N, 3)),
                                      ("scales", torch.float32, (N, 3))])
             g_means3D, g_scales, g_rot = g["means3D"], g["scales"], g["rot"]
-            flags = 1
         else:
             g_opac, g_colors = sink["opacities"], sink["colors"]
             g_means3D, g_scales, g_rot = sink["means3D"], sink["scales"], sink["rotations"]
-            flags = 1 | 2
+            flags |= 2
         with torch.cuda.device(device):
             _lib.check(L.lograst_backward(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
                                           _ptr(saved["radii"]), _ptr(saved["geom"]), _ptr(saved["state"]),
                                           _ptr(saved["plist"]), _ptr(saved["final_T"]), _ptr(saved["n_contrib"]),
                                           _ptr(grad_image), _ptr(g_means2D), _ptr(g_conic), _ptr(g_opac),
-                                          _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot),
+                                          _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot), _ptr(pw),
                                           flags, _stream_ptr(device)))
         del keep
         self.last_conic_grad = g_conic if _debug_keep else None   # test introspection only (pins the whole block)

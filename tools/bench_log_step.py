@@ -1,11 +1,12 @@
-"""One LoG training view, end to end on the GPU (BASELINE.json configs[2] shape: LoD tree with level selection on, SH
+"""One LoG training view, end to end on the GPU (BASELINE.json configs[2], "C3": LoD tree with level selection on, SH
 colours, 1080p): select -> gather/activate -> rasterize fwd+bwd -> id histogram -> counter -> sparse Adam.
 Two pipelines around the SAME rasterizer (this repo's drop-in packages):
   torch : every other stage as the reference runs it today, restated with torch ops on the device
           (tensor_tree.py:131-185, level_of_gaussian.py:65-88,262-296, activation.py:27-44, renderer.py:156-159,
           counter.py:36-68, sparse_optimizer.py:41-78,163-249);
   fused : the drop-ins of log_amd/{lod,get_all,counter,sparse_optimizer}.py.
-    python tools/bench_log_step.py [roots] [levels] [sh_degree] [views] [root_scale]  -> one JSON line"""
+    python tools/bench_log_step.py [roots] [levels] [sh_degree] [views] [root_scale]  -> one JSON line
+Importable: ``c3_pipeline(...)`` is the C3 leg of bench.py."""
 import json
 import math
 import os
@@ -17,59 +18,73 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
-from log_amd import lod, get_all, counter, sparse_optimizer, scenes, _lib, rasterizer as R  # noqa: E402
-from log_amd.compute_radius import compute_radius_module  # noqa: E402
-from lod_util import synth_tree  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-R0 = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
-LV = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-D = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-V = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-RS = float(sys.argv[5]) if len(sys.argv) > 5 else 0.03     # root scale: 3-sigma radius of a root ~ 3 * RS * 2139 / 3 px
-assert D <= 1, "the torch pipeline in this tool restates the degree-1 SH terms only"
-K = max((D + 1) ** 2 - 1, 3)
 MIN_PX = 3.0
 W, H = 1920, 1080
-dev = torch.device("cuda:0")
-s = synth_tree(R0, LV, 4, split_prob=0.5, hole_prob=0.02, seed=0, root_scale=RS)
-P = s["xyz"].shape[0]
-t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-gen = torch.Generator(device=dev).manual_seed(0)
-bufs = {"scaling": t(s["scaling"]), "colors": torch.randn(P, 3, device=dev, generator=gen),
-        "xyz": t(s["xyz"]), "opacity": torch.randn(P, 1, device=dev, generator=gen) + 1.0,
-        "rotation": t(s["rotation"]), "shs": torch.randn(P, K, 3, device=dev, generator=gen) * 0.2}
-keys = list(bufs)
-tree = types.SimpleNamespace(node_index=t(s["node_index"]), tree=t(s["tree"]), depth=t(s["depth"]), max_level=30,
-                             min_resolution_pixel=MIN_PX)
-roots = t(s["root_index"])
-cams = scenes.orbit_cameras(V, W=W, H=H)
-wloss = torch.rand(3, H, W, device=dev)
-C0, C1 = 0.28209479177387814, 0.4886025119029199
 LR = {"colors": 0.0025, "shs": 0.000125, "opacity": 0.05, "rotation": 0.001}
 CDT = {"weights_max": torch.float32, "weights_sum": torch.float32, "grad_sum": torch.float32, "radii_max": torch.int16,
        "visible_count": torch.int16, "radii_max_max": torch.int32, "area_sum": torch.int32, "create_steps": torch.int32}
 
+# Real SH basis without the DC term, degrees 1..3, as (coefficient, monomial) in the order LoG stores the coefficients
+# (the basis of /root/reference/LoG/model/sh_utils.py:31-68); only used by the "torch" pipeline of this tool.
+_A, _B, _C = 0.4886025119029199, 1.0925484305920792, 0.5900435899266435
+SH_TERMS = [
+    (-_A, lambda x, y, z: y), (_A, lambda x, y, z: z), (-_A, lambda x, y, z: x),
+    (_B, lambda x, y, z: x * y), (-_B, lambda x, y, z: y * z), (0.31539156525252005, lambda x, y, z: 2 * z * z - x * x - y * y),
+    (-_B, lambda x, y, z: x * z), (0.5462742152960396, lambda x, y, z: x * x - y * y),
+    (-_C, lambda x, y, z: y * (3 * x * x - y * y)), (2.890611442640554, lambda x, y, z: x * y * z),
+    (-0.4570457994644658, lambda x, y, z: y * (4 * z * z - x * x - y * y)),
+    (0.3731763325901154, lambda x, y, z: z * (2 * z * z - 3 * x * x - 3 * y * y)),
+    (-0.4570457994644658, lambda x, y, z: x * (4 * z * z - x * x - y * y)),
+    (1.445305721320277, lambda x, y, z: z * (x * x - y * y)), (-_C, lambda x, y, z: x * (x * x - 3 * y * y)),
+]
 
-def rasterizer_for(cam):
-    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
-    rs = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=math.tan(cam["FoVx"] * 0.5), tanfovy=math.tan(cam["FoVy"] * 0.5),
-        bg=T([1.0, 1.0, 1.0]), scale_modifier=1.0, viewmatrix=T(cam["world_view_transform"]),
-        projmatrix=T(cam["full_proj_transform"]), sh_degree=0, campos=T(cam["camera_center"]), prefiltered=False,
-        debug=False)
-    return GaussianRasterizer(raster_settings=rs), {"camera_center": T(cam["camera_center"])}
+
+class Workload:
+    """Tree, model buffers, cameras and loss weights of one C3-shaped run (all on `dev`)."""
+
+    def __init__(self, roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, dev=None):
+        from log_amd import scenes
+        self.dev = dev or torch.device("cuda:0")
+        self.D, self.V, self.R0, self.LV, self.RS = int(sh_degree), int(views), int(roots), int(levels), float(root_scale)
+        assert 0 <= self.D <= 3
+        self.K = max((self.D + 1) ** 2 - 1, 3)
+        s = scenes.synth_tree(self.R0, self.LV, 4, split_prob=0.5, hole_prob=0.02, seed=0, root_scale=self.RS)
+        self.P = P = s["xyz"].shape[0]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        gen = torch.Generator(device=self.dev).manual_seed(0)
+        self.bufs = {"scaling": t(s["scaling"]), "colors": torch.randn(P, 3, device=self.dev, generator=gen),
+                     "xyz": t(s["xyz"]), "opacity": torch.randn(P, 1, device=self.dev, generator=gen) + 1.0,
+                     "rotation": t(s["rotation"]), "shs": torch.randn(P, self.K, 3, device=self.dev, generator=gen) * 0.2}
+        self.keys = list(self.bufs)
+        self.tree = types.SimpleNamespace(node_index=t(s["node_index"]), tree=t(s["tree"]), depth=t(s["depth"]),
+                                          max_level=30, min_resolution_pixel=MIN_PX)
+        self.num_nodes, self.tree_levels = int(s["tree"].shape[0]), int(s["depth"].max())
+        self.roots = t(s["root_index"])
+        self.cams = scenes.orbit_cameras(self.V, W=W, H=H)
+        self.wloss = torch.rand(3, H, W, device=self.dev)
+
+    def rasterizer_for(self, cam):
+        from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
+        T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=self.dev)
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam["FoVx"] * 0.5), tanfovy=math.tan(cam["FoVy"] * 0.5),
+            bg=T([1.0, 1.0, 1.0]), scale_modifier=1.0, viewmatrix=T(cam["world_view_transform"]),
+            projmatrix=T(cam["full_proj_transform"]), sh_degree=0, campos=T(cam["camera_center"]), prefiltered=False,
+            debug=False)
+        return GaussianRasterizer(raster_settings=rs), {"camera_center": T(cam["camera_center"])}
 
 
 class State:
     """Model buffers + counter + optimizer of one pipeline (each pipeline trains its own copy)."""
 
-    def __init__(self):
-        self.bufs = {k: v.clone() for k, v in bufs.items()}
+    def __init__(self, wl):
+        P, dev, D = wl.P, wl.dev, wl.D
+        self.bufs = {k: v.clone() for k, v in wl.bufs.items()}
         self.gaussian = types.SimpleNamespace(
-            keys=keys, active_sh_degree=D, items=lambda: ((k, self.bufs[k]) for k in keys), visibility_flag=None,
+            keys=wl.keys, active_sh_degree=D, items=lambda: ((k, self.bufs[k]) for k in wl.keys), visibility_flag=None,
             activation=types.SimpleNamespace(scaling_activation=torch.exp, rotation_activation=torch.nn.functional.normalize),
             **self.bufs)
         self.model = types.SimpleNamespace(gaussian=self.gaussian, fix_parent=True, training=True)
@@ -81,13 +96,14 @@ class State:
         self.model_ns = types.SimpleNamespace(**self.bufs)
 
 
-def split_leaf_node(index_all):
-    leaf = (tree.node_index[index_all] == -1) & (tree.depth[index_all] > 0)     # level_of_gaussian.py:244-251
+def split_leaf_node(wl, index_all):
+    leaf = (wl.tree.node_index[index_all] == -1) & (wl.tree.depth[index_all] > 0)     # level_of_gaussian.py:244-251
     return index_all[leaf], index_all[~leaf]
 
 
 # ---- torch stages ------------------------------------------------------------------------------------------------
-def torch_radius(st, index, rast):
+def torch_radius(wl, st, index, rast):
+    from log_amd.compute_radius import compute_radius_module
     rs = rast.raster_settings
     fx, fy = W / (2 * rs.tanfovx), H / (2 * rs.tanfovy)
     return compute_radius_module.compute_radius(st.bufs["xyz"][index], torch.exp(st.bufs["scaling"][index]),
@@ -95,17 +111,17 @@ def torch_radius(st, index, rast):
                                                 rs.viewmatrix, fx, fy, rs.tanfovx, rs.tanfovy)
 
 
-def torch_select(st, rast):
-    ni, tr = tree.node_index, tree.tree
-    keep = (torch_radius(st, roots, rast) < MIN_PX) | (ni[roots] == -1)
+def torch_select(wl, st, rast):
+    ni, tr, roots = wl.tree.node_index, wl.tree.tree, wl.roots
+    keep = (torch_radius(wl, st, roots, rast) < MIN_PX) | (ni[roots] == -1)
     out, index, level = [roots[keep]], roots[~keep], 1
     while True:
-        if level > tree.max_level:
+        if level > wl.tree.max_level:
             out.append(index)
             break
         child = tr[ni[index].long()].flatten().long()
         child = child[child != -1]
-        keep = (torch_radius(st, child, rast) < MIN_PX) | (ni[child] == -1)
+        keep = (torch_radius(wl, st, child, rast) < MIN_PX) | (ni[child] == -1)
         out.append(child[keep])
         if (~keep).sum() == 0:
             break
@@ -113,16 +129,17 @@ def torch_select(st, rast):
     return torch.cat(out)
 
 
-def torch_gather(st, index, index_node, camera):
+def torch_gather(wl, st, index, index_node, camera):
     params = {k: torch.nn.Parameter(v[index]) for k, v in st.bufs.items()}
     full = {k: torch.cat([params[k], v[index_node]]) for k, v in st.bufs.items()}
-    colors = full["colors"] * C0 + 0.5
-    if D > 0:
+    colors = full["colors"] * 0.28209479177387814 + 0.5
+    if wl.D > 0:
         d = full["xyz"].detach() - camera["camera_center"][None]
         d = d / torch.norm(d, dim=-1, keepdim=True)
         x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
-        sh = full["shs"]
-        colors = colors + (-C1 * y * sh[:, 0] + C1 * z * sh[:, 1] - C1 * x * sh[:, 2])   # degree-1 terms (D = 1 default)
+        for k in range((wl.D + 1) ** 2 - 1):
+            c, mono = SH_TERMS[k]
+            colors = colors + (c * mono(x, y, z)) * full["shs"][:, k]
     act = {"xyz": full["xyz"], "scaling": torch.exp(full["scaling"]), "opacity": torch.sigmoid(full["opacity"]),
            "rotation": torch.nn.functional.normalize(full["rotation"]), "colors": colors}
     return params, act
@@ -152,14 +169,14 @@ def torch_counter(c, visible_index, grad, radii, pw, ids, counts):
     return flag_vis
 
 
-def torch_adam(st, index, params, flag_vis):
+def torch_adam(wl, st, index, params, flag_vis):
     opt = st.opt
     opt.global_steps += 1
     idx = index[flag_vis]
     idx.cpu()
     step = int(opt.global_steps.item())
-    ea = {k: opt.exp_avg[k][idx] for k in keys}
-    es = {k: opt.exp_avg_sq[k][idx] for k in keys}
+    ea = {k: opt.exp_avg[k][idx] for k in wl.keys}
+    es = {k: opt.exp_avg_sq[k][idx] for k in wl.keys}
     for k, param in params.items():
         if param.grad is None:
             continue
@@ -171,34 +188,35 @@ def torch_adam(st, index, params, flag_vis):
         denom = (es[k].sqrt() / math.sqrt(bc2)).add_(1e-15)
         p.add_(-(lr / bc1) * (ea[k] / denom))
         st.bufs[k][idx] = p
-    for k in keys:
+    for k in wl.keys:
         opt.exp_avg[k][idx] = ea[k]
         opt.exp_avg_sq[k][idx] = es[k]
 
 
 # ---- one view -----------------------------------------------------------------------------------------------------
-def view(st, cam_pack, fused, clock):
+def view(wl, st, cam_pack, fused, clock):
+    from log_amd import lod, get_all, counter, sparse_optimizer
     rast, camera = cam_pack
-    tick = clock("select")
-    index_all = lod.traverse(tree, st.gaussian, roots, rast) if fused else torch_select(st, rast)
-    index, index_node = split_leaf_node(index_all)
-    tick = clock("gather_activate")
+    clock("select")
+    index_all = lod.traverse(wl.tree, st.gaussian, wl.roots, rast) if fused else torch_select(wl, st, rast)
+    index, index_node = split_leaf_node(wl, index_all)
+    clock("gather_activate")
     if fused:
         st.gaussian.visibility_flag = {"index": index, "index_node": index_node}
         act = get_all.get_all(st.model, camera, rast)
         params = st.gaussian.visibility_flag["params"]
     else:
-        params, act = torch_gather(st, index, index_node, camera)
-    tick = clock("rasterize_fwd_bwd")
+        params, act = torch_gather(wl, st, index, index_node, camera)
+    clock("rasterize_fwd_bwd")
     means2D = torch.zeros_like(act["xyz"], requires_grad=True)
     image, radii, pid, pwp, pw = rast(means3D=act["xyz"], means2D=means2D, shs=None, colors_precomp=act["colors"],
                                       opacities=act["opacity"], scales=act["scaling"], rotations=act["rotation"],
                                       cov3D_precomp=None)
-    image.backward(gradient=wloss)
-    tick = clock("id_histogram")
+    image.backward(gradient=wl.wloss)
+    clock("id_histogram")
     n = int(act["xyz"].shape[0])
     ids, counts = counter.unique_ids(pid, n) if fused else torch_unique(pid)
-    tick = clock("counter")
+    clock("counter")
     visible_index = torch.cat([index, index_node])
     if fused:
         out = {"render": [image], "visibility_flag": [{"index": index, "index_node": index_node}],
@@ -207,55 +225,74 @@ def view(st, cam_pack, fused, clock):
         flag_vis = out["visibility_flag"][0]["flag_vis"]
     else:
         flag_vis = torch_counter(st.counter, visible_index, means2D.grad, radii, pw, ids, counts)
-    tick = clock("adam")
+    clock("adam")
     flag_leaf = flag_vis[:index.shape[0]]                                    # level_of_gaussian.py:383-385
     if fused:
         sparse_optimizer.step(st.opt, st.model_ns, index, params, flag_leaf)
     else:
-        torch_adam(st, index, params, flag_leaf)
+        torch_adam(wl, st, index, params, flag_leaf)
     clock(None)
     return n, int(ids.numel())
 
 
-def run(fused, staged):
-    st = State()
-    st.model_ns = types.SimpleNamespace(**st.bufs)
-    packs = [rasterizer_for(c) for c in cams]
-    stages = {}
+def run(wl, fused, staged):
+    st = State(wl)
+    packs = [wl.rasterizer_for(c) for c in wl.cams]
+    stages, cur = {}, {"t": None, "name": None}
 
-    def clock(name, _s={"t": None, "name": None}):
+    def clock(name):
         if staged:
             torch.cuda.synchronize()
             now = time.perf_counter()
-            if _s["name"] is not None:
-                stages[_s["name"]] = stages.get(_s["name"], 0.0) + (now - _s["t"])
-            _s["t"], _s["name"] = now, name
+            if cur["name"] is not None:
+                stages[cur["name"]] = stages.get(cur["name"], 0.0) + (now - cur["t"])
+            cur["t"], cur["name"] = now, name
 
-    view(st, packs[0], fused, clock)             # warm-up (allocator, lazy inits)
+    view(wl, st, packs[0], fused, clock)             # warm-up (allocator, lazy inits)
     stages.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    info = [view(st, p, fused, clock) for p in packs]
+    info = [view(wl, st, p, fused, clock) for p in packs]
     torch.cuda.synchronize()
     total = (time.perf_counter() - t0) / len(packs) * 1e3
     return total, {k: v / len(packs) * 1e3 for k, v in stages.items()}, info, st
 
 
-tot_f, _, info, st_f = run(True, False)
-tot_t, _, _, st_t = run(False, False)
-_lib.profile_enable(True)
-_lib.profile_reset()
-_, stg_f, _, _ = run(True, True)
-prof = _lib.profile_read()
-_lib.profile_enable(False)
-kern = {k: round(v[0] / (V + 1) * 1e3, 1) for k, v in prof.items()}       # us per view (V timed views + the warm-up)
-inst = R.last_state_info()
-_, stg_t, _, _ = run(False, True)
-same = {k: float((st_f.bufs[k] - st_t.bufs[k]).norm() / st_t.bufs[k].norm()) for k in keys}
-print(json.dumps({
-    "bench": "log_step", "points": P, "nodes": int(s["tree"].shape[0]), "roots": R0, "tree_levels": int(s["depth"].max()),
-    "sh_degree": D, "views": V, "root_scale": RS, "selected_per_view": float(np.mean([i[0] for i in info])),
-    "distinct_winners_per_view": float(np.mean([i[1] for i in info])),
-    "ms_per_view_fused": tot_f, "ms_per_view_torch": tot_t, "speedup": tot_t / tot_f,
-    "stages_ms_fused": stg_f, "kernels_us_per_view_fused": kern,
-    "last_view_tile_instances": int(inst[0]), "last_view_longest_tile_list": int(inst[2]), "stages_ms_torch": stg_t, "model_rel_l2_fused_vs_torch_after_views": same}))
+def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, with_torch=False, dev=None):
+    """-> dict for the C3 leg: ms per training view of the fused (drop-in) pipeline, its stage and kernel breakdown,
+    and (with_torch) the same step with everything except the rasterizer done the reference's way in torch."""
+    from log_amd import _lib, rasterizer as R
+    wl = Workload(roots, levels, sh_degree, views, root_scale, dev)
+    tot_f, _, info, st_f = run(wl, True, False)
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    _, stg_f, _, _ = run(wl, True, True)
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    inst = R.last_state_info()
+    sel = float(np.mean([i[0] for i in info]))
+    out = {"workload": "C3: %d-point 4-ary LoD tree (%d roots, %d levels), SH degree %d, level selection on "
+                       "(min_resolution_pixel %g), %dx%d, %d orbit views; one LoG training view = select -> gather/activate"
+                       " -> rasterize fwd+bwd -> id histogram -> counter -> sparse Adam, through the drop-ins"
+                       % (wl.P, wl.R0, wl.tree_levels, wl.D, MIN_PX, W, H, wl.V),
+           "points": wl.P, "nodes": wl.num_nodes, "roots": wl.R0, "tree_levels": wl.tree_levels, "sh_degree": wl.D,
+           "views": wl.V, "root_scale": wl.RS, "selected_per_view": sel,
+           "distinct_winners_per_view": float(np.mean([i[1] for i in info])),
+           "ms_per_view": tot_f, "selected_gaussians_per_s": sel / (tot_f * 1e-3),
+           "stages_ms": stg_f, "kernels_us_per_view": {k: round(v[0] / (wl.V + 1) * 1e3, 1) for k, v in prof.items()},
+           "last_view_tile_instances": int(inst[0]), "last_view_longest_tile_list": int(inst[2])}
+    if with_torch:
+        tot_t, _, _, st_t = run(wl, False, False)
+        _, stg_t, _, _ = run(wl, False, True)
+        out.update(ms_per_view_torch=tot_t, speedup_vs_torch=tot_t / tot_f, stages_ms_torch=stg_t,
+                   model_rel_l2_fused_vs_torch_after_views={
+                       k: float((st_f.bufs[k] - st_t.bufs[k]).norm() / st_t.bufs[k].norm()) for k in wl.keys})
+    return out
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    res = c3_pipeline(int(a[0]) if len(a) > 0 else 40000, int(a[1]) if len(a) > 1 else 7, int(a[2]) if len(a) > 2 else 3,
+                      int(a[3]) if len(a) > 3 else 8, float(a[4]) if len(a) > 4 else 0.03, with_torch=True)
+    res["bench"] = "log_step"
+    print(json.dumps(res))

@@ -8,7 +8,7 @@ N=${ABL_N:-30000000}
 i=0
 for envs in "$@"; do
   i=$((i+1))
-  env $envs timeout 400 python bench.py --gaussians $N --steps 2 --warmup 1 --streams 1 --no-cpu-baseline > $D/${TAG}_$i.log 2>&1
+  env $envs timeout 400 python bench.py --gaussians $N --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-secondary --no-dropin-mode > $D/${TAG}_$i.log 2>&1
   grep -h '^{' $D/${TAG}_$i.log | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
@@ -16,7 +16,7 @@ print('[$envs]', 'ms/view', round(d['ms_per_view'],3), ' '.join('%s=%.0f'%(k,v['
 done
 if [ -n "$ABL_TRACE" ]; then
   rm -rf $D/${TAG}_trace
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $D/${TAG}_trace -o t -- python bench.py --gaussians $N --views 4 --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-kernel-timing > $D/${TAG}_trace.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $D/${TAG}_trace -o t -- python bench.py --gaussians $N --views 4 --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-kernel-timing --no-secondary --no-dropin-mode > $D/${TAG}_trace.log 2>&1
   python - <<PY
 import csv
 rows=list(csv.DictReader(open("$D/${TAG}_trace/t_kernel_stats.csv")))

@@ -12,7 +12,12 @@ sc = scenes.random_scene(N, seed=0, opacity=0.999)
 rs = G.settings(cam, (1, 1, 1), dev)
 t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
 m, s, r, o, c = t(sc["xyz"]), t(sc["scaling"]), t(sc["rotation"]), t(sc["opacity"]).reshape(-1), t(sc["colors"])
-for _ in range(2):
-    out = R._backend.forward(rs, R.WODILATE, True, m, s, r, o, c)
+from log_amd import _lib
+out = R._backend.forward(rs, R.WODILATE, True, m, s, r, o, c)
+torch.cuda.synchronize()
+_lib.profile_reset(); _lib.profile_enable(True)
+for _ in range(3):
+    out = R._backend.forward(rs, R.WODILATE, True, m, s, r, o, c, scratch_floats=7)
     torch.cuda.synchronize()
-print(R.last_state_info())
+_lib.profile_enable(False)
+print(os.environ.get("TAG", ""), R.last_state_info(), {k: round(1e3 * v[0] / v[1]) for k, v in _lib.profile_read().items()})

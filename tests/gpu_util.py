@@ -21,13 +21,15 @@ def settings(cam, bg, dev, scale_modifier=1.0):
         prefiltered=False, debug=False)
 
 
-def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", scale_modifier=1.0):
-    """Raw backend call (keeps the intermediates).  Returns dict of numpy arrays + the torch `saved`."""
+def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", scale_modifier=1.0, scratch_floats=0):
+    """Raw backend call (keeps the intermediates).  Returns dict of numpy arrays + the torch `saved`.
+    scratch_floats=11: have the forward prepare the backward's accumulators, as the autograd path does."""
     dev = torch.device(dev)
     rs = settings(cam, bg, dev, scale_modifier)
     t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
     m, s, r, o, c = t(sc["xyz"]), t(sc["scaling"]), t(sc["rotation"]), t(sc["opacity"]).reshape(-1), t(sc["colors"])
-    image, radii, pid, pwp, pw, saved = R._backend.forward(rs, flavour, use_filter, m, s, r, o, c)
+    image, radii, pid, pwp, pw, saved = R._backend.forward(rs, flavour, use_filter, m, s, r, o, c,
+                                                           scratch_floats=scratch_floats)
     torch.cuda.synchronize()
     W, H = cam["image_width"], cam["image_height"]
     offs = R.tile_offsets_of(saved, W, H).cpu().numpy().astype(np.uint32)
@@ -48,7 +50,12 @@ def hip_backward(hf, dL):
     g = torch.tensor(np.ascontiguousarray(dL, np.float32), device=m.device)
     g_m3, g_m2, g_c, g_o, g_s, g_r = R._backend.backward(rs, flavour, use_filter, m, s, r, saved, g)
     torch.cuda.synchronize()
-    return dict(conic=R._backend.last_conic_grad.cpu().numpy(), means3D=g_m3.cpu().numpy(), means2D=g_m2.cpu().numpy(), colors=g_c.cpu().numpy(),
+    conic = R._backend.last_conic_grad.clone()
+    if saved.get("point_weight") is not None:
+        # rows of Gaussians that contributed to no pixel are neither cleared nor read on large inputs (their dL/dconic
+        # is zero by construction; lograst.h: LOGRAST_BWD_CONIC_TOUCHED_ONLY)
+        conic[saved["point_weight"] == 0] = 0
+    return dict(conic=conic.cpu().numpy(), means3D=g_m3.cpu().numpy(), means2D=g_m2.cpu().numpy(), colors=g_c.cpu().numpy(),
                 opacities=g_o.cpu().numpy().reshape(-1, 1), scales=g_s.cpu().numpy(), rotations=g_r.cpu().numpy())
 
 

@@ -475,8 +475,8 @@ class HipBackend:
                     width = int(model_p[0].numel()) if num_points else 1
                     for t in (model_p, m1, m2) + ((mmax,) if mmax is not None else ()):
                         if t.device != device or t.dtype != torch.float32 or not t.is_contiguous() or t.shape != model_p.shape:
-                            raise NotImplementedError("parameters and Adam moments must be contiguous fp32 tensors on "
-                                                      "the parameter's device (CPU-resident optimizer state is not supported)")
+                            raise ValueError("parameters and Adam moments must be contiguous fp32 tensors on the parameter's "
+                                             "device (log_amd.sparse_optimizer.step moves host-resident moments there)")
                     p, g = _dev_f32(param, device), _dev_f32(grad, device)
                     if int(p.numel()) != m * width or int(g.numel()) != m * width:
                         raise ValueError("param / grad rows do not match index")

@@ -24,6 +24,23 @@ def _host_steps(opt):
     return n
 
 
+def _migrate_state(opt, device):
+    """The reference parks the Adam moments in host memory above 50 M / 100 M points (LoG/model/splitter.py:198-204) and
+    gathers / scatters the visible rows over PCIe every step (sparse_optimizer.py:198-248) -- a 24 GB-card measure.  An
+    MI355X holds 288 GB: moments found on another device are moved next to the parameters, once, and stay there
+    (100 M points x 59 floats x 2 moments = 47 GB)."""
+    dicts = [opt.exp_avg, opt.exp_avg_sq] + ([opt.max_exp_avg_sq] if getattr(opt, "use_amsgrad", False) else [])
+    for d in dicts:
+        for key in (list(d.keys) if not isinstance(d, dict) else list(d)):
+            t = d[key]
+            if t.device != device:
+                moved = t.to(device)
+                if isinstance(d, dict):
+                    d[key] = moved
+                else:
+                    setattr(d, key, moved)       # BufferDict (nn.Module): replaces the registered buffer
+
+
 def step(self, model, index, params, flag_vis):
     """Same signature and effects as SparseOptimizer.step: rows ``index[flag_vis]`` of every ``getattr(model, key)``
     with a gradient, and of its Adam moments, are updated; ``self.xyz_lr`` and ``self.global_steps`` advance."""
@@ -32,6 +49,7 @@ def step(self, model, index, params, flag_vis):
     self._lograst_steps = steps
     bc1 = 1 - BETA1 ** steps
     bc2 = 1 - BETA2 ** steps
+    _migrate_state(self, next(iter(params.values())).device)
     entries = []
     for key, param in params.items():
         if param.grad is None:

@@ -58,7 +58,7 @@ def _worker(rank, world, port, P, out):
 
 
 def test_two_rank_gradient_sum_matches_single_process(tmp_path):
-    P, world = 37, 2   # 37*14 = 518: exercises the padding to a multiple of world
+    P, world = 37, 2   # odd row count: exercises the padding of every attribute block to a multiple of world rows
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -73,7 +73,11 @@ def test_two_rank_gradient_sum_matches_single_process(tmp_path):
         gv = torch.Generator().manual_seed(view)
         loss = sum((p * torch.rand(p.shape, generator=gv)).sum() for p in params.values())
         loss.backward()
-    np.testing.assert_allclose(got[0][:P * COLS].numpy(), b.flat.numpy(), rtol=1e-6)
+    # the two-rank bucket pads every attribute block to a multiple of world rows: compare attribute by attribute
+    b2 = GradientBucket(P, "cpu", world=world)
+    b2.flat.copy_(got[0])
+    for n, _ in LAYOUT:
+        np.testing.assert_allclose(b2.views[n].numpy(), b.views[n].numpy(), rtol=1e-6)
 
 
 def _band_worker(rank, world, port, H, W, q):
@@ -111,3 +115,106 @@ def test_image_bands_partition_and_gather(world, H):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
+
+
+# ---- owner-computes optimizer step ---------------------------------------------------------
+GOLD_OWNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "owner_adam.npz")
+NAMES = ("means3D", "scales", "rotations", "opacities", "colors", "shs")
+
+
+def _owner_run(rank, world, g, n_ranks_views=1):
+    """Replays the golden's steps through GradientBucket / FlatParams / OwnerAdam on `rank` of `world`.  The step's
+    gradient is split into `world` addends (as if each rank had rendered some of the views): rank r contributes
+    grad * w_r with w = exact binary fractions, and a disjoint part of the seen mask."""
+    from log_amd.dist import FlatParams, GradientBucket, OwnerAdam
+    P = int(g["P"])
+    tensors = {n: torch.from_numpy(g["init_" + n].copy()) for n in NAMES}
+    params = FlatParams(tensors, "cpu", world)
+    bucket = GradientBucket(P, "cpu", world, sh_coeffs=15)
+    opt = OwnerAdam(params, rank)
+    w = [1.0] if world == 1 else [0.25, 0.75]
+    for it in range(int(g["n_steps"])):
+        bucket.zero()
+        seen = torch.from_numpy(g[f"s{it}_seen"])
+        for n in NAMES:
+            bucket.views[n].copy_(torch.from_numpy(g[f"s{it}_grad_{n}"]).reshape(bucket.views[n].shape) * w[rank])
+        radii = torch.where(seen & ((torch.arange(P) % world) == rank), 5, 0)      # each row is "seen" by one rank
+        bucket.mark_seen(radii)
+        lr = {"means3D": float(g[f"s{it}_lr_means3D"]), "scales": float(g[f"s{it}_lr_scales"]), "rotations": 0.001,
+              "opacities": 0.05, "colors": 0.0025, "shs": 0.000125}
+        opt.step(bucket, params, lr)
+    return params, opt
+
+
+def _owner_worker(rank, world, port, out):
+    import oracle_backend
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle_backend.install(oracle_backend.OracleBackend())
+        params, opt = _owner_run(rank, world, np.load(GOLD_OWNER))
+        torch.save({"flat": params.flat.clone(), "exp_avg": opt.exp_avg, "exp_avg_sq": opt.exp_avg_sq},
+                   os.path.join(out, f"o{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_owner_adam_world1_reproduces_reference_optimizer(oracle_mod):
+    """world = 1: the owner-computes step IS SparseOptimizer.step (golden produced by the reference's own class)."""
+    import oracle_backend
+    g = np.load(GOLD_OWNER)
+    old = oracle_backend.install(oracle_backend.OracleBackend())
+    try:
+        params, opt = _owner_run(0, 1, g)
+    finally:
+        oracle_backend.install(old)
+    for n in NAMES:
+        np.testing.assert_allclose(params.views[n].numpy().reshape(g["final_" + n].shape), g["final_" + n], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(opt.exp_avg[n].numpy().reshape(g["final_exp_avg_" + n].shape), g["final_exp_avg_" + n],
+                                   rtol=2e-6, atol=1e-12)
+        np.testing.assert_allclose(opt.exp_avg_sq[n].numpy().reshape(g["final_exp_avg_sq_" + n].shape),
+                                   g["final_exp_avg_sq_" + n], rtol=2e-6, atol=1e-15)
+
+
+def test_owner_adam_two_ranks_match_one(tmp_path, oracle_mod):
+    """world = 2 (gloo): each rank steps only its rows, with moments for those rows only; after the all-gather both
+    replicas hold the world-1 result (the two addends 0.25 g + 0.75 g sum to g exactly), and the moments of rank r are
+    the world-1 moments of its rows."""
+    import oracle_backend
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_owner_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"o{r}.pt")) for r in range(world)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"])
+    old = oracle_backend.install(oracle_backend.OracleBackend())
+    try:
+        ref_params, ref_opt = _owner_run(0, 1, np.load(GOLD_OWNER))
+    finally:
+        oracle_backend.install(old)
+    from log_amd.dist import FlatParams
+    P = ref_params.P
+    two = FlatParams({n: ref_params.views[n] for n in NAMES}, "cpu", world)      # same layout as the workers' buffers
+    two.flat.copy_(got[0]["flat"])
+    for n in NAMES:
+        assert torch.equal(two.views[n], ref_params.views[n]), n
+        Pr = two.Pr
+        for r in range(world):
+            rows = slice(r * Pr, min((r + 1) * Pr, P))
+            k = rows.stop - rows.start
+            assert torch.equal(got[r]["exp_avg"][n][:k], ref_opt.exp_avg[n][rows]), (n, r)
+            assert torch.equal(got[r]["exp_avg_sq"][n][:k], ref_opt.exp_avg_sq[n][rows]), (n, r)
+
+
+def test_bucket_carries_sh_columns_and_seen_counts():
+    from log_amd.dist import GradientBucket, layout
+    b = GradientBucket(7, "cpu", world=2, sh_coeffs=15)
+    assert dict(b.layout)["shs"] == 45 and b.views["shs"].shape == (7, 15, 3) and b.cols == COLS + 45
+    assert b.flat.numel() == 8 * (COLS + 45) and b.Pr == 4                     # 7 rows padded to 2 x 4
+    assert layout(0) == LAYOUT
+    b.mark_seen(torch.tensor([3, 0, 1, 0, 0, 9, 0]))
+    b.mark_seen(torch.tensor([0, 2]), index=torch.tensor([1, 0]))             # a level-of-detail selection: rows 1, 0
+    assert b.seen.tolist() == [2.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0]
+    b.zero()
+    assert float(b.seen.sum()) == 0.0

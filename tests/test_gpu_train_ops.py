@@ -1,6 +1,8 @@
 """N4 on the GPU: lograst_id_histogram / lograst_counter_update / lograst_sparse_adam through the drop-ins
 (log_amd/counter.py, log_amd/sparse_optimizer.py) against results of the reference's own Counter / SparseOptimizer /
 torch.unique (tests/golden/*.npz) and against the oracle (same fp32 op sequence: compared bit for bit)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -149,3 +151,65 @@ def test_sparse_adam_many_rows_and_untouched_rows():
         sel = index[flag_vis]
         torch.testing.assert_close(now[sel] - before[k][sel], -lr * torch.sign(params[k].grad[flag_vis]), rtol=1e-3, atol=1e-6)
     assert float(opt.global_steps) == 1.0
+
+
+def test_host_resident_adam_moments_are_moved_to_the_device():
+    """LoG parks the moments on the host above 50 M points (LoG/model/splitter.py:198-204); the drop-in moves them
+    next to the parameters at the first step (288 GB of HBM) instead of refusing, and the step equals the all-device one."""
+    from log_amd import sparse_optimizer
+    import types
+    P, m = 5000, 2000
+    gen = torch.Generator(device=DEV).manual_seed(3)
+
+    def fresh(state_dev):
+        g2 = torch.Generator(device=DEV).manual_seed(4)
+        model = types.SimpleNamespace(xyz=torch.randn(P, 3, device=DEV, generator=g2), opacity=torch.randn(P, 1, device=DEV, generator=g2))
+        z = lambda: {k: torch.zeros(getattr(model, k).shape, device=state_dev) for k in ("xyz", "opacity")}
+        opt = types.SimpleNamespace(global_steps=torch.tensor(0., device=DEV), lr_dict={"opacity": 0.05}, exp_avg=z(),
+                                    exp_avg_sq=z(), use_amsgrad=False, xyz_lr=None,
+                                    xyz_scheduler_args=lambda step: 1e-3, scaling_scheduler_args=lambda step: 5e-3)
+        return model, opt
+
+    index = torch.randperm(P, device=DEV, generator=gen)[:m]
+    flag_vis = torch.rand(m, device=DEV, generator=gen) < 0.7
+    grads = {"xyz": torch.randn(m, 3, device=DEV, generator=gen), "opacity": torch.randn(m, 1, device=DEV, generator=gen)}
+    results = []
+    for state_dev in ("cpu", DEV):
+        model, opt = fresh(state_dev)
+        for _ in range(2):
+            params = {}
+            for k in ("xyz", "opacity"):
+                p = torch.nn.Parameter(getattr(model, k)[index].clone())
+                p.grad = grads[k].clone()
+                params[k] = p
+            sparse_optimizer.step(opt, model, index, params, flag_vis)
+        assert all(t.device.type == "cuda" for d in (opt.exp_avg, opt.exp_avg_sq) for t in d.values())
+        results.append((model, opt))
+    (m0, o0), (m1, o1) = results
+    for k in ("xyz", "opacity"):
+        assert torch.equal(getattr(m0, k), getattr(m1, k)) and torch.equal(o0.exp_avg[k], o1.exp_avg[k])
+
+
+def test_owner_computes_step_on_device_matches_reference_golden():
+    """log_amd.dist.OwnerAdam at world = 1 through the HIP Adam kernel: the golden produced by the reference's own
+    SparseOptimizer (tests/golden/make_golden_owner.py)."""
+    from log_amd.dist import FlatParams, GradientBucket, OwnerAdam
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "owner_adam.npz"))
+    names = ("means3D", "scales", "rotations", "opacities", "colors", "shs")
+    P = int(g["P"])
+    params = FlatParams({n: torch.from_numpy(g["init_" + n].copy()).to(DEV) for n in names}, DEV, 1)
+    bucket = GradientBucket(P, DEV, 1, sh_coeffs=15)
+    opt = OwnerAdam(params, 0)
+    for it in range(int(g["n_steps"])):
+        bucket.zero()
+        for n in names:
+            bucket.views[n].copy_(torch.from_numpy(g[f"s{it}_grad_{n}"]).to(DEV).reshape(bucket.views[n].shape))
+        bucket.mark_seen(torch.from_numpy(g[f"s{it}_seen"]).to(DEV).to(torch.int32) * 3)
+        lr = {"means3D": float(g[f"s{it}_lr_means3D"]), "scales": float(g[f"s{it}_lr_scales"]), "rotations": 0.001,
+              "opacities": 0.05, "colors": 0.0025, "shs": 0.000125}
+        moved = opt.step(bucket, params, lr)
+        assert int(moved) == int(g[f"s{it}_seen"].sum())
+    for n in names:
+        np.testing.assert_allclose(params.views[n].cpu().numpy().reshape(g["final_" + n].shape), g["final_" + n], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(opt.exp_avg[n].cpu().numpy().reshape(g["final_exp_avg_" + n].shape),
+                                   g["final_exp_avg_" + n], rtol=2e-6, atol=1e-12)

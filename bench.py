@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--no-fused-accumulate", action="store_true",
                     help="let autograd accumulate each view's gradients (5 extra passes per view) instead of the "
                          "rasterizer adding them straight into the step's gradient bucket")
+    ap.add_argument("--no-graphs", action="store_true",
+                    help="pipelined mode: enqueue every view's ~15 launches from Python instead of replaying one captured "
+                         "HIP graph per view")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 / C3 legs (they run at N = 1 only)")
@@ -129,9 +132,11 @@ class RasterWorkload:
         return out
 
 
-def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True):
+def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, graphs=False):
     """Times `steps` steps of workload `wl` with S views in flight.  sync_free=False + S=1 + fused=False is the drop-in
-    default mode.  -> dict(elapsed, t_enqueued, V, I, I_rect, prof_timed, prof_serial, bucket_floats)."""
+    default mode.  graphs: every view (forward + backward, a fixed sequence of ~15 launches once the capacity is fixed)
+    is captured into one HIP graph per (stream, camera) after the warm-up and replayed in the timed region.
+    -> dict(elapsed, t_enqueued, V, I, I_rect, prof_timed, prof_serial, bucket_floats, graphs)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -147,6 +152,8 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True):
         lanes.append((leaves, bk))
     bucket = lanes[0][1]
 
+    lane_graphs = None
+
     def step():
         main = torch.cuda.current_stream(dev)
         for st in streams:
@@ -154,7 +161,10 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True):
         for li, (leaves, bk) in enumerate(lanes):
             with torch.cuda.stream(streams[li]):
                 bk.zero()
-                if fused:
+                if lane_graphs is not None:
+                    for g in lane_graphs[li]:
+                        g.replay()
+                elif fused:
                     with R.accumulate_grads_into(bk.views):
                         for rast in wl.rasts[li::S]:
                             wl.one_view(rast, leaves)
@@ -186,7 +196,33 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True):
     R.overflow_since_reset(dev)         # clear the status block: from here on every forward is recorded in it
     for _ in range(warmup):
         step()
-    if timing:
+    res["graphs"] = False
+    if graphs and sync_free and fused:
+        # One HIP graph per (stream, camera): the view's forward and backward -- memset, projection, scan, fill, sorts,
+        # compositing, reverse walk, chain rule, plus the two torch kernels around them -- replayed with one call.
+        # Buffers come from a private pool per stream (views of different streams run concurrently).
+        try:
+            torch.cuda.synchronize()
+            built = []
+            for li, (leaves, bk) in enumerate(lanes):
+                pool, gl = torch.cuda.graph_pool_handle(), []
+                with R.accumulate_grads_into(bk.views):
+                    for rast in wl.rasts[li::S]:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool, stream=streams[li]):
+                            wl.one_view(rast, leaves)
+                        gl.append(g)
+                built.append(gl)
+            torch.cuda.synchronize()
+            lane_graphs = built
+            step()                      # one replayed step before the clock starts
+            res["graphs"] = True
+        except Exception as e:          # capture is an optimisation of the enqueue path only: say so and go on eagerly
+            lane_graphs = None
+            res["graphs_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+            torch.cuda.synchronize()
+    kernel_timing = timing and lane_graphs is None      # HIP events are not recorded inside a replayed graph
+    if kernel_timing:
         _lib.profile_reset()
         _lib.profile_enable(True)
     torch.cuda.synchronize()
@@ -204,9 +240,10 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True):
     res["elapsed"] = time.perf_counter() - t0
     res["prof_timed"] = res["prof_serial"] = None
     if timing:
-        _lib.profile_enable(False)
-        res["prof_timed"] = _lib.profile_read()
-        if S > 1:
+        if kernel_timing:
+            _lib.profile_enable(False)
+            res["prof_timed"] = _lib.profile_read()
+        if S > 1 or not kernel_timing:
             # With several views in flight the kernels time-share the chip, so their HIP-event durations in the
             # timed region measure sharing, not the kernel.  One extra, untimed, single-stream step gives the
             # per-kernel durations that profiles/ (rocprofv3, serialized) can be compared with.
@@ -228,7 +265,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True):
         t = torch.tensor([res["elapsed"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         res["elapsed"] = float(t.item())
-    del lanes, bucket
+    del lane_graphs, lanes, bucket
     return res
 
 
@@ -275,7 +312,7 @@ def main():
     fused = not args.no_fused_accumulate
     wl = RasterWorkload(args, N, dev, rank, world, torch, np)
     S = auto_streams(args, N)
-    r = measure(args, wl, S, fused, args.steps, args.warmup, world, timing)
+    r = measure(args, wl, S, fused, args.steps, args.warmup, world, timing, graphs=not args.no_graphs)
     V, I, I_rect, elapsed = r["V"], r["I"], r["I_rect"], r["elapsed"]
     head = mode_summary(N, args.views, world, args.steps, r)
 
@@ -297,7 +334,7 @@ def main():
                            ", %d view(s) in flight per GPU (HIP streams)" % S,
         },
         "ms_per_view": head["ms_per_view"], "host_enqueue_ms_per_view": head["host_enqueue_ms_per_view"],
-        "modes": {"pipelined": dict(head, streams=S, sync_free=True, fused_gradient_accumulation=fused,
+        "modes": {"pipelined": dict(head, streams=S, sync_free=True, fused_gradient_accumulation=fused, hip_graphs=r["graphs"],
                                     note="value of this line: capacity from the warm-up, no host sync in forward(), "
                                          "gradients added by the backward kernels into the step's bucket")},
     }
@@ -320,10 +357,17 @@ def main():
         copy_gbs = measured_copy_bandwidth(dev)
         result["measured_copy_GBs"] = copy_gbs
         result["algorithmic_frac_of_measured_copy"] = result["algorithmic_GBs_whole_view"] / copy_gbs
+        if r.get("graphs_error"):
+            result["graphs_error"] = r["graphs_error"]
         if timing:
             if r["prof_serial"] is None:
                 result["kernels"], result["roofline"] = roof(r["prof_timed"], alg, N, W, H)
                 result["roofline"]["measured"] = "HIP events on the launch stream inside the timed region (one stream)"
+            elif r["prof_timed"] is None:
+                result["kernels"], result["roofline"] = roof(r["prof_serial"], alg, N, W, H)
+                result["roofline"]["measured"] = ("HIP events on the launch stream, one eagerly launched single-stream step "
+                                                  "run right after the timed region (inside it the views are replayed "
+                                                  "HIP graphs, which carry no events)")
             else:
                 # S > 1: the kernel's own duration comes from the single-stream step (this is what rocprofv3, which
                 # serialises kernels, reports for the same command); the time-shared durations of the timed region
@@ -344,12 +388,13 @@ def main():
             if N != 1_000_000:
                 wl2 = RasterWorkload(args, 1_000_000, dev, rank, world, torch, np)
                 S2, steps2 = auto_streams(args, 1_000_000), max(args.steps, 5)
-                r2 = measure(args, wl2, S2, fused, steps2, max(args.warmup, 2), world, timing)
+                r2 = measure(args, wl2, S2, fused, steps2, max(args.warmup, 2), world, timing, graphs=not args.no_graphs)
                 c2 = {"workload": "C2 (BASELINE.json configs[1]): 1000000 random Gaussians (seed 0, opacity %s), %dx%d, "
                                   "%d orbit views, same harness as the headline"
                                   % ("rand" if args.opacity < 0 else args.opacity, W, H, args.views),
                       "visible_per_view": r2["V"], "tile_instances_per_view": r2["I"],
-                      "modes": {"pipelined": dict(mode_summary(1_000_000, args.views, 1, steps2, r2), streams=S2)}}
+                      "modes": {"pipelined": dict(mode_summary(1_000_000, args.views, 1, steps2, r2), streams=S2,
+                                                  hip_graphs=r2["graphs"])}}
                 if timing:
                     alg2 = algorithmic_bytes(1_000_000, r2["V"], r2["I"], Px)
                     c2["kernels"], c2["roofline"] = roof(r2["prof_serial"] or r2["prof_timed"], alg2, 1_000_000, W, H)

@@ -24,6 +24,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_off, hipStream_t s);
 void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, hipStream_t s);
+void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
                     int zero_block_floats, int rebased, hipStream_t s);
@@ -273,7 +274,7 @@ static int lr_stage1(const LrView& v, int32_t n, const float* means3d, const flo
   // counter per 64 B.  Header and counters are zeroed by ONE memset (offsets/cursors are fully rewritten by the scan).
   const uint32_t cs = bt.batch ? 1u : (uint32_t)LR_CTR_STRIDE;
   const uint32_t big_off = bt.batch ? lr_ranked_off(tiles) + tiles : lr_big_off(tiles);
-  LR_HIP(hipMemsetAsync(st, 0, sizeof(uint32_t) * (size_t)(big_off + tiles * cs), s));
+  lr_launch_zero_words(st, ((size_t)(big_off + tiles * cs) + 3) & ~(size_t)3, s);   // the words behind the counters (offsets[]) are rewritten by the scan
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
                     st + big_off, st, st + lr_basetab_off(tiles), (int)bt.batch, (int)bt.planes, lr_tile_cull(), s);
   lr_launch_scan(st, tiles, cs, big_off, s);
@@ -314,8 +315,8 @@ static int lr_check_stage1_args(int32_t n, const float* means3d, const float* sc
   if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
   if (n > 0 && (!means3d || !scales || !rotations || !opacities || !colors || !radii || !geom))
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
-  if ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(geom)) & 15u)
-    return lr_fail(LOGRAST_ERR_ARG, "rotations / geom must be 16-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(geom) | reinterpret_cast<uintptr_t>(tile_state)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "rotations / geom / tile_state must be 16-byte aligned");
   return LOGRAST_OK;
 }
 

@@ -753,3 +753,17 @@ void lr_launch_zero_touched(int N, const float* pw, float* conic, hipStream_t s)
   hipLaunchKernelGGL(lr_zero_touched_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, pw, reinterpret_cast<float4*>(conic));
   lr_prof_end(LRK_ZERO_TOUCHED, s);
 }
+
+// Clears the header + per-tile counters of a tile_state before the projection (a kernel rather than hipMemsetAsync: the
+// launch sequence of a view is captured into HIP graphs, several of which replay concurrently on different streams, and
+// memset nodes of concurrently replayed graphs were observed to leave the counters of one of them uncleared).
+__global__ void __launch_bounds__(256)
+lr_zero_words_kernel(uint4* __restrict__ p, uint32_t n4) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n4) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s) {
+  const uint32_t n4 = (uint32_t)((words + 3) / 4);   // callers pad to 16 bytes (LR_HDR_WORDS and the counter arrays are multiples of 4 words)
+  if (!n4) return;
+  hipLaunchKernelGGL(lr_zero_words_kernel, dim3((n4 + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n4);
+}

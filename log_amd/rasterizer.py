@@ -63,6 +63,7 @@ _capacity_hint = None
 _max_len_hint = 0
 _status = {}          # device -> int32[8] status block (sticky across forwards, all streams)
 _debug_keep = False   # tests: keep dL/dconic of the last backward (HipBackend.last_conic_grad)
+_DEBUG_ADDR = bool(int(__import__('os').environ.get('LOGRAST_DEBUG_ADDR', '0')))
 
 
 def set_instance_capacity(n, max_tile_len=0):
@@ -262,6 +263,8 @@ class HipBackend:
                     _ptr(o["image"]), _ptr(k["final_T"]), _ptr(k["n_contrib"]), _ptr(o.get("pid")), _ptr(o.get("pwp")),
                     _ptr(o.get("pw")), _ptr(k.get("bwd_scratch")), scratch_floats if "bwd_scratch" in k else 0,
                     _ptr(status), stream))
+        if _DEBUG_ADDR:
+            print("fwd state@%x keys@%x capacity=%d stream=%x" % (k["state"].data_ptr(), keys.data_ptr(), capacity, stream.value or 0), flush=True)
         del keys, keep
         saved = dict(radii=o["radii"], geom=k["geom"].view(f32), state=k["state"].view(i32), plist=plist,
                      final_T=k["final_T"], n_contrib=k["n_contrib"], bwd_scratch=k.get("bwd_scratch"),

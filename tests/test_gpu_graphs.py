@@ -85,8 +85,16 @@ def test_captured_view_replays_identically_alone_and_concurrently():
                 r_img, r_m2, r_flat = ref[li]
                 assert torch.equal(img, r_img), (mode, li)          # the forward is deterministic: bit for bit
                 assert float((m2.grad - r_m2).norm() / r_m2.norm()) < 1e-5, (mode, li)
-                # (the chain-rule columns amplify the atomic-order noise of ill-conditioned rows: the 1e-4 bar of the path)
-                assert float((bk.flat - r_flat).norm() / r_flat.norm()) < 1e-4, (mode, li)
+                rb = GradientBucket(n, dev, 1)
+                rb.flat.copy_(r_flat)
+                for k in ("opacities", "colors"):                    # reverse-walk outputs: every row
+                    assert float((bk.views[k] - rb.views[k]).norm() / rb.views[k].norm()) < 1e-5, (mode, li, k)
+                for k in ("means3D", "scales", "rotations"):         # chain rule: pancake-flat rows amplify the atomics' order
+                    d = (bk.views[k] - rb.views[k]).norm(dim=1)
+                    ref_n = rb.views[k].norm(dim=1)
+                    live = ref_n > 1e-6 * ref_n.max()
+                    rel = (d[live] / ref_n[live]).float().cpu()
+                    assert float(rel.median()) < 1e-5 and float(torch.quantile(rel, 0.97)) < 1e-3, (mode, li, k)
         chk = R.overflow_since_reset(dev)
         assert not chk["overflowed"] and chk["forwards"] >= 6
     finally:

@@ -147,14 +147,16 @@ lr_sort_rb_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint
 // owning thread ranking the bucket key by key, n^2 DEPENDENT LDS reads at ~150 ns each under load -- cost 20-30 us per
 // 12 K-key window (wall_clock64 per phase), i.e. most of the long-list sort; one thread per KEY, each counting the
 // smaller keys of its own bucket (~20 dependent round trips per key), measured 37 us.
-// Call with the whole wave converged; `valid` = this lane owns a bucket.  bk[] and out[] are indexed by list position.
-LR_DEV void lr_emit_bucket(const uint64_t* __restrict__ bk, uint32_t st, uint32_t en, bool valid,
-                           uint32_t* __restrict__ out) {
+// Call with the whole wave converged; `valid` = this lane owns a bucket.  key_at(pos) returns the key staged for list
+// position pos (from LDS, or -- long lists -- through an LDS index into the tile's key slice); out[] is indexed by
+// list position.
+template <typename KeyAt>
+LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, uint32_t* __restrict__ out) {
   const uint32_t n = valid ? en - st : 0u;
   if (n <= 8u) {
     uint64_t r[8];
 #pragma unroll
-    for (int m = 0; m < 8; m++) r[m] = (uint32_t)m < n ? bk[st + m] : ~0ull;
+    for (int m = 0; m < 8; m++) r[m] = (uint32_t)m < n ? key_at(st + (uint32_t)m) : ~0ull;
     lr_sort8(r);
 #pragma unroll
     for (int m = 0; m < 8; m++)
@@ -162,19 +164,28 @@ LR_DEV void lr_emit_bucket(const uint64_t* __restrict__ bk, uint32_t st, uint32_
   }
   uint64_t big = __ballot(n > 8u);
   const uint32_t lane = threadIdx.x & 63u;
-  while (big) {
-    const int src = __builtin_ctzll(big);
-    big &= big - 1;
-    const uint32_t bst = (uint32_t)lr_readlane_i((int)st, src);
-    const uint32_t bn = min((uint32_t)lr_readlane_i((int)n, src), 64u);   // <= LR_BUCKET_MAX by the callers' check
-    const uint64_t key = lane < bn ? bk[bst + lane] : ~0ull;
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-    uint32_t smaller = 0;
-    for (uint32_t j = 0; j < bn; j++) {
-      const uint64_t kj = ((uint64_t)(uint32_t)lr_readlane_i((int)khi, (int)j) << 32) | (uint32_t)lr_readlane_i((int)klo, (int)j);
-      smaller += kj < key ? 1u : 0u;
+  while (big) {   // four big buckets per round: their keys are requested together (key_at may be a two-level gather)
+    uint32_t bst[4], bn[4];
+    uint64_t key[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const bool have = big != 0;
+      const int src = have ? __builtin_ctzll(big) : 0;
+      big &= big - 1;                                        // no-op once big == 0
+      bst[q] = (uint32_t)lr_readlane_i((int)st, src);
+      bn[q] = have ? min((uint32_t)lr_readlane_i((int)n, src), 64u) : 0u;   // <= LR_BUCKET_MAX by the callers' check
+      key[q] = lane < bn[q] ? key_at(bst[q] + lane) : ~0ull;
     }
-    if (lane < bn) out[bst + smaller] = klo;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t klo = (uint32_t)key[q], khi = (uint32_t)(key[q] >> 32);
+      uint32_t smaller = 0;
+      for (uint32_t j = 0; j < bn[q]; j++) {
+        const uint64_t kj = ((uint64_t)(uint32_t)lr_readlane_i((int)khi, (int)j) << 32) | (uint32_t)lr_readlane_i((int)klo, (int)j);
+        smaller += kj < key[q] ? 1u : 0u;
+      }
+      if (lane < bn[q]) out[bst[q] + smaller] = klo;
+    }
   }
 }
 // LONG = false: blockIdx.x is the tile; the keys are also staged in network layout so that the workgroup can fall
@@ -291,14 +302,18 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
 
 // ---- long lists: the same depth-bucket sort, keys in memory ----------------------------------------------------
 // One 1024-thread workgroup per long tile (biglist entry); bucket counters in LDS, keys streamed from memory:
-//   pass 1  min / max depth;
+//   pass 1  depth range of the first eighth of the list (a random sample: the keys arrive in no particular order);
 //   pass 2  bucket + rank of every key (returning LDS atomic); a 4-byte (bucket, rank) code per key goes to the
 //           scratch half of the key buffer (coalesced);
 //   scan    bucket starts;
-//   then, window by window (LR_LONG_WIN list positions, cut at bucket boundaries): every key whose destination falls
-//           into the window (known from its code: 4 B re-read per key and window, cache-resident) is fetched and
-//           dropped into an LDS copy of that window, ranked inside its bucket there, and its id written to its final
-//           list position.
+//   then, window by window (7680 list positions, cut at bucket boundaries): every key whose destination falls into
+//           the window (known from its code: 4 B re-read per key and window, cache-resident) is fetched and dropped at
+//           its bucket position in an LDS copy of that window; one thread per bucket then orders the bucket's keys in
+//           registers and writes the ids to their final list positions (lr_emit_bucket).
+// (Measured alternative, removed: 16-bit key INDICES in the window instead of the keys -- one window then covers a
+// 20 K-key list and the staging runs once (5.6 instead of 4 x 7.5 us per tile) -- but the final order has to gather the
+// keys back through the indices, 8-byte reads scattered over the tile's 176 KB slice while 500 other tiles do the same:
+// 50 us per tile instead of 4 x 9.)
 // (Measured alternative, removed: one 1024-thread workgroup per tile holding the depth bits of all its keys in VGPRs --
 // 24 per thread, keys read from memory once -- needs all 128 VGPRs, i.e. ONE workgroup per CU, and every phase of this
 // sort is a short chain of LDS round trips at ~150 ns each: 60 us per 20 K-key tile against 2 x 57 us here with two
@@ -309,11 +324,12 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
 // clustered (a bucket above LR_BUCKET_MAX keys) is left to the network paths below, a finished one is flagged in
 // its biglist entry so that they skip it.
 #define LR_LONG_NB 4096     // bucket counters in LDS
-#define LR_LONG_WIN 6144    // list positions ranked in LDS at a time
+#define LR_LONG_WIN_BYTES 61440   // LDS window: 7680 keys staged at a time (16 KB counters + this: two workgroups per CU)
 #define LR_LONG_UNR 8       // independent loads in flight per thread in the streaming passes
 __global__ void __launch_bounds__(1024)
 lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity) {
+  constexpr uint32_t LR_LONG_WIN = LR_LONG_WIN_BYTES / sizeof(uint64_t);
   extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
   uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
   __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[16];
@@ -326,6 +342,13 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   const uint64_t* k = keys + beg;
   uint32_t* rk = ranks + beg;
   uint32_t* pl = plist + beg;
+#ifdef LR_LONG_TICKS   // phase timing experiment (-DLR_LONG_TICKS): wall_clock64 per phase, printed by three workgroups
+  uint64_t tk[16]; int tn = 0;
+#define LR_TICK() do { if (tn < 16) tk[tn++] = wall_clock64(); } while (0)
+#else
+#define LR_TICK() do { } while (0)
+#endif
+  LR_TICK();
   uint32_t P2 = 8;
   while (P2 < L) P2 <<= 1;
   const uint32_t nb = min((uint32_t)LR_LONG_NB, P2 >> 1);
@@ -354,6 +377,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   __syncthreads();
   if ((tid & 63u) == 0u) { atomicMin(&sh_min, dmin); atomicMax(&sh_max, dmax); }
   __syncthreads();
+  LR_TICK();
   const float fmin = __uint_as_float(sh_min), range = __uint_as_float(sh_max) - fmin;
   const float scale = (float)nb / range;
   auto bucket_of = [&](uint64_t key) -> uint32_t {
@@ -375,6 +399,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
       if (i + u * 1024u < L) rk[i + u * 1024u] = cd[u];
   }
   __syncthreads();
+  LR_TICK();
   // exclusive scan of the nb counts: thread t owns counters [t * per, (t + 1) * per); every wave scans the 16 wave totals
   const uint32_t per = (nb + 1023u) / 1024u;               // <= LR_LONG_NB / 1024
   uint32_t cown[LR_LONG_NB / 1024];
@@ -412,6 +437,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
     }
   }
   __syncthreads();
+  LR_TICK();
   // windows of whole buckets: [b0, b1) with start(b1) - start(b0) <= LR_LONG_WIN (a bucket holds <= LR_BUCKET_MAX keys)
   uint32_t b0 = 0;
   while (b0 < nb) {
@@ -443,20 +469,31 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
       }
     }
     __syncthreads();
+    LR_TICK();
     for (uint32_t bb = b0; bb < b1; bb += 1024u) {           // (uniform trip count: the emit needs whole waves)
       const uint32_t b = bb + tid;
       const bool valid = b < b1;
-      lr_emit_bucket(win - w0, valid ? lcnt[b] : 0u, valid ? ((b + 1u < nb) ? lcnt[b + 1u] : L) : 0u, valid, pl);   // win[] holds positions [w0, w1)
+      lr_emit_bucket([&](uint32_t pos) -> uint64_t { return win[pos - w0]; },   // win[] holds positions [w0, w1)
+                     valid ? lcnt[b] : 0u, valid ? ((b + 1u < nb) ? lcnt[b + 1u] : L) : 0u, valid, pl);
     }
     __syncthreads();
+    LR_TICK();
     b0 = b1;
   }
 
   if (tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
+#ifdef LR_LONG_TICKS
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700 || blockIdx.x == 2000)) {
+    printf("longsort blk %u L %u nb %u ticks(10ns):", blockIdx.x, L, nb);
+    for (int q = 1; q < tn; q++) printf(" %llu", (unsigned long long)(tk[q] - tk[q - 1]));
+    printf("\n");
+  }
+#endif
+#undef LR_TICK
 }
 
 static inline size_t lr_long_lds_bytes() {
-  return sizeof(uint32_t) * LR_LONG_NB + sizeof(uint64_t) * (LR_LONG_WIN + LR_BUCKET_MAX);
+  return sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_t) * LR_BUCKET_MAX;
 }
 
 // Single-block network fallback for long tiles of (LR_LONG_LIST, LR_SORT_BLOCK] keys the bucket sort gave up on.

@@ -32,7 +32,7 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
                     uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, hipStream_t s);
+                         int* pid, float* pwp, float* pw, float* zero_conic, hipStream_t s);
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
@@ -40,7 +40,6 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, const float* pw,
                            float* g_means3d, float* g_scales, float* g_rots, bool accumulate, hipStream_t s);
-void lr_launch_zero_touched(int N, const float* pw, float* conic, hipStream_t s);
 
 size_t lr_knn_scratch_bytes(int P);
 hipError_t lr_launch_knn(int P, const float* pts, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
@@ -143,7 +142,7 @@ static int lr_tile_cull() {
 static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
     "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
     "blend_fwd", "blend_bwd", "project_bwd", "knn3", "lod_traverse", "counter_update", "sparse_adam",
-    "id_histogram", "gather_activate", "activate_bwd", "count_huge", "rebase_slots", "zero_touched"};
+    "id_histogram", "gather_activate", "activate_bwd", "count_huge", "rebase_slots", "reserved"};
 struct ProfRec { int slot; hipEvent_t a, b; bool own_a; };
 // Consecutive launches inside one entry point share an event: the end of kernel k is the begin of kernel k+1 (N+1
 // events for a chain of N kernels instead of 2N; every recorded event costs ~1.4 us of stream time).
@@ -290,8 +289,9 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   if (n == 0 && status)   // no fill kernel runs: this forward's entries of the status block
     LR_HIP(hipMemsetAsync(status + LOGRAST_STATUS_LAST_INSTANCES, 0, 4 * sizeof(uint32_t), s));
   // point_weight (atomicMax target) and the optional backward scratch are cleared by the fill kernel -- except, in
-  // the 5-tuple flavour, the scratch's leading dL/dconic block [n,4]: only the rows of Gaussians that contributed to
-  // a pixel (point_weight > 0, known after compositing) will ever be read, and they are cleared below
+  // the 5-tuple flavour on large inputs, the scratch's leading dL/dconic block [n,4]: only the rows of Gaussians that
+  // contribute to a pixel will ever be read, and the compositing kernel clears exactly those when it meets them
+  // (a separate pass over point_weight afterwards cost 70 us per 30 M-Gaussian view, the stores inside the kernel 30)
   const bool touched_only = v.extras && bwd_scratch_floats >= 4 && lr_big_input(n);
   float* zero_block = bwd_scratch_floats > 0 ? bwd_scratch : nullptr;
   int zero_floats = bwd_scratch_floats;
@@ -303,8 +303,7 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
-                      point_weight_pixel, point_weight, s);
-  if (touched_only) lr_launch_zero_touched(n, point_weight, bwd_scratch, s);
+                      point_weight_pixel, point_weight, touched_only ? bwd_scratch : nullptr, s);
   return LOGRAST_OK;
 }
 

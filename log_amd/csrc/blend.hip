@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(256)
 lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
-                    int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw, int xcd_mode,
-                    int cull) {
+                    int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
+                    float4* __restrict__ zero_conic, int xcd_mode, int cull) {
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
@@ -196,7 +196,12 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (EXTRAS) {
           if (w0 > wmax) { wmax = w0; wid = gid; }
           const uint32_t m = lr_wave_umax_to63(__float_as_uint(w0));  // w >= 0: unsigned order == float order
-          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
+          if (lane == 63) {
+            atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
+            // training forward: this Gaussian contributes, so the reverse walk will add to its dL/dconic row -- clear it
+            // (every wave that meets the Gaussian stores the same zeros; rows of Gaussians nobody meets are never read)
+            if (zero_conic) zero_conic[gid] = float4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
       if (hit1) {
@@ -206,7 +211,12 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (EXTRAS) {
           if (w1 > wmax) { wmax = w1; wid = gid; }
           const uint32_t m = lr_wave_umax_to63(__float_as_uint(w1));
-          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
+          if (lane == 63) {
+            atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
+            // training forward: this Gaussian contributes, so the reverse walk will add to its dL/dconic row -- clear it
+            // (every wave that meets the Gaussian stores the same zeros; rows of Gaussians nobody meets are never read)
+            if (zero_conic) zero_conic[gid] = float4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
       if (!(hit0 | hit1) && __all(done)) break;
@@ -227,7 +237,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, hipStream_t s) {
+                         int* pid, float* pwp, float* pw, float* zero_conic, hipStream_t s) {
   static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
   static const size_t lds_fwd = (size_t)lr_env_int("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;
@@ -235,10 +245,12 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   lr_prof_begin(LRK_BLEND_FWD, s);
   if (v.extras)
     hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw,
+                       reinterpret_cast<float4*>(zero_conic), xcd_mode, cull);
   else
     hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw, xcd_mode, cull);
+                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw,
+                       reinterpret_cast<float4*>(zero_conic), xcd_mode, cull);
   lr_prof_end(LRK_BLEND_FWD, s);
 }
 

@@ -399,7 +399,7 @@ struct ActBwdArgs {
 enum LrKernelSlot {
   LRK_RADIUS = 0, LRK_PROJECT, LRK_SCAN, LRK_FILL, LRK_SORT_SMALL, LRK_SORT_LARGE, LRK_SORT_HUGE,
   LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_LOD, LRK_COUNTER, LRK_ADAM, LRK_HIST, LRK_GATHER, LRK_GATHER_BWD, LRK_RESERVED,
-  LRK_REBASE, LRK_ZERO_TOUCHED
+  LRK_REBASE, LRK_SPARE
 };
 void lr_prof_begin(int slot, hipStream_t s);
 void lr_prof_end(int slot, hipStream_t s);

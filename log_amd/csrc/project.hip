@@ -230,6 +230,28 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
 // one XCD within microseconds of each other.  It also divides the reservation atomics by S.
 // 82 VGPRs: one 1024-thread workgroup per CU.  Forcing two (amdgpu_waves_per_eu(8): 64 VGPRs, 19 spilled) is slower
 // at every size (1 M: 62 -> 81 us, 30 M: 1.06 -> 1.68 ms).
+// 4x4 transpose of float4 "elements" inside every group of four consecutive lanes: on entry lane m of a group holds
+// (a, b, c, d) = its own four values, on exit value k of lane m is what lane k held in slot m.  Two butterfly stages of
+// DPP quad permutes (lane ^ 1, lane ^ 2), per dword.
+template <int CTRL>
+LR_DEV float lr_quad_perm_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+LR_DEV void lr_quad_exchange(float4& lo, float4& hi, bool upper) {
+  // lanes with `upper` send lo and keep hi; the others send hi and keep lo; each receives its partner's value in the slot it sent
+  const float4 send = upper ? lo : hi;
+  const float4 got = {lr_quad_perm_f<CTRL>(send.x), lr_quad_perm_f<CTRL>(send.y), lr_quad_perm_f<CTRL>(send.z),
+                      lr_quad_perm_f<CTRL>(send.w)};
+  if (upper) lo = got; else hi = got;
+}
+LR_DEV void lr_quad_transpose(float4& a, float4& b, float4& c, float4& d, int m) {
+  lr_quad_exchange<0xB1>(a, b, (m & 1) != 0);   // quad_perm [1,0,3,2]
+  lr_quad_exchange<0xB1>(c, d, (m & 1) != 0);
+  lr_quad_exchange<0x4E>(a, c, (m & 2) != 0);   // quad_perm [2,3,0,1]
+  lr_quad_exchange<0x4E>(b, d, (m & 2) != 0);
+}
+
 #define LR_MAX_PLANES 4
 __global__ void __launch_bounds__(LR_BATCH_THREADS)
 lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
@@ -252,19 +274,37 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   int i = i_begin + (int)threadIdx.x;
   LrInputs nxt;
   if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors);
-  for (; i < i_end; i += LR_BATCH_THREADS) {
+  // (trip count uniform per wave: the record stores below are cooperative among groups of four lanes)
+  for (; (i & ~63) < i_end; i += LR_BATCH_THREADS) {
+    const bool mine = i < i_end;
     const LrInputs in = nxt;
     if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors);
-    const int plane = (i - i_begin) / B;                    // B is a multiple of the workgroup size: uniform per iteration
+    const int plane = ((i & ~63) - i_begin) / B;            // B is a multiple of the workgroup size: uniform per iteration
     const LrLdsCounters ctr{lr_lds_ctr + plane * tiles};
-    float4 g0, g1, g2, g3;
-    int rad;
-    bool huge;
-    lr_project_one<true>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
-    if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
-    radii[i] = rad;
-    float4* rec = geom + LR_REC_QUADS * (size_t)i;
-    rec[0] = g0; rec[1] = g1; rec[2] = g2; rec[3] = g3;     // q3 is not read in this mode: written to complete the 64-byte line
+    float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+    int rad = 0;
+    bool huge = false;
+    if (mine) {
+      lr_project_one<true>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
+      if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
+      radii[i] = rad;
+    }
+    // Records leave as full 64-byte lines: a lane's four quads are 64 B apart from its neighbour's, so storing them
+    // lane by lane makes every store instruction touch 64 lines with 16 B each (four partial writes per line at the
+    // L2).  A 4x4 transpose inside every group of four lanes (two DPP quad-permute stages) gives lane m the quad m of
+    // its group's four Gaussians: each store instruction then writes 16 complete lines.
+    {
+      const int m = (int)threadIdx.x & 3;
+      float4 t0 = g0, t1 = g1, t2 = g2, t3 = g3;
+      lr_quad_transpose(t0, t1, t2, t3, m);                  // t[k] = quad m of Gaussian (i - m + k)
+      const int ib = i - m;
+      float4* rec = geom + LR_REC_QUADS * (size_t)ib + m;
+      if (ib + 0 < i_end) rec[0 * LR_REC_QUADS] = t0;
+      if (ib + 1 < i_end) rec[1 * LR_REC_QUADS] = t1;
+      if (ib + 2 < i_end) rec[2 * LR_REC_QUADS] = t2;
+      if (ib + 3 < i_end) rec[3 * LR_REC_QUADS] = t3;       // (q3 is not read in this mode: written to complete the 64-byte line)
+    }
+    if (!mine) continue;
     // Fill record (16 B, its own coalesced array behind the records): everything lr_fill_kernel needs, so that it
     // does not fetch half of every 64-byte record again.  x = depth bits; y = x0 | y0<<13 | (w-1)<<26 | (h-1)<<28 |
     // big<<30 (all ones = nothing to fill); ranked: z,w = four 16-bit ranks inside the batch (0xffff = tile dropped
@@ -323,11 +363,15 @@ __global__ void __launch_bounds__(256)
 lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,
                      const uint32_t* __restrict__ hugecount, int B, int tile_cull, int defer_tiles, int chunk) {
   extern __shared__ uint32_t lr_lds_ctr[];
-  const int base = blockIdx.x * chunk;
+  // (the grid is capped at a few workgroups per CU: each walks its share of the chunks and skips, with one scalar
+  // read, those whose batches deferred nothing -- 58 K workgroups that only return cost a 30 M-Gaussian view 30 us)
+  for (int chunk_id = blockIdx.x; chunk_id * chunk < N; chunk_id += gridDim.x) {
+  const int base = chunk_id * chunk;
   const int b0 = base / B, b1 = min(N - 1, base + chunk - 1) / B;
   uint32_t any = 0;
   for (int b = b0; b <= b1; b++) any |= hugecount[b];
-  if (!any) return;
+  if (!any) continue;
+  __syncthreads();                                           // (the previous chunk's flush has read the counters)
   for (int t = threadIdx.x; t < tiles; t += 256) lr_lds_ctr[t] = 0u;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -371,6 +415,7 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
     const uint32_t c = lr_lds_ctr[t];
     if (c) atomicAdd(&big[t], c);   // dense counters in batched mode
   }
+  }
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
@@ -400,7 +445,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        basetab, hugecount, tile_cull, batch, planes, defer_tiles);
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
-    hipLaunchKernelGGL(lr_count_huge_kernel, dim3((N + chunk - 1) / chunk), dim3(256), lds, s, N, v.gx,
+    hipLaunchKernelGGL(lr_count_huge_kernel, dim3(min((N + chunk - 1) / chunk, 2048)), dim3(256), lds, s, N, v.gx,
                        tiles, reinterpret_cast<const float4*>(geom), big, (const uint32_t*)hugecount, batch, tile_cull,
                        defer_tiles, chunk);
     lr_prof_end(LRK_RESERVED, s);
@@ -737,21 +782,6 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
                      reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, max_len_hint, status, zero_n,
                      zero_block, zero_block_floats, xcd_order, fill_nt, ablate, rebased);
   lr_prof_end(LRK_FILL, s);
-}
-
-// After compositing (5-tuple flavour, training forward): clear dL/dconic [N,4] for the Gaussians that contributed to a
-// pixel (point_weight > 0).  The rows of all the others are never read (lr_project_bwd_kernel<., true>), so the
-// forward does not spend 16 B per Gaussian zero-filling them.
-__global__ void __launch_bounds__(256)
-lr_zero_touched_kernel(int N, const float* __restrict__ pw, float4* __restrict__ conic) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < N && pw[i] > 0.f) conic[i] = float4{0.f, 0.f, 0.f, 0.f};
-}
-void lr_launch_zero_touched(int N, const float* pw, float* conic, hipStream_t s) {
-  if (N <= 0) return;
-  lr_prof_begin(LRK_ZERO_TOUCHED, s);
-  hipLaunchKernelGGL(lr_zero_touched_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, pw, reinterpret_cast<float4*>(conic));
-  lr_prof_end(LRK_ZERO_TOUCHED, s);
 }
 
 // Clears the header + per-tile counters of a tile_state before the projection (a kernel rather than hipMemsetAsync: the

@@ -8,7 +8,7 @@
 // TOUCHED (lograst_backward with a point_weight array): a Gaussian whose forward blend weight stayed 0 contributed
 // to no pixel, so the reverse walk added nothing to its dL/dmean2D and dL/dconic -- both are exactly zero and so is
 // everything the chain rule would compute from them.  Such rows are skipped without reading their 56 input bytes or
-// their accumulators (whose conic part the forward then need not even zero-fill) and without the 80-byte read-modify-
+// their accumulators (whose conic part the forward then does not zero-fill: the compositing kernel clears the rows it meets) and without the 80-byte read-modify-
 // write of the running sums: in an opaque scene most Gaussians are hidden (30 M random Gaussians at opacity 0.999:
 // the kernel went from 0.83 ms, at the copy rate, to the touched rows' share).
 template <bool ACCUMULATE, bool TOUCHED>

@@ -148,10 +148,9 @@ lr_sort_rb_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint
 // 12 K-key window (wall_clock64 per phase), i.e. most of the long-list sort; one thread per KEY, each counting the
 // smaller keys of its own bucket (~20 dependent round trips per key), measured 37 us.
 // Call with the whole wave converged; `valid` = this lane owns a bucket.  key_at(pos) returns the key staged for list
-// position pos (from LDS, or -- long lists -- through an LDS index into the tile's key slice); out[] is indexed by
-// list position.
+// position pos; out[ostride * pos] receives the id of list position pos.
 template <typename KeyAt>
-LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, uint32_t* __restrict__ out) {
+LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, uint32_t* out, uint32_t ostride = 1u) {
   const uint32_t n = valid ? en - st : 0u;
   if (n <= 8u) {
     uint64_t r[8];
@@ -160,7 +159,7 @@ LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, u
     lr_sort8(r);
 #pragma unroll
     for (int m = 0; m < 8; m++)
-      if ((uint32_t)m < n) out[st + m] = (uint32_t)r[m];
+      if ((uint32_t)m < n) out[(size_t)ostride * (st + m)] = (uint32_t)r[m];
   }
   uint64_t big = __ballot(n > 8u);
   const uint32_t lane = threadIdx.x & 63u;
@@ -184,7 +183,7 @@ LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, u
         const uint64_t kj = ((uint64_t)(uint32_t)lr_readlane_i((int)khi, (int)j) << 32) | (uint32_t)lr_readlane_i((int)klo, (int)j);
         smaller += kj < key[q] ? 1u : 0u;
       }
-      if (lane < bn[q]) out[bst[q] + smaller] = klo;
+      if (lane < bn[q]) out[(size_t)ostride * (bst[q] + smaller)] = klo;
     }
   }
 }
@@ -473,8 +472,17 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
     for (uint32_t bb = b0; bb < b1; bb += 1024u) {           // (uniform trip count: the emit needs whole waves)
       const uint32_t b = bb + tid;
       const bool valid = b < b1;
+      // the ordered ids go back into the (now consumed) window slots of their bucket, low word of the slot at the final
+      // position: the copy-out below then writes the list in full lines instead of 4-byte pieces 20 bytes apart
       lr_emit_bucket([&](uint32_t pos) -> uint64_t { return win[pos - w0]; },   // win[] holds positions [w0, w1)
-                     valid ? lcnt[b] : 0u, valid ? ((b + 1u < nb) ? lcnt[b + 1u] : L) : 0u, valid, pl);
+                     valid ? lcnt[b] : 0u, valid ? ((b + 1u < nb) ? lcnt[b + 1u] : L) : 0u, valid,
+                     reinterpret_cast<uint32_t*>(win) - 2 * (size_t)w0, 2u);
+    }
+    __syncthreads();
+    {
+      const uint32_t w1 = b1 < nb ? lcnt[b1] : L;
+      const uint32_t* ids = reinterpret_cast<const uint32_t*>(win);
+      for (uint32_t p = w0 + tid; p < w1; p += 1024u) pl[p] = ids[2u * (p - w0)];
     }
     __syncthreads();
     LR_TICK();

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -25,27 +25,24 @@ def stats(path, title, out):
     open(out, "w").write("\n".join(o) + "\n")
 
 
-for n, t in (("b_default", "default"), ("b_s1", "streams1"), ("b_10M", "10M"), ("b_30M", "30M")):
+for n, t in (("b_default", "default"), ("b_oprand", "opacity_rand"), ("b_10M", "10M")):
     f = os.path.join(G, n + ".log")
     if os.path.exists(f) and any(l.startswith("{") for l in open(f)):
         line = [l for l in open(f) if l.startswith("{")][-1]
         json.dump(json.loads(line), open(os.path.join(P, f"{tag}_bench_{t}.json"), "w"), indent=1)
-cmd = "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
-for d, suffix, extra in ((f"{tag}_trace", "", " --streams 1 (serialized kernels)"), (f"{tag}_trace_default", "_default", " (default: 3 streams)")):
-    src = os.path.join(G, d, "c2_kernel_stats.csv")
-    if os.path.exists(src):
-        stats(src, f"rocprofv3 --kernel-trace --stats -- {cmd}{extra}; C2 workload", os.path.join(P, f"{tag}_kernel_stats{suffix}.md"))
-        shutil.copy(src, os.path.join(P, f"{tag}_kernel_stats{suffix}.csv"))
-src = os.path.join(G, f"{tag}_trace_log_step", "step_kernel_stats.csv")
+cmd = ("python bench.py --views 4 --steps 1 --warmup 0 --streams 1 --no-graphs --no-cpu-baseline --no-kernel-timing "
+       "--no-secondary --no-dropin-mode")
+WORKLOAD = "the bench headline: 30 M random Gaussians @1080p, 4 views (stats pass + 1 step), one stream, eager launches"
+src = os.path.join(G, f"{tag}_trace", "h30_kernel_stats.csv")
 if os.path.exists(src):
-    stats(src, "rocprofv3 --kernel-trace --stats -- python tools/bench_log_step.py 40000 7 1 4 (one LoG training view end to "
-          "end, fused and torch pipelines, 4 views each + warm-ups)", os.path.join(P, f"{tag}_kernel_stats_log_step.md"))
+    stats(src, f"rocprofv3 --kernel-trace --stats -- {cmd}; {WORKLOAD}", os.path.join(P, f"{tag}_kernel_stats.md"))
+    shutil.copy(src, os.path.join(P, f"{tag}_kernel_stats.csv"))
 pm = os.path.join(ROOT, "tools", "pmc_summary.py")
-sq = os.path.join(G, f"{tag}_pmc_sq", "c2_counter_collection.csv")
-fe = os.path.join(G, f"{tag}_pmc_fetch", "c2_counter_collection.csv")
-wr = os.path.join(G, f"{tag}_pmc_write", "c2_counter_collection.csv")
+sq = os.path.join(G, f"{tag}_pmc_sq", "h30_counter_collection.csv")
+fe = os.path.join(G, f"{tag}_pmc_fetch", "h30_counter_collection.csv")
+wr = os.path.join(G, f"{tag}_pmc_write", "h30_counter_collection.csv")
 if all(os.path.exists(x) for x in (sq, fe, wr)):
-    out = ["# rocprofv3 --pmc (separate passes), mean per launch, C2 workload serialized (--streams 1)", "", "## SQ",
+    out = ["# rocprofv3 --pmc (separate passes), mean per launch; " + WORKLOAD, "", "## SQ",
            subprocess.check_output([sys.executable, pm, sq], text=True), "",
            "## TCC FETCH_SIZE / WRITE_SIZE (KB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, see "
            "MI355X_MICROARCH.md)", subprocess.check_output([sys.executable, pm, fe, wr], text=True)]
@@ -61,12 +58,15 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
         return {k: agg[k] / cnt[k] for k in agg}
     f, w = load(fe, "FETCH_SIZE"), load(wr, "WRITE_SIZE")
     names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_fwd_kernel<true>": "blend_fwd", "lr_project_kernel": "project", "lr_project_batched_kernel": "project",
-             "lr_fill_kernel": "fill_keys", "lr_project_bwd_kernel<true>": "project_bwd"}
-    tj = os.path.join(P, f"{tag}_traffic.json")
-    d = json.load(open(tj)) if os.path.exists(tj) else {
-        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --streams 1",
-        "correction": "traffic_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section)",
-        "workload": {"gaussians": 1000000, "width": 1920, "height": 1080}}
+             "lr_fill_kernel": "fill_keys", "lr_project_bwd_kernel<true, true>": "project_bwd", "lr_sort_long_kernel": "sort"}
+    tj = os.path.join(P, f"{tag}_traffic_30M.json")
+    d = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): " + cmd,
+         "correction": "traffic_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE "
+                       "tallies the 128-byte requests of wide coalesced reads at 64 B; the factor is exact for the streaming "
+                       "kernels and an upper bound for the gathers of the compositing kernels)",
+         "note": "30 M Gaussians: 1.7 GB of inputs + 1.9 GB of records per view, far past the 256 MiB Infinity Cache, so the "
+                 "counters are memory-side traffic (SURVEY 8d)",
+         "workload": {"gaussians": 30000000, "width": 1920, "height": 1080}}
     d["kernels"] = {s: {"fetch_kb": f[k], "write_kb": w[k], "traffic_bytes": (2 * f[k] + w[k]) * 1024}
                     for k, s in names.items() if k in f and k in w}
     # VALU issue utilisation from the SQ pass: SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD; 1024 SIMDs, 2.4 GHz peak
@@ -78,11 +78,4 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
             avg = sum(durs[k]) / len(durs[k])
             d["kernels"][sname]["valu_active_frac_at_2p4GHz"] = act[k] * 4.0 / (1024 * avg * 2.4e9)
     json.dump(d, open(tj, "w"), indent=1)
-for n, out in (("knn_bench.log", "knn_bench.json"), ("radius_10M.log", "radius_10000000.json"),
-               ("sh_10M.log", "sh3_10M.json"), ("lod_bench.log", "lod_bench.json"),
-               ("train_ops_bench.log", "train_ops_bench.json"), ("get_all_deg3.log", "get_all_deg3.json"),
-               ("get_all_deg1.log", "get_all_deg1.json"), ("log_step.log", "log_step.json")):
-    f = os.path.join(G, n)
-    if os.path.exists(f) and any(l.startswith("{") for l in open(f)):
-        json.dump(json.loads([l for l in open(f) if l.startswith("{")][-1]), open(os.path.join(P, f"{tag}_{out}"), "w"), indent=1)
 print(sorted(os.listdir(P)))

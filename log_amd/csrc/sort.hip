@@ -377,11 +377,15 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   if ((tid & 63u) == 0u) { atomicMin(&sh_min, dmin); atomicMax(&sh_max, dmax); }
   __syncthreads();
   LR_TICK();
-  const float fmin = __uint_as_float(sh_min), range = __uint_as_float(sh_max) - fmin;
+  // (the sampled range widened by 1 % on either side: the few keys beyond the sample's extremes lie just outside it and
+  // get buckets of their own there; clamped into the first / last bucket they overflow it -- measured: every eighth
+  // tile of the 30 M-Gaussian workload then took the network fallback)
+  const float smin = __uint_as_float(sh_min), srange = __uint_as_float(sh_max) - smin;
+  const float fmin = smin - 0.01f * srange, range = 1.02f * srange;
   const float scale = (float)nb / range;
   auto bucket_of = [&](uint64_t key) -> uint32_t {
     const float rel = (__uint_as_float((uint32_t)(key >> 32)) - fmin) * scale;
-    return rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;  // below the sampled range / NaN (range == 0) -> bucket 0
+    return rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;  // below the widened range / NaN (range == 0) -> bucket 0
   };
   for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // rank inside the bucket
     uint64_t kk[LR_LONG_UNR];

@@ -137,6 +137,51 @@ lr_sort_rb_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint
 // Same total order, hence the same list as the network, bit for bit.  If the depths are so clustered that a bucket
 // holds more than LR_BUCKET_MAX keys the workgroup falls back to the network on the keys it already staged.
 #define LR_BUCKET_MAX 32
+// ---- depth -> bucket map, equalised over a sample ------------------------------------------------------------------
+// A linear map of [min depth, max depth] onto the buckets spends most of them on gaps when the depths cluster -- a
+// foreground object in front of a background, a surface seen nearly head-on plus a few strays -- and the clusters then
+// overflow their few buckets (LR_BUCKET_MAX keys) and send the tile to the network fallback.  So the range is cut into
+// LR_CELLS cells, a SAMPLE of the list (its first keys: arrival order is unrelated to depth) is histogrammed over them,
+// and every cell gets one bucket plus a share of the remaining buckets proportional to its sample count; inside a cell
+// the map is linear.  Monotone in depth, so the order it produces is the same total order.  One extra LDS read per key.
+#define LR_CELLS 64
+struct LrDepthMap {
+  float fmin, cscale;            // cell coordinate = (depth - fmin) * cscale
+  uint32_t ncells;
+  const uint32_t* table;         // [ncells] in LDS: first bucket | buckets << 16
+};
+LR_DEV uint32_t lr_depth_cell(const LrDepthMap& m, uint32_t dbits, float& frac) {
+  const float rel = (__uint_as_float(dbits) - m.fmin) * m.cscale;
+  const uint32_t c = rel >= 0.f ? (uint32_t)fminf(rel, (float)(m.ncells - 1u)) : 0u;   // below the range / NaN -> cell 0
+  frac = fminf(rel - (float)c, 0.99999994f);              // inf / NaN (range == 0) -> the cell's last bucket, for every key
+  frac = frac >= 0.f ? frac : 0.f;
+  return c;
+}
+LR_DEV uint32_t lr_depth_bucket(const LrDepthMap& m, uint32_t dbits) {
+  float frac;
+  const uint32_t t = m.table[lr_depth_cell(m, dbits, frac)];
+  const uint32_t n = t >> 16;
+  return (t & 0xffffu) + min((uint32_t)(frac * (float)n), n - 1u);
+}
+// Built by the whole workgroup: cellcnt[LR_CELLS] must be zero and hold the sample histogram on entry (filled with
+// lr_depth_cell on a map whose table is not used yet); `sampled` = keys histogrammed; nb = buckets to hand out
+// (nb >= 2 * ncells).  Needs a barrier before and after.
+LR_DEV void lr_depth_map_build(uint32_t* table, const uint32_t* cellcnt, uint32_t ncells, uint32_t sampled, uint32_t nb,
+                                   bool equalize = true) {
+  if (threadIdx.x < 64u) {                                  // one wave: LR_CELLS <= 64
+    const uint32_t t = threadIdx.x;
+    const uint32_t c = t < ncells ? cellcnt[t] : 0u;
+    const uint32_t n = t >= ncells ? 0u : (equalize ? 1u + (uint32_t)(((uint64_t)c * (nb - ncells)) / max(sampled, 1u)) : nb / ncells);
+    uint32_t inc = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(inc, d);
+      if ((int)t >= d) inc += up;
+    }
+    if (t < ncells) table[t] = (inc - n) | (n << 16);
+  }
+}
+
 // Final order inside buckets, one thread per BUCKET: consecutive threads read consecutive LDS addresses (every key
 // once, no bank conflicts -- ranking every key against its bucket read each key ~6 times from random banks and was
 // LDS-bandwidth bound), sort up to 8 keys in registers with the network's 8-key kernel (eight independent LDS loads:
@@ -163,11 +208,11 @@ LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, u
   }
   uint64_t big = __ballot(n > 8u);
   const uint32_t lane = threadIdx.x & 63u;
-  while (big) {   // four big buckets per round: their keys are requested together (key_at may be a two-level gather)
-    uint32_t bst[4], bn[4];
-    uint64_t key[4];
+  while (big) {   // two big buckets per round: their keys are requested together
+    uint32_t bst[2], bn[2];
+    uint64_t key[2];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 2; q++) {
       const bool have = big != 0;
       const int src = have ? __builtin_ctzll(big) : 0;
       big &= big - 1;                                        // no-op once big == 0
@@ -176,7 +221,7 @@ LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, u
       key[q] = lane < bn[q] ? key_at(bst[q] + lane) : ~0ull;
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 2; q++) {
       const uint32_t klo = (uint32_t)key[q], khi = (uint32_t)(key[q] >> 32);
       uint32_t smaller = 0;
       for (uint32_t j = 0; j < bn[q]; j++) {
@@ -193,13 +238,13 @@ LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, u
 template <int NT, int KPT, bool LONG>
 __global__ void __launch_bounds__(NT)
 lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
-                      uint32_t* __restrict__ plist, uint32_t lo, uint32_t capacity) {
+                      uint32_t* __restrict__ plist, uint32_t lo, uint32_t capacity, int equalize) {
   constexpr uint32_t CAP = NT * KPT;                       // longest list of this class (a power of two)
   extern __shared__ __attribute__((aligned(16))) uint64_t s[];  // [A[CAP + CAP/8] (network layout)] | B[CAP] | cnt[CAP/4]
   uint64_t* const A = s;
   uint64_t* const Bk = LONG ? s : s + (CAP + (CAP >> 3));
   uint32_t* const cnt = reinterpret_cast<uint32_t*>(Bk + CAP);
-  __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[NT / 64];
+  __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[NT / 64], cellcnt[LR_CELLS], celltab[LR_CELLS];
   if (lr_bail(state, capacity)) return;
   if (LONG && blockIdx.x >= state[LR_HDR_NBIG]) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -214,6 +259,7 @@ lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64
   while (P2 < L) P2 <<= 1;
   const uint32_t nb = max(P2 >> 2, 8u);                    // buckets (power of two, >= L/4; cnt[] holds CAP/4)
   if (tid == 0) { sh_min = 0xffffffffu; sh_max = 0u; sh_maxcnt = 0u; }
+  if (tid < LR_CELLS) cellcnt[tid] = 0u;
   for (uint32_t b = tid; b < nb; b += NT) cnt[b] = 0u;
   uint64_t key[KPT];
   uint32_t dmin = 0xffffffffu, dmax = 0u;
@@ -224,52 +270,82 @@ lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64
     if (!LONG && i < P2) A[lr_phys(i)] = key[k];           // staged for the fallback
     if (i < L) { const uint32_t d = (uint32_t)(key[k] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d));
+    dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d));
+  }
   __syncthreads();
-  atomicMin(&sh_min, dmin);
-  atomicMax(&sh_max, dmax);
+  if ((tid & 63u) == 0u) { atomicMin(&sh_min, dmin); atomicMax(&sh_max, dmax); }
   __syncthreads();
-  const float fmin = __uint_as_float(sh_min), range = __uint_as_float(sh_max) - fmin;
-  const float scale = (float)nb / range;                   // inf / nan when range == 0: every key lands in bucket 0
+  // depth -> bucket map: first the plain linear one; if a bucket overflows, once more with the map equalised over ALL
+  // keys of the list (they sit in registers; a sample of a few hundred keys over 64 cells starves cells of buckets).
+  // (Equalised from the start loses on smooth distributions: a cell the list only partly covers -- the range's ends, a
+  // silhouette -- concentrates its buckets' keys by the inverse of the covered fraction; measured at 30 M Gaussians,
+  // a few tiles per view then took the network fallback.)
+  LrDepthMap dmap;
+  dmap.fmin = __uint_as_float(sh_min);
+  dmap.ncells = min((uint32_t)LR_CELLS, nb >> 1);
+  dmap.cscale = (float)dmap.ncells / (__uint_as_float(sh_max) - dmap.fmin);   // inf / nan when the range is 0: one bucket for all
+  dmap.table = celltab;
   uint32_t bkt[KPT], rnk[KPT];
+  uint32_t run = 0;
+  for (int attempt = 0;; attempt++) {
+    const bool eq = attempt == 1;
+    if (eq) {
 #pragma unroll
-  for (int k = 0; k < KPT; k++) {
-    const uint32_t i = tid + (uint32_t)k * NT;
-    bkt[k] = 0u; rnk[k] = 0u;
-    if (i < L) {
-      const float rel = (__uint_as_float((uint32_t)(key[k] >> 32)) - fmin) * scale;
-      const uint32_t b = rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;   // NaN (range == 0) -> 0
-      bkt[k] = b;
-      rnk[k] = atomicAdd(&cnt[b], 1u);
+      for (int k = 0; k < KPT; k++) {
+        const uint32_t i = tid + (uint32_t)k * NT;
+        if (i < L) { float fr; atomicAdd(&cellcnt[lr_depth_cell(dmap, (uint32_t)(key[k] >> 32), fr)], 1u); }
+      }
     }
-  }
-  __syncthreads();
-  // exclusive scan of cnt[0..nb): thread t owns counters [t*per, (t+1)*per)
-  const uint32_t per = (nb + NT - 1) / NT;
-  uint32_t local = 0, lmax = 0;
-  for (uint32_t q = 0; q < per; q++) {
-    const uint32_t b = tid * per + q;
-    const uint32_t c = b < nb ? cnt[b] : 0u;
-    local += c; lmax = max(lmax, c);
-  }
-  uint32_t inc = local;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(inc, d);
-    if ((int)(tid & 63u) >= d) inc += up;
-  }
-  if ((tid & 63u) == 63u) wave_tot[tid >> 6] = inc;
-  atomicMax(&sh_maxcnt, lmax);
-  __syncthreads();
-  uint32_t run = inc - local;
-  for (uint32_t w = 0; w < (tid >> 6); w++) run += wave_tot[w];
-  if (sh_maxcnt > LR_BUCKET_MAX) {                         // clustered depths: the network, on the staged keys
-    if (LONG) return;                                       // ... or the fallback kernels
     __syncthreads();
-    lr_lds_sort<NT>(A, P2, tid);
-    for (uint32_t i = tid; i < L; i += NT) plist[beg + i] = (uint32_t)A[lr_phys(i)];
-    return;
+    lr_depth_map_build(celltab, cellcnt, dmap.ncells, L, nb, eq);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+      const uint32_t i = tid + (uint32_t)k * NT;
+      bkt[k] = 0u; rnk[k] = 0u;
+      if (i < L) {
+        const uint32_t b = lr_depth_bucket(dmap, (uint32_t)(key[k] >> 32));
+        bkt[k] = b;
+        rnk[k] = atomicAdd(&cnt[b], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..nb): thread t owns counters [t*per, (t+1)*per)
+    const uint32_t per = (nb + NT - 1) / NT;
+    uint32_t local = 0, lmax = 0;
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t b = tid * per + q;
+      const uint32_t c = b < nb ? cnt[b] : 0u;
+      local += c; lmax = max(lmax, c);
+    }
+    uint32_t inc = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(inc, d);
+      if ((int)(tid & 63u) >= d) inc += up;
+    }
+    if ((tid & 63u) == 63u) wave_tot[tid >> 6] = inc;
+    atomicMax(&sh_maxcnt, lmax);
+    __syncthreads();
+    run = inc - local;
+    for (uint32_t w = 0; w < (tid >> 6); w++) run += wave_tot[w];
+    if (sh_maxcnt <= LR_BUCKET_MAX) break;
+    if (eq || !equalize) {                                   // clustered beyond the map's reach: the network, on the staged keys
+      if (LONG) return;                                       // ... or the fallback kernels
+      __syncthreads();
+      lr_lds_sort<NT>(A, P2, tid);
+      for (uint32_t i = tid; i < L; i += NT) plist[beg + i] = (uint32_t)A[lr_phys(i)];
+      return;
+    }
+    __syncthreads();                                          // every thread has read sh_maxcnt and its counts
+    if (tid == 0) sh_maxcnt = 0u;
+    for (uint32_t b = tid; b < nb; b += NT) cnt[b] = 0u;
   }
   __syncthreads();                                          // every thread has read its counts
+  const uint32_t per = (nb + NT - 1) / NT;
   for (uint32_t q = 0; q < per; q++) {
     const uint32_t b = tid * per + q;
     if (b < nb) { const uint32_t c = cnt[b]; cnt[b] = run; run += c; }   // cnt becomes the bucket start
@@ -324,14 +400,14 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
 // its biglist entry so that they skip it.
 #define LR_LONG_NB 4096     // bucket counters in LDS
 #define LR_LONG_WIN_BYTES 61440   // LDS window: 7680 keys staged at a time (16 KB counters + this: two workgroups per CU)
-#define LR_LONG_UNR 8       // independent loads in flight per thread in the streaming passes
-__global__ void __launch_bounds__(1024)
+#define LR_LONG_UNR 6       // independent loads in flight per thread in the streaming passes (8: VGPR spills at the 64 the two workgroups per CU allow)
+__global__ void __launch_bounds__(1024, 8)   // two workgroups per CU: 64 VGPRs (at 77 the kernel ran one per CU: 0.62 -> 0.86 ms at 30 M)
 lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
-                    uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity) {
+                    uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity, int equalize) {
   constexpr uint32_t LR_LONG_WIN = LR_LONG_WIN_BYTES / sizeof(uint64_t);
   extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
   uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
-  __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[16];
+  __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[16], cellcnt[LR_CELLS], celltab[LR_CELLS];
   if (lr_bail(state, capacity) || blockIdx.x >= state[LR_HDR_NBIG]) return;
   const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
   if (entry & LR_LONG_DONE) return;                        // done in LDS / registers by an earlier launch
@@ -352,6 +428,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   while (P2 < L) P2 <<= 1;
   const uint32_t nb = min((uint32_t)LR_LONG_NB, P2 >> 1);
   if (tid == 0) { sh_min = 0xffffffffu; sh_max = 0u; sh_maxcnt = 0u; }
+  if (tid < LR_CELLS) cellcnt[tid] = 0u;
   for (uint32_t b = tid; b < nb; b += 1024) lcnt[b] = 0u;
   uint32_t dmin = 0xffffffffu, dmax = 0u;
   // (the streaming loops are unrolled by hand: LR_LONG_UNR independent loads in flight per thread -- every pass is a
@@ -359,7 +436,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   // Depth range from the first eighth of the list (the keys arrive in no particular order, so this is a random
   // sample): the range only has to spread the keys over the buckets, keys outside it clamp into the first / last
   // bucket, and a bucket that overflows sends the tile to the fallback as before.
-  const uint32_t Ls = min(L, max(L >> 3, 4096u));
+  const uint32_t Ls = min(L, max(L >> 3, 8192u));
   for (uint32_t i = tid; i < Ls; i += LR_LONG_UNR * 1024u) {
     uint64_t kk[LR_LONG_UNR];
 #pragma unroll
@@ -381,48 +458,65 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   // get buckets of their own there; clamped into the first / last bucket they overflow it -- measured: every eighth
   // tile of the 30 M-Gaussian workload then took the network fallback)
   const float smin = __uint_as_float(sh_min), srange = __uint_as_float(sh_max) - smin;
-  const float fmin = smin - 0.01f * srange, range = 1.02f * srange;
-  const float scale = (float)nb / range;
-  auto bucket_of = [&](uint64_t key) -> uint32_t {
-    const float rel = (__uint_as_float((uint32_t)(key >> 32)) - fmin) * scale;
-    return rel >= 0.f ? (uint32_t)fminf(rel, (float)(nb - 1u)) : 0u;  // below the widened range / NaN (range == 0) -> bucket 0
-  };
-  for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // rank inside the bucket
-    uint64_t kk[LR_LONG_UNR];
-#pragma unroll
-    for (int u = 0; u < LR_LONG_UNR; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
-    uint32_t cd[LR_LONG_UNR];
-#pragma unroll
-    for (int u = 0; u < LR_LONG_UNR; u++) {                  // (bucket, rank) code: all a window pass needs to skip a key
-      const uint32_t b = bucket_of(kk[u]);
-      cd[u] = (i + u * 1024u < L) ? ((b << 8) | min(atomicAdd(&lcnt[b], 1u), 255u)) : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < LR_LONG_UNR; u++)
-      if (i + u * 1024u < L) rk[i + u * 1024u] = cd[u];
-  }
-  __syncthreads();
-  LR_TICK();
-  // exclusive scan of the nb counts: thread t owns counters [t * per, (t + 1) * per); every wave scans the 16 wave totals
+  LrDepthMap dmap;
+  dmap.fmin = smin - 0.01f * srange;
+  dmap.ncells = min((uint32_t)LR_CELLS, nb >> 1);
+  dmap.cscale = (float)dmap.ncells / (1.02f * srange);
+  dmap.table = celltab;
+  auto bucket_of = [&](uint64_t key) -> uint32_t { return lr_depth_bucket(dmap, (uint32_t)(key >> 32)); };
+  // first the plain linear map; if a bucket overflows, once more with the map equalised over the first 8192 keys
+  // (cache-resident: just read for the range) -- see lr_sort_bucket_kernel
   const uint32_t per = (nb + 1023u) / 1024u;               // <= LR_LONG_NB / 1024
   uint32_t cown[LR_LONG_NB / 1024];
-  uint32_t local = 0, lmax = 0;
+  uint32_t local = 0, inc = 0;
+  for (int attempt = 0;; attempt++) {
+    const bool eq = attempt == 1;
+    const uint32_t Lh = min(Ls, 8192u);
+    if (eq)
+      for (uint32_t i = tid; i < Lh; i += 1024u) { float fr; atomicAdd(&cellcnt[lr_depth_cell(dmap, (uint32_t)(k[i] >> 32), fr)], 1u); }
+    __syncthreads();
+    lr_depth_map_build(celltab, cellcnt, dmap.ncells, Lh, nb, eq);
+    __syncthreads();
+    for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // rank inside the bucket
+      uint64_t kk[LR_LONG_UNR];
 #pragma unroll
-  for (uint32_t q = 0; q < LR_LONG_NB / 1024; q++) {
-    const uint32_t b = tid * per + q;
-    cown[q] = (q < per && b < nb) ? lcnt[b] : 0u;
-    local += cown[q]; lmax = max(lmax, cown[q]);
+      for (int u = 0; u < LR_LONG_UNR; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
+      uint32_t cd[LR_LONG_UNR];
+#pragma unroll
+      for (int u = 0; u < LR_LONG_UNR; u++) {                  // (bucket, rank) code: all a window pass needs to skip a key
+        const uint32_t b = bucket_of(kk[u]);
+        cd[u] = (i + u * 1024u < L) ? ((b << 8) | min(atomicAdd(&lcnt[b], 1u), 255u)) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < LR_LONG_UNR; u++)
+        if (i + u * 1024u < L) rk[i + u * 1024u] = cd[u];
+    }
+    __syncthreads();
+    LR_TICK();
+    // exclusive scan of the nb counts: thread t owns counters [t * per, (t + 1) * per); every wave scans the 16 wave totals
+    uint32_t lmax = 0;
+    local = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < LR_LONG_NB / 1024; q++) {
+      const uint32_t b = tid * per + q;
+      cown[q] = (q < per && b < nb) ? lcnt[b] : 0u;
+      local += cown[q]; lmax = max(lmax, cown[q]);
+    }
+    inc = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(inc, d);
+      if ((int)(tid & 63u) >= d) inc += up;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d));
+    if ((tid & 63u) == 63u) { wave_tot[tid >> 6] = inc; atomicMax(&sh_maxcnt, lmax); }
+    __syncthreads();
+    if (sh_maxcnt <= LR_BUCKET_MAX || eq || !equalize) break;
+    __syncthreads();                                          // every thread has read sh_maxcnt and its counts
+    if (tid == 0) sh_maxcnt = 0u;
+    for (uint32_t b = tid; b < nb; b += 1024) lcnt[b] = 0u;
   }
-  uint32_t inc = local;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(inc, d);
-    if ((int)(tid & 63u) >= d) inc += up;
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d));
-  if ((tid & 63u) == 63u) { wave_tot[tid >> 6] = inc; atomicMax(&sh_maxcnt, lmax); }
-  __syncthreads();
   if (sh_maxcnt > LR_BUCKET_MAX) return;                    // clustered depths: network fallback (entry stays unflagged)
   {
     const uint32_t wt = (tid & 63u) < 16u ? wave_tot[tid & 63u] : 0u;
@@ -681,6 +775,7 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   if (max_len == 0 || max_len > capacity) max_len = capacity;
   // LOGRAST_BUCKET_SORT=0: bitonic network only (the reference implementation of the same total order)
   static const int bucket = lr_env_int("LOGRAST_BUCKET_SORT", 1);
+  static const int equalize = lr_env_int("LOGRAST_EQUALIZE", 1);   // 0: plain linear depth -> bucket map (experiments)
   // biglist holds the tiles with more than LR_LONG_LIST keys, so there are at most capacity / LR_LONG_LIST of them
   const uint32_t nlong = min(tiles, capacity / LR_LONG_LIST + 1u);
   const uint32_t nfb = bucket ? min(nlong, 256u) : nlong;  // network fallback kernels: a chip-sized grid that walks biglist[]
@@ -688,12 +783,12 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
     // depth buckets in LDS up to LR_LONG_LIST keys (a separate one-wave network launch for tiny lists costs more than it saves)
     lr_prof_begin(LRK_SORT_SMALL, s);
     hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 4, false>), dim3(tiles), dim3(256), lr_bucket_lds_bytes(1024), s, state,
-                       tiles, keys, plist, 0u, capacity);
+                       tiles, keys, plist, 0u, capacity, equalize);
     lr_prof_end(LRK_SORT_SMALL, s);
     if (max_len > 1024u) {
       lr_prof_begin(LRK_SORT_LARGE, s);
       hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 16, false>), dim3(min(tiles, capacity / 1024u + 1u)), dim3(256),
-                         lr_bucket_lds_bytes(LR_LONG_LIST), s, state, tiles, keys, plist, 1024u, capacity);
+                         lr_bucket_lds_bytes(LR_LONG_LIST), s, state, tiles, keys, plist, 1024u, capacity, equalize);
       lr_prof_end(LRK_SORT_LARGE, s);
     }
   } else {
@@ -718,9 +813,9 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
       // beyond; what they give up on falls through to the networks
       hipLaunchKernelGGL((lr_sort_bucket_kernel<512, 16, true>), dim3(nlong), dim3(512),
                          lr_bucket_lds_bytes(LR_SORT_BLOCK, false), s, state, tiles, keys, plist, (uint32_t)LR_LONG_LIST,
-                         capacity);
+                         capacity, equalize);
       hipLaunchKernelGGL(lr_sort_long_kernel, dim3(nlong), dim3(1024), lr_long_lds_bytes(), s, state, tiles,
-                         keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity);
+                         keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize);
       hipLaunchKernelGGL(lr_sort_long_fallback_kernel, dim3(nfb), dim3(256), lr_sort_lds_bytes(LR_SORT_BLOCK), s, state,
                          tiles, keys, plist, capacity);
     }

@@ -143,3 +143,23 @@ def test_mark_visible_and_settings_fields():
         assert hasattr(rast.raster_settings, f)          # read at level_of_gaussian.py:73-78
     vis = rast.markVisible(torch.tensor(sc["xyz"], device=DEV))
     assert vis.dtype == torch.bool and vis.shape == (200,) and bool(vis.all())
+
+
+@pytest.mark.parametrize("n", [300_000, 8_000_000], ids=["short_lists", "long_lists"])
+def test_layered_depths_keep_the_bucket_sort_and_match_the_oracle(oracle_mod, n):
+    """Two thin slabs perpendicular to the view direction with a gap between them (a foreground in front of a
+    background): every tile's depths fall into two narrow clusters.  A linear depth -> bucket map spends its buckets on
+    the gap; the sample-equalised map (sort.hip: LrDepthMap) keeps the clusters spread.  Lists and image vs the oracle."""
+    import gpu_util as G
+    from log_amd import scenes
+    rng = np.random.default_rng(9)
+    cam = scenes.orbit_cameras(8, W=1920, H=1080)[0]                   # at (3, 0, 0), looking down -x
+    sc = scenes.random_scene(n, seed=9, opacity=None)
+    layer = np.where(rng.random(n) < 0.5, 0.45, -0.45).astype(np.float32)
+    sc["xyz"][:, 0] = layer + (rng.standard_normal(n) * 2e-3).astype(np.float32)
+    hf = G.hip_forward(cam, sc, (0.0, 0.0, 0.0))
+    v, of = G.oracle_forward(oracle_mod, cam, sc, (0.0, 0.0, 0.0))
+    st = G.compare_forward(hf, of)
+    for k in ("radii_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch", "image_bits_mismatch", "pid_mismatch"):
+        assert st[k] == 0, (k, st)
+    assert np.diff(of["tile_offsets"].astype(np.int64)).max() > (8192 if n > 1_000_000 else 400)

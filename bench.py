@@ -10,8 +10,10 @@ Headline workload = the north-star point of BASELINE.json (configs[3] per GPU; S
 30,000,000 random Gaussians (seed 0, opacity 0.999, scales U(0, 0.5 N^-1/3)), 1920x1080, 8 orbit cameras PER GPU,
 through the drop-in ``diff_gaussian_rasterization_wodilate`` package (5-tuple flavour), loss = sum(image * w),
 backward to all Gaussian attributes + means2D.  A "step" = every rank renders its 8 views forward+backward, gradients are
-added by the backward kernels into one flat buffer per stream, summed per rank, and (N > 1) one reduce-scatter +
-all-gather sums them across ranks (view-sharded data parallelism, weak scaling: per-GPU work is fixed).  Inputs are
+added by the backward kernels into one flat buffer per stream, summed per rank, and (N > 1) summed across ranks by
+reduce-scatter + all-gather (view-sharded data parallelism, weak scaling: per-GPU work is fixed; the views of a step go in
+--exchange-parts groups and a group's reduce-scatter runs on a side stream under the next group's rendering,
+log_amd.dist.StepExchange).  Inputs are
 resident in HBM before the timed region; the timed region contains no host synchronisation (tile-instance capacity
 comes from the warm-up; every forward records itself in the rasterizer's status block, checked afterwards).
 
@@ -61,6 +63,8 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true",
                     help="pipelined mode: enqueue every view's ~15 launches from Python instead of replaying one captured "
                          "HIP graph per view")
+    ap.add_argument("--exchange-parts", type=int, default=int(os.environ.get("LOGRAST_EXCHANGE_PARTS", "4")),
+                    help="N > 1: groups of views per step, each reduce-scattered under the next group's rendering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 / C3 legs (they run at N = 1 only)")
@@ -141,16 +145,22 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     import torch
     import torch.distributed as dist
     from log_amd import _lib, rasterizer as R
-    from log_amd.dist import GradientBucket
+    from log_amd.dist import GradientBucket, StepExchange
     dev, N = wl.dev, wl.N
+    rank = dist.get_rank() if world > 1 else 0
+    parts = max(1, min(int(args.exchange_parts), len(wl.rasts) // S)) if world > 1 else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    # The step's gradient exchange (log_amd.dist.StepExchange): the rank's views in `parts` consecutive groups with a
+    # bucket each; group g's reduce-scatter runs on a side stream under the rendering of group g + 1.
+    ex = StepExchange(N, dev, world, rank, parts=parts)
     lanes = []
-    for _ in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient bucket
+    for li in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient buckets
         leaves = {k: v.detach().requires_grad_(True) for k, v in wl.base.items()}
-        bk = GradientBucket(N, dev, world)
-        bk.attach(leaves)
-        lanes.append((leaves, bk))
-    bucket = lanes[0][1]
+        bks = ex.buckets if li == 0 else [GradientBucket(N, dev, world) for _ in range(parts)]
+        bks[0].attach(leaves)
+        lanes.append((leaves, bks))
+    lane_views = [wl.rasts[li::S] for li in range(S)]
+    part_of = [[min(j * parts // max(len(lv), 1), parts - 1) for j in range(len(lv))] for lv in lane_views]
 
     lane_graphs = None
 
@@ -158,24 +168,34 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         main = torch.cuda.current_stream(dev)
         for st in streams:
             st.wait_stream(main)
-        for li, (leaves, bk) in enumerate(lanes):
+        for li, (_, bks) in enumerate(lanes):
             with torch.cuda.stream(streams[li]):
-                bk.zero()
-                if lane_graphs is not None:
-                    for g in lane_graphs[li]:
-                        g.replay()
-                elif fused:
-                    with R.accumulate_grads_into(bk.views):
-                        for rast in wl.rasts[li::S]:
-                            wl.one_view(rast, leaves)
-                else:
-                    for rast in wl.rasts[li::S]:
-                        wl.one_view(rast, leaves)
-        for st in streams:
-            main.wait_stream(st)
-        for _, bk in lanes[1:]:
-            bucket.flat.add_(bk.flat)
-        bucket.reduce()
+                for bk in bks:
+                    bk.zero()
+        for part in range(parts):
+            for li, (leaves, bks) in enumerate(lanes):
+                mine = [j for j in range(len(lane_views[li])) if part_of[li][j] == part]
+                with torch.cuda.stream(streams[li]):
+                    if lane_graphs is not None:
+                        for j in mine:
+                            lane_graphs[li][j].replay()
+                    elif fused:
+                        with R.accumulate_grads_into(bks[part].views):
+                            for j in mine:
+                                wl.one_view(lane_views[li][j], leaves)
+                    else:
+                        if parts > 1:
+                            bks[part].attach(leaves)
+                        for j in mine:
+                            wl.one_view(lane_views[li][j], leaves)
+            for st in streams:
+                main.wait_stream(st)                    # (a dependency on the device, not a host wait)
+            for _, bks in lanes[1:]:
+                ex.buckets[part].flat.add_(bks[part].flat)
+            if world > 1:
+                ex.launch(part)
+        if world > 1:
+            ex.all_gather_grads(ex.finish())            # every rank ends the step with the whole gradient sum
 
     # ---- V and I per view, measured once in exact mode (one 4-byte read-back per view) ----
     R.set_instance_capacity(None)
@@ -187,7 +207,8 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         assert not over
         del out
     res = {"V": float(np.mean([s[0] for s in stats])), "I": float(np.mean([s[1] for s in stats])),
-           "I_rect": float(np.mean([s[3] for s in stats])), "bucket_floats": int(bucket.flat.numel())}
+           "I_rect": float(np.mean([s[3] for s in stats])), "bucket_floats": int(ex.buckets[0].flat.numel()),
+           "exchange_parts": parts}
     cap = int(max(s[1] for s in stats) * 1.02) + 1024
     if sync_free:
         # from here on: no host sync inside forward(); the longest tile list (it picks the sort's multi-block levels)
@@ -204,14 +225,14 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         try:
             torch.cuda.synchronize()
             built = []
-            for li, (leaves, bk) in enumerate(lanes):
+            for li, (leaves, bks) in enumerate(lanes):
                 pool, gl = torch.cuda.graph_pool_handle(), []
-                with R.accumulate_grads_into(bk.views):
-                    for rast in wl.rasts[li::S]:
+                for j, rast in enumerate(lane_views[li]):
+                    with R.accumulate_grads_into(bks[part_of[li][j]].views):
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, pool=pool, stream=streams[li]):
                             wl.one_view(rast, leaves)
-                        gl.append(g)
+                    gl.append(g)
                 built.append(gl)
             torch.cuda.synchronize()
             lane_graphs = built
@@ -249,7 +270,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             # per-kernel durations that profiles/ (rocprofv3, serialized) can be compared with.
             _lib.profile_reset()
             _lib.profile_enable(True)
-            lv0, bk0 = lanes[0]
+            lv0, bk0 = lanes[0][0], lanes[0][1][0]
             bk0.zero()
             with R.accumulate_grads_into(bk0.views):
                 for rast in wl.rasts:
@@ -265,7 +286,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         t = torch.tensor([res["elapsed"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         res["elapsed"] = float(t.item())
-    del lane_graphs, lanes, bucket
+    del lane_graphs, lanes, ex
     return res
 
 
@@ -329,8 +350,9 @@ def main():
             "gaussians": N, "width": W, "height": H, "views_per_gpu": args.views,
             "visible_per_view": V, "tile_instances_per_view": I, "tile_instances_per_view_reference_rect_rule": I_rect,
             "streams_per_gpu": S, "fused_gradient_accumulation": fused,
-            "parallelism": ("view-sharded dp%d, 1 reduce-scatter+all-gather of %d floats/step" %
-                            (n_ranks, r["bucket_floats"]) if world > 1 else "single GPU") +
+            "parallelism": ("view-sharded dp%d, reduce-scatter of %d floats/step in %d groups of views (each under the next "
+                            "group's rendering, side stream) + one all-gather" %
+                            (n_ranks, r["bucket_floats"], r["exchange_parts"]) if world > 1 else "single GPU") +
                            ", %d view(s) in flight per GPU (HIP streams)" % S,
         },
         "ms_per_view": head["ms_per_view"], "host_enqueue_ms_per_view": head["host_enqueue_ms_per_view"],

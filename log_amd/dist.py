@@ -16,6 +16,19 @@ is a view into it), so a step needs exactly one exchange.  Two forms:
     replace).  The reference updates only the rows seen this step (``flag_vis``, sparse_optimizer.py:167): the bucket
     carries a per-row ``seen`` count next to the gradients for exactly that.
 
+Two refinements of the exchange, both optional and both leaving the result unchanged:
+
+  * **touched-row blocks** (``block_rows`` > 0, ``compact=True``): a level-of-detail step touches a fraction of the model's
+    rows, and a row no view saw has an exactly zero gradient and does not move.  The ranks first agree on which
+    ``block_rows``-row blocks anyone touched (a max-reduce of world x nb flags: P / block_rows bytes), then only those
+    blocks travel: owner r receives the sum of ITS touched blocks, and publishes only those after the update.  Every rank
+    derives the same block lists from the same bitmap, padded per owner to the longest list with UNTOUCHED blocks of that
+    owner (zero gradients / unchanged attributes: sending them is a no-op, so there is no mask and no variable-size
+    collective).  Falls back to the dense form when most blocks are touched;
+  * **overlap** (``StepExchange``, ``parts`` > 1): the step's views are split into `parts` groups with a bucket each; the
+    reduce-scatter of group g is issued on a side stream as soon as g's last backward is enqueued and runs under the
+    rendering of group g + 1.  Only the last group's reduce-scatter and the closing all-gather are exposed.
+
 With world_size == 1 nothing is communicated and results are bit-identical to the single-GPU path.
 """
 import math
@@ -39,8 +52,40 @@ def shard_views(n_views, rank, world):
     return list(range(rank, n_views, world))
 
 
-def rows_per_rank(num_points, world):
-    return (int(num_points) + max(int(world), 1) - 1) // max(int(world), 1)
+def rows_per_rank(num_points, world, block_rows=0):
+    """Rows owned by one rank; a whole number of `block_rows`-row blocks when the touched-block exchange is on."""
+    per = (int(num_points) + max(int(world), 1) - 1) // max(int(world), 1)
+    if block_rows:
+        per = (per + int(block_rows) - 1) // int(block_rows) * int(block_rows)
+    return per
+
+
+def _active(world):
+    return world > 1 and dist.is_initialized()
+
+
+def _reduce_scatter(out, inp, group=None):
+    """out[numel / world] = this rank's slice of the sum of `inp` over ranks.  gloo (the CPU tests) has no
+    reduce_scatter_tensor: all_reduce of a copy, then the slice."""
+    if dist.get_backend(group) == "gloo":
+        tmp = inp.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        r, n = dist.get_rank(group), out.numel()
+        out.copy_(tmp[r * n:(r + 1) * n])
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+def _all_gather(out, inp, group=None):
+    """out[world * numel] = the ranks' `inp` in rank order."""
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(inp) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, inp.contiguous(), group=group)
+        out.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(out, inp.contiguous(), group=group)
+    return out
 
 
 def _shape(name, rows, cols):
@@ -51,10 +96,11 @@ class _Flat:
     """One flat fp32 buffer holding every attribute as a contiguous [P_pad, c] block, P_pad = world * ceil(P / world), so
     that rank r's rows [r * Pr, (r + 1) * Pr) are a contiguous slice of every block."""
 
-    def __init__(self, num_points, device, world=1, sh_coeffs=0):
+    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0):
         self.P, self.world = int(num_points), max(int(world), 1)
         self.layout = layout(sh_coeffs)
-        self.Pr = rows_per_rank(self.P, self.world)
+        self.block_rows = int(block_rows)
+        self.Pr = rows_per_rank(self.P, self.world, self.block_rows)
         self.Ppad = self.Pr * self.world
         self.cols = sum(c for _, c in self.layout)
         self.flat = torch.zeros(self.Ppad * self.cols, dtype=torch.float32, device=device)
@@ -71,14 +117,39 @@ class _Flat:
         return self.blocks[name][rank * self.Pr * c:(rank + 1) * self.Pr * c].view(self.Pr, c)
 
 
+class TouchedBlocks:
+    """Which `block_rows`-row blocks of each owner any rank touched this step, as every rank computes it from the same
+    max-reduced bitmap: ``order[r]`` = owner r's block ids, touched ones first (ascending), and ``kmax`` = the longest
+    touched list over the owners (one small device -> host read: the collectives below need their sizes on the host).
+    Entries [count_r, kmax) of ``order[r]`` are untouched blocks of owner r -- padding that carries zeros / unchanged
+    rows."""
+
+    def __init__(self, bitmap):
+        self.bitmap = bitmap                                   # bool [world, nb]
+        self.world, self.nb = bitmap.shape
+        self.counts = bitmap.sum(1)
+        self.kmax = max(int(self.counts.max().item()), 1)       # (nothing touched: one block of padding)
+        self.order = torch.argsort((~bitmap).to(torch.uint8), dim=1, stable=True)[:, :self.kmax].contiguous()
+
+    def union(self, other):
+        return TouchedBlocks(self.bitmap | other.bitmap)
+
+    @property
+    def fraction(self):
+        """Share of the dense exchange the compact one moves (padding included)."""
+        return self.kmax / max(self.nb, 1)
+
+
 class GradientBucket(_Flat):
     """Flat gradient buffer, attribute-major, with one contiguous view per attribute, and the per-row `seen` count."""
+    DENSE_ABOVE = 0.85     # touched-block exchange only when it moves less than this share of the dense one
 
-    def __init__(self, num_points, device, world=1, sh_coeffs=0):
-        super().__init__(num_points, device, world, sh_coeffs)
+    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0):
+        super().__init__(num_points, device, world, sh_coeffs, block_rows)
         self.pad = self.flat.numel() - self.P * self.cols
         self.seen = torch.zeros(self.Ppad, dtype=torch.float32, device=device)   # views that saw the row this step
         self._seen_reduced = False
+        self.touched = None                                   # TouchedBlocks of the last compact exchange (else None)
 
     def attach(self, params):
         """params: dict name -> leaf tensor (requires_grad).  Their .grad become views of the bucket,
@@ -92,6 +163,7 @@ class GradientBucket(_Flat):
         self.flat.zero_()
         self.seen.zero_()
         self._seen_reduced = False
+        self.touched = None
 
     def mark_seen(self, radii, index=None):
         """Record which rows one view touched: radii > 0 (what the reference's step calls flag_vis,
@@ -104,13 +176,13 @@ class GradientBucket(_Flat):
             self.seen.index_add_(0, index, vis)
 
     def _sum_seen(self, group):
-        if self.world > 1 and dist.is_initialized() and not self._seen_reduced:
+        if _active(self.world) and not self._seen_reduced:
             dist.all_reduce(self.seen, op=dist.ReduceOp.SUM, group=group)
         self._seen_reduced = True
 
     def reduce(self, group=None):
         """Sum across ranks.  reduce-scatter + all-gather: every xGMI link carries 1/world of the buffer."""
-        if self.world <= 1 or not dist.is_initialized():
+        if not _active(self.world):
             return self.flat
         self._sum_seen(group)
         if dist.get_backend(group) == "gloo":
@@ -122,22 +194,49 @@ class GradientBucket(_Flat):
         dist.all_gather_into_tensor(self.flat, mine, group=group)
         return self.flat
 
-    def reduce_scatter_rows(self, rank, group=None):
-        """Owner-computes exchange, first half: -> dict name -> [Pr, c] = the sum over ranks of this rank's rows (one
-        reduce-scatter per attribute block, all issued back to back), and the summed `seen` counts of all rows."""
-        if self.world <= 1 or not dist.is_initialized():
-            return {name: self.rows(name, 0) for name, _ in self.layout}
-        self._sum_seen(group)
-        out = {}
-        gloo = dist.get_backend(group) == "gloo"
-        for name, c in self.layout:
-            if gloo:
-                dist.all_reduce(self.blocks[name], op=dist.ReduceOp.SUM, group=group)
-                out[name] = self.rows(name, rank)
-            else:
-                mine = torch.empty(self.Pr * c, dtype=torch.float32, device=self.flat.device)
-                dist.reduce_scatter_tensor(mine, self.blocks[name], op=dist.ReduceOp.SUM, group=group)
-                out[name] = mine.view(self.Pr, c)
+    def touched_blocks(self, group=None):
+        """The step's TouchedBlocks: local `seen` per block, max-reduced over the ranks (world * nb int32: tiny)."""
+        assert self.block_rows > 0, "construct the bucket with block_rows > 0 for the touched-block exchange"
+        nb = self.Pr // self.block_rows
+        flags = (self.seen.view(self.world, nb, self.block_rows).amax(-1) > 0).to(torch.int32)
+        if _active(self.world):
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+        return TouchedBlocks(flags > 0)
+
+    def _columns(self):
+        """(name, [P_pad * c] block, c) of everything that is exchanged: the attribute gradients and the seen counts."""
+        return [(name, self.blocks[name], c) for name, c in self.layout] + [("seen", self.seen, 1)]
+
+    def reduce_scatter_rows(self, rank, group=None, compact=False):
+        """Owner-computes exchange, first half: -> dict name -> [Pr, c] = the sum over ranks of this rank's rows of every
+        attribute, plus "seen" -> [Pr] (how many views of all ranks saw each of them).  One reduce-scatter per column
+        block, issued back to back.  compact: only the blocks some rank touched travel (TouchedBlocks; needs
+        block_rows > 0), the rest of the returned rows are zeros -- which is what their sum is."""
+        self.touched = None
+        if not _active(self.world):
+            out = {name: self.rows(name, 0) for name, _ in self.layout}
+            out["seen"] = self.seen[:self.Pr]
+            return out
+        dev, out = self.flat.device, {}
+        tb = self.touched_blocks(group) if compact and self.block_rows > 0 else None
+        if tb is not None and tb.fraction >= self.DENSE_ABOVE:
+            tb = None
+        if tb is None:
+            for name, blk, c in self._columns():
+                mine = torch.empty(self.Pr * c, dtype=torch.float32, device=dev)
+                _reduce_scatter(mine, blk, group)
+                out[name] = mine.view(self.Pr, c) if name != "seen" else mine
+            return out
+        self.touched = tb
+        B, nb, k = self.block_rows, tb.nb, tb.kmax
+        owner = torch.arange(self.world, device=dev)[:, None]
+        for name, blk, c in self._columns():
+            packed = blk.view(self.world, nb, B * c)[owner, tb.order]            # [world, kmax, B c]: owner-major
+            mine = torch.empty(k * B * c, dtype=torch.float32, device=dev)
+            _reduce_scatter(mine, packed.reshape(-1), group)
+            full = torch.zeros(nb, B * c, dtype=torch.float32, device=dev)
+            full[tb.order[rank]] = mine.view(k, B * c)
+            out[name] = full.view(self.Pr, c) if name != "seen" else full.view(self.Pr)
         return out
 
 
@@ -145,23 +244,27 @@ class FlatParams(_Flat):
     """The Gaussian attributes themselves in the bucket's layout (``views[name]`` are the tensors to render from), so
     that the owner-computes step can publish the rows it updated with one all-gather per attribute block."""
 
-    def __init__(self, tensors, device, world=1):
+    def __init__(self, tensors, device, world=1, block_rows=0):
         k = int(tensors["shs"].shape[1]) if "shs" in tensors else 0
-        super().__init__(next(iter(tensors.values())).shape[0], device, world, k)
+        super().__init__(next(iter(tensors.values())).shape[0], device, world, k, block_rows)
         for name, _ in self.layout:
             self.views[name].copy_(tensors[name].reshape(self.views[name].shape))
 
-    def all_gather_rows(self, rank, group=None):
-        """Owner-computes exchange, second half: every rank publishes its (updated) rows of every attribute."""
-        if self.world <= 1 or not dist.is_initialized():
+    def all_gather_rows(self, rank, group=None, touched=None):
+        """Owner-computes exchange, second half: every rank publishes its (updated) rows of every attribute; with
+        `touched` (the TouchedBlocks of the gradient exchange) only the blocks that can have moved."""
+        if not _active(self.world):
             return
+        dev = self.flat.device
         for name, c in self.layout:
-            if dist.get_backend(group) == "gloo":
-                parts = [torch.empty(self.Pr * c, dtype=torch.float32) for _ in range(self.world)]
-                dist.all_gather(parts, self.rows(name, rank).reshape(-1).clone(), group=group)
-                self.blocks[name].copy_(torch.cat(parts))
-            else:
-                dist.all_gather_into_tensor(self.blocks[name], self.rows(name, rank).reshape(-1).clone(), group=group)
+            if touched is None:
+                _all_gather(self.blocks[name], self.rows(name, rank).reshape(-1).clone(), group)
+                continue
+            B, nb, k = self.block_rows, touched.nb, touched.kmax
+            blocks = self.blocks[name].view(self.world, nb, B * c)
+            recv = torch.empty(self.world * k * B * c, dtype=torch.float32, device=dev)
+            _all_gather(recv, blocks[rank][touched.order[rank]].reshape(-1), group)
+            blocks[torch.arange(self.world, device=dev)[:, None], touched.order] = recv.view(self.world, k, B * c)
 
 
 class OwnerAdam:
@@ -179,15 +282,19 @@ class OwnerAdam:
         self.max_exp_avg_sq = {name: z(name, c) for name, c in params.layout} if amsgrad else None
         self._index = torch.arange(params.Pr, dtype=torch.int64, device=params.flat.device)
 
-    def step(self, bucket, params, lr, group=None):
+    def step(self, bucket, params, lr, group=None, compact=False):
         """One optimizer step from the gradients accumulated in `bucket` (all views of all ranks): reduce-scatter,
         Adam on the owned rows that some view saw, all-gather of the attributes.  Returns the number of rows of this
-        rank that moved (a device tensor; no synchronisation)."""
+        rank that moved (a device tensor; no synchronisation).  compact: touched-block form of both exchanges."""
+        grads = bucket.reduce_scatter_rows(self.rank, group, compact=compact)
+        return self.step_rows(grads, params, lr, group, touched=bucket.touched)
+
+    def step_rows(self, grads, params, lr, group=None, touched=None):
+        """The same step from already reduce-scattered rows (``GradientBucket.reduce_scatter_rows`` /
+        ``StepExchange.finish``): dict name -> [Pr, c] and "seen" -> [Pr]."""
         from . import rasterizer as _r
         self.steps += 1
-        grads = bucket.reduce_scatter_rows(self.rank, group)
-        r0 = self.rank * params.Pr
-        flag = (bucket.seen[r0:r0 + params.Pr] > 0)
+        flag = grads["seen"] > 0
         bc1, bc2 = 1 - self.BETA1 ** self.steps, 1 - self.BETA2 ** self.steps
         entries = []
         for name, _ in params.layout:
@@ -199,8 +306,87 @@ class OwnerAdam:
         if entries:
             with torch.no_grad():
                 _r._backend.sparse_adam(self._index, flag, entries, self.BETA1, self.BETA2, math.sqrt(bc2), self.EPS)
-        params.all_gather_rows(self.rank, group)
+        params.all_gather_rows(self.rank, group, touched=touched)
         return flag.sum()
+
+
+class StepExchange:
+    """The gradient exchange of one training step in `parts` pieces, so that most of it runs under the rendering.
+
+    The step's views are split into `parts` consecutive groups (``bucket_of``), each accumulating into its own
+    GradientBucket.  ``launch(g)`` -- called once group g's last backward has been enqueued -- issues g's reduce-scatter:
+    on a HIP device it goes to a side stream that waits for the compute stream's work so far, so RCCL moves group g while
+    group g + 1 renders; ``finish()`` joins the side stream and sums the groups' shards (P / world rows each).  What stays
+    exposed is the last group's reduce-scatter (1 / parts of the bytes) and whatever the caller does with the shard
+    (``OwnerAdam.step_rows`` + its all-gather, or ``all_gather_grads`` for replicated optimizers).  Costs parts x the
+    bucket memory (30 M Gaussians x 14 columns: 1.7 GB each out of 288).  The sum is the same set of addends as one
+    bucket's, grouped by part."""
+
+    def __init__(self, num_points, device, world=1, rank=0, sh_coeffs=0, parts=1, block_rows=0, group=None):
+        self.world, self.rank, self.parts, self.group = max(int(world), 1), int(rank), max(int(parts), 1), group
+        self.buckets = [GradientBucket(num_points, device, world, sh_coeffs, block_rows) for _ in range(self.parts)]
+        self.device = self.buckets[0].flat.device
+        self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.world > 1) else None
+        self._shards = [None] * self.parts
+        self.touched = None
+
+    def bucket_of(self, view, n_views):
+        """The bucket view `view` of the rank's `n_views` accumulates into (consecutive views share a group)."""
+        return self.buckets[min(int(view) * self.parts // max(int(n_views), 1), self.parts - 1)]
+
+    def last_view_of(self, part, n_views):
+        return max(v for v in range(n_views) if self.bucket_of(v, n_views) is self.buckets[part])
+
+    def zero(self):
+        for b in self.buckets:
+            b.zero()
+        self._shards = [None] * self.parts
+        self.touched = None
+
+    def launch(self, part, compact=False):
+        b = self.buckets[part]
+        if self.side is None:
+            self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact)
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact)
+
+    def finish(self):
+        """-> dict name -> [Pr, c] (+ "seen" -> [Pr]): this rank's rows of the sum over all groups and ranks."""
+        for g in range(self.parts):
+            if self._shards[g] is None:
+                self.launch(g)
+        if self.side is not None:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self.side)
+            for sh in self._shards:
+                for t in sh.values():
+                    t.record_stream(main)
+        total = dict(self._shards[0])
+        if self.parts > 1:
+            total = {k: v.clone() for k, v in total.items()} if not _active(self.world) else total
+            for sh in self._shards[1:]:
+                for k in total:
+                    total[k] += sh[k]
+        tbs = [b.touched for b in self.buckets]
+        self.touched = None
+        if all(t is not None for t in tbs):
+            self.touched = tbs[0]
+            for t in tbs[1:]:
+                self.touched = self.touched.union(t)
+        return total
+
+    def all_gather_grads(self, total):
+        """Replicated-optimizer form: every rank receives every row of the summed gradients, in buckets[0]."""
+        b0 = self.buckets[0]
+        if not _active(self.world):
+            for name, _ in b0.layout:
+                b0.rows(name, 0).copy_(total[name])
+            return b0.flat
+        for name, c in b0.layout:
+            _all_gather(b0.blocks[name], total[name].reshape(-1), self.group)
+        return b0.flat
 
 
 # ---- second axis (SURVEY 8e, C5): the image split into bands of tile rows, one band per rank ----------------------

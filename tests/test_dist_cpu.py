@@ -122,37 +122,56 @@ GOLD_OWNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", 
 NAMES = ("means3D", "scales", "rotations", "opacities", "colors", "shs")
 
 
-def _owner_run(rank, world, g, n_ranks_views=1):
+def _owner_run(rank, world, g, mode="dense"):
     """Replays the golden's steps through GradientBucket / FlatParams / OwnerAdam on `rank` of `world`.  The step's
     gradient is split into `world` addends (as if each rank had rendered some of the views): rank r contributes
-    grad * w_r with w = exact binary fractions, and a disjoint part of the seen mask."""
-    from log_amd.dist import FlatParams, GradientBucket, OwnerAdam
+    grad * w_r with w = exact binary fractions, and a disjoint part of the seen mask.
+    mode: "dense" | "compact" (touched-block exchange, 2-row blocks) | "parts" (StepExchange, two groups of views that see
+    alternating 2-row blocks) | "parts_compact"."""
+    from log_amd.dist import FlatParams, GradientBucket, OwnerAdam, StepExchange
     P = int(g["P"])
+    compact, parts = mode.endswith("compact"), 2 if mode.startswith("parts") else 1
+    blk = 2 if compact else 0
     tensors = {n: torch.from_numpy(g["init_" + n].copy()) for n in NAMES}
-    params = FlatParams(tensors, "cpu", world)
-    bucket = GradientBucket(P, "cpu", world, sh_coeffs=15)
+    params = FlatParams(tensors, "cpu", world, block_rows=blk)
+    ex = StepExchange(P, "cpu", world, rank, sh_coeffs=15, parts=parts, block_rows=blk)
     opt = OwnerAdam(params, rank)
     w = [1.0] if world == 1 else [0.25, 0.75]
-    for it in range(int(g["n_steps"])):
-        bucket.zero()
-        seen = torch.from_numpy(g[f"s{it}_seen"])
-        for n in NAMES:
-            bucket.views[n].copy_(torch.from_numpy(g[f"s{it}_grad_{n}"]).reshape(bucket.views[n].shape) * w[rank])
-        radii = torch.where(seen & ((torch.arange(P) % world) == rank), 5, 0)      # each row is "seen" by one rank
-        bucket.mark_seen(radii)
-        lr = {"means3D": float(g[f"s{it}_lr_means3D"]), "scales": float(g[f"s{it}_lr_scales"]), "rotations": 0.001,
-              "opacities": 0.05, "colors": 0.0025, "shs": 0.000125}
-        opt.step(bucket, params, lr)
+    old = GradientBucket.DENSE_ABOVE
+    GradientBucket.DENSE_ABOVE = 2.0 if compact else old     # (63 % of the golden's rows are seen: force the compact form)
+    try:
+        for it in range(int(g["n_steps"])):
+            ex.zero()
+            seen = torch.from_numpy(g[f"s{it}_seen"])
+            mine = seen & ((torch.arange(P) % world) == rank)                          # each row is "seen" by one rank
+            for part, bucket in enumerate(ex.buckets):
+                # the rows of this group of views: all of them, or blocks of two rows alternating between the groups; a
+                # row nobody saw in a group has a zero gradient there (as after a real backward)
+                rows = torch.ones(P, dtype=torch.bool) if parts == 1 else ((torch.arange(P) // 2) % 2) == part
+                live = (seen & rows).to(torch.float32)
+                for n in NAMES:
+                    gr = torch.from_numpy(g[f"s{it}_grad_{n}"]).reshape(P, -1) * live[:, None] * w[rank]
+                    bucket.views[n].copy_(gr.reshape(bucket.views[n].shape))
+                bucket.mark_seen(torch.where(mine & rows, 5, 0))
+                ex.launch(part, compact=compact)
+            lr = {"means3D": float(g[f"s{it}_lr_means3D"]), "scales": float(g[f"s{it}_lr_scales"]), "rotations": 0.001,
+                  "opacities": 0.05, "colors": 0.0025, "shs": 0.000125}
+            total = ex.finish()
+            if compact and world > 1:
+                assert ex.touched is not None and ex.touched.kmax < ex.touched.nb     # some blocks did stay home
+            opt.step_rows(total, params, lr, touched=ex.touched)
+    finally:
+        GradientBucket.DENSE_ABOVE = old
     return params, opt
 
 
-def _owner_worker(rank, world, port, out):
+def _owner_worker(rank, world, port, out, mode="dense"):
     import oracle_backend
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         oracle_backend.install(oracle_backend.OracleBackend())
-        params, opt = _owner_run(rank, world, np.load(GOLD_OWNER))
+        params, opt = _owner_run(rank, world, np.load(GOLD_OWNER), mode)
         torch.save({"flat": params.flat.clone(), "exp_avg": opt.exp_avg, "exp_avg_sq": opt.exp_avg_sq},
                    os.path.join(out, f"o{rank}.pt"))
     finally:
@@ -176,16 +195,18 @@ def test_owner_adam_world1_reproduces_reference_optimizer(oracle_mod):
                                    g["final_exp_avg_sq_" + n], rtol=2e-6, atol=1e-15)
 
 
-def test_owner_adam_two_ranks_match_one(tmp_path, oracle_mod):
+@pytest.mark.parametrize("mode", ["dense", "compact", "parts", "parts_compact"])
+def test_owner_adam_two_ranks_match_one(tmp_path, oracle_mod, mode):
     """world = 2 (gloo): each rank steps only its rows, with moments for those rows only; after the all-gather both
     replicas hold the world-1 result (the two addends 0.25 g + 0.75 g sum to g exactly), and the moments of rank r are
-    the world-1 moments of its rows."""
+    the world-1 moments of its rows.  The same through the touched-block exchange (only blocks some rank saw travel) and
+    through StepExchange (two groups of views, reduce-scattered one after the other), alone and together."""
     import oracle_backend
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_owner_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_owner_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     got = [torch.load(os.path.join(tmp_path, f"o{r}.pt")) for r in range(world)]
     assert torch.equal(got[0]["flat"], got[1]["flat"])
     old = oracle_backend.install(oracle_backend.OracleBackend())
@@ -195,7 +216,8 @@ def test_owner_adam_two_ranks_match_one(tmp_path, oracle_mod):
         oracle_backend.install(old)
     from log_amd.dist import FlatParams
     P = ref_params.P
-    two = FlatParams({n: ref_params.views[n] for n in NAMES}, "cpu", world)      # same layout as the workers' buffers
+    two = FlatParams({n: ref_params.views[n] for n in NAMES}, "cpu", world,      # same layout as the workers' buffers
+                     block_rows=2 if mode.endswith("compact") else 0)
     two.flat.copy_(got[0]["flat"])
     for n in NAMES:
         assert torch.equal(two.views[n], ref_params.views[n]), n
@@ -218,3 +240,69 @@ def test_bucket_carries_sh_columns_and_seen_counts():
     assert b.seen.tolist() == [2.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0]
     b.zero()
     assert float(b.seen.sum()) == 0.0
+
+
+def _blocks_worker(rank, world, port, out):
+    from log_amd.dist import GradientBucket, StepExchange
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, B = 1000, 16
+        gen = torch.Generator().manual_seed(7 + rank)
+        lo = 0 if rank == 0 else 608                     # rank 0's views see rows [0, 41), rank 1's rows [608, 649): three 16-row blocks each
+        radii = torch.zeros(P, dtype=torch.int32)
+        radii[lo:lo + 41] = 3
+        res = {}
+        for compact in (False, True):
+            b = GradientBucket(P, "cpu", world, sh_coeffs=4, block_rows=B)
+            for name, c in b.layout:
+                gr = torch.zeros(P, c)
+                gr[lo:lo + 41] = torch.randn(41, c, generator=torch.Generator().manual_seed(11 + rank))
+                b.views[name].copy_(gr.reshape(b.views[name].shape))
+            b.mark_seen(radii)
+            rows = b.reduce_scatter_rows(rank, compact=compact)
+            res[compact] = {k: v.clone() for k, v in rows.items()}
+            if compact:
+                res["kmax"], res["nb"] = b.touched.kmax, b.touched.nb
+        # replicated-optimizer form through StepExchange: two groups, then every rank holds the whole sum
+        ex = StepExchange(P, "cpu", world, rank, parts=2, block_rows=B)
+        for part, b in enumerate(ex.buckets):
+            b.views["means3D"].fill_(float(rank + 1) * (part + 1))
+            b.mark_seen(radii)
+            ex.launch(part)
+        flat = ex.all_gather_grads(ex.finish())
+        res["full"] = ex.buckets[0].views["means3D"].clone()
+        torch.save(res, os.path.join(out, f"b{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_touched_block_exchange_moves_only_touched_blocks(tmp_path):
+    """rows in 3 of each owner's 32 blocks are seen -> 3 blocks per owner travel instead of 32, and the rows
+    every owner receives are identical to the dense reduce-scatter's (untouched rows: exact zeros either way)."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_blocks_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"b{r}.pt")) for r in range(world)]
+    for r in range(world):
+        assert got[r]["kmax"] == 3 and got[r]["nb"] == 32
+        for k in got[r][False]:
+            assert torch.equal(got[r][False][k], got[r][True][k]), (r, k)
+        assert float(got[r][True]["seen"].sum()) == 41.0          # each owner's 41 seen rows, once each
+        assert torch.equal(got[r]["full"], torch.full((1000, 3), 9.0))   # (1 + 2) * (1 + 2): both ranks, both groups
+
+
+def test_step_exchange_groups_consecutive_views():
+    from log_amd.dist import StepExchange
+    ex = StepExchange(10, "cpu", parts=3)
+    groups = [ex.buckets.index(ex.bucket_of(v, 8)) for v in range(8)]
+    assert groups == sorted(groups) and set(groups) == {0, 1, 2}
+    assert [ex.last_view_of(g, 8) for g in range(3)] == [max(v for v in range(8) if groups[v] == g) for g in range(3)]
+    # one rank, several groups: finish() is the plain sum of the groups' rows
+    for i, b in enumerate(ex.buckets):
+        b.views["colors"].fill_(float(i + 1))
+        b.mark_seen(torch.ones(10))
+    total = ex.finish()
+    assert torch.equal(total["colors"], torch.full((10, 3), 6.0)) and torch.equal(total["seen"], torch.full((10,), 3.0))

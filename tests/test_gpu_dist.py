@@ -43,3 +43,98 @@ def test_bench_line_carries_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+# ---- log_amd.dist.StepExchange on the device: two ranks (sharing the GPU, gloo) vs one process -----------------------
+def _render_views(ex_or_bucket, views, n_views_rank, dev, parts_of=None):
+    """Renders `views` (list of (index within the rank, camera)) forward + backward with the gradients added by the
+    backward kernels into the bucket of the view's group."""
+    import math
+    import numpy as np
+    import torch
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
+    from log_amd import rasterizer as R, scenes
+    N, W, H = 60000, 320, 208
+    sc = scenes.random_scene(N, seed=5, opacity=None, smax=0.03)
+    sc["xyz"] = sc["xyz"].copy()
+    sc["xyz"][(np.arange(N) // 256) % 2 == 1] += 1000.0        # every other 256-row block is out of every view
+    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
+    leaves = dict(means3D=T(sc["xyz"]), scales=T(sc["scaling"]), rotations=T(sc["rotation"]), opacities=T(sc["opacity"]),
+                  colors=T(sc["colors"]))
+    leaves = {k: v.requires_grad_(True) for k, v in leaves.items()}
+    w = T(np.random.default_rng(2).random((3, H, W), dtype=np.float32))
+    for j, cam in views:
+        bucket = ex_or_bucket.bucket_of(j, n_views_rank) if hasattr(ex_or_bucket, "bucket_of") else ex_or_bucket
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam["FoVx"] * 0.5), tanfovy=math.tan(cam["FoVy"] * 0.5),
+            bg=T([0, 0, 0]), scale_modifier=1.0, viewmatrix=T(cam["world_view_transform"]),
+            projmatrix=T(cam["full_proj_transform"]), sh_degree=0, campos=T(cam["camera_center"]), prefiltered=False,
+            debug=False)
+        m2 = torch.zeros(N, 3, device=dev, requires_grad=True)
+        with R.accumulate_grads_into(bucket.views):
+            out = GaussianRasterizer(raster_settings=rs)(
+                means3D=leaves["means3D"], means2D=m2, shs=None, colors_precomp=leaves["colors"],
+                opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+            out[0].backward(gradient=w)
+        bucket.mark_seen(out[1])
+        if hasattr(ex_or_bucket, "bucket_of") and j == ex_or_bucket.last_view_of(ex_or_bucket.buckets.index(bucket), n_views_rank):
+            ex_or_bucket.launch(ex_or_bucket.buckets.index(bucket), compact=parts_of == "compact")
+    return N
+
+
+def _exchange_worker(rank, world, port, out, mode):
+    import torch
+    import torch.distributed as dist
+    from log_amd import scenes
+    from log_amd.dist import StepExchange
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        cams = scenes.orbit_cameras(8, W=320, H=208, focal=300.0)
+        mine = [(j, cams[i]) for j, i in enumerate(range(rank, 8, world))]
+        ex = StepExchange(60000, dev, world, rank, parts=2, block_rows=256 if mode == "compact" else 0)
+        _render_views(ex, mine, len(mine), dev, parts_of=mode)
+        total = ex.finish()
+        assert (ex.touched is not None and ex.touched.kmax <= ex.touched.nb // 2 + 1) == (mode == "compact")
+        seen_rows = total["seen"].clone()
+        flat = ex.all_gather_grads(total).clone()
+        torch.cuda.synchronize()
+        torch.save({"flat": flat.cpu(), "seen": seen_rows.cpu(), "Pr": ex.buckets[0].Pr}, os.path.join(out, f"x{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["dense", "compact"])
+def test_step_exchange_two_ranks_equals_one_process(tmp_path, mode):
+    """Eight views: rank r of 2 renders four of them in two groups, every group reduce-scattered from the side stream as
+    soon as its last backward is enqueued; after finish() + all_gather_grads both ranks hold the sum one process
+    accumulates over all eight views (float atomics: 1e-5), and the seen counts of their own rows."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from log_amd import scenes
+    from log_amd.dist import FlatParams, GradientBucket
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"x{r}.pt")) for r in range(world)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"])
+    dev = torch.device("cuda:0")
+    cams = scenes.orbit_cameras(8, W=320, H=208, focal=300.0)
+    ref = GradientBucket(60000, dev)
+    _render_views(ref, list(enumerate(cams)), 8, dev)
+    torch.cuda.synchronize()
+    two = GradientBucket(60000, "cpu", world, block_rows=256 if mode == "compact" else 0)
+    two.flat.copy_(got[0]["flat"])
+    assert float(ref.flat.abs().sum()) > 0
+    for name, _ in ref.layout:
+        a, b = ref.views[name].cpu(), two.views[name]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-7, name
+    Pr = got[0]["Pr"]
+    seen = ref.seen.cpu()
+    for r in range(world):
+        rows = seen[r * Pr:(r + 1) * Pr]
+        assert torch.equal(got[r]["seen"][:rows.numel()], rows), r

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LOGRAST_VERSION 1
+#define LOGRAST_VERSION 2   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d */
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
 
@@ -71,6 +71,14 @@ typedef struct lograst_view {
    * image rows, gradients and point_weight cover this band only, radii is 0 for Gaussians that do not reach it, and
    * pixels outside the band come out as background.  Both 0 = the whole image. */
   int32_t tile_row_begin, tile_row_end;
+  /* The rasterizer's `cov3D_precomp` argument (the third-party forward's alternative to scales + rotations; LoG itself
+   * never passes it, /root/reference/LoG/render/renderer.py:134,149): device, n x 6 floats, the upper triangle
+   * (xx, xy, xz, yy, yz, zz) of every Gaussian's world-space covariance, or NULL.  When set, `scales` / `rotations` are
+   * not read (they may be NULL) and scale_modifier has no effect (it scales the `scales` only); the backward entry points
+   * then write dL/dcov3D (n x 6, off-diagonal entries carry both symmetric positions: 2 x the matrix partial) to
+   * `dl_dcov3d` and leave dl_dscales / dl_drotations (may be NULL) alone. */
+  const float* cov3d_precomp;
+  float* dl_dcov3d;
 } lograst_view;
 
 int lograst_version(void);

@@ -23,6 +23,7 @@ class LograstView(ctypes.Structure):
         ("filter_mode", c_int32), ("ndc_cull", c_int32), ("extras", c_int32),
         ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("bg", c_void_p),
         ("tile_row_begin", c_int32), ("tile_row_end", c_int32),
+        ("cov3d_precomp", c_void_p), ("dl_dcov3d", c_void_p),
     ]
 
 
@@ -104,7 +105,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.lograst_version() != 1:
+        if L.lograst_version() != 2:
             raise LograstError("liblograst.so version mismatch; rebuild")
         _lib = L
     return _lib

@@ -226,6 +226,7 @@ static int lr_make_view(const lograst_view* in, LrView* out) {
   out->scale_modifier = in->scale_modifier;
   out->filter_mode = in->filter_mode; out->ndc_cull = in->ndc_cull; out->extras = in->extras;
   out->view = in->viewmatrix; out->proj = in->projmatrix; out->bg = in->bg;
+  out->cov3d = in->cov3d_precomp; out->g_cov3d = in->dl_dcov3d;
   return LOGRAST_OK;
 }
 
@@ -307,15 +308,28 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   return LOGRAST_OK;
 }
 
-static int lr_check_stage1_args(int32_t n, const float* means3d, const float* scales, const float* rotations,
-                                const float* opacities, const float* colors, const int32_t* radii, const void* geom,
-                                const void* tile_state) {
+static int lr_check_stage1_args(const LrView& v, int32_t n, const float* means3d, const float* scales,
+                                const float* rotations, const float* opacities, const float* colors,
+                                const int32_t* radii, const void* geom, const void* tile_state) {
   if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
   if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
-  if (n > 0 && (!means3d || !scales || !rotations || !opacities || !colors || !radii || !geom))
+  if (n > 0 && (!means3d || !opacities || !colors || !radii || !geom))
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (n > 0 && !v.cov3d && (!scales || !rotations))
+    return lr_fail(LOGRAST_ERR_ARG, "scales / rotations are NULL and the view carries no cov3d_precomp");
   if ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(geom) | reinterpret_cast<uintptr_t>(tile_state)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "rotations / geom / tile_state must be 16-byte aligned");
+  return LOGRAST_OK;
+}
+
+// backward: scales + rotations with their gradient outputs, or the view's cov3d_precomp with dl_dcov3d
+static int lr_check_cov_args(const LrView& v, const float* scales, const float* rotations, const float* dl_dscales,
+                             const float* dl_drotations) {
+  if (v.cov3d) {
+    if (!v.g_cov3d) return lr_fail(LOGRAST_ERR_ARG, "cov3d_precomp is set but dl_dcov3d is NULL");
+    return LOGRAST_OK;
+  }
+  if (!scales || !rotations || !dl_dscales || !dl_drotations) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   return LOGRAST_OK;
 }
 
@@ -343,7 +357,7 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
-  rc = lr_check_stage1_args(n, means3d, scales, rotations, opacities, colors, radii, geom, tile_state);
+  rc = lr_check_stage1_args(v, n, means3d, scales, rotations, opacities, colors, radii, geom, tile_state);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
@@ -390,7 +404,7 @@ int lograst_forward(const lograst_view* view, int32_t n, const float* means3d, c
   LrView v;
   int rc = lr_make_view(view, &v);
   if (rc) return rc;
-  rc = lr_check_stage1_args(n, means3d, scales, rotations, opacities, colors, radii, geom, tile_state);
+  rc = lr_check_stage1_args(v, n, means3d, scales, rotations, opacities, colors, radii, geom, tile_state);
   if (rc) return rc;
   rc = lr_check_stage2_args(v, n, tile_state, keys, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
                             point_weight_pixel, point_weight, bwd_scratch, bwd_scratch_floats);
@@ -438,9 +452,11 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   if (rc) return rc;
   if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
   if (n == 0) return LOGRAST_OK;
-  if (!means3d || !scales || !rotations || !radii || !geom || !tile_state || !final_t || !n_contrib || !dl_dimage ||
-      !dl_dmeans2d || !dl_dconic || !dl_dopacities || !dl_dcolors || !dl_dmeans3d || !dl_dscales || !dl_drotations)
+  if (!means3d || !radii || !geom || !tile_state || !final_t || !n_contrib || !dl_dimage ||
+      !dl_dmeans2d || !dl_dconic || !dl_dopacities || !dl_dcolors || !dl_dmeans3d)
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  rc = lr_check_cov_args(v, scales, rotations, dl_dscales, dl_drotations);
+  if (rc) return rc;
   if ((reinterpret_cast<uintptr_t>(dl_dconic) | reinterpret_cast<uintptr_t>(rotations) |
        reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");
@@ -477,9 +493,10 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
   if (rc) return rc;
   if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
   if (n == 0) return LOGRAST_OK;
-  if (!means3d || !scales || !rotations || !radii || !dl_dmeans2d || !dl_dconic || !dl_dmeans3d || !dl_dscales ||
-      !dl_drotations)
+  if (!means3d || !radii || !dl_dmeans2d || !dl_dconic || !dl_dmeans3d)
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  rc = lr_check_cov_args(v, scales, rotations, dl_dscales, dl_drotations);
+  if (rc) return rc;
   if ((reinterpret_cast<uintptr_t>(dl_dconic) | reinterpret_cast<uintptr_t>(rotations) |
        reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");

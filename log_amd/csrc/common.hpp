@@ -77,6 +77,8 @@ struct LrView {
   const float* view;
   const float* proj;
   const float* bg;
+  const float* cov3d;   // precomputed world-space covariances (n x 6) instead of scales + rotations, or nullptr
+  float* g_cov3d;       // backward: dL/dcov3D (n x 6) when cov3d is set
 };
 
 #define LR_DEV __device__ __forceinline__

@@ -65,13 +65,21 @@ struct LrInputs {
   float4 q;
   float op;
 };
+// (cov3d: the rasterizer's cov3D_precomp instead of scales + rotations -- its six floats travel in s[] and q.xyz, so the
+// prefetch holds no more registers)
 LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const float* __restrict__ scales,
                                const float* __restrict__ rots, const float* __restrict__ opac,
-                               const float* __restrict__ colors) {
+                               const float* __restrict__ colors, const float* __restrict__ cov3d) {
   LrInputs in;
   in.p[0] = means[3 * i]; in.p[1] = means[3 * i + 1]; in.p[2] = means[3 * i + 2];
-  in.s[0] = scales[3 * i]; in.s[1] = scales[3 * i + 1]; in.s[2] = scales[3 * i + 2];
-  in.q = reinterpret_cast<const float4*>(rots)[i];
+  if (cov3d) {
+    const float* __restrict__ c6 = cov3d + 6 * (size_t)i;
+    in.s[0] = c6[0]; in.s[1] = c6[1]; in.s[2] = c6[2];
+    in.q = float4{c6[3], c6[4], c6[5], 0.f};
+  } else {
+    in.s[0] = scales[3 * i]; in.s[1] = scales[3 * i + 1]; in.s[2] = scales[3 * i + 2];
+    in.q = reinterpret_cast<const float4*>(rots)[i];
+  }
   in.op = opac[i];
   in.c[0] = colors[3 * i]; in.c[1] = colors[3 * i + 1]; in.c[2] = colors[3 * i + 2];
   return in;
@@ -102,10 +110,15 @@ LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, c
   float pw = 1.0f / (hw + 0.0000001f);
   float nx = hx * pw, ny = hy * pw;
   if (v.ndc_cull && (nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) return;
-  float s[3] = {in.s[0] * v.scale_modifier, in.s[1] * v.scale_modifier, in.s[2] * v.scale_modifier};
-  float q[4] = {in.q.x, in.q.y, in.q.z, in.q.w};
-  float R[9], Sg[6];
-  lr_cov3d(s, q, R, Sg);
+  float Sg[6];
+  if (v.cov3d) {   // cov3D_precomp (wave-uniform): see lr_load_inputs
+    Sg[0] = in.s[0]; Sg[1] = in.s[1]; Sg[2] = in.s[2]; Sg[3] = in.q.x; Sg[4] = in.q.y; Sg[5] = in.q.z;
+  } else {
+    float s[3] = {in.s[0] * v.scale_modifier, in.s[1] * v.scale_modifier, in.s[2] * v.scale_modifier};
+    float q[4] = {in.q.x, in.q.y, in.q.z, in.q.w};
+    float R[9];
+    lr_cov3d(s, q, R, Sg);
+  }
   LrEwa e;
   lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
   float det = e.a * e.c - e.b * e.b;
@@ -193,7 +206,7 @@ lr_project_kernel(LrView v, int N, const float* __restrict__ means, const float*
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
     if (i < N) {
       int rad;
-      const LrInputs in = lr_load_inputs(i, means, scales, rots, opac, colors);
+      const LrInputs in = lr_load_inputs(i, means, scales, rots, opac, colors, v.cov3d);
       bool huge;
       lr_project_one<false>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge);
       radii[i] = rad;
@@ -273,12 +286,12 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   // is 16 waves on one CU, so there is little other work to hide the loads behind)
   int i = i_begin + (int)threadIdx.x;
   LrInputs nxt;
-  if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors);
+  if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors, v.cov3d);
   // (trip count uniform per wave: the record stores below are cooperative among groups of four lanes)
   for (; (i & ~63) < i_end; i += LR_BATCH_THREADS) {
     const bool mine = i < i_end;
     const LrInputs in = nxt;
-    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors);
+    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
     const int plane = ((i & ~63) - i_begin) / B;            // B is a multiple of the workgroup size: uniform per iteration
     const LrLdsCounters ctr{lr_lds_ctr + plane * tiles};
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;

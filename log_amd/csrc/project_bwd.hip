@@ -11,7 +11,7 @@
 // their accumulators (whose conic part the forward then does not zero-fill: the compositing kernel clears the rows it meets) and without the 80-byte read-modify-
 // write of the running sums: in an opaque scene most Gaussians are hidden (30 M random Gaussians at opacity 0.999:
 // the kernel went from 0.83 ms, at the copy rate, to the touched rows' share).
-template <bool ACCUMULATE, bool TOUCHED>
+template <bool ACCUMULATE, bool TOUCHED, bool COV>
 __global__ void __launch_bounds__(256)
 lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                       const float* __restrict__ rots, const int* __restrict__ radii,
@@ -26,12 +26,18 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     const float* __restrict__ V = v.view;
     const float* __restrict__ Pm = v.proj;
     float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    float s[3] = {scales[3 * i] * v.scale_modifier, scales[3 * i + 1] * v.scale_modifier,
-                  scales[3 * i + 2] * v.scale_modifier};
-    const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
-    float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     float R[9], Sg[6];
-    lr_cov3d(s, q, R, Sg);
+    if (COV) {   // cov3D_precomp (the view carries n x 6 covariances): the chain stops at dL/dSigma
+#pragma unroll
+      for (int k = 0; k < 6; k++) Sg[k] = v.cov3d[6 * (size_t)i + k];
+    } else {
+      s[0] = scales[3 * i] * v.scale_modifier; s[1] = scales[3 * i + 1] * v.scale_modifier;
+      s[2] = scales[3 * i + 2] * v.scale_modifier;
+      const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+      lr_cov3d(s, q, R, Sg);
+    }
     LrEwa e;
     lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
     const float a = e.a, b = e.b, c = e.c;
@@ -92,6 +98,14 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     m1 += Pm[4] * ghx + Pm[5] * ghy + Pm[7] * ghw;
     m2 += Pm[8] * ghx + Pm[9] * ghy + Pm[11] * ghw;
     gm[0] = m0; gm[1] = m1; gm[2] = m2;
+    if (COV) {
+      // the six stored entries; an off-diagonal one stands for both symmetric positions of Sigma (the upstream backward's
+      // "off-diagonal elements appear twice" rule)
+      const float g6[6] = {gS[0], 2.f * gS[1], 2.f * gS[2], gS[4], 2.f * gS[5], gS[8]};
+      float* __restrict__ o = v.g_cov3d + 6 * (size_t)i;
+#pragma unroll
+      for (int k = 0; k < 6; k++) o[k] = ACCUMULATE ? o[k] + g6[k] : g6[k];
+    } else {
     // Sigma = M M^T, M_ik = R_ik s_k
     float M[9], gM[9], gR[9];
 #pragma unroll
@@ -114,6 +128,21 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     gq[1] = 2.f * (y * gR[1] + z * gR[2] + y * gR[3] - 2.f * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - 2.f * x * gR[8]);
     gq[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2.f * y * gR[8]);
     gq[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
+    }
+  } else if (COV && !ACCUMULATE) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) v.g_cov3d[6 * (size_t)i + k] = 0.f;
+  }
+  if (COV) {   // dL/dmeans3D only; scales / rotations take no part
+    if (ACCUMULATE) {
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] += gm[k];
+      }
+    } else {
+      g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];
+    }
+    return;
   }
   if (ACCUMULATE) {  // running sums over views (log_amd.dist): culled / untouched Gaussians contribute nothing, skip the traffic
     if (live) {
@@ -136,10 +165,12 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
   if (N <= 0) return;
   lr_prof_begin(LRK_PROJECT_BWD, s);
   const dim3 grid((N + 255) / 256), block(256);
-#define LR_PBWD(A, T) hipLaunchKernelGGL((lr_project_bwd_kernel<A, T>), grid, block, 0, s, v, N, means, scales, rots, \
-                                         radii, g_mean2d, g_conic, pw, g_means3d, g_scales, g_rots)
-  if (accumulate) { if (pw) LR_PBWD(true, true); else LR_PBWD(true, false); }
-  else { if (pw) LR_PBWD(false, true); else LR_PBWD(false, false); }
+#define LR_PBWD(A, T, C) hipLaunchKernelGGL((lr_project_bwd_kernel<A, T, C>), grid, block, 0, s, v, N, means, scales, \
+                                            rots, radii, g_mean2d, g_conic, pw, g_means3d, g_scales, g_rots)
+#define LR_PBWD_C(A, T) do { if (v.cov3d) LR_PBWD(A, T, true); else LR_PBWD(A, T, false); } while (0)
+  if (accumulate) { if (pw) LR_PBWD_C(true, true); else LR_PBWD_C(true, false); }
+  else { if (pw) LR_PBWD_C(false, true); else LR_PBWD_C(false, false); }
+#undef LR_PBWD_C
 #undef LR_PBWD
   lr_prof_end(LRK_PROJECT_BWD, s);
 }

@@ -189,7 +189,8 @@ class HipBackend:
                 "the HIP kernels are the only implementation -- there is no CPU fallback")
         return _lib.lib()
 
-    def make_view(self, rs, flavour, use_filter, device):
+    def make_view(self, rs, flavour, use_filter, device, cov3D=None, g_cov3D=None):
+        """cov3D / g_cov3D: the `cov3D_precomp` input ([N, 6]) and, for a backward, where dL/dcov3D goes."""
         keep = (_dev_f32(rs.viewmatrix, device), _dev_f32(rs.projmatrix, device), _dev_f32(rs.bg, device).reshape(-1))
         if keep[0].numel() != 16 or keep[1].numel() != 16 or keep[2].numel() != 3:
             raise ValueError("viewmatrix/projmatrix must be 4x4 and bg must have 3 entries")
@@ -201,6 +202,8 @@ class HipBackend:
         v.ndc_cull, v.extras = flavour.ndc_cull, flavour.extras
         v.viewmatrix, v.projmatrix, v.bg = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
         v.tile_row_begin, v.tile_row_end = _tile_rows.get()
+        v.cov3d_precomp = cov3D.data_ptr() if cov3D is not None else None
+        v.dl_dcov3d = g_cov3D.data_ptr() if g_cov3D is not None else None
         return v, keep
 
     @staticmethod
@@ -217,14 +220,16 @@ class HipBackend:
         arena = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
         return {name: arena[off:off + n].view(dt).view(shape) for (name, dt, shape), (off, n) in zip(parts, spans)}
 
-    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0):
+    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0,
+                cov3D=None):
         """scratch_floats: 0, or the fp32 words per Gaussian of backward scratch to allocate and have the forward
-        zero-fill (7 with a gradient sink, 11 without): saved as `bwd_scratch` and consumed by the first backward."""
+        zero-fill (7 with a gradient sink, 11 without): saved as `bwd_scratch` and consumed by the first backward.
+        cov3D: the rasterizer's cov3D_precomp ([N, 6] fp32) instead of scales / rotations (both None then)."""
         device = means3D.device
         L = self.require(device)
         N = means3D.shape[0]
         H, W = int(rs.image_height), int(rs.image_width)
-        view, keep = self.make_view(rs, flavour, use_filter, device)
+        view, keep = self.make_view(rs, flavour, use_filter, device, cov3D=cov3D)
         stream = _stream_ptr(device)
         status = _status_block(device)
         i32, f32, u8 = torch.int32, torch.float32, torch.uint8
@@ -271,13 +276,19 @@ class HipBackend:
                      point_weight=o.get("pw"), tile_rows=(view.tile_row_begin, view.tile_row_end))
         return o["image"], o["radii"], o.get("pid"), o.get("pwp"), o.get("pw"), saved
 
-    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None):
+    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None, cov3D=None):
         """sink: optional dict of running-sum tensors (means3D, scales, rotations, opacities, colors) that this call
-        adds into (LOGRAST_BWD_ACCUMULATE); the corresponding returned gradients are then None."""
+        adds into (LOGRAST_BWD_ACCUMULATE); the corresponding returned gradients are then None.
+        cov3D (the forward's cov3D_precomp; no sink): the last two results are (dL/dcov3D [N, 6], None)."""
         device = means3D.device
         L = self.require(device)
         N = means3D.shape[0]
-        view, keep = self.make_view(rs, flavour, use_filter, device)
+        g_cov = None
+        if cov3D is not None:
+            if sink is not None:
+                raise ValueError("a gradient sink has no cov3D_precomp entry")
+            g_cov = torch.empty(N, 6, dtype=torch.float32, device=device)
+        view, keep = self.make_view(rs, flavour, use_filter, device, cov3D=cov3D, g_cov3D=g_cov)
         view.tile_row_begin, view.tile_row_end = saved.get("tile_rows", (0, 0))   # the band the forward rendered
         f32 = dict(dtype=torch.float32, device=device)
         grad_image = grad_image.to(torch.float32).contiguous()
@@ -317,6 +328,8 @@ class HipBackend:
         self.last_conic_grad = g_conic if _debug_keep else None   # test introspection only (pins the whole block)
         if sink is not None:
             return None, g_means2D, None, None, None, None
+        if cov3D is not None:
+            return g_means3D, g_means2D, g_colors, g_opac, g_cov, None
         return g_means3D, g_means2D, g_colors, g_opac, g_scales, g_rot
 
     def sh_forward(self, means3D, campos, shs, degree):
@@ -346,12 +359,15 @@ class HipBackend:
                                              _stream_ptr(device)))
         return g_shs if into is None else None
 
-    def project_backward(self, rs, flavour, use_filter, means3D, scales, rotations, radii, g_means2D, g_conic):
-        """Stage A6b alone (lograst_project_backward): used by the parity tests."""
+    def project_backward(self, rs, flavour, use_filter, means3D, scales, rotations, radii, g_means2D, g_conic,
+                         cov3D=None):
+        """Stage A6b alone (lograst_project_backward): used by the parity tests.  With cov3D: -> (dL/dmeans3D,
+        dL/dcov3D, None)."""
         device = means3D.device
         L = self.require(device)
         N = means3D.shape[0]
-        view, keep = self.make_view(rs, flavour, use_filter, device)
+        g_cov = torch.empty(N, 6, dtype=torch.float32, device=device) if cov3D is not None else None
+        view, keep = self.make_view(rs, flavour, use_filter, device, cov3D=cov3D, g_cov3D=g_cov)
         f32 = dict(dtype=torch.float32, device=device)
         g_means3D, g_scales, g_rot = torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, 4, **f32)
         with torch.cuda.device(device):
@@ -359,6 +375,8 @@ class HipBackend:
                                                   _ptr(radii), _ptr(g_means2D), _ptr(g_conic), _ptr(g_means3D),
                                                   _ptr(g_scales), _ptr(g_rot), _stream_ptr(device)))
         del keep
+        if cov3D is not None:
+            return g_means3D, g_cov, None
         return g_means3D, g_scales, g_rot
 
     def compute_radius(self, means3D, scales, rotations, projmatrix, viewmatrix, fx, fy, tanfovx, tanfovy):
@@ -586,10 +604,19 @@ class accumulate_grads_into:
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, colors, shs, opacities, scales, rotations, rs, flavour, use_filter):
+    def forward(ctx, means3D, means2D, colors, shs, opacities, scales, rotations, rs, flavour, use_filter, cov3D=None):
         m = means3D.detach().to(torch.float32).contiguous()
-        s = scales.detach().to(torch.float32).contiguous()
-        r = rotations.detach().to(torch.float32).contiguous()
+        cov = None
+        if cov3D is not None:   # the packages' cov3D_precomp input (not LoG's path): scales / rotations are absent
+            cov = cov3D.detach().to(torch.float32).contiguous()
+            if cov.shape != (m.shape[0], 6):
+                raise ValueError("cov3D_precomp must be [N, 6]")
+            if _grad_sink is not None:
+                raise ValueError("accumulate_grads_into has no entry for cov3D_precomp")
+            s, r = m.new_zeros(m.shape[0], 3), m.new_zeros(m.shape[0], 4)    # placeholders: never read
+        else:
+            s = scales.detach().to(torch.float32).contiguous()
+            r = rotations.detach().to(torch.float32).contiguous()
         o = opacities.detach().to(torch.float32).contiguous().reshape(-1)
         n = m.shape[0]
         sh = clamped = None
@@ -605,8 +632,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                              "colors_precomp[N,3], opacities[N,1]")
         wants_grad = any(ctx.needs_input_grad[:7])   # all False under torch.no_grad()
         scratch_floats = 0 if not wants_grad else (7 if (_grad_sink is not None and (sh is None or "shs" in _grad_sink)) else 11)
-        image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c,
-                                                             scratch_floats=scratch_floats)
+        wants_grad = wants_grad or (cov is not None and ctx.needs_input_grad[10])
+        if cov is not None:
+            scratch_floats = 11 if wants_grad else 0
+            image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, None, None, o, c,
+                                                                 scratch_floats=scratch_floats, cov3D=cov)
+        else:
+            image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, s, r, o, c,
+                                                                 scratch_floats=scratch_floats)
+        ctx.cov = cov
         ctx.rs, ctx.flavour, ctx.use_filter = rs, flavour, use_filter
         ctx.set_materialize_grads(False)   # no zero-filled gradients for radii / the fork maps (4 fill kernels per view)
         ctx.saved = saved
@@ -623,9 +657,17 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_image, *unused):
         m, s, r = ctx.saved_tensors
         if grad_image is None:   # only non-differentiable outputs were used downstream
-            return (None,) * 10
+            return (None,) * 11
         m2_shape, o_shape = ctx.shapes
         sh, clamped = ctx.sh
+        if ctx.cov is not None:
+            g_m3, g_m2, g_c, g_o, g_cov, _ = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, None, None,
+                                                               ctx.saved, grad_image, cov3D=ctx.cov)
+            g_sh = None
+            if sh is not None:
+                g_sh = _backend.sh_backward(m, ctx.rs.campos, sh, int(ctx.rs.sh_degree), clamped, g_c.contiguous(), g_m3)
+                g_c = None
+            return g_m3, g_m2.reshape(m2_shape), g_c, g_sh, g_o.reshape(o_shape), None, None, None, None, None, g_cov
         sink = _grad_sink
         if sink is not None and (sh is None or "shs" in sink):
             n = m.shape[0]
@@ -646,14 +688,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                         grad_image, sink=dict(sink, colors=g_c))
                 _backend.sh_backward(m, ctx.rs.campos, sh, int(ctx.rs.sh_degree), clamped, g_c, sink["means3D"],
                                      into=sink["shs"])
-            return None, g_m2.reshape(m2_shape), None, None, None, None, None, None, None, None
+            return None, g_m2.reshape(m2_shape), None, None, None, None, None, None, None, None, None
         g_m3, g_m2, g_c, g_o, g_s, g_r = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved,
                                                            grad_image)
         g_sh = None
         if sh is not None:
             g_sh = _backend.sh_backward(m, ctx.rs.campos, sh, int(ctx.rs.sh_degree), clamped, g_c.contiguous(), g_m3)
             g_c = None
-        return g_m3, g_m2.reshape(m2_shape), g_c, g_sh, g_o.reshape(o_shape), g_s, g_r, None, None, None
+        return g_m3, g_m2.reshape(m2_shape), g_c, g_sh, g_o.reshape(o_shape), g_s, g_r, None, None, None, None
 
 
 class GaussianRasterizer(nn.Module):
@@ -696,10 +738,8 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         if shs is not None and not 0 <= int(self.raster_settings.sh_degree) <= 3:
             raise ValueError("sh_degree must be 0..3")
-        if cov3D_precomp is not None:
-            raise NotImplementedError("log_amd: cov3D_precomp is not on LoG's path (renderer.py:134,149)")
         return _RasterizeGaussians.apply(means3D, means2D, colors_precomp, shs, opacities, scales, rotations,
-                                         self.raster_settings, flavour, use_filter)
+                                         self.raster_settings, flavour, use_filter, cov3D_precomp)
 
 
 class UpstreamGaussianRasterizer(GaussianRasterizer):

@@ -133,11 +133,15 @@ def lod_traverse(node_index, tree, xyz, scaling, rotation, root_index, proj, vie
     return np.concatenate(out).astype(np.int64)
 
 
-def forward(view, means, scales, rots, opac, colors, extras=True):
-    """Full forward.  Returns a dict with every intermediate the HIP path is compared against."""
-    means, scales, rots = _f32(means), _f32(scales), _f32(rots)
-    opac, colors = _f32(opac).reshape(-1), _f32(colors)
+def forward(view, means, scales, rots, opac, colors, extras=True, cov3d=None):
+    """Full forward.  Returns a dict with every intermediate the HIP path is compared against.
+    cov3d ([N, 6], the rasterizer's cov3D_precomp) replaces scales + rots when given."""
+    means = _f32(means)
     N = means.shape[0]
+    cov3d = None if cov3d is None else _f32(cov3d).reshape(N, 6)
+    scales = _f32(scales) if cov3d is None else np.zeros((N, 3), np.float32)
+    rots = _f32(rots) if cov3d is None else np.zeros((N, 4), np.float32)
+    opac, colors = _f32(opac).reshape(-1), _f32(colors)
     W, H = view.width, view.height
     gx, gy = grid(view)
     T = gx * gy
@@ -146,7 +150,7 @@ def forward(view, means, scales, rots, opac, colors, extras=True):
     touched = np.zeros(max(N, 1), np.uint32)
     L = lib()
     I = L.ora_project(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots), _p(opac),
-                      _p(colors), _p(radii), _p(rec), _p(touched))
+                      _p(colors), _p(radii), _p(rec), _p(touched), _p(cov3d) if cov3d is not None else None)
     offsets = np.zeros(T + 1, np.uint32)
     plist = np.zeros(max(int(I), 1), np.uint32)
     rc = L.ora_bin(ctypes.byref(view), ctypes.c_int32(N), _p(radii), _p(rec), _p(offsets), _p(plist))
@@ -163,7 +167,7 @@ def forward(view, means, scales, rots, opac, colors, extras=True):
     return dict(N=N, I=int(I), radii=radii, rec=rec[:N], tiles_touched=touched[:N], tile_offsets=offsets,
                 point_list=plist[:int(I)], image=image, final_T=final_T, n_contrib=n_contrib,
                 point_id_pixel=pid, point_weight_pixel=pwp, point_weight=(pw[:N] if extras else None),
-                inputs=(means, scales, rots, opac, colors))
+                inputs=(means, scales, rots, opac, colors), cov3d=cov3d)
 
 
 def instance_support(view, fwd):
@@ -193,10 +197,16 @@ def backward(view, fwd, dL_dimage):
     L.ora_blend_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(rec), _p(fwd["tile_offsets"]), _p(plist),
                     _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL), _p(g_mean2d), _p(g_conic), _p(g_opac),
                     _p(g_col))
+    cov3d = fwd.get("cov3d")
+    g_cov = np.zeros((n, 6), np.float32) if cov3d is not None else None
     L.ora_project_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots),
-                      _p(fwd["radii"]), _p(g_mean2d), _p(g_conic), _p(g_means), _p(g_scales), _p(g_rots))
-    return dict(means3D=g_means[:N], means2D=g_mean2d[:N], scales=g_scales[:N], rotations=g_rots[:N],
-                opacities=g_opac[:N].reshape(-1, 1), colors=g_col[:N], conic=g_conic[:N])
+                      _p(fwd["radii"]), _p(g_mean2d), _p(g_conic), _p(g_means), _p(g_scales), _p(g_rots),
+                      _p(cov3d) if cov3d is not None else None, _p(g_cov) if cov3d is not None else None)
+    out = dict(means3D=g_means[:N], means2D=g_mean2d[:N], scales=g_scales[:N], rotations=g_rots[:N],
+               opacities=g_opac[:N].reshape(-1, 1), colors=g_col[:N], conic=g_conic[:N])
+    if cov3d is not None:
+        out["cov3D"] = g_cov[:N]
+    return out
 
 
 def project_backward(view, fwd, g_mean2d, g_conic):
@@ -209,9 +219,15 @@ def project_backward(view, fwd, g_mean2d, g_conic):
     g_means = np.zeros((n, 3), np.float32)
     g_scales = np.zeros((n, 3), np.float32)
     g_rots = np.zeros((n, 4), np.float32)
+    cov3d = fwd.get("cov3d")
+    g_cov = np.zeros((n, 6), np.float32) if cov3d is not None else None
     lib().ora_project_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots),
-                          _p(fwd["radii"]), _p(gm2), _p(gc), _p(g_means), _p(g_scales), _p(g_rots))
-    return dict(means3D=g_means[:N], scales=g_scales[:N], rotations=g_rots[:N])
+                          _p(fwd["radii"]), _p(gm2), _p(gc), _p(g_means), _p(g_scales), _p(g_rots),
+                          _p(cov3d) if cov3d is not None else None, _p(g_cov) if cov3d is not None else None)
+    out = dict(means3D=g_means[:N], scales=g_scales[:N], rotations=g_rots[:N])
+    if cov3d is not None:
+        out["cov3D"] = g_cov[:N]
+    return out
 
 
 def sh_forward(means, campos, shs, degree):

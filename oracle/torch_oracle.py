@@ -29,8 +29,9 @@ def _rot(q):
 
 
 def render(width, height, tanfovx, tanfovy, viewmatrix, projmatrix, bg, means3D, means2D, scales,
-           rotations, opacities, colors, scale_modifier=1.0, filter_mode=FILTER_CLAMP, ndc_cull=True):
-    """Returns (image[3,H,W], radii[N] int, aux dict).  All tensor inputs float64 (cast inside)."""
+           rotations, opacities, colors, scale_modifier=1.0, filter_mode=FILTER_CLAMP, ndc_cull=True, cov3D_precomp=None):
+    """Returns (image[3,H,W], radii[N] int, aux dict).  All tensor inputs float64 (cast inside).
+    cov3D_precomp ([N, 6]: xx, xy, xz, yy, yz, zz) replaces scales / rotations when given (both then unused)."""
     dt = torch.float64
     V = viewmatrix.to(dt)
     P = projmatrix.to(dt)
@@ -49,10 +50,15 @@ def render(width, height, tanfovx, tanfovy, viewmatrix, projmatrix, bg, means3D,
     if ndc_cull:
         nd = ndc.detach()
         vis = vis & (nd[:, 0] >= -1.3) & (nd[:, 0] <= 1.3) & (nd[:, 1] >= -1.3) & (nd[:, 1] <= 1.3)
-    s = scales.to(dt) * scale_modifier
-    R = _rot(rotations.to(dt))
-    M = R * s[:, None, :]
-    Sigma = M @ M.transpose(1, 2)
+    if cov3D_precomp is not None:
+        c6 = cov3D_precomp.to(dt)
+        Sigma = torch.stack([c6[:, 0], c6[:, 1], c6[:, 2], c6[:, 1], c6[:, 3], c6[:, 4], c6[:, 2], c6[:, 4], c6[:, 5]],
+                            dim=-1).reshape(-1, 3, 3)
+    else:
+        s = scales.to(dt) * scale_modifier
+        R = _rot(rotations.to(dt))
+        M = R * s[:, None, :]
+        Sigma = M @ M.transpose(1, 2)
     limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
     tzs = torch.where(vis, tz, torch.ones_like(tz))  # keep culled rows finite
     ux = torch.clamp(t[:, 0] / tzs, -limx, limx)

@@ -27,21 +27,25 @@ class OracleBackend:
                                 rs.bg.detach().cpu().numpy(), scale_modifier=float(rs.scale_modifier),
                                 filter_mode=fm, ndc_cull=flavour.ndc_cull)
 
-    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0):
+    def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0,
+                cov3D=None):
         v = self._view(rs, flavour, use_filter)
-        f = oracle.forward(v, means3D.numpy(), scales.numpy(), rotations.numpy(), opacities.numpy(), colors.numpy(),
-                           extras=bool(flavour.extras))
+        f = oracle.forward(v, means3D.numpy(), None if scales is None else scales.numpy(),
+                           None if rotations is None else rotations.numpy(), opacities.numpy(), colors.numpy(),
+                           extras=bool(flavour.extras), cov3d=None if cov3D is None else cov3D.numpy())
         t = torch.from_numpy
         image, radii = t(f["image"]), t(f["radii"])
         if flavour.extras:
             return image, radii, t(f["point_id_pixel"]), t(f["point_weight_pixel"]), t(f["point_weight"].copy()), (v, f)
         return image, radii, None, None, None, (v, f)
 
-    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None):
+    def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None, cov3D=None):
         assert sink is None, 'the CPU test double does not implement the accumulate path'
         v, f = saved
         g = oracle.backward(v, f, grad_image.detach().cpu().numpy())
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        if cov3D is not None:
+            return (t(g["means3D"]), t(g["means2D"]), t(g["colors"]), t(g["opacities"].reshape(-1)), t(g["cov3D"]), None)
         return (t(g["means3D"]), t(g["means2D"]), t(g["colors"]), t(g["opacities"].reshape(-1)), t(g["scales"]),
                 t(g["rotations"]))
 

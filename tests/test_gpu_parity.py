@@ -376,3 +376,53 @@ def test_large_tile_grids(oracle_mod, W, H):
     for k in ("radii_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch", "image_bits_mismatch",
               "pid_mismatch"):
         assert st[k] == 0, (k, st)
+
+
+@pytest.mark.parametrize("package", ["wodilate", "upstream"])
+def test_cov3d_precomp_vs_oracle(oracle_mod, package):
+    """The module's `cov3D_precomp` input (third-party forward signature; LoG itself passes scales + rotations,
+    renderer.py:134,149): the kernels read the [N, 6] covariances instead of computing them -- image / radii / fork maps
+    bit-identical to the oracle's cov3D path, dL/dcov3D and the other gradients within 1e-4, scales / rotations absent
+    from the graph, scale_modifier without effect."""
+    import diff_gaussian_rasterization as up
+    import diff_gaussian_rasterization_wodilate as wo
+    import gpu_util as G
+    from log_amd import rasterizer as R
+    from oracle import torch_oracle
+    cam, sc = _case("ragged")
+    dev = torch.device("cuda:0")
+    Rm = torch_oracle._rot(torch.tensor(sc["rotation"], dtype=torch.float64))
+    M = Rm * torch.tensor(sc["scaling"], dtype=torch.float64)[:, None, :]
+    S = (M @ M.transpose(1, 2)).numpy()
+    cov = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1).astype(np.float32)
+    mod, flavour = (wo, R.WODILATE) if package == "wodilate" else (up, R.UPSTREAM)
+    bg = (0.2, 0.5, 0.1)
+    from util import cam_tan
+    tfx, tfy = cam_tan(cam)
+    v = oracle_mod.make_view(cam["image_width"], cam["image_height"], tfx, tfy, cam["world_view_transform"],
+                             cam["full_proj_transform"], bg, filter_mode=flavour.filter_mode, ndc_cull=flavour.ndc_cull)
+    of = oracle_mod.forward(v, sc["xyz"], None, None, sc["opacity"], sc["colors"], cov3d=cov, extras=bool(flavour.extras))
+    dL = np.random.default_rng(4).random(of["image"].shape, dtype=np.float32)
+    og = oracle_mod.backward(v, of, dL)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=True)
+    m3, op, col, cv = T(sc["xyz"]), T(sc["opacity"]), T(sc["colors"]), T(cov)
+    m2 = torch.zeros_like(m3, requires_grad=True)
+    rast = mod.GaussianRasterizer(raster_settings=G.settings(cam, bg, dev, scale_modifier=0.37))   # (no effect here)
+    out = rast(means3D=m3, means2D=m2, shs=None, colors_precomp=col, opacities=op, scales=None, rotations=None,
+               cov3D_precomp=cv)
+    assert len(out) == (5 if flavour.extras else 2)
+    assert np.array_equal(out[0].detach().cpu().numpy(), of["image"])
+    assert np.array_equal(out[1].cpu().numpy(), of["radii"])
+    if flavour.extras:
+        assert np.array_equal(out[2].cpu().numpy(), of["point_id_pixel"])
+        assert np.array_equal(out[4].cpu().numpy(), of["point_weight"])
+    out[0].backward(gradient=torch.tensor(dL, device=dev))
+    assert cv.grad.shape == (len(cov), 6)
+    for name, leaf in (("cov3D", cv), ("means3D", m3), ("opacities", op), ("colors", col), ("means2D", m2)):
+        assert rel_l2(leaf.grad.cpu().numpy().reshape(og[name].shape), og[name]) < 1e-4, name
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=m3, means2D=m2, shs=None, colors_precomp=col, opacities=op, scales=T(sc["scaling"]),
+             rotations=None, cov3D_precomp=cv)
+    with pytest.raises(ValueError, match=r"\[N, 6\]"):
+        rast(means3D=m3, means2D=m2, shs=None, colors_precomp=col, opacities=op, scales=None, rotations=None,
+             cov3D_precomp=cv[:, :5])

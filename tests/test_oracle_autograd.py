@@ -105,3 +105,83 @@ def test_empty_inputs(oracle_mod):
     assert f["I"] == 0 and (f["image"] == 0.5).all() and (f["n_contrib"] == 0).all()
     g = oracle_mod.backward(v, f, np.ones_like(f["image"]))
     assert g["means3D"].shape == (0, 3)
+
+
+def _cov6(sc):
+    """The covariances the scales / rotations of a scene stand for, in float64 (xx, xy, xz, yy, yz, zz)."""
+    from oracle import torch_oracle
+    R = torch_oracle._rot(torch.tensor(sc["rotation"], dtype=torch.float64))
+    M = R * torch.tensor(sc["scaling"], dtype=torch.float64)[:, None, :]
+    S = (M @ M.transpose(1, 2)).numpy()
+    return np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1)
+
+
+@pytest.mark.parametrize("seed,filter_mode", [(0, 2), (2, 1)])
+def test_cov3d_precomp_vs_float64_autograd(oracle_mod, seed, filter_mode):
+    """The rasterizer's `cov3D_precomp` input (third-party forward; LoG never passes it, renderer.py:134,149): the C
+    oracle's forward from [N, 6] covariances and its dL/dcov3D (off-diagonal entries carry both symmetric positions)
+    against float64 autograd with the covariance as the leaf; and the same image as the scales / rotations path when the
+    covariances are the ones those stand for."""
+    from oracle import torch_oracle
+    cam, sc = small_case(seed=seed)
+    bg = [0.3, 0.6, 0.9]
+    v = oracle_view(oracle_mod, cam, bg, filter_mode, 1)
+    cov = _cov6(sc).astype(np.float32)
+    f = oracle_mod.forward(v, sc["xyz"], None, None, sc["opacity"], sc["colors"], cov3d=cov)
+    f_sr = oracle_mod.forward(v, sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["colors"])
+    assert f["I"] > 100 and rel_l2(f["image"], f_sr["image"]) < 1e-5 and (f["radii"] != f_sr["radii"]).mean() < 0.01
+    dL = np.random.default_rng(1).random(f["image"].shape, dtype=np.float32)
+    g = oracle_mod.backward(v, f, dL)
+    assert g["cov3D"].shape == (len(cov), 6) and float(np.abs(g["scales"]).max()) == 0.0
+    T = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    leaves = dict(means3D=T(sc["xyz"]), cov=T(cov), opacities=T(sc["opacity"]), colors=T(sc["colors"]))
+    m2 = torch.zeros(len(cov), 3, dtype=torch.float64, requires_grad=True)
+    tfx, tfy = cam_tan(cam)
+    img, radii, _ = torch_oracle.render(
+        cam["image_width"], cam["image_height"], tfx, tfy, torch.tensor(cam["world_view_transform"]),
+        torch.tensor(cam["full_proj_transform"]), torch.tensor(bg), leaves["means3D"], m2, None, None,
+        leaves["opacities"], leaves["colors"], filter_mode=filter_mode, ndc_cull=True, cov3D_precomp=leaves["cov"])
+    (img * torch.tensor(dL, dtype=torch.float64)).sum().backward()
+    assert (radii.numpy() == f["radii"]).all() and rel_l2(f["image"], img.detach().numpy()) < 1e-5
+    assert rel_l2(g["cov3D"], leaves["cov"].grad.numpy()) < 1e-4
+    assert rel_l2(g["means3D"], leaves["means3D"].grad.numpy()) < 1e-4
+    assert rel_l2(g["opacities"], leaves["opacities"].grad.numpy()) < 1e-4
+    assert rel_l2(g["means2D"], m2.grad.numpy()) < 1e-4
+    # scale_modifier scales the `scales` only: a precomputed covariance is taken as is
+    v2 = oracle_view(oracle_mod, cam, bg, filter_mode, 1)
+    v2.scale_modifier = 0.5
+    f2 = oracle_mod.forward(v2, sc["xyz"], None, None, sc["opacity"], sc["colors"], cov3d=cov)
+    assert np.array_equal(f2["image"], f["image"])
+
+
+def test_module_cov3d_precomp_through_the_test_double(oracle_mod):
+    """log_amd.rasterizer's autograd surface with `cov3D_precomp` (CPU, oracle-backed test double): gradient lands on the
+    covariance leaf, none on scales / rotations, and equals the oracle's own backward."""
+    import oracle_backend
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
+    cam, sc = small_case(seed=6)
+    cov = _cov6(sc).astype(np.float32)
+    tfx, tfy = cam_tan(cam)
+    t = lambda a: torch.tensor(np.asarray(a, np.float32))
+    rs = GaussianRasterizationSettings(
+        image_height=cam["image_height"], image_width=cam["image_width"], tanfovx=tfx, tanfovy=tfy, bg=t([0.1, 0.2, 0.3]),
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]),
+        sh_degree=0, campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    old = oracle_backend.install(oracle_backend.OracleBackend())
+    try:
+        L = lambda a: torch.tensor(np.asarray(a, np.float32), requires_grad=True)
+        m3, op, col, cv = L(sc["xyz"]), L(sc["opacity"]), L(sc["colors"]), L(cov)
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        out = GaussianRasterizer(raster_settings=rs)(means3D=m3, means2D=m2, shs=None, colors_precomp=col, opacities=op,
+                                                     scales=None, rotations=None, cov3D_precomp=cv)
+        w = torch.rand(out[0].shape, generator=torch.Generator().manual_seed(0))
+        out[0].backward(gradient=w)
+    finally:
+        oracle_backend.install(old)
+    v = oracle_view(oracle_mod, cam, [0.1, 0.2, 0.3], 2, 1)
+    f = oracle_mod.forward(v, sc["xyz"], None, None, sc["opacity"], sc["colors"], cov3d=cov)
+    g = oracle_mod.backward(v, f, w.numpy())
+    assert np.array_equal(out[0].detach().numpy(), f["image"])
+    # (the oracle's reverse walk adds with float atomics under OpenMP: two runs agree to rounding, not bit for bit)
+    for leaf, name in ((cv, "cov3D"), (m3, "means3D"), (op, "opacities"), (m2, "means2D"), (col, "colors")):
+        assert rel_l2(leaf.grad.numpy(), g[name]) < 1e-5, name

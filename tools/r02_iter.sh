@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 D=$PWD/gpurun_out
 mkdir -p "$D"
 TAG=${1:-it}
-(timeout 900 python -m pytest tests -m gpu -x -q --timeout 900 > $D/${TAG}_pytest.log 2>&1; echo pytest_exit=$? >> $D/${TAG}_pytest.log)
+(timeout 900 python -m pytest tests -m gpu -q --timeout 900 > $D/${TAG}_pytest.log 2>&1; echo pytest_exit=$? >> $D/${TAG}_pytest.log)
 tail -n 5 $D/${TAG}_pytest.log
 timeout 400 python bench.py --gaussians 30000000 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-secondary --no-dropin-mode > $D/${TAG}_30M_s1.log 2>&1
 timeout 400 python bench.py --gaussians 1000000 --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-secondary --no-dropin-mode > $D/${TAG}_1M_s1.log 2>&1

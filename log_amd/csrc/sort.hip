@@ -400,7 +400,7 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
 // its biglist entry so that they skip it.
 #define LR_LONG_NB 4096     // bucket counters in LDS
 #define LR_LONG_WIN_BYTES 61440   // LDS window: 7680 keys staged at a time (16 KB counters + this: two workgroups per CU)
-#define LR_LONG_UNR 6       // independent loads in flight per thread in the streaming passes (8: VGPR spills at the 64 the two workgroups per CU allow)
+#define LR_LONG_UNR 8       // independent loads in flight per thread in the streaming passes (64 VGPRs: two workgroups per CU, no spills)
 __global__ void __launch_bounds__(1024, 8)   // two workgroups per CU: 64 VGPRs (at 77 the kernel ran one per CU: 0.62 -> 0.86 ms at 30 M)
 lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity, int equalize) {
@@ -415,7 +415,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg, tid = threadIdx.x;
   const uint64_t* k = keys + beg;
-  uint32_t* rk = ranks + beg;
+  uint16_t* rk = reinterpret_cast<uint16_t*>(ranks) + beg;   // one 16-bit bucket id per key (nb <= 4096)
   uint32_t* pl = plist + beg;
 #ifdef LR_LONG_TICKS   // phase timing experiment (-DLR_LONG_TICKS): wall_clock64 per phase, printed by three workgroups
   uint64_t tk[16]; int tn = 0;
@@ -433,14 +433,20 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   uint32_t dmin = 0xffffffffu, dmax = 0u;
   // (the streaming loops are unrolled by hand: LR_LONG_UNR independent loads in flight per thread -- every pass is a
   // latency chain per workgroup, 1024 threads x 8 loads x 8 B = 64 KB in flight)
-  // Depth range from the first eighth of the list (the keys arrive in no particular order, so this is a random
-  // sample): the range only has to spread the keys over the buckets, keys outside it clamp into the first / last
-  // bucket, and a bucket that overflows sends the tile to the fallback as before.
-  const uint32_t Ls = min(L, max(L >> 3, 8192u));
+  // Depth range from a sample: Ls keys in 64-key pieces (one coalesced 512-byte read per wave) spread evenly over the
+  // list -- the keys arrive in Gaussian order, which is no particular depth order for a random cloud but IS one for a
+  // level-of-detail selection (coarse levels first), so a prefix would be a biased sample.  The range only has to
+  // spread the keys over the buckets: keys outside it clamp into the first / last bucket, and a bucket that overflows
+  // sends the tile to the second attempt / the fallback as before.
+  const uint32_t Ls = min(L, max(L >> 4, 2048u)) & ~63u;    // (L > LR_SORT_BLOCK here: at least 2048)
+  const uint32_t npieces = Ls >> 6;
+  auto sample_at = [&](uint32_t j) -> uint32_t {            // list position of sample j
+    return (uint32_t)(((uint64_t)(j >> 6) * L) / npieces) + (j & 63u);
+  };
   for (uint32_t i = tid; i < Ls; i += LR_LONG_UNR * 1024u) {
     uint64_t kk[LR_LONG_UNR];
 #pragma unroll
-    for (int u = 0; u < LR_LONG_UNR; u++) kk[u] = (i + u * 1024u < Ls) ? k[i + u * 1024u] : 0ull;
+    for (int u = 0; u < LR_LONG_UNR; u++) kk[u] = (i + u * 1024u < Ls) ? k[sample_at(i + u * 1024u)] : 0ull;
 #pragma unroll
     for (int u = 0; u < LR_LONG_UNR; u++)
       if (i + u * 1024u < Ls) { const uint32_t d = (uint32_t)(kk[u] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
@@ -473,23 +479,23 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
     const bool eq = attempt == 1;
     const uint32_t Lh = min(Ls, 8192u);
     if (eq)
-      for (uint32_t i = tid; i < Lh; i += 1024u) { float fr; atomicAdd(&cellcnt[lr_depth_cell(dmap, (uint32_t)(k[i] >> 32), fr)], 1u); }
+      for (uint32_t i = tid; i < Lh; i += 1024u) { float fr; atomicAdd(&cellcnt[lr_depth_cell(dmap, (uint32_t)(k[sample_at(i)] >> 32), fr)], 1u); }
     __syncthreads();
     lr_depth_map_build(celltab, cellcnt, dmap.ncells, Lh, nb, eq);
     __syncthreads();
-    for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // rank inside the bucket
+    for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // bucket of every key + the bucket sizes
       uint64_t kk[LR_LONG_UNR];
 #pragma unroll
       for (int u = 0; u < LR_LONG_UNR; u++) kk[u] = (i + u * 1024u < L) ? k[i + u * 1024u] : 0ull;
       uint32_t cd[LR_LONG_UNR];
 #pragma unroll
-      for (int u = 0; u < LR_LONG_UNR; u++) {                  // (bucket, rank) code: all a window pass needs to skip a key
-        const uint32_t b = bucket_of(kk[u]);
-        cd[u] = (i + u * 1024u < L) ? ((b << 8) | min(atomicAdd(&lcnt[b], 1u), 255u)) : 0u;
+      for (int u = 0; u < LR_LONG_UNR; u++) {                  // the bucket id is all a window pass needs to skip a key
+        cd[u] = bucket_of(kk[u]);
+        if (i + u * 1024u < L) atomicAdd(&lcnt[cd[u]], 1u);   // (count only: no returning atomic, nothing waits for it)
       }
 #pragma unroll
       for (int u = 0; u < LR_LONG_UNR; u++)
-        if (i + u * 1024u < L) rk[i + u * 1024u] = cd[u];
+        if (i + u * 1024u < L) rk[i + u * 1024u] = (uint16_t)cd[u];
     }
     __syncthreads();
     LR_TICK();
@@ -546,23 +552,28 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
       if (st_mid <= w0 + (uint32_t)LR_LONG_WIN) lo_b = mid; else hi_b = mid - 1u;
     }
     const uint32_t b1 = lo_b;                              // window = list positions [start(b0), start(b1))
-    for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // 4 B per key; the 8-byte key only if it lands in this window
+    for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // 2 B per key; the 8-byte key only if it lands in this window
       uint32_t cc[LR_LONG_UNR];
 #pragma unroll
-      for (int u = 0; u < LR_LONG_UNR; u++) cc[u] = (i + u * 1024u < L) ? rk[i + u * 1024u] : 0xffffffffu;
+      for (int u = 0; u < LR_LONG_UNR; u++) cc[u] = (i + u * 1024u < L) ? (uint32_t)rk[i + u * 1024u] : 0xffffu;
       uint64_t kv[LR_LONG_UNR];
-      uint32_t st[LR_LONG_UNR];
 #pragma unroll
-      for (int u = 0; u < LR_LONG_UNR; u++) {                // all key loads and bucket starts requested before the first is used
-        const uint32_t b = cc[u] >> 8;                       // cc == ~0 (past the end): b = 2^24-1 >= nb
-        const bool in = b >= b0 && b < b1;
-        kv[u] = in ? k[i + u * 1024u] : 0ull;
-        st[u] = lcnt[in ? b : b0];
+      for (int u = 0; u < LR_LONG_UNR; u++) {                // all key loads requested before the first is used
+        const uint32_t b = cc[u];                            // 0xffff (past the end) >= nb
+        kv[u] = (b >= b0 && b < b1) ? k[i + u * 1024u] : 0ull;
+      }
+      // the key's slot: the bucket's start counter doubles as its fill cursor (any order inside the bucket will do, the
+      // emit below orders it by the full key); after the pass lcnt[b] = end of bucket b = start of bucket b + 1
+      uint32_t ps[LR_LONG_UNR];
+#pragma unroll
+      for (int u = 0; u < LR_LONG_UNR; u++) {
+        const uint32_t b = cc[u];
+        ps[u] = (b >= b0 && b < b1) ? atomicAdd(&lcnt[b], 1u) : 0u;
       }
 #pragma unroll
       for (int u = 0; u < LR_LONG_UNR; u++) {
-        const uint32_t b = cc[u] >> 8;
-        if (b >= b0 && b < b1) win[st[u] + (cc[u] & 255u) - w0] = kv[u];
+        const uint32_t b = cc[u];
+        if (b >= b0 && b < b1) win[ps[u] - w0] = kv[u];
       }
     }
     __syncthreads();
@@ -573,7 +584,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
       // the ordered ids go back into the (now consumed) window slots of their bucket, low word of the slot at the final
       // position: the copy-out below then writes the list in full lines instead of 4-byte pieces 20 bytes apart
       lr_emit_bucket([&](uint32_t pos) -> uint64_t { return win[pos - w0]; },   // win[] holds positions [w0, w1)
-                     valid ? lcnt[b] : 0u, valid ? ((b + 1u < nb) ? lcnt[b + 1u] : L) : 0u, valid,
+                     valid ? (b == b0 ? w0 : lcnt[b - 1u]) : 0u, valid ? lcnt[b] : 0u, valid,
                      reinterpret_cast<uint32_t*>(win) - 2 * (size_t)w0, 2u);
     }
     __syncthreads();

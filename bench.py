@@ -123,10 +123,14 @@ class RasterWorkload:
                 prefiltered=False, debug=False)
             self.rasts.append(GaussianRasterizer(raster_settings=rs))
         self.torch = torch
+        self.zero_means2d = True
 
     def one_view(self, rast, leaves):
         torch = self.torch
-        means2D = torch.zeros(self.N, 3, device=self.dev, requires_grad=True)
+        # means2D is the third-party API's placeholder that receives dL/dmeans2D; no kernel reads its values.  LoG's
+        # renderer.py zero-fills a fresh one per view (the drop-in default mode does the same); the pipelined step
+        # allocates it uninitialised (30 M Gaussians: a 360 MB memset per view less).
+        means2D = (torch.zeros if self.zero_means2d else torch.empty)(self.N, 3, device=self.dev).requires_grad_(True)
         out = rast(means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors"],
                    opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
                    cov3D_precomp=None)
@@ -147,6 +151,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     from log_amd import _lib, rasterizer as R
     from log_amd.dist import GradientBucket, StepExchange
     dev, N = wl.dev, wl.N
+    wl.zero_means2d = not (sync_free and fused)
     rank = dist.get_rank() if world > 1 else 0
     parts = max(1, min(int(args.exchange_parts), len(wl.rasts) // S)) if world > 1 else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
@@ -282,6 +287,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     assert not chk["overflowed"] and chk["max_instances"] <= cap, \
         "tile-instance capacity overflow inside the timed region: result invalid (%r)" % (chk,)
     R.set_instance_capacity(None)
+    wl.zero_means2d = True
     if world > 1:
         t = torch.tensor([res["elapsed"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -16,7 +16,8 @@
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
 // [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_LONG_LIST
 // [4] tile instances of the plain rect rule (before the support cull; reporting only)
-// [5] support cull applied by the projection kernel (0/1)  [6] projection batch size (0 = unbatched)  [7..15] reserved
+// [5] support cull applied by the projection kernel (0/1)  [6] projection batch size (0 = unbatched)
+// [7] some rect was deferred to lr_count_huge_kernel  [8..15] reserved
 // then per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic targets
 // spread over the memory channels instead of 8160 counters sharing 32 KB); header, ranked and big are
 // contiguous so that ONE memset prepares a forward:
@@ -40,6 +41,7 @@
 #define LR_HDR_BATCH 6  // Gaussians per projection batch (0 = unbatched kernel: slots in q3 are absolute)
 #define LR_HDR_CULL 5  // 1 if lr_project_kernel applied the support cull (the fill kernel must repeat it)
 #define LR_HDR_RECT 4  // tile instances of the plain rect rule (what the reference would sort), before the support cull
+#define LR_HDR_HUGE 7  // batched projection: some workgroup deferred a rect to lr_count_huge_kernel (else that kernel returns at once)
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_LONG_LIST 4096   // lists longer than this go to biglist[] (long-list sort paths)
 #define LR_LONG_DONE 0x80000000u  // biglist entry flag: the depth-bucket sort finished this tile

@@ -364,7 +364,10 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       }
     }
   }
-  if ((int)threadIdx.x < nplanes) hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];   // complete: the barrier after the Gaussian loop
+  if ((int)threadIdx.x < nplanes) {   // complete: the barrier after the Gaussian loop
+    hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];
+    if (lr_huge_cnt[threadIdx.x]) atomicOr(&hdr[LR_HDR_HUGE], 1u);
+  }
   lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
 }
 
@@ -374,16 +377,31 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
 // returns at once when its batches left nothing (the common case: small splats only).
 __global__ void __launch_bounds__(256)
 lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,
-                     const uint32_t* __restrict__ hugecount, int B, int tile_cull, int defer_tiles, int chunk) {
-  extern __shared__ uint32_t lr_lds_ctr[];
-  // (the grid is capped at a few workgroups per CU: each walks its share of the chunks and skips, with one scalar
-  // read, those whose batches deferred nothing -- 58 K workgroups that only return cost a 30 M-Gaussian view 30 us)
-  for (int chunk_id = blockIdx.x; chunk_id * chunk < N; chunk_id += gridDim.x) {
+                     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ hugecount, int B, int tile_cull,
+                     int defer_tiles, int chunk) {
+  extern __shared__ uint32_t lr_lds_ctr[];                   // [tiles] counters | [256] chunk flags
+  uint32_t* const lr_chunk_todo = lr_lds_ctr + tiles;
+  if (!hdr[LR_HDR_HUGE]) return;                             // no workgroup deferred anything: the common case
+  // (the grid is capped at a few workgroups per CU: each walks its share of the chunks and skips those whose batches
+  // deferred nothing -- 58 K workgroups that only return cost a 30 M-Gaussian view 30 us.  The flags of up to 256 chunks
+  // are fetched by as many threads at once: one dependent scalar read per chunk was a 28 us chain of round trips.)
+  for (int first = blockIdx.x; (long long)first * chunk < N; first += 256 * gridDim.x) {
+  {
+    const long long cid = (long long)first + (long long)threadIdx.x * gridDim.x;
+    uint32_t any = 0;
+    if (cid * chunk < N) {
+      const int base = (int)cid * chunk;
+      const int b0 = base / B, b1 = min(N - 1, base + chunk - 1) / B;
+      for (int b = b0; b <= b1; b++) any |= hugecount[b];
+    }
+    __syncthreads();                                         // (the previous round's readers are done)
+    lr_chunk_todo[threadIdx.x] = any;
+    __syncthreads();
+  }
+  for (int slot = 0; slot < 256; slot++) {
+  if (!lr_chunk_todo[slot]) continue;
+  const int chunk_id = first + slot * (int)gridDim.x;
   const int base = chunk_id * chunk;
-  const int b0 = base / B, b1 = min(N - 1, base + chunk - 1) / B;
-  uint32_t any = 0;
-  for (int b = b0; b <= b1; b++) any |= hugecount[b];
-  if (!any) continue;
   __syncthreads();                                           // (the previous chunk's flush has read the counters)
   for (int t = threadIdx.x; t < tiles; t += 256) lr_lds_ctr[t] = 0u;
   __syncthreads();
@@ -429,6 +447,7 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
     if (c) atomicAdd(&big[t], c);   // dense counters in batched mode
   }
   }
+  }
 }
 
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
@@ -458,9 +477,9 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        basetab, hugecount, tile_cull, batch, planes, defer_tiles);
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
-    hipLaunchKernelGGL(lr_count_huge_kernel, dim3(min((N + chunk - 1) / chunk, 2048)), dim3(256), lds, s, N, v.gx,
-                       tiles, reinterpret_cast<const float4*>(geom), big, (const uint32_t*)hugecount, batch, tile_cull,
-                       defer_tiles, chunk);
+    hipLaunchKernelGGL(lr_count_huge_kernel, dim3(min((N + chunk - 1) / chunk, 2048)), dim3(256), lds + 1024, s, N, v.gx,
+                       tiles, reinterpret_cast<const float4*>(geom), big, (const uint32_t*)hdr, (const uint32_t*)hugecount,
+                       batch, tile_cull, defer_tiles, chunk);
     lr_prof_end(LRK_RESERVED, s);
     return;
   } else {
@@ -531,12 +550,26 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
   // 1080p here, where they overlap the LDS phases below (25 vs 28 us).
   constexpr bool LATE = CHMAX > 8;
   uint32_t run = run0;
+  // Length buckets scaled to the longest list of this view (a fixed 16 keys per bucket put every list above 4080 keys
+  // -- at 30 M Gaussians all of them -- into the last bucket: no order among them, and 8160 LDS atomics on one word).
+#pragma unroll
+  for (int k = 0; k < CHMAX; k++) lmax = max(lmax, tot[k]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d));
+  if ((tid & 63u) == 0u) part[16 + (tid >> 6)] = lmax;      // (part[0..15] / part[32..47] hold the scan's wave totals)
+  __syncthreads();
+  {
+    uint32_t m = part[16 + (tid & 15u)];
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    lmax = m;                                                // longest list of the view, in every thread
+  }
+  const uint32_t lsh = lmax > 255u ? (uint32_t)(24 - __clz((int)lmax)) : 0u;   // lmax >> lsh <= 255
 #pragma unroll
   for (int k = 0; k < CHMAX; k++) {
     const uint32_t t = b + (uint32_t)k;
     if ((uint32_t)k < chunk && t < tiles) {
-      atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u);
-      lmax = max(lmax, tot[k]);
+      atomicAdd(&hist[tot[k] >> lsh], 1u);
       if (!LATE) {
         offsets[t] = run;
         cursor[t * LR_CTR_STRIDE] = run + nr[k];  // big instances go behind the ranked ones (64 B apart: the fill's atomics hit random tiles)
@@ -544,8 +577,6 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
       }
     }
   }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d));
   // Longest-processing-time-first dispatch order for the blend kernels: a tile's list is walked serially by
   // its waves, so the longest lists must start first or they become the tail of the launch.  Counting sort
   // of the tiles into 256 length buckets (16 entries wide), longest bucket first.
@@ -569,17 +600,27 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
 #pragma unroll
   for (int k = 0; k < CHMAX; k++) {
     const uint32_t t = b + (uint32_t)k;
-    if ((uint32_t)k < chunk && t < tiles) {
-      order[atomicAdd(&hist[min(255u, tot[k] >> 4)], 1u)] = t;
+    const bool in = (uint32_t)k < chunk && t < tiles;
+    if (in) {
+      order[atomicAdd(&hist[tot[k] >> lsh], 1u)] = t;
       if (LATE) {
         offsets[t] = run;
         cursor[t * LR_CTR_STRIDE] = run + nr[k];
         run += tot[k];
       }
-      if (tot[k] > LR_LONG_LIST) biglist[atomicAdd(&state[LR_HDR_NBIG], 1u)] = t;  // long-list sort paths
+    }
+    // long-list sort paths: one memory-side atomic per wave reserves the slots of all its long tiles (one per tile was
+    // 3000 returning atomics on one address at 30 M Gaussians)
+    const bool lng = in && tot[k] > LR_LONG_LIST;
+    const uint64_t lm = __ballot(lng);
+    if (lm) {
+      uint32_t first = 0;
+      if ((tid & 63u) == 0u) first = atomicAdd(&state[LR_HDR_NBIG], (uint32_t)__popcll(lm));
+      first = (uint32_t)__shfl((int)first, 0);
+      if (lng) biglist[first + (uint32_t)__popcll(lm & ((1ull << (tid & 63u)) - 1ull))] = t;
     }
   }
-  if ((tid & 63u) == 0u && lmax) atomicMax(&state[LR_HDR_MAXLEN], lmax);
+  if (tid == 0u && lmax) atomicMax(&state[LR_HDR_MAXLEN], lmax);
   if (tid == 1023) {
     offsets[tiles] = grand;
     state[LR_HDR_NUM] = grand;

@@ -104,6 +104,60 @@ LR_DEV void lr_lds_sort(uint64_t* s, uint32_t P2, uint32_t tid) {
   }
 }
 
+// ---- the network on a list longer than one LDS block, by ONE workgroup -----------------------------------------
+// The same ascending-only bitonic network over a[0, L) (virtually padded with +inf to a power of two), split by stride:
+// levels whose stride is >= LR_SORT_BLOCK are passes over the list in global memory (one compare-exchange per pair; the
+// 160 KB slice of a 20 K-key tile stays in L2), everything below that stride runs block by block in LDS with the
+// register-blocked code above.  A list of B*2^m keys costs m(m+1)/2 global passes + (m+1) LDS passes over its blocks.
+// This is the fallback of the long-list kernels for depths a bucket map cannot spread (a surface exactly parallel to
+// the image plane: identical depths), so it only has to be correct and not absurd: it runs inside the workgroup that
+// found the list unsortable by buckets -- no extra launches (a separate multi-workgroup version of the same passes cost
+// every view eight launches of idle workgroups, 54 us at 30 M Gaussians, to be there for the rare tile that needs it).
+// s: LDS, lr_sort_lds_bytes(LR_SORT_BLOCK) bytes.  All NT threads call; workgroup-scope visibility of the global
+// stores between passes comes from the barriers (one workgroup = one CU = one vector L1).
+template <int NT>
+LR_DEV void lr_wg_hybrid_sort(uint64_t* __restrict__ a, uint32_t L, uint64_t* s, uint32_t tid) {
+  uint32_t P2 = LR_SORT_BLOCK;
+  while (P2 < L) P2 <<= 1;
+  for (uint32_t b0 = 0; b0 < L; b0 += LR_SORT_BLOCK) {       // stage 0: every block sorted on its own
+    const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, L - b0);
+    uint32_t p2 = 8;
+    while (p2 < cnt) p2 <<= 1;
+    for (uint32_t i = tid; i < p2; i += NT) s[lr_phys(i)] = i < cnt ? a[b0 + i] : ~0ull;
+    __syncthreads();
+    lr_lds_sort<NT>(s, p2, tid);
+    for (uint32_t i = tid; i < cnt; i += NT) a[b0 + i] = s[lr_phys(i)];
+    __syncthreads();
+  }
+  const uint32_t pairs = P2 >> 1;
+  for (uint64_t k = 2ull * LR_SORT_BLOCK; (k >> 1) < L; k <<= 1) {   // phase k merges sorted runs of k/2 keys
+    const uint32_t kk = (uint32_t)k, half = kk >> 1;
+    for (uint32_t p = tid; p < pairs; p += NT) {             // the flip level: i <-> mirror of i inside its k-block
+      const uint32_t off = p & (half - 1u), blk = (p - off) << 1;
+      const uint32_t i = blk + off, l = blk + (kk - 1u - off);
+      if (l < L) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+    }
+    __syncthreads();
+    for (uint32_t j = kk >> 2; j >= LR_SORT_BLOCK; j >>= 1) { // half-cleaners with strides >= one block
+      for (uint32_t p = tid; p < pairs; p += NT) {
+        const uint32_t low = p & (j - 1u);
+        const uint32_t i = ((p - low) << 1) | low, l = i + j;
+        if (l < L) { const uint64_t x = a[i], y = a[l]; if (x > y) { a[i] = y; a[l] = x; } }
+      }
+      __syncthreads();
+    }
+    for (uint32_t b0 = 0; b0 < L; b0 += LR_SORT_BLOCK) {     // strides below one block: block by block in LDS
+      const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, L - b0);
+      for (uint32_t i = tid; i < LR_SORT_BLOCK; i += NT) s[lr_phys(i)] = i < cnt ? a[b0 + i] : ~0ull;
+      __syncthreads();
+      lr_lds_halfcleaners<NT>(s, LR_SORT_BLOCK >> 3, tid, 12);   // strides 4096 ... 1  (LR_SORT_BLOCK == 8192)
+      for (uint32_t i = tid; i < cnt; i += NT) a[b0 + i] = s[lr_phys(i)];
+      __syncthreads();
+    }
+  }
+}
+static_assert(LR_SORT_BLOCK == 8192, "lr_wg_hybrid_sort hard-codes the top stride exponent of a block");
+
 // Tiles with lo < L <= hi: the whole list in one workgroup's LDS.
 template <int NT>
 __global__ void __launch_bounds__(NT)
@@ -333,11 +387,19 @@ lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64
     run = inc - local;
     for (uint32_t w = 0; w < (tid >> 6); w++) run += wave_tot[w];
     if (sh_maxcnt <= LR_BUCKET_MAX) break;
-    if (eq || !equalize) {                                   // clustered beyond the map's reach: the network, on the staged keys
-      if (LONG) return;                                       // ... or the fallback kernels
+    if (eq || !equalize) {                                   // clustered beyond the map's reach: the network
       __syncthreads();
+      if (LONG) {                                             // (keys in registers: they take over the bucket arrays' LDS)
+#pragma unroll
+        for (int k = 0; k < KPT; k++) {
+          const uint32_t i = tid + (uint32_t)k * NT;
+          if (i < P2) A[lr_phys(i)] = key[k];                 // key[k] = +inf beyond the list
+        }
+        __syncthreads();
+      }
       lr_lds_sort<NT>(A, P2, tid);
       for (uint32_t i = tid; i < L; i += NT) plist[beg + i] = (uint32_t)A[lr_phys(i)];
+      if (LONG && tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
       return;
     }
     __syncthreads();                                          // every thread has read sh_maxcnt and its counts
@@ -402,8 +464,9 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
 #define LR_LONG_WIN_BYTES 61440   // LDS window: 7680 keys staged at a time (16 KB counters + this: two workgroups per CU)
 #define LR_LONG_UNR 8       // independent loads in flight per thread in the streaming passes (64 VGPRs: two workgroups per CU, no spills)
 __global__ void __launch_bounds__(1024, 8)   // two workgroups per CU: 64 VGPRs (at 77 the kernel ran one per CU: 0.62 -> 0.86 ms at 30 M)
-lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
-                    uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity, int equalize) {
+lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
+                    uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity, int equalize,
+                    int network_only) {
   constexpr uint32_t LR_LONG_WIN = LR_LONG_WIN_BYTES / sizeof(uint64_t);
   extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
   uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
@@ -417,6 +480,18 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
   const uint64_t* k = keys + beg;
   uint16_t* rk = reinterpret_cast<uint16_t*>(ranks) + beg;   // one 16-bit bucket id per key (nb <= 4096)
   uint32_t* pl = plist + beg;
+  // Clustered depths (a bucket above LR_BUCKET_MAX keys after both maps) or LOGRAST_BUCKET_SORT=0: the network, by this
+  // workgroup, in place on the tile's keys (the whole dynamic LDS block as its staging area), then the ids.
+  auto network = [&]() {
+    __syncthreads();
+    lr_wg_hybrid_sort<1024>(keys + beg, L, reinterpret_cast<uint64_t*>(lcnt), tid);
+    for (uint32_t i = tid; i < L; i += 1024u) pl[i] = (uint32_t)k[i];
+    if (tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
+  };
+  if (network_only) {                                       // (lists up to one block were sorted by lr_sort_rb_kernel)
+    if (L > LR_SORT_BLOCK) network();
+    return;
+  }
 #ifdef LR_LONG_TICKS   // phase timing experiment (-DLR_LONG_TICKS): wall_clock64 per phase, printed by three workgroups
   uint64_t tk[16]; int tn = 0;
 #define LR_TICK() do { if (tn < 16) tk[tn++] = wall_clock64(); } while (0)
@@ -523,7 +598,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
     if (tid == 0) sh_maxcnt = 0u;
     for (uint32_t b = tid; b < nb; b += 1024) lcnt[b] = 0u;
   }
-  if (sh_maxcnt > LR_BUCKET_MAX) return;                    // clustered depths: network fallback (entry stays unflagged)
+  if (sh_maxcnt > LR_BUCKET_MAX) { network(); return; }
   {
     const uint32_t wt = (tid & 63u) < 16u ? wave_tot[tid & 63u] : 0u;
     uint32_t winc = wt;
@@ -609,155 +684,18 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t
 #undef LR_TICK
 }
 
+static inline size_t lr_sort_lds_bytes(uint32_t cap) { return sizeof(uint64_t) * (size_t)(cap + (cap >> 3)); }
 static inline size_t lr_long_lds_bytes() {
   return sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_t) * LR_BUCKET_MAX;
 }
-
-// Single-block network fallback for long tiles of (LR_LONG_LIST, LR_SORT_BLOCK] keys the bucket sort gave up on.
-__global__ void __launch_bounds__(256)
-lr_sort_long_fallback_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
-                             uint32_t* __restrict__ plist, uint32_t capacity) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (lr_bail(state, capacity)) return;
-  const uint32_t nbig = state[LR_HDR_NBIG];
-  const uint32_t* offsets = state + lr_offsets_off(tiles);
-  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
-    const uint32_t entry = state[lr_biglist_off(tiles) + e];
-    if (entry & LR_LONG_DONE) continue;
-    const uint32_t beg = offsets[entry], L = offsets[entry + 1] - beg;
-    if (L > LR_SORT_BLOCK) continue;                        // hybrid path
-    const uint32_t tid = threadIdx.x;
-    uint32_t P2 = 8;
-    while (P2 < L) P2 <<= 1;
-    for (uint32_t i = tid; i < P2; i += 256) s[lr_phys(i)] = i < L ? keys[beg + i] : ~0ull;
-    __syncthreads();
-    lr_lds_sort<256>(s, P2, tid);
-    for (uint32_t i = tid; i < L; i += 256) plist[beg + i] = (uint32_t)s[lr_phys(i)];
-    __syncthreads();
-  }
-}
-
-// ---- lists longer than LR_SORT_BLOCK: hybrid network ------------------------------------------------------------
-// The same ascending-only bitonic network over the tile's whole list, split by stride: levels whose stride is
-// >= LR_SORT_BLOCK are single streaming passes over the tile's slice of the key buffer in global memory (one
-// compare-exchange per pair, every workgroup of the launch works on its share of pairs); everything below that
-// stride stays inside an LR_SORT_BLOCK-key block and runs in LDS with the register-blocked code above.  A list of
-// B*2^m keys costs m(m+1)/2 global passes + m+1 LDS passes instead of ~log^2 passes through global memory
-// (measured before: 27 ms per view at 30 M Gaussians).  Launches are ordered by the stream; tiles that do not take
-// part in a level (list too short) exit at once.  blockIdx.x indexes the big-tile list written by the scan kernel.
-struct LrBigTile { uint32_t beg, L, P2; bool ok; };
-// The network-fallback kernels below walk biglist[] with a SMALL grid (entry e = blockIdx.x, += gridDim.x): normally
-// every entry is already flagged done by the depth-bucket sort, and a launch of thousands of idle workgroups (each
-// with its LDS allocation) costs 15-30 us where a few dozen that skim the flags cost 3.
-LR_DEV LrBigTile lr_big_tile(const uint32_t* __restrict__ state, uint32_t tiles, uint32_t e) {
-  LrBigTile t{0u, 0u, 0u, false};
-  const uint32_t entry = state[lr_biglist_off(tiles) + e];
-  if (entry & LR_LONG_DONE) return t;  // the depth-bucket sort already produced this tile's list
-  const uint32_t tile = entry;
-  const uint32_t* offsets = state + lr_offsets_off(tiles);
-  t.beg = offsets[tile];
-  t.L = offsets[tile + 1] - t.beg;
-  if (t.L <= LR_SORT_BLOCK) return t;  // (LR_LONG_LIST, LR_SORT_BLOCK]: the single-block fallback takes it
-  t.P2 = LR_SORT_BLOCK;
-  while (t.P2 < t.L) t.P2 <<= 1;
-  t.ok = true;
-  return t;
-}
-
-// Stage 0: every LR_SORT_BLOCK-key block of a big tile sorted on its own (blockIdx.y = block).
-template <int NT>
-__global__ void __launch_bounds__(NT)
-lr_bigsort_blocks_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
-                         uint32_t capacity) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (lr_bail(state, capacity)) return;
-  const uint32_t nbig = state[LR_HDR_NBIG];
-  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
-    const LrBigTile t = lr_big_tile(state, tiles, e);
-    const uint32_t b0 = blockIdx.y * LR_SORT_BLOCK;
-    if (!t.ok || b0 >= t.L) continue;
-    const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, t.L - b0), tid = threadIdx.x;
-    uint32_t P2 = 8;
-    while (P2 < cnt) P2 <<= 1;
-    uint64_t* k = keys + t.beg + b0;
-    for (uint32_t i = tid; i < P2; i += NT) s[lr_phys(i)] = i < cnt ? k[i] : ~0ull;
-    __syncthreads();
-    lr_lds_sort<NT>(s, P2, tid);
-    for (uint32_t i = tid; i < cnt; i += NT) k[i] = s[lr_phys(i)];
-    __syncthreads();
-  }
-}
-
-// One global level of phase k: the flip level (j == 0) or the half-cleaner with stride j >= LR_SORT_BLOCK.
-__global__ void __launch_bounds__(256)
-lr_bigsort_global_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
-                         uint32_t capacity, uint32_t k, uint32_t j) {
-  if (lr_bail(state, capacity)) return;
-  const uint32_t nbig = state[LR_HDR_NBIG];
-  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
-    const LrBigTile t = lr_big_tile(state, tiles, e);
-    if (!t.ok || (k >> 1) >= t.L) continue;  // phase k only merges something when the list reaches past k/2
-    uint64_t* a = keys + t.beg;
-    const uint32_t pairs = t.P2 >> 1;
-    for (uint32_t p = blockIdx.y * 256 + threadIdx.x; p < pairs; p += gridDim.y * 256) {
-      uint32_t i, l;
-      if (j == 0) {
-        const uint32_t half = k >> 1, off = p & (half - 1u), blk = (p - off) << 1;
-        i = blk + off; l = blk + (k - 1u - off);
-      } else {
-        const uint32_t low = p & (j - 1u);
-        i = ((p - low) << 1) | low; l = i + j;
-      }
-      if (l < t.L) {
-        const uint64_t x = a[i], y = a[l];
-        if (x > y) { a[i] = y; a[l] = x; }
-      }
-    }
-  }
-}
-
-// Tail of phase k: all strides below LR_SORT_BLOCK, block by block in LDS (blockIdx.y = block).
-template <int NT>
-__global__ void __launch_bounds__(NT)
-lr_bigsort_tail_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
-                       uint32_t capacity, uint32_t k) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t s[];
-  if (lr_bail(state, capacity)) return;
-  const uint32_t nbig = state[LR_HDR_NBIG];
-  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
-    const LrBigTile t = lr_big_tile(state, tiles, e);
-    const uint32_t b0 = blockIdx.y * LR_SORT_BLOCK;
-    if (!t.ok || (k >> 1) >= t.L || b0 >= t.L) continue;
-    const uint32_t cnt = min((uint32_t)LR_SORT_BLOCK, t.L - b0), tid = threadIdx.x;
-    uint64_t* kk = keys + t.beg + b0;
-    for (uint32_t i = tid; i < LR_SORT_BLOCK; i += NT) s[lr_phys(i)] = i < cnt ? kk[i] : ~0ull;
-    __syncthreads();
-    lr_lds_halfcleaners<NT>(s, LR_SORT_BLOCK >> 3, tid, 12);  // strides 4096 ... 1  (LR_SORT_BLOCK == 8192)
-    for (uint32_t i = tid; i < cnt; i += NT) kk[i] = s[lr_phys(i)];
-    __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(256)
-lr_bigsort_emit_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
-                       uint32_t* __restrict__ plist, uint32_t capacity) {
-  if (lr_bail(state, capacity)) return;
-  const uint32_t nbig = state[LR_HDR_NBIG];
-  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
-    const LrBigTile t = lr_big_tile(state, tiles, e);
-    if (!t.ok) continue;
-    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < t.L; i += gridDim.y * 256)
-      plist[t.beg + i] = (uint32_t)keys[t.beg + i];
-  }
-}
+static_assert(sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_t) * LR_BUCKET_MAX >=
+              sizeof(uint64_t) * (LR_SORT_BLOCK + (LR_SORT_BLOCK >> 3)), "the fallback network stages one block in the same LDS");
 
 // Size classes: the LDS footprint (9 B/key with padding) sets how many workgroups a CU can hold, so small
 // lists must not pay for the largest class.
 #define LR_SORT_CAP0 512             // 64 threads (one wave), 4.5 KB
 #define LR_SORT_CAP1 2048            // 256 threads, 18 KB
 #define LR_SORT_CAP2 LR_SORT_BLOCK   // 256 threads, 72 KB (dynamic LDS beyond the 64 KB static limit)
-static_assert(LR_SORT_BLOCK == 8192, "lr_bigsort_tail_kernel hard-codes the top stride exponent");
-static inline size_t lr_sort_lds_bytes(uint32_t cap) { return sizeof(uint64_t) * (size_t)(cap + (cap >> 3)); }
 
 // max_len: upper bound on the longest tile list known to the HOST (exact count from stage 1, a hint in sync-free
 // operation, or 0 = unknown -> assume `capacity`).  It only decides how many multi-block levels are launched.
@@ -768,12 +706,6 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   if (!attr_set) {
     const int big = (int)lr_sort_lds_bytes(LR_SORT_BLOCK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_rb_kernel<256>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_fallback_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_bigsort_blocks_kernel<512>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_bigsort_tail_kernel<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_bucket_kernel<256, 16, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_bucket_lds_bytes(4096));
@@ -789,7 +721,6 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   static const int equalize = lr_env_int("LOGRAST_EQUALIZE", 1);   // 0: plain linear depth -> bucket map (experiments)
   // biglist holds the tiles with more than LR_LONG_LIST keys, so there are at most capacity / LR_LONG_LIST of them
   const uint32_t nlong = min(tiles, capacity / LR_LONG_LIST + 1u);
-  const uint32_t nfb = bucket ? min(nlong, 256u) : nlong;  // network fallback kernels: a chip-sized grid that walks biglist[]
   if (bucket) {
     // depth buckets in LDS up to LR_LONG_LIST keys (a separate one-wave network launch for tiny lists costs more than it saves)
     lr_prof_begin(LRK_SORT_SMALL, s);
@@ -819,33 +750,15 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   }
   if (max_len > LR_LONG_LIST && (bucket || max_len > LR_SORT_BLOCK)) {
     lr_prof_begin(LRK_SORT_HUGE, s);
-    if (bucket) {
-      // long lists: depth buckets in LDS up to LR_SORT_BLOCK keys (keys held in registers), with the keys in memory
-      // beyond; what they give up on falls through to the networks
+    // long lists: depth buckets in LDS up to LR_SORT_BLOCK keys (keys held in registers), with the keys in memory beyond;
+    // a workgroup whose list defeats the bucket maps runs the network on it by itself (no fallback launches)
+    if (bucket)
       hipLaunchKernelGGL((lr_sort_bucket_kernel<512, 16, true>), dim3(nlong), dim3(512),
                          lr_bucket_lds_bytes(LR_SORT_BLOCK, false), s, state, tiles, keys, plist, (uint32_t)LR_LONG_LIST,
                          capacity, equalize);
+    if (max_len > LR_SORT_BLOCK)
       hipLaunchKernelGGL(lr_sort_long_kernel, dim3(nlong), dim3(1024), lr_long_lds_bytes(), s, state, tiles,
-                         keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize);
-      hipLaunchKernelGGL(lr_sort_long_fallback_kernel, dim3(nfb), dim3(256), lr_sort_lds_bytes(LR_SORT_BLOCK), s, state,
-                         tiles, keys, plist, capacity);
-    }
-    if (max_len > LR_SORT_BLOCK) {
-      const uint32_t nblk = (max_len + LR_SORT_BLOCK - 1u) / LR_SORT_BLOCK;
-      const uint32_t ypass = min(64u, max(1u, nblk * 4u));  // workgroups per tile for the streaming passes
-      const size_t lds = lr_sort_lds_bytes(LR_SORT_BLOCK);
-      hipLaunchKernelGGL(lr_bigsort_blocks_kernel<512>, dim3(nfb, nblk), dim3(512), lds, s, state, tiles, keys, capacity);
-      for (uint64_t k = 2ull * LR_SORT_BLOCK; (k >> 1) < max_len; k <<= 1) {
-        hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nfb, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
-                           (uint32_t)k, 0u);
-        for (uint64_t j = k >> 2; j >= LR_SORT_BLOCK; j >>= 1)
-          hipLaunchKernelGGL(lr_bigsort_global_kernel, dim3(nfb, ypass), dim3(256), 0, s, state, tiles, keys, capacity,
-                             (uint32_t)k, (uint32_t)j);
-        hipLaunchKernelGGL(lr_bigsort_tail_kernel<512>, dim3(nfb, nblk), dim3(512), lds, s, state, tiles, keys, capacity,
-                           (uint32_t)k);
-      }
-      hipLaunchKernelGGL(lr_bigsort_emit_kernel, dim3(nfb, ypass), dim3(256), 0, s, state, tiles, keys, plist, capacity);
-    }
+                         keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize, bucket ? 0 : 1);
     lr_prof_end(LRK_SORT_HUGE, s);
   }
 }

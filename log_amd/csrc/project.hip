@@ -564,12 +564,17 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
     for (int d = 8; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     lmax = m;                                                // longest list of the view, in every thread
   }
-  const uint32_t lsh = lmax > 255u ? (uint32_t)(24 - __clz((int)lmax)) : 0u;   // lmax >> lsh <= 255
+  // bucket(L) = L / 32 below 4096 keys (128 buckets: the sort's size classes start at multiples of 32, so every tile in
+  // front of a list of more than 1024 keys in order[] holds at least 1024 itself -- lr_launch_sort sizes its grids by
+  // that), 128 + (L - 4096) >> lsh above, lsh from the longest list so that the last bucket is 255
+  const uint32_t over = lmax > 4096u ? lmax - 4096u : 0u;
+  const uint32_t lsh = over > 127u ? (uint32_t)(25 - __clz((int)over)) : 0u;    // over >> lsh <= 127
+  auto len_bucket = [&](uint32_t len) -> uint32_t { return len < 4096u ? len >> 5 : 128u + ((len - 4096u) >> lsh); };
 #pragma unroll
   for (int k = 0; k < CHMAX; k++) {
     const uint32_t t = b + (uint32_t)k;
     if ((uint32_t)k < chunk && t < tiles) {
-      atomicAdd(&hist[tot[k] >> lsh], 1u);
+      atomicAdd(&hist[len_bucket(tot[k])], 1u);
       if (!LATE) {
         offsets[t] = run;
         cursor[t * LR_CTR_STRIDE] = run + nr[k];  // big instances go behind the ranked ones (64 B apart: the fill's atomics hit random tiles)
@@ -602,7 +607,7 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
     const uint32_t t = b + (uint32_t)k;
     const bool in = (uint32_t)k < chunk && t < tiles;
     if (in) {
-      order[atomicAdd(&hist[tot[k] >> lsh], 1u)] = t;
+      order[atomicAdd(&hist[len_bucket(tot[k])], 1u)] = t;
       if (LATE) {
         offsets[t] = run;
         cursor[t * LR_CTR_STRIDE] = run + nr[k];

@@ -286,28 +286,20 @@ LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, u
     }
   }
 }
-// LONG = false: blockIdx.x is the tile; the keys are also staged in network layout so that the workgroup can fall
-// back to the network by itself.  LONG = true: blockIdx.x indexes biglist[] (tiles above LR_LONG_LIST keys); no
-// staging (LDS budget) -- on clustered depths the entry is simply left unflagged for the fallback kernels.
+// LONG = false: the keys are also staged in network layout so that the workgroup can fall back to the network on them;
+// LONG = true (lists of up to NT * KPT = LR_SORT_BLOCK keys): no staging (LDS budget) -- the keys stay in registers and
+// are staged for the network only when it is needed.
+// One tile's list (keys[beg, beg + L), L <= NT * KPT) by the workgroup's NT threads; s = the workgroup's dynamic LDS,
+// lr_bucket_lds_bytes(NT * KPT, !LONG) bytes.
 template <int NT, int KPT, bool LONG>
-__global__ void __launch_bounds__(NT)
-lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
-                      uint32_t* __restrict__ plist, uint32_t lo, uint32_t capacity, int equalize) {
+LR_DEV void lr_bucket_tile(const uint64_t* __restrict__ keys, uint32_t* __restrict__ plist, uint32_t beg, uint32_t L,
+                           int equalize, uint64_t* s) {
   constexpr uint32_t CAP = NT * KPT;                       // longest list of this class (a power of two)
-  extern __shared__ __attribute__((aligned(16))) uint64_t s[];  // [A[CAP + CAP/8] (network layout)] | B[CAP] | cnt[CAP/4]
+  // s: [A[CAP + CAP/8] (network layout)] | B[CAP] | cnt[CAP/4]; LONG: B and cnt only, A takes them over for the fallback
   uint64_t* const A = s;
   uint64_t* const Bk = LONG ? s : s + (CAP + (CAP >> 3));
   uint32_t* const cnt = reinterpret_cast<uint32_t*>(Bk + CAP);
   __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[NT / 64], cellcnt[LR_CELLS], celltab[LR_CELLS];
-  if (lr_bail(state, capacity)) return;
-  if (LONG && blockIdx.x >= state[LR_HDR_NBIG]) return;
-  const uint32_t* offsets = state + lr_offsets_off(tiles);
-  // lo > 0: blockIdx.x walks the longest-first dispatch order, so a grid of capacity / lo workgroups reaches every tile
-  // with more than lo keys (each holds more than lo of the capacity) instead of launching one workgroup per tile
-  const uint32_t tile = LONG ? (state[lr_biglist_off(tiles) + blockIdx.x] & ~LR_LONG_DONE)
-                             : (lo ? state[lr_order_off(tiles) + blockIdx.x] : blockIdx.x);
-  const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg;
-  if (L <= lo || L > CAP) return;
   const uint32_t tid = threadIdx.x;
   uint32_t P2 = 8;
   while (P2 < L) P2 <<= 1;
@@ -399,7 +391,6 @@ lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64
       }
       lr_lds_sort<NT>(A, P2, tid);
       for (uint32_t i = tid; i < L; i += NT) plist[beg + i] = (uint32_t)A[lr_phys(i)];
-      if (LONG && tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
       return;
     }
     __syncthreads();                                          // every thread has read sh_maxcnt and its counts
@@ -431,7 +422,17 @@ lr_sort_bucket_kernel(uint32_t* __restrict__ state, uint32_t tiles, const uint64
       plist[beg + st + smaller] = (uint32_t)key[k];
     }
   }
-  if (LONG && tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
+}
+// Lists of up to 1024 keys: one 256-thread workgroup per tile (most tiles of a small scene).
+__global__ void __launch_bounds__(256)
+lr_sort_small_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const uint64_t* __restrict__ keys,
+                     uint32_t* __restrict__ plist, uint32_t capacity, int equalize) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lr_sort_lds[];
+  if (lr_bail(state, capacity)) return;
+  const uint32_t* offsets = state + lr_offsets_off(tiles);
+  const uint32_t beg = offsets[blockIdx.x], L = offsets[blockIdx.x + 1] - beg;
+  if (L == 0 || L > 1024u) return;
+  lr_bucket_tile<256, 4, false>(keys, plist, beg, L, equalize, lr_sort_lds);
 }
 static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
   return (staged ? sizeof(uint64_t) * (size_t)(cap + (cap >> 3)) : 0) + sizeof(uint64_t) * cap + sizeof(uint32_t) * (cap >> 2);
@@ -471,12 +472,13 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
   extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
   uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
   __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[16], cellcnt[LR_CELLS], celltab[LR_CELLS];
-  if (lr_bail(state, capacity) || blockIdx.x >= state[LR_HDR_NBIG]) return;
-  const uint32_t entry = state[lr_biglist_off(tiles) + blockIdx.x];
-  if (entry & LR_LONG_DONE) return;                        // done in LDS / registers by an earlier launch
-  const uint32_t tile = entry;
+  if (lr_bail(state, capacity)) return;
+  // blockIdx.x walks the longest-first dispatch order: every tile in front of a list of more than 1024 keys holds at
+  // least 1024 itself (lr_scan_kernel's length buckets), so capacity / 1024 + 1 workgroups reach all of them
+  const uint32_t tile = state[lr_order_off(tiles) + blockIdx.x];
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg, tid = threadIdx.x;
+  if (L <= 1024u) return;                                   // lr_sort_small_kernel's
   const uint64_t* k = keys + beg;
   uint16_t* rk = reinterpret_cast<uint16_t*>(ranks) + beg;   // one 16-bit bucket id per key (nb <= 4096)
   uint32_t* pl = plist + beg;
@@ -486,12 +488,14 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
     __syncthreads();
     lr_wg_hybrid_sort<1024>(keys + beg, L, reinterpret_cast<uint64_t*>(lcnt), tid);
     for (uint32_t i = tid; i < L; i += 1024u) pl[i] = (uint32_t)k[i];
-    if (tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
   };
   if (network_only) {                                       // (lists up to one block were sorted by lr_sort_rb_kernel)
     if (L > LR_SORT_BLOCK) network();
     return;
   }
+  // up to 4096 keys: the whole list in LDS, same code as the small lists.  (Up to 8192 the keys could sit in registers --
+  // that was a kernel of its own, 145 VGPRs -- but not at the 64 this kernel is held to: they stream like the longer ones.)
+  if (L <= LR_LONG_LIST) { lr_bucket_tile<1024, 4, false>(keys, plist, beg, L, equalize, reinterpret_cast<uint64_t*>(lcnt)); return; }
 #ifdef LR_LONG_TICKS   // phase timing experiment (-DLR_LONG_TICKS): wall_clock64 per phase, printed by three workgroups
   uint64_t tk[16]; int tn = 0;
 #define LR_TICK() do { if (tn < 16) tk[tn++] = wall_clock64(); } while (0)
@@ -673,7 +677,6 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
     b0 = b1;
   }
 
-  if (tid == 0) state[lr_biglist_off(tiles) + blockIdx.x] = tile | LR_LONG_DONE;
 #ifdef LR_LONG_TICKS
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700 || blockIdx.x == 2000)) {
     printf("longsort blk %u L %u nb %u ticks(10ns):", blockIdx.x, L, nb);
@@ -685,7 +688,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
 }
 
 static inline size_t lr_sort_lds_bytes(uint32_t cap) { return sizeof(uint64_t) * (size_t)(cap + (cap >> 3)); }
-static inline size_t lr_long_lds_bytes() {
+static inline size_t lr_long_lds_bytes() {   // (also >= lr_bucket_lds_bytes(4096) = lr_bucket_lds_bytes(8192, false) = 73728)
   return sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_t) * LR_BUCKET_MAX;
 }
 static_assert(sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_t) * LR_BUCKET_MAX >=
@@ -707,10 +710,6 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
     const int big = (int)lr_sort_lds_bytes(LR_SORT_BLOCK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_rb_kernel<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_bucket_kernel<256, 16, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_bucket_lds_bytes(4096));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_bucket_kernel<512, 16, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_bucket_lds_bytes(LR_SORT_BLOCK, false));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_long_lds_bytes());
     attr_set = true;
@@ -719,20 +718,15 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   // LOGRAST_BUCKET_SORT=0: bitonic network only (the reference implementation of the same total order)
   static const int bucket = lr_env_int("LOGRAST_BUCKET_SORT", 1);
   static const int equalize = lr_env_int("LOGRAST_EQUALIZE", 1);   // 0: plain linear depth -> bucket map (experiments)
-  // biglist holds the tiles with more than LR_LONG_LIST keys, so there are at most capacity / LR_LONG_LIST of them
-  const uint32_t nlong = min(tiles, capacity / LR_LONG_LIST + 1u);
+  // Two launches: one 256-thread workgroup per tile for the lists of up to 1024 keys, and one 1024-thread workgroup
+  // (78 KB of LDS, two per CU) per list above that, walking the longest-first order -- LDS-resident up to 4096 keys,
+  // keys in registers up to 8192, streamed from memory beyond.  (They used to be four launches by size class: at 30 M
+  // Gaussians, where every list is long, the three that found nothing to do cost 100 us of idle workgroups per view.)
   if (bucket) {
-    // depth buckets in LDS up to LR_LONG_LIST keys (a separate one-wave network launch for tiny lists costs more than it saves)
     lr_prof_begin(LRK_SORT_SMALL, s);
-    hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 4, false>), dim3(tiles), dim3(256), lr_bucket_lds_bytes(1024), s, state,
-                       tiles, keys, plist, 0u, capacity, equalize);
+    hipLaunchKernelGGL(lr_sort_small_kernel, dim3(tiles), dim3(256), lr_bucket_lds_bytes(1024), s, state, tiles, keys,
+                       plist, capacity, equalize);
     lr_prof_end(LRK_SORT_SMALL, s);
-    if (max_len > 1024u) {
-      lr_prof_begin(LRK_SORT_LARGE, s);
-      hipLaunchKernelGGL((lr_sort_bucket_kernel<256, 16, false>), dim3(min(tiles, capacity / 1024u + 1u)), dim3(256),
-                         lr_bucket_lds_bytes(LR_LONG_LIST), s, state, tiles, keys, plist, 1024u, capacity, equalize);
-      lr_prof_end(LRK_SORT_LARGE, s);
-    }
   } else {
     lr_prof_begin(LRK_SORT_SMALL, s);
     hipLaunchKernelGGL(lr_sort_rb_kernel<64>, dim3(tiles), dim3(64), lr_sort_lds_bytes(LR_SORT_CAP0), s, state, tiles,
@@ -748,17 +742,11 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
       lr_prof_end(LRK_SORT_LARGE, s);
     }
   }
-  if (max_len > LR_LONG_LIST && (bucket || max_len > LR_SORT_BLOCK)) {
+  if (bucket ? max_len > 1024u : max_len > LR_SORT_BLOCK) {
     lr_prof_begin(LRK_SORT_HUGE, s);
-    // long lists: depth buckets in LDS up to LR_SORT_BLOCK keys (keys held in registers), with the keys in memory beyond;
-    // a workgroup whose list defeats the bucket maps runs the network on it by itself (no fallback launches)
-    if (bucket)
-      hipLaunchKernelGGL((lr_sort_bucket_kernel<512, 16, true>), dim3(nlong), dim3(512),
-                         lr_bucket_lds_bytes(LR_SORT_BLOCK, false), s, state, tiles, keys, plist, (uint32_t)LR_LONG_LIST,
-                         capacity, equalize);
-    if (max_len > LR_SORT_BLOCK)
-      hipLaunchKernelGGL(lr_sort_long_kernel, dim3(nlong), dim3(1024), lr_long_lds_bytes(), s, state, tiles,
-                         keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize, bucket ? 0 : 1);
+    hipLaunchKernelGGL(lr_sort_long_kernel, dim3(min(tiles, capacity / 1024u + 1u)), dim3(1024), lr_long_lds_bytes(), s,
+                       state, tiles, keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize,
+                       bucket ? 0 : 1);
     lr_prof_end(LRK_SORT_HUGE, s);
   }
 }

@@ -14,7 +14,7 @@
 #define LR_TILE 16
 
 // ---- tile_state layout (uint32 words) ------------------------------------------------------------
-// [0] num_instances  [1] overflow flag  [2] longest tile list  [3] number of tiles longer than LR_LONG_LIST
+// [0] num_instances  [1] overflow flag  [2] longest tile list  [3] reserved
 // [4] tile instances of the plain rect rule (before the support cull; reporting only)
 // [5] support cull applied by the projection kernel (0/1)  [6] projection batch size (0 = unbatched)
 // [7] some rect was deferred to lr_count_huge_kernel  [8..15] reserved
@@ -28,7 +28,6 @@
 // then offsets[Tp]: exclusive offsets (T+1 entries)                                   -- read by sort/blend
 //   cursor[T*S]   fill cursor for the big instances, initialised to offset + ranked
 // then order[T]: tile ids by descending list length (longest-first dispatch order for the blend kernels)
-// then biglist[T]: ids of the tiles whose list exceeds LR_LONG_LIST keys (long-list sort paths; bit 31 = sorted)
 #ifndef LR_CTR_STRIDE
 #define LR_CTR_STRIDE 16
 #endif
@@ -37,14 +36,12 @@
 #define LR_HDR_NUM 0
 #define LR_HDR_OVERFLOW 1
 #define LR_HDR_MAXLEN 2
-#define LR_HDR_NBIG 3
 #define LR_HDR_BATCH 6  // Gaussians per projection batch (0 = unbatched kernel: slots in q3 are absolute)
 #define LR_HDR_CULL 5  // 1 if lr_project_kernel applied the support cull (the fill kernel must repeat it)
 #define LR_HDR_RECT 4  // tile instances of the plain rect rule (what the reference would sort), before the support cull
 #define LR_HDR_HUGE 7  // batched projection: some workgroup deferred a rect to lr_count_huge_kernel (else that kernel returns at once)
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
-#define LR_LONG_LIST 4096   // lists longer than this go to biglist[] (long-list sort paths)
-#define LR_LONG_DONE 0x80000000u  // biglist entry flag: the depth-bucket sort finished this tile
+#define LR_LONG_LIST 4096   // longer lists are sorted with their keys streamed from memory (shorter ones: LDS-resident)
 #define LR_REC_QUADS 4  // float4 per projected record (64 B)
 __host__ __device__ inline uint32_t lr_tpad(uint32_t tiles) { return (tiles + 1 + 15u) & ~15u; }
 // header | ranked | big are contiguous: one memset clears everything a forward needs zeroed
@@ -53,9 +50,8 @@ __host__ __device__ inline uint32_t lr_big_off(uint32_t tiles) { return lr_ranke
 __host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { return lr_big_off(tiles) + tiles * LR_CTR_STRIDE; }
 __host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_offsets_off(tiles) + lr_tpad(tiles); }
 __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
-__host__ __device__ inline uint32_t lr_biglist_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
 // then basetab[batches][T]: start of every projection batch's reservation inside each tile's ranked range
-__host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_biglist_off(tiles) + lr_tpad(tiles); }
+__host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
 // then hugecount[batches]: how many Gaussians of the batch left their (more than LR_COOP_TILES tile) rect to
 // lr_count_huge_kernel
 __host__ __device__ inline size_t lr_hugecount_off(uint32_t tiles, uint32_t batches) {

@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256)
 lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,
                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ hugecount, int B, int tile_cull,
                      int defer_tiles, int chunk) {
-  extern __shared__ uint32_t lr_lds_ctr[];                   // [tiles] counters | [256] chunk flags
+  extern __shared__ uint32_t lr_lds_ctr[];                   // [tiles] counters | [256] chunks with work | their number
   uint32_t* const lr_chunk_todo = lr_lds_ctr + tiles;
   if (!hdr[LR_HDR_HUGE]) return;                             // no workgroup deferred anything: the common case
   // (the grid is capped at a few workgroups per CU: each walks its share of the chunks and skips those whose batches
@@ -395,12 +395,14 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
       for (int b = b0; b <= b1; b++) any |= hugecount[b];
     }
     __syncthreads();                                         // (the previous round's readers are done)
-    lr_chunk_todo[threadIdx.x] = any;
+    if (threadIdx.x == 0) lr_chunk_todo[256] = 0u;
+    __syncthreads();
+    if (any) lr_chunk_todo[atomicAdd(&lr_chunk_todo[256], 1u)] = threadIdx.x;   // compact list of the chunks with work
     __syncthreads();
   }
-  for (int slot = 0; slot < 256; slot++) {
-  if (!lr_chunk_todo[slot]) continue;
-  const int chunk_id = first + slot * (int)gridDim.x;
+  const int ntodo = (int)lr_chunk_todo[256];
+  for (int q = 0; q < ntodo; q++) {
+  const int chunk_id = first + (int)lr_chunk_todo[q] * (int)gridDim.x;
   const int base = chunk_id * chunk;
   __syncthreads();                                           // (the previous chunk's flush has read the counters)
   for (int t = threadIdx.x; t < tiles; t += 256) lr_lds_ctr[t] = 0u;
@@ -477,7 +479,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        basetab, hugecount, tile_cull, batch, planes, defer_tiles);
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
-    hipLaunchKernelGGL(lr_count_huge_kernel, dim3(min((N + chunk - 1) / chunk, 2048)), dim3(256), lds + 1024, s, N, v.gx,
+    hipLaunchKernelGGL(lr_count_huge_kernel, dim3(min((N + chunk - 1) / chunk, 2048)), dim3(256), lds + 1028, s, N, v.gx,
                        tiles, reinterpret_cast<const float4*>(geom), big, (const uint32_t*)hdr, (const uint32_t*)hugecount,
                        batch, tile_cull, defer_tiles, chunk);
     lr_prof_end(LRK_RESERVED, s);
@@ -507,7 +509,6 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
   uint32_t* offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
   uint32_t* order = state + lr_order_off(tiles);
-  uint32_t* biglist = state + lr_biglist_off(tiles);
   const uint32_t tid = threadIdx.x;
   uint32_t lmax = 0;
   const uint32_t chunk = (tiles + 1023u) / 1024u;
@@ -613,16 +614,6 @@ lr_scan_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t cs, uint32
         cursor[t * LR_CTR_STRIDE] = run + nr[k];
         run += tot[k];
       }
-    }
-    // long-list sort paths: one memory-side atomic per wave reserves the slots of all its long tiles (one per tile was
-    // 3000 returning atomics on one address at 30 M Gaussians)
-    const bool lng = in && tot[k] > LR_LONG_LIST;
-    const uint64_t lm = __ballot(lng);
-    if (lm) {
-      uint32_t first = 0;
-      if ((tid & 63u) == 0u) first = atomicAdd(&state[LR_HDR_NBIG], (uint32_t)__popcll(lm));
-      first = (uint32_t)__shfl((int)first, 0);
-      if (lng) biglist[first + (uint32_t)__popcll(lm & ((1ull << (tid & 63u)) - 1ull))] = t;
     }
   }
   if (tid == 0u && lmax) atomicMax(&state[LR_HDR_MAXLEN], lmax);

@@ -1,10 +1,10 @@
 // sort.hip -- A4: per-tile depth sort.  Replaces the third-party package's global 64-bit radix sort of
 // (tile|depth) keys + identifyTileRanges: tiles are already separated by the bucket fill, so each tile's
-// (depth,id) keys are sorted independently -- one workgroup per tile, keys staged in LDS, register-blocked
-// bitonic network with ascending-only comparators (lists are padded with +inf to a power of two).
+// (depth,id) keys are sorted independently, one workgroup per tile: a depth-bucket distribution sort (O(L)), with a
+// register-blocked bitonic network (ascending-only comparators, lists padded with +inf to a power of two) as the
+// fallback for depths no bucket map can spread and as the LOGRAST_BUCKET_SORT=0 reference of the same total order.
 // Keys are unique (the Gaussian index is the low word), hence the order is total and equals the
-// stable (tile, depth) order of index-ordered input.  Output: point_list[I] = Gaussian ids.  Lists longer than one
-// LDS block (8192 keys) take the hybrid multi-block path at the end of this file.
+// stable (tile, depth) order of index-ordered input.  Output: point_list[I] = Gaussian ids.
 #include "common.hpp"
 
 // ---- register-blocked LDS path -----------------------------------------------------------------------------
@@ -286,18 +286,16 @@ LR_DEV void lr_emit_bucket(KeyAt key_at, uint32_t st, uint32_t en, bool valid, u
     }
   }
 }
-// LONG = false: the keys are also staged in network layout so that the workgroup can fall back to the network on them;
-// LONG = true (lists of up to NT * KPT = LR_SORT_BLOCK keys): no staging (LDS budget) -- the keys stay in registers and
-// are staged for the network only when it is needed.
 // One tile's list (keys[beg, beg + L), L <= NT * KPT) by the workgroup's NT threads; s = the workgroup's dynamic LDS,
-// lr_bucket_lds_bytes(NT * KPT, !LONG) bytes.
-template <int NT, int KPT, bool LONG>
+// lr_bucket_lds_bytes(NT * KPT) bytes.  The keys are also staged in network layout so that the workgroup can fall back
+// to the network on them.
+template <int NT, int KPT>
 LR_DEV void lr_bucket_tile(const uint64_t* __restrict__ keys, uint32_t* __restrict__ plist, uint32_t beg, uint32_t L,
                            int equalize, uint64_t* s) {
   constexpr uint32_t CAP = NT * KPT;                       // longest list of this class (a power of two)
-  // s: [A[CAP + CAP/8] (network layout)] | B[CAP] | cnt[CAP/4]; LONG: B and cnt only, A takes them over for the fallback
+  // s: [A[CAP + CAP/8] (network layout)] | B[CAP] | cnt[CAP/4]
   uint64_t* const A = s;
-  uint64_t* const Bk = LONG ? s : s + (CAP + (CAP >> 3));
+  uint64_t* const Bk = s + (CAP + (CAP >> 3));
   uint32_t* const cnt = reinterpret_cast<uint32_t*>(Bk + CAP);
   __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[NT / 64], cellcnt[LR_CELLS], celltab[LR_CELLS];
   const uint32_t tid = threadIdx.x;
@@ -313,7 +311,7 @@ LR_DEV void lr_bucket_tile(const uint64_t* __restrict__ keys, uint32_t* __restri
   for (int k = 0; k < KPT; k++) {
     const uint32_t i = tid + (uint32_t)k * NT;
     key[k] = i < L ? keys[beg + i] : ~0ull;
-    if (!LONG && i < P2) A[lr_phys(i)] = key[k];           // staged for the fallback
+    if (i < P2) A[lr_phys(i)] = key[k];                    // staged for the fallback
     if (i < L) { const uint32_t d = (uint32_t)(key[k] >> 32); dmin = min(dmin, d); dmax = max(dmax, d); }
   }
 #pragma unroll
@@ -381,14 +379,6 @@ LR_DEV void lr_bucket_tile(const uint64_t* __restrict__ keys, uint32_t* __restri
     if (sh_maxcnt <= LR_BUCKET_MAX) break;
     if (eq || !equalize) {                                   // clustered beyond the map's reach: the network
       __syncthreads();
-      if (LONG) {                                             // (keys in registers: they take over the bucket arrays' LDS)
-#pragma unroll
-        for (int k = 0; k < KPT; k++) {
-          const uint32_t i = tid + (uint32_t)k * NT;
-          if (i < P2) A[lr_phys(i)] = key[k];                 // key[k] = +inf beyond the list
-        }
-        __syncthreads();
-      }
       lr_lds_sort<NT>(A, P2, tid);
       for (uint32_t i = tid; i < L; i += NT) plist[beg + i] = (uint32_t)A[lr_phys(i)];
       return;
@@ -432,35 +422,36 @@ lr_sort_small_kernel(const uint32_t* __restrict__ state, uint32_t tiles, const u
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[blockIdx.x], L = offsets[blockIdx.x + 1] - beg;
   if (L == 0 || L > 1024u) return;
-  lr_bucket_tile<256, 4, false>(keys, plist, beg, L, equalize, lr_sort_lds);
+  lr_bucket_tile<256, 4>(keys, plist, beg, L, equalize, lr_sort_lds);
 }
-static inline size_t lr_bucket_lds_bytes(uint32_t cap, bool staged = true) {
-  return (staged ? sizeof(uint64_t) * (size_t)(cap + (cap >> 3)) : 0) + sizeof(uint64_t) * cap + sizeof(uint32_t) * (cap >> 2);
+static inline size_t lr_bucket_lds_bytes(uint32_t cap) {
+  return sizeof(uint64_t) * (size_t)(cap + (cap >> 3)) + sizeof(uint64_t) * cap + sizeof(uint32_t) * (cap >> 2);
 }
 
-// ---- long lists: the same depth-bucket sort, keys in memory ----------------------------------------------------
-// One 1024-thread workgroup per long tile (biglist entry); bucket counters in LDS, keys streamed from memory:
-//   pass 1  depth range of the first eighth of the list (a random sample: the keys arrive in no particular order);
-//   pass 2  bucket + rank of every key (returning LDS atomic); a 4-byte (bucket, rank) code per key goes to the
-//           scratch half of the key buffer (coalesced);
+// ---- lists above 1024 keys: one 1024-thread workgroup each, longest first ----------------------------------------
+// blockIdx.x walks lr_scan_kernel's longest-first order.  Up to LR_LONG_LIST keys the list is sorted in LDS by the code
+// above; beyond, the same depth-bucket sort runs with the keys streamed from memory and only the bucket counters in LDS:
+//   pass 1  depth range of a sample (64-key pieces spread over the list);
+//   pass 2  bucket of every key, counted with a non-returning LDS atomic; a 16-bit bucket id per key goes to the scratch
+//           half of the key buffer (coalesced);
 //   scan    bucket starts;
-//   then, window by window (7680 list positions, cut at bucket boundaries): every key whose destination falls into
-//           the window (known from its code: 4 B re-read per key and window, cache-resident) is fetched and dropped at
-//           its bucket position in an LDS copy of that window; one thread per bucket then orders the bucket's keys in
-//           registers and writes the ids to their final list positions (lr_emit_bucket).
-// (Measured alternative, removed: 16-bit key INDICES in the window instead of the keys -- one window then covers a
-// 20 K-key list and the staging runs once (5.6 instead of 4 x 7.5 us per tile) -- but the final order has to gather the
-// keys back through the indices, 8-byte reads scattered over the tile's 176 KB slice while 500 other tiles do the same:
-// 50 us per tile instead of 4 x 9.)
-// (Measured alternative, removed: one 1024-thread workgroup per tile holding the depth bits of all its keys in VGPRs --
-// 24 per thread, keys read from memory once -- needs all 128 VGPRs, i.e. ONE workgroup per CU, and every phase of this
-// sort is a short chain of LDS round trips at ~150 ns each: 60 us per 20 K-key tile against 2 x 57 us here with two
-// workgroups per CU overlapping, the same 0.66 ms per 30 M-Gaussian view.)
-// Nothing is scattered through memory except the final ids inside one window at a time (an earlier version scattered
-// the keys into a bucket-ordered scratch copy: 8-byte stores all over a 160 KB region from 512 concurrent workgroups
-// cost more HBM traffic than the whole network sort).  O(L) work instead of n log^2 n; a tile whose depths are too
-// clustered (a bucket above LR_BUCKET_MAX keys) is left to the network paths below, a finished one is flagged in
-// its biglist entry so that they skip it.
+//   then, window by window (7680 list positions, cut at bucket boundaries): every key whose bucket falls into the window
+//           (known from its id: 2 B re-read per key and window, cache-resident) is fetched and dropped into an LDS copy of
+//           that window at the slot the bucket's start counter hands out (it doubles as the fill cursor); one thread per
+//           bucket then orders the bucket's keys in registers, the ids go back into the window and leave in full lines.
+// O(L) work instead of n log^2 n; nothing is scattered through memory (an earlier version scattered the keys into a
+// bucket-ordered scratch copy: 8-byte stores all over a 160 KB region from 512 concurrent workgroups cost more HBM traffic
+// than the whole network sort).  A list whose depths defeat both bucket maps is sorted by the network, by the same
+// workgroup (lr_wg_hybrid_sort).
+// (Measured alternatives, removed.  16-bit key INDICES in the window instead of the keys -- one window then covers a 20 K-
+// key list and the staging runs once -- but the final order has to gather the keys back through the indices, 8-byte reads
+// scattered over the tile's 176 KB slice while 500 other tiles do the same: 50 us per tile instead of 4 x 9.  One
+// workgroup per tile holding the depth bits of all its keys in VGPRs -- keys read from memory once -- needs all 128 VGPRs,
+// i.e. ONE workgroup per CU, and every phase of this sort is a short chain of LDS round trips at ~150 ns each: 60 us per
+// 20 K-key tile against 2 x 57 us with two workgroups per CU overlapping.  Separate launches per size class -- (1024, 4096]
+// in LDS with 256 threads, (4096, 8192] with the keys in registers, the rest here -- each with a grid that could reach
+// every tile: at 30 M Gaussians, where every list is long, the launches that found nothing to do cost 100 us of idle
+// workgroups per view, and the lists of the class in work never overlapped those of the next.)
 #define LR_LONG_NB 4096     // bucket counters in LDS
 #define LR_LONG_WIN_BYTES 61440   // LDS window: 7680 keys staged at a time (16 KB counters + this: two workgroups per CU)
 #define LR_LONG_UNR 8       // independent loads in flight per thread in the streaming passes (64 VGPRs: two workgroups per CU, no spills)
@@ -495,7 +486,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
   }
   // up to 4096 keys: the whole list in LDS, same code as the small lists.  (Up to 8192 the keys could sit in registers --
   // that was a kernel of its own, 145 VGPRs -- but not at the 64 this kernel is held to: they stream like the longer ones.)
-  if (L <= LR_LONG_LIST) { lr_bucket_tile<1024, 4, false>(keys, plist, beg, L, equalize, reinterpret_cast<uint64_t*>(lcnt)); return; }
+  if (L <= LR_LONG_LIST) { lr_bucket_tile<1024, 4>(keys, plist, beg, L, equalize, reinterpret_cast<uint64_t*>(lcnt)); return; }
 #ifdef LR_LONG_TICKS   // phase timing experiment (-DLR_LONG_TICKS): wall_clock64 per phase, printed by three workgroups
   uint64_t tk[16]; int tn = 0;
 #define LR_TICK() do { if (tn < 16) tk[tn++] = wall_clock64(); } while (0)
@@ -688,7 +679,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
 }
 
 static inline size_t lr_sort_lds_bytes(uint32_t cap) { return sizeof(uint64_t) * (size_t)(cap + (cap >> 3)); }
-static inline size_t lr_long_lds_bytes() {   // (also >= lr_bucket_lds_bytes(4096) = lr_bucket_lds_bytes(8192, false) = 73728)
+static inline size_t lr_long_lds_bytes() {   // (also >= lr_bucket_lds_bytes(4096) = 73728)
   return sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_t) * LR_BUCKET_MAX;
 }
 static_assert(sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_t) * LR_BUCKET_MAX >=

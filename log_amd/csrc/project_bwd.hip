@@ -11,6 +11,124 @@
 // their accumulators (whose conic part the forward then does not zero-fill: the compositing kernel clears the rows it meets) and without the 80-byte read-modify-
 // write of the running sums: in an opaque scene most Gaussians are hidden (30 M random Gaussians at opacity 0.999:
 // the kernel went from 0.83 ms, at the copy rate, to the touched rows' share).
+// The chain rule of ONE Gaussian the forward composited (gm, gs, gq, and dL/dcov3D written / added in place when COV).
+template <bool ACCUMULATE, bool COV>
+LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__ means, const float* __restrict__ scales,
+                               const float* __restrict__ rots, const float* __restrict__ g_mean2d,
+                               const float* __restrict__ g_conic, float gm[3], float gs[3], float gq[4]) {
+  const float* __restrict__ V = v.view;
+  const float* __restrict__ Pm = v.proj;
+  float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+  float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  float R[9], Sg[6];
+  if (COV) {   // cov3D_precomp (the view carries n x 6 covariances): the chain stops at dL/dSigma
+#pragma unroll
+    for (int k = 0; k < 6; k++) Sg[k] = v.cov3d[6 * (size_t)i + k];
+  } else {
+    s[0] = scales[3 * i] * v.scale_modifier; s[1] = scales[3 * i + 1] * v.scale_modifier;
+    s[2] = scales[3 * i + 2] * v.scale_modifier;
+    const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    lr_cov3d(s, q, R, Sg);
+  }
+  LrEwa e;
+  lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
+  const float a = e.a, b = e.b, c = e.c;
+  const float det = a * c - b * b;
+  const float di2 = 1.f / (det * det);
+  const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
+  const float gA = gc4.x, gB = gc4.y, gC = gc4.z;
+  // conic = (c, -b, a) / det
+  float ga = di2 * (-c * c * gA + b * c * gB - b * b * gC);
+  float gb = di2 * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
+  float gc = di2 * (-b * b * gA + a * b * gB - a * a * gC);
+  if (v.filter_mode == LOGRAST_FILTER_CLAMP) {
+    if (!(e.a_raw >= 0.3f)) ga = 0.f;
+    if (!(e.c_raw >= 0.3f)) gc = 0.f;
+  }
+  const float hb = 0.5f * gb;
+  // dL/dSigma = T^T G2 T
+  float gS[9];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      gS[3 * j + k] = ga * e.T0[j] * e.T0[k] + hb * (e.T0[j] * e.T1[k] + e.T1[j] * e.T0[k]) + gc * e.T1[j] * e.T1[k];
+  // dL/dT = 2 G2 T Sigma
+  const float S3[9] = {Sg[0], Sg[1], Sg[2], Sg[1], Sg[3], Sg[4], Sg[2], Sg[4], Sg[5]};
+  float gT0[3], gT1[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float ts0 = e.T0[0] * S3[k] + e.T0[1] * S3[3 + k] + e.T0[2] * S3[6 + k];
+    float ts1 = e.T1[0] * S3[k] + e.T1[1] * S3[3 + k] + e.T1[2] * S3[6 + k];
+    gT0[k] = 2.f * (ga * ts0 + hb * ts1);
+    gT1[k] = 2.f * (hb * ts0 + gc * ts1);
+  }
+  float gj00 = 0.f, gj02 = 0.f, gj11 = 0.f, gj12 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    gj00 += gT0[j] * V[4 * j + 0]; gj02 += gT0[j] * V[4 * j + 2];
+    gj11 += gT1[j] * V[4 * j + 1]; gj12 += gT1[j] * V[4 * j + 2];
+  }
+  const float tz = e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+  const float g_txc = -v.fx / tz2 * gj02, g_tyc = -v.fy / tz2 * gj12;
+  float g_tz = -v.fx / tz2 * gj00 - v.fy / tz2 * gj11 + 2.f * v.fx * e.txc / tz3 * gj02 +
+               2.f * v.fy * e.tyc / tz3 * gj12;
+  float g_tx, g_ty;
+  if (e.cx) { g_tx = 0.f; g_tz += e.ux * g_txc; } else { g_tx = g_txc; }
+  if (e.cy) { g_ty = 0.f; g_tz += e.uy * g_tyc; } else { g_ty = g_tyc; }
+  float m0 = V[0] * g_tx + V[1] * g_ty + V[2] * g_tz;
+  float m1 = V[4] * g_tx + V[5] * g_ty + V[6] * g_tz;
+  float m2 = V[8] * g_tx + V[9] * g_ty + V[10] * g_tz;
+  // centre path: ndc = h.xy / (h.w + eps)
+  const float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
+  const float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], p[0], p[1], p[2], Pm[13]);
+  const float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], p[0], p[1], p[2], Pm[15]);
+  const float pw = 1.0f / (hw + 0.0000001f);
+  const float gnx = g_mean2d[3 * (size_t)i], gny = g_mean2d[3 * (size_t)i + 1];
+  const float ghx = gnx * pw, ghy = gny * pw, ghw = -(gnx * hx + gny * hy) * pw * pw;
+  m0 += Pm[0] * ghx + Pm[1] * ghy + Pm[3] * ghw;
+  m1 += Pm[4] * ghx + Pm[5] * ghy + Pm[7] * ghw;
+  m2 += Pm[8] * ghx + Pm[9] * ghy + Pm[11] * ghw;
+  gm[0] = m0; gm[1] = m1; gm[2] = m2;
+  if (COV) {
+    // the six stored entries; an off-diagonal one stands for both symmetric positions of Sigma (the upstream backward's
+    // "off-diagonal elements appear twice" rule)
+    const float g6[6] = {gS[0], 2.f * gS[1], 2.f * gS[2], gS[4], 2.f * gS[5], gS[8]};
+    float* __restrict__ o = v.g_cov3d + 6 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 6; k++) o[k] = ACCUMULATE ? o[k] + g6[k] : g6[k];
+  } else {
+  // Sigma = M M^T, M_ik = R_ik s_k
+  float M[9], gM[9], gR[9];
+#pragma unroll
+  for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) M[3 * ii + k] = R[3 * ii + k] * s[k];
+#pragma unroll
+  for (int ii = 0; ii < 3; ii++)
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      gM[3 * ii + k] = 2.f * (gS[3 * ii + 0] * M[0 + k] + gS[3 * ii + 1] * M[3 + k] + gS[3 * ii + 2] * M[6 + k]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    gs[k] = v.scale_modifier * (gM[k] * R[k] + gM[3 + k] * R[3 + k] + gM[6 + k] * R[6 + k]);
+#pragma unroll
+    for (int ii = 0; ii < 3; ii++) gR[3 * ii + k] = gM[3 * ii + k] * s[k];
+  }
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  gq[0] = 2.f * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
+  gq[1] = 2.f * (y * gR[1] + z * gR[2] + y * gR[3] - 2.f * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - 2.f * x * gR[8]);
+  gq[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2.f * y * gR[8]);
+  gq[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
+  }
+}
+
+// One workgroup owns LR_PBWD_ROWS consecutive Gaussians.  Their live flags are read coalesced; the live rows are
+// COMPACTED into an LDS list and the chain rule (~600 VALU instructions per row) then runs on full waves: with 15 % of
+// the rows live (30 M Gaussians, opacity 0.999) every wave of a one-thread-per-Gaussian kernel still met a live lane and
+// ran all of it at 15 % lane occupancy (VALU busy 71 % of the launch).
+#define LR_PBWD_ROWS 1024
 template <bool ACCUMULATE, bool TOUCHED, bool COV>
 __global__ void __launch_bounds__(256)
 lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
@@ -18,144 +136,56 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
                       const float* __restrict__ g_mean2d, const float* __restrict__ g_conic,
                       const float* __restrict__ pw, float* __restrict__ g_means3d, float* __restrict__ g_scales,
                       float* __restrict__ g_rots) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  float gm[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool live = radii[i] > 0 && (!TOUCHED || pw[i] > 0.f);
-  if (live) {
-    const float* __restrict__ V = v.view;
-    const float* __restrict__ Pm = v.proj;
-    float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    float R[9], Sg[6];
-    if (COV) {   // cov3D_precomp (the view carries n x 6 covariances): the chain stops at dL/dSigma
+  __shared__ uint32_t live_list[LR_PBWD_ROWS];
+  __shared__ uint32_t live_count;
+  const int tid = threadIdx.x, base = blockIdx.x * LR_PBWD_ROWS;
+  if (tid == 0) live_count = 0u;
+  __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 6; k++) Sg[k] = v.cov3d[6 * (size_t)i + k];
-    } else {
-      s[0] = scales[3 * i] * v.scale_modifier; s[1] = scales[3 * i + 1] * v.scale_modifier;
-      s[2] = scales[3 * i + 2] * v.scale_modifier;
-      const float4 q4 = reinterpret_cast<const float4*>(rots)[i];
-      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
-      lr_cov3d(s, q, R, Sg);
+  for (int k = 0; k < LR_PBWD_ROWS / 256; k++) {
+    const int i = base + k * 256 + tid;
+    const bool live = i < N && radii[i] > 0 && (!TOUCHED || pw[i] > 0.f);
+    if (!ACCUMULATE && i < N && !live) {   // culled / untouched: zero gradients (running sums are simply left alone)
+      g_means3d[3 * (size_t)i + 0] = 0.f; g_means3d[3 * (size_t)i + 1] = 0.f; g_means3d[3 * (size_t)i + 2] = 0.f;
+      if (COV) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) v.g_cov3d[6 * (size_t)i + c] = 0.f;
+      } else {
+        g_scales[3 * (size_t)i + 0] = 0.f; g_scales[3 * (size_t)i + 1] = 0.f; g_scales[3 * (size_t)i + 2] = 0.f;
+        reinterpret_cast<float4*>(g_rots)[i] = float4{0.f, 0.f, 0.f, 0.f};
+      }
     }
-    LrEwa e;
-    lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
-    const float a = e.a, b = e.b, c = e.c;
-    const float det = a * c - b * b;
-    const float di2 = 1.f / (det * det);
-    const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
-    const float gA = gc4.x, gB = gc4.y, gC = gc4.z;
-    // conic = (c, -b, a) / det
-    float ga = di2 * (-c * c * gA + b * c * gB - b * b * gC);
-    float gb = di2 * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
-    float gc = di2 * (-b * b * gA + a * b * gB - a * a * gC);
-    if (v.filter_mode == LOGRAST_FILTER_CLAMP) {
-      if (!(e.a_raw >= 0.3f)) ga = 0.f;
-      if (!(e.c_raw >= 0.3f)) gc = 0.f;
+    const uint64_t m = __ballot(live);
+    if (m) {
+      uint32_t first = 0;
+      if ((tid & 63) == 0) first = atomicAdd(&live_count, (uint32_t)__popcll(m));
+      first = (uint32_t)__shfl((int)first, 0);
+      if (live) live_list[first + (uint32_t)__popcll(m & ((1ull << (tid & 63)) - 1ull))] = (uint32_t)i;
     }
-    const float hb = 0.5f * gb;
-    // dL/dSigma = T^T G2 T
-    float gS[9];
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-        gS[3 * j + k] = ga * e.T0[j] * e.T0[k] + hb * (e.T0[j] * e.T1[k] + e.T1[j] * e.T0[k]) + gc * e.T1[j] * e.T1[k];
-    // dL/dT = 2 G2 T Sigma
-    const float S3[9] = {Sg[0], Sg[1], Sg[2], Sg[1], Sg[3], Sg[4], Sg[2], Sg[4], Sg[5]};
-    float gT0[3], gT1[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      float ts0 = e.T0[0] * S3[k] + e.T0[1] * S3[3 + k] + e.T0[2] * S3[6 + k];
-      float ts1 = e.T1[0] * S3[k] + e.T1[1] * S3[3 + k] + e.T1[2] * S3[6 + k];
-      gT0[k] = 2.f * (ga * ts0 + hb * ts1);
-      gT1[k] = 2.f * (hb * ts0 + gc * ts1);
-    }
-    float gj00 = 0.f, gj02 = 0.f, gj11 = 0.f, gj12 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      gj00 += gT0[j] * V[4 * j + 0]; gj02 += gT0[j] * V[4 * j + 2];
-      gj11 += gT1[j] * V[4 * j + 1]; gj12 += gT1[j] * V[4 * j + 2];
-    }
-    const float tz = e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-    const float g_txc = -v.fx / tz2 * gj02, g_tyc = -v.fy / tz2 * gj12;
-    float g_tz = -v.fx / tz2 * gj00 - v.fy / tz2 * gj11 + 2.f * v.fx * e.txc / tz3 * gj02 +
-                 2.f * v.fy * e.tyc / tz3 * gj12;
-    float g_tx, g_ty;
-    if (e.cx) { g_tx = 0.f; g_tz += e.ux * g_txc; } else { g_tx = g_txc; }
-    if (e.cy) { g_ty = 0.f; g_tz += e.uy * g_tyc; } else { g_ty = g_tyc; }
-    float m0 = V[0] * g_tx + V[1] * g_ty + V[2] * g_tz;
-    float m1 = V[4] * g_tx + V[5] * g_ty + V[6] * g_tz;
-    float m2 = V[8] * g_tx + V[9] * g_ty + V[10] * g_tz;
-    // centre path: ndc = h.xy / (h.w + eps)
-    const float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
-    const float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], p[0], p[1], p[2], Pm[13]);
-    const float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], p[0], p[1], p[2], Pm[15]);
-    const float pw = 1.0f / (hw + 0.0000001f);
-    const float gnx = g_mean2d[3 * (size_t)i], gny = g_mean2d[3 * (size_t)i + 1];
-    const float ghx = gnx * pw, ghy = gny * pw, ghw = -(gnx * hx + gny * hy) * pw * pw;
-    m0 += Pm[0] * ghx + Pm[1] * ghy + Pm[3] * ghw;
-    m1 += Pm[4] * ghx + Pm[5] * ghy + Pm[7] * ghw;
-    m2 += Pm[8] * ghx + Pm[9] * ghy + Pm[11] * ghw;
-    gm[0] = m0; gm[1] = m1; gm[2] = m2;
-    if (COV) {
-      // the six stored entries; an off-diagonal one stands for both symmetric positions of Sigma (the upstream backward's
-      // "off-diagonal elements appear twice" rule)
-      const float g6[6] = {gS[0], 2.f * gS[1], 2.f * gS[2], gS[4], 2.f * gS[5], gS[8]};
-      float* __restrict__ o = v.g_cov3d + 6 * (size_t)i;
-#pragma unroll
-      for (int k = 0; k < 6; k++) o[k] = ACCUMULATE ? o[k] + g6[k] : g6[k];
-    } else {
-    // Sigma = M M^T, M_ik = R_ik s_k
-    float M[9], gM[9], gR[9];
-#pragma unroll
-    for (int ii = 0; ii < 3; ii++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) M[3 * ii + k] = R[3 * ii + k] * s[k];
-#pragma unroll
-    for (int ii = 0; ii < 3; ii++)
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-        gM[3 * ii + k] = 2.f * (gS[3 * ii + 0] * M[0 + k] + gS[3 * ii + 1] * M[3 + k] + gS[3 * ii + 2] * M[6 + k]);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      gs[k] = v.scale_modifier * (gM[k] * R[k] + gM[3 + k] * R[3 + k] + gM[6 + k] * R[6 + k]);
-#pragma unroll
-      for (int ii = 0; ii < 3; ii++) gR[3 * ii + k] = gM[3 * ii + k] * s[k];
-    }
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    gq[0] = 2.f * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
-    gq[1] = 2.f * (y * gR[1] + z * gR[2] + y * gR[3] - 2.f * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - 2.f * x * gR[8]);
-    gq[2] = 2.f * (-2.f * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2.f * y * gR[8]);
-    gq[3] = 2.f * (-2.f * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2.f * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
-    }
-  } else if (COV && !ACCUMULATE) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) v.g_cov3d[6 * (size_t)i + k] = 0.f;
   }
-  if (COV) {   // dL/dmeans3D only; scales / rotations take no part
-    if (ACCUMULATE) {
-      if (live) {
+  __syncthreads();
+  const uint32_t n = live_count;
+  for (uint32_t j = (uint32_t)tid; j < n; j += 256u) {
+    const int i = (int)live_list[j];
+    float gm[3], gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    lr_project_bwd_row<ACCUMULATE, COV>(v, i, means, scales, rots, g_mean2d, g_conic, gm, gs, gq);
+    if (ACCUMULATE) {  // running sums over views (log_amd.dist)
 #pragma unroll
-        for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] += gm[k];
+      for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] += gm[k];
+      if (!COV) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) g_scales[3 * (size_t)i + k] += gs[k];
+        float4 q = reinterpret_cast<float4*>(g_rots)[i];
+        q.x += gq[0]; q.y += gq[1]; q.z += gq[2]; q.w += gq[3];
+        reinterpret_cast<float4*>(g_rots)[i] = q;
       }
     } else {
       g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];
+      if (!COV) {
+        g_scales[3 * (size_t)i + 0] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2];
+        reinterpret_cast<float4*>(g_rots)[i] = float4{gq[0], gq[1], gq[2], gq[3]};
+      }
     }
-    return;
-  }
-  if (ACCUMULATE) {  // running sums over views (log_amd.dist): culled / untouched Gaussians contribute nothing, skip the traffic
-    if (live) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) { g_means3d[3 * (size_t)i + k] += gm[k]; g_scales[3 * (size_t)i + k] += gs[k]; }
-      float4 q = reinterpret_cast<float4*>(g_rots)[i];
-      q.x += gq[0]; q.y += gq[1]; q.z += gq[2]; q.w += gq[3];
-      reinterpret_cast<float4*>(g_rots)[i] = q;
-    }
-  } else {
-    g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];
-    g_scales[3 * (size_t)i + 0] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2];
-    reinterpret_cast<float4*>(g_rots)[i] = float4{gq[0], gq[1], gq[2], gq[3]};
   }
 }
 
@@ -164,7 +194,7 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
                            float* g_means3d, float* g_scales, float* g_rots, bool accumulate, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_PROJECT_BWD, s);
-  const dim3 grid((N + 255) / 256), block(256);
+  const dim3 grid((N + LR_PBWD_ROWS - 1) / LR_PBWD_ROWS), block(256);
 #define LR_PBWD(A, T, C) hipLaunchKernelGGL((lr_project_bwd_kernel<A, T, C>), grid, block, 0, s, v, N, means, scales, \
                                             rots, radii, g_mean2d, g_conic, pw, g_means3d, g_scales, g_rots)
 #define LR_PBWD_C(A, T) do { if (v.cov3d) LR_PBWD(A, T, true); else LR_PBWD(A, T, false); } while (0)

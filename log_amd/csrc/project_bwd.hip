@@ -128,7 +128,9 @@ LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__
 // COMPACTED into an LDS list and the chain rule (~600 VALU instructions per row) then runs on full waves: with 15 % of
 // the rows live (30 M Gaussians, opacity 0.999) every wave of a one-thread-per-Gaussian kernel still met a live lane and
 // ran all of it at 15 % lane occupancy (VALU busy 71 % of the launch).
+#ifndef LR_PBWD_ROWS
 #define LR_PBWD_ROWS 1024
+#endif
 template <bool ACCUMULATE, bool TOUCHED, bool COV>
 __global__ void __launch_bounds__(256)
 lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,

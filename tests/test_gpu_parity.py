@@ -38,6 +38,12 @@ def _case(name):
             sc["xyz"][start:start + k] = sc["xyz"][start:start + k] * 0.02 + c
             start += k
         return cam, sc
+    if name == "giant_tile":  # one list of ~300 K keys (the scan's length buckets above 4096 are 4096 wide then) next to
+        # many lists around the 1024-key class boundary: every list above 1024 keys must still lie inside the
+        # capacity / 1024 + 1 workgroups lr_launch_sort gives the long-list kernel
+        cam, sc = small_case(n=400000, W=160, H=112, focal=150.0, seed=13, smax=0.003)
+        sc["xyz"][:300000] = sc["xyz"][:300000] * 0.004 + np.array([0.0, 0.12, -0.07], np.float32)
+        return cam, sc
     if name.startswith("flat_depth_"):
         # all Gaussians at (almost) the same view depth, n of them inside one or two tiles: the depth-bucket sorts overflow
         # their buckets and every size class must fall back to the network (LDS class, long LDS class, hybrid)
@@ -53,7 +59,7 @@ def _case(name):
     raise KeyError(name)
 
 
-CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "dense_tile", "huge_tiles", "flat_depth_3000",
+CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "dense_tile", "huge_tiles", "giant_tile", "flat_depth_3000",
          "flat_depth_6000", "flat_depth_14000"]
 
 

@@ -415,7 +415,7 @@ def main():
         try:
             if N != 1_000_000:
                 wl2 = RasterWorkload(args, 1_000_000, dev, rank, world, torch, np)
-                S2, steps2 = auto_streams(args, 1_000_000), max(args.steps, 5)
+                S2, steps2 = auto_streams(args, 1_000_000), max(args.steps, 20)   # (a 0.65 ms view: 20 steps = 0.1 s)
                 r2 = measure(args, wl2, S2, fused, steps2, max(args.warmup, 2), world, timing, graphs=not args.no_graphs)
                 c2 = {"workload": "C2 (BASELINE.json configs[1]): 1000000 random Gaussians (seed 0, opacity %s), %dx%d, "
                                   "%d orbit views, same harness as the headline"

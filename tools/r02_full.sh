@@ -19,3 +19,4 @@ print('c2', {k:(round(v['ms_per_view'],3) if isinstance(v,dict) and 'ms_per_view
 print('c3', json.dumps(s.get('c3'))[:600])
 print('cpu', d.get('cpu_baseline'))
 " || tail -n 20 $D/${TAG}_bench.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $D/${TAG}_smoke.log 2>&1; tail -n 2 $D/${TAG}_smoke.log

@@ -157,11 +157,11 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     # The step's gradient exchange (log_amd.dist.StepExchange): the rank's views in `parts` consecutive groups with a
     # bucket each; group g's reduce-scatter runs on a side stream under the rendering of group g + 1.
-    ex = StepExchange(N, dev, world, rank, parts=parts)
+    ex = StepExchange(N, dev, world, rank, parts=parts, track_seen=False)   # (the gradient sum only: no optimizer here)
     lanes = []
     for li in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient buckets
         leaves = {k: v.detach().requires_grad_(True) for k, v in wl.base.items()}
-        bks = ex.buckets if li == 0 else [GradientBucket(N, dev, world) for _ in range(parts)]
+        bks = ex.buckets if li == 0 else [GradientBucket(N, dev, world, track_seen=False) for _ in range(parts)]
         bks[0].attach(leaves)
         lanes.append((leaves, bks))
     lane_views = [wl.rasts[li::S] for li in range(S)]

@@ -144,10 +144,14 @@ class GradientBucket(_Flat):
     """Flat gradient buffer, attribute-major, with one contiguous view per attribute, and the per-row `seen` count."""
     DENSE_ABOVE = 0.85     # touched-block exchange only when it moves less than this share of the dense one
 
-    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0):
+    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0, track_seen=True):
+        """track_seen=False: no per-row `seen` counts (nothing to exchange for them) -- for a caller that only wants the
+        gradient sum, like bench.py; the owner-computes step needs them."""
         super().__init__(num_points, device, world, sh_coeffs, block_rows)
         self.pad = self.flat.numel() - self.P * self.cols
-        self.seen = torch.zeros(self.Ppad, dtype=torch.float32, device=device)   # views that saw the row this step
+        self.track_seen = bool(track_seen)
+        # views that saw the row this step (one float when not tracked: mark_seen / the touched-block exchange then refuse)
+        self.seen = torch.zeros(self.Ppad if self.track_seen else 1, dtype=torch.float32, device=device)
         self._seen_reduced = False
         self.touched = None                                   # TouchedBlocks of the last compact exchange (else None)
 
@@ -169,6 +173,8 @@ class GradientBucket(_Flat):
         """Record which rows one view touched: radii > 0 (what the reference's step calls flag_vis,
         /root/reference/LoG/model/counter.py:48,50), for all rows or for the rows `index` a level-of-detail selection
         handed to the rasterizer."""
+        if not self.track_seen:
+            raise RuntimeError("this bucket was built with track_seen=False")
         vis = (radii > 0).to(torch.float32)
         if index is None:
             self.seen[:vis.numel()] += vis
@@ -176,7 +182,7 @@ class GradientBucket(_Flat):
             self.seen.index_add_(0, index, vis)
 
     def _sum_seen(self, group):
-        if _active(self.world) and not self._seen_reduced:
+        if _active(self.world) and not self._seen_reduced and self.track_seen:
             dist.all_reduce(self.seen, op=dist.ReduceOp.SUM, group=group)
         self._seen_reduced = True
 
@@ -197,6 +203,7 @@ class GradientBucket(_Flat):
     def touched_blocks(self, group=None):
         """The step's TouchedBlocks: local `seen` per block, max-reduced over the ranks (world * nb int32: tiny)."""
         assert self.block_rows > 0, "construct the bucket with block_rows > 0 for the touched-block exchange"
+        assert self.track_seen, "the touched-block exchange reads the seen counts"
         nb = self.Pr // self.block_rows
         flags = (self.seen.view(self.world, nb, self.block_rows).amax(-1) > 0).to(torch.int32)
         if _active(self.world):
@@ -205,7 +212,7 @@ class GradientBucket(_Flat):
 
     def _columns(self):
         """(name, [P_pad * c] block, c) of everything that is exchanged: the attribute gradients and the seen counts."""
-        return [(name, self.blocks[name], c) for name, c in self.layout] + [("seen", self.seen, 1)]
+        return [(name, self.blocks[name], c) for name, c in self.layout] + ([("seen", self.seen, 1)] if self.track_seen else [])
 
     def reduce_scatter_rows(self, rank, group=None, compact=False):
         """Owner-computes exchange, first half: -> dict name -> [Pr, c] = the sum over ranks of this rank's rows of every
@@ -215,10 +222,11 @@ class GradientBucket(_Flat):
         self.touched = None
         if not _active(self.world):
             out = {name: self.rows(name, 0) for name, _ in self.layout}
-            out["seen"] = self.seen[:self.Pr]
+            if self.track_seen:
+                out["seen"] = self.seen[:self.Pr]
             return out
         dev, out = self.flat.device, {}
-        tb = self.touched_blocks(group) if compact and self.block_rows > 0 else None
+        tb = self.touched_blocks(group) if compact and self.block_rows > 0 and self.track_seen else None
         if tb is not None and tb.fraction >= self.DENSE_ABOVE:
             tb = None
         if tb is None:
@@ -293,6 +301,8 @@ class OwnerAdam:
         """The same step from already reduce-scattered rows (``GradientBucket.reduce_scatter_rows`` /
         ``StepExchange.finish``): dict name -> [Pr, c] and "seen" -> [Pr]."""
         from . import rasterizer as _r
+        if "seen" not in grads:
+            raise ValueError("the owner-computes step needs the seen counts (GradientBucket(track_seen=True) + mark_seen)")
         self.steps += 1
         flag = grads["seen"] > 0
         bc1, bc2 = 1 - self.BETA1 ** self.steps, 1 - self.BETA2 ** self.steps
@@ -322,9 +332,11 @@ class StepExchange:
     bucket memory (30 M Gaussians x 14 columns: 1.7 GB each out of 288).  The sum is the same set of addends as one
     bucket's, grouped by part."""
 
-    def __init__(self, num_points, device, world=1, rank=0, sh_coeffs=0, parts=1, block_rows=0, group=None):
+    def __init__(self, num_points, device, world=1, rank=0, sh_coeffs=0, parts=1, block_rows=0, group=None,
+                 track_seen=True):
         self.world, self.rank, self.parts, self.group = max(int(world), 1), int(rank), max(int(parts), 1), group
-        self.buckets = [GradientBucket(num_points, device, world, sh_coeffs, block_rows) for _ in range(self.parts)]
+        self.buckets = [GradientBucket(num_points, device, world, sh_coeffs, block_rows, track_seen)
+                        for _ in range(self.parts)]
         self.device = self.buckets[0].flat.device
         self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.world > 1) else None
         self._shards = [None] * self.parts

@@ -306,3 +306,21 @@ def test_step_exchange_groups_consecutive_views():
         b.mark_seen(torch.ones(10))
     total = ex.finish()
     assert torch.equal(total["colors"], torch.full((10, 3), 6.0)) and torch.equal(total["seen"], torch.full((10,), 3.0))
+
+
+def test_bucket_without_seen_counts():
+    """track_seen=False (bench.py: the gradient sum only): nothing is kept or exchanged for the seen counts, and the
+    consumers that need them say so."""
+    from log_amd.dist import FlatParams, GradientBucket, OwnerAdam, StepExchange
+    b = GradientBucket(9, "cpu", world=1, track_seen=False)
+    assert b.seen.numel() == 1 and "seen" not in b.reduce_scatter_rows(0)
+    with pytest.raises(RuntimeError, match="track_seen"):
+        b.mark_seen(torch.ones(9))
+    ex = StepExchange(9, "cpu", parts=2, track_seen=False)
+    for i, bk in enumerate(ex.buckets):
+        bk.views["means3D"].fill_(float(i + 1))
+    total = ex.finish()
+    assert "seen" not in total and torch.equal(total["means3D"], torch.full((9, 3), 3.0))
+    params = FlatParams({n: torch.zeros(9, c) for n, c in b.layout}, "cpu")
+    with pytest.raises(ValueError, match="seen counts"):
+        OwnerAdam(params, 0).step_rows(total, params, {"means3D": 1e-3})

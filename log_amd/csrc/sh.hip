@@ -233,13 +233,19 @@ ga_fwd_kernel(GatherArgs a) {
   if (L > 0) {
     float* const wl = lr_sh_lds + wave * 64 * (L + 1);
     lr_sh_wave_sync();                                      // rowid[] written by this wave
-    const uint32_t magic = 0xffffffffu / (uint32_t)L + 1u;  // e / L for e < 65536
+    const uint32_t magic = 0xffffffffu / (uint32_t)a.K + 1u;  // e / K for e < 65536
     float* const out = a.r_shs + (size_t)i0 * L;
-    for (int e = lane; e < rows * L; e += 64) {             // lanes walk the rows' coefficients contiguously
-      const int g = (int)__umulhi((uint32_t)e, magic), j = e - g * L;
-      const float v = a.shs[(size_t)rowid[wave][g] * L + j];
-      out[e] = v;                                           // the raw copy is contiguous in e
-      wl[g * (L + 1) + j] = v;
+    // lanes walk the rows' coefficients contiguously, one (r, g, b) triple = 12 bytes per access (a float at a time this
+    // loop was 45 dependent 4-byte gathers per lane at degree 3), four in flight
+#pragma unroll 4
+    for (int e = lane; e < rows * a.K; e += 64) {
+      const int g = (int)__umulhi((uint32_t)e, magic), j = e - g * a.K;
+      const float* __restrict__ src = a.shs + (size_t)rowid[wave][g] * L + 3 * j;
+      const float v0 = src[0], v1 = src[1], v2 = src[2];
+      float* o = out + 3 * (size_t)e;                         // the raw copy is contiguous in e
+      o[0] = v0; o[1] = v1; o[2] = v2;
+      float* w = wl + g * (L + 1) + 3 * j;
+      w[0] = v0; w[1] = v1; w[2] = v2;
     }
     lr_sh_wave_sync();
     if (ok && a.deg > 0) {

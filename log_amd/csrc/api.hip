@@ -25,6 +25,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
 void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_off, hipStream_t s);
 void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, hipStream_t s);
 void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
+void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
                     int zero_block_floats, int rebased, hipStream_t s);
@@ -297,8 +298,15 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   float* zero_block = bwd_scratch_floats > 0 ? bwd_scratch : nullptr;
   int zero_floats = bwd_scratch_floats;
   if (touched_only) { zero_block += 4 * (size_t)n; zero_floats -= 4; }
+  float* zero_n = v.extras ? point_weight : nullptr;
+  static const int separate_zero = lr_env_int("LOGRAST_SEPARATE_ZERO", 1);   // 0: always inside the fill kernel (experiments)
+  if (separate_zero && lr_big_input(n)) {   // large inputs: streamed by kernels of their own (see lr_zero_floats_kernel)
+    lr_launch_zero_floats(zero_n, (size_t)n, s);
+    if (zero_floats > 0) lr_launch_zero_floats(zero_block, (size_t)zero_floats * (size_t)n, s);
+    zero_n = nullptr; zero_floats = 0;
+  }
   lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, max_tile_len, status,
-                 v.extras ? point_weight : nullptr, zero_floats > 0 ? zero_block : nullptr, zero_floats,
+                 zero_n, zero_floats > 0 ? zero_block : nullptr, zero_floats,
                  lr_big_input(n) ? 1 : 0, s);
   static const int stop_after_fill = lr_env_int("LOGRAST_STOP_AFTER_FILL", 0);   // timing experiments (tools/) only
   if (stop_after_fill) return LOGRAST_OK;

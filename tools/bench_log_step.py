@@ -281,6 +281,26 @@ def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, wi
            "ms_per_view": tot_f, "selected_gaussians_per_s": sel / (tot_f * 1e-3),
            "stages_ms": stg_f, "kernels_us_per_view": {k: round(v[0] / (wl.V + 1) * 1e3, 1) for k, v in prof.items()},
            "last_view_tile_instances": int(inst[0]), "last_view_longest_tile_list": int(inst[2])}
+    # (the "rasterize_fwd_bwd" stage clock spans image.backward(), i.e. also the activation backward of get_all: the
+    # rasterizer's own kernels, from the HIP-event profile, are summed here)
+    rk = ("project", "count_huge", "scan_tiles", "rebase_slots", "fill_keys", "sort_small", "sort_large", "sort_huge",
+          "blend_fwd", "blend_bwd", "project_bwd")
+    out["rasterizer_kernels_us_per_view"] = round(sum(out["kernels_us_per_view"].get(k, 0.0) for k in rk), 1)
+    # the same view with the rasterizer's sync-free mode (log_amd.rasterizer.set_instance_capacity: no 4-byte read-back in the
+    # forward, one C-ABI call): capacity and longest-list hint from the views just run, +10 %, checked afterwards
+    dev0 = st_f.bufs["xyz"].device
+    chk = R.overflow_since_reset(dev0)
+    R.set_instance_capacity(int(chk["max_instances"] * 1.1) + 1024, max_tile_len=int(chk["max_tile_len"] * 1.1) + 64)
+    try:
+        tot_h, _, _, _ = run(wl, True, False)
+        _, stg_h, _, _ = run(wl, True, True)
+        chk = R.overflow_since_reset(dev0)
+        if not chk["overflowed"]:
+            out.update(ms_per_view_capacity_hint=tot_h, stages_ms_capacity_hint=stg_h)
+        else:
+            out.update(capacity_hint_overflowed=True)
+    finally:
+        R.set_instance_capacity(None)
     if with_torch:
         tot_t, _, _, st_t = run(wl, False, False)
         _, stg_t, _, _ = run(wl, False, True)

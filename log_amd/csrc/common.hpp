@@ -61,7 +61,7 @@ __host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batche
   return lr_hugecount_off(tiles, batches) + ((batches + 15u) & ~15u);
 }
 #define LR_COOP_TILES 16   // rects above this many tiles are expanded by a whole wave (lanes = tiles), not by their lane
-#define LR_HUGE_CHUNK 512  // Gaussians per workgroup of lr_count_huge_kernel (2048: a chunk full of 81-tile rects ran 0.36 ms)
+#define LR_HUGE_CHUNK 256  // Gaussians per workgroup of lr_count_huge_kernel (a chunk full of 81-tile rects is a serial walk per wave: 2048 ran 0.36 ms on the tree-ordered view, 512 0.14, 256 0.093)
 #define LR_BATCH_THREADS 1024
 #define LR_BATCH_MAX_TILES 40000  // 4 B x tiles of LDS counters must fit one workgroup (160 KB): up to 3840x2160
 #define LR_BATCH_LDS_BYTES (160 * 1024 - 512)  // dynamic LDS a projection workgroup may use (counter planes)

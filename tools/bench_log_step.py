@@ -263,6 +263,7 @@ def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, wi
     and (with_torch) the same step with everything except the rasterizer done the reference's way in torch."""
     from log_amd import _lib, rasterizer as R
     wl = Workload(roots, levels, sh_degree, views, root_scale, dev)
+    R.overflow_since_reset(wl.dev)          # (the status block's running maxima start with THIS workload's forwards)
     tot_f, _, info, st_f = run(wl, True, False)
     _lib.profile_reset()
     _lib.profile_enable(True)
@@ -286,6 +287,12 @@ def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, wi
     rk = ("project", "count_huge", "scan_tiles", "rebase_slots", "fill_keys", "sort_small", "sort_large", "sort_huge",
           "blend_fwd", "blend_bwd", "project_bwd")
     out["rasterizer_kernels_us_per_view"] = round(sum(out["kernels_us_per_view"].get(k, 0.0) for k in rk), 1)
+    if with_torch:
+        tot_t, _, _, st_t = run(wl, False, False)
+        _, stg_t, _, _ = run(wl, False, True)
+        out.update(ms_per_view_torch=tot_t, speedup_vs_torch=tot_t / tot_f, stages_ms_torch=stg_t,
+                   model_rel_l2_fused_vs_torch_after_views={
+                       k: float((st_f.bufs[k] - st_t.bufs[k]).norm() / st_t.bufs[k].norm()) for k in wl.keys})
     # the same view with the rasterizer's sync-free mode (log_amd.rasterizer.set_instance_capacity: no 4-byte read-back in the
     # forward, one C-ABI call): capacity and longest-list hint from the views just run, +10 %, checked afterwards
     dev0 = st_f.bufs["xyz"].device
@@ -301,12 +308,6 @@ def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, wi
             out.update(capacity_hint_overflowed=True)
     finally:
         R.set_instance_capacity(None)
-    if with_torch:
-        tot_t, _, _, st_t = run(wl, False, False)
-        _, stg_t, _, _ = run(wl, False, True)
-        out.update(ms_per_view_torch=tot_t, speedup_vs_torch=tot_t / tot_f, stages_ms_torch=stg_t,
-                   model_rel_l2_fused_vs_torch_after_views={
-                       k: float((st_f.bufs[k] - st_t.bufs[k]).norm() / st_t.bufs[k].norm()) for k in wl.keys})
     return out
 
 

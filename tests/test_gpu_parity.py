@@ -432,3 +432,25 @@ def test_cov3d_precomp_vs_oracle(oracle_mod, package):
     with pytest.raises(ValueError, match=r"\[N, 6\]"):
         rast(means3D=m3, means2D=m2, shs=None, colors_precomp=col, opacities=op, scales=None, rotations=None,
              cov3D_precomp=cv[:, :5])
+
+
+def test_psnr_against_the_float64_twin(oracle_mod):
+    """"image PSNR vs oracle / reference <= 0.05 dB apart".  Against the C oracle the image is bit-identical
+    (test_forward_bit_exact, incl. the C1 geometry: PSNR = inf); against the independent float64 autograd restatement
+    (oracle/torch_oracle.py) the fp32 kernels' image differs by rounding only: PSNR far above any visible level."""
+    import gpu_util as G
+    from oracle import torch_oracle
+    from util import cam_tan
+    cam, sc = _case("ragged")
+    bg = (0.3, 0.6, 0.9)
+    hf = G.hip_forward(cam, sc, bg)
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    tfx, tfy = cam_tan(cam)
+    img, radii, _ = torch_oracle.render(
+        cam["image_width"], cam["image_height"], tfx, tfy, T(cam["world_view_transform"]), T(cam["full_proj_transform"]),
+        T(bg), T(sc["xyz"]), torch.zeros(len(sc["xyz"]), 3, dtype=torch.float64), T(sc["scaling"]), T(sc["rotation"]),
+        T(sc["opacity"]), T(sc["colors"]), filter_mode=2, ndc_cull=True)
+    mse = float(((torch.tensor(hf["image"], dtype=torch.float64) - img) ** 2).mean())
+    psnr = 10.0 * np.log10(1.0 / max(mse, 1e-30))
+    assert psnr > 100.0, psnr
+    assert (radii.numpy() == hf["radii"]).all()

@@ -132,8 +132,10 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
  * a kernel it launches anyway) for a caller that will run lograst_backward on this view: carve dL_dconic[n,4],
  * dL_dmeans2d[n,3] (7 floats per Gaussian, in this order) and, without LOGRAST_BWD_ACCUMULATE, dL_dopacities[n],
  * dL_dcolors[n,3] (11) out of it and pass LOGRAST_BWD_SCRATCH_ZEROED -- no separate memset launches.  With
- * view->extras the leading dL_dconic block is cleared only in the rows of Gaussians that contributed to a pixel
- * (point_weight > 0): pass point_weight and LOGRAST_BWD_CONIC_TOUCHED_ONLY to lograst_backward.
+ * view->extras on large inputs (n >= 4,000,000, env LOGRAST_HELPER_MIN_N) the leading dL_dconic block is cleared only
+ * in the rows of Gaussians that contributed to a pixel (point_weight > 0; below that size the whole block is cleared):
+ * always pass point_weight and LOGRAST_BWD_CONIC_TOUCHED_ONLY to lograst_backward after a forward with view->extras
+ * (correct at every size; lograst_backward rejects LOGRAST_BWD_SCRATCH_ZEROED without point_weight on large inputs).
  * max_tile_len is also CHECKED on the device: when the real longest list exceeds a non-zero max_tile_len (or the
  * instance count exceeds capacity) nothing is sorted or composited and the overflow flag of tile_state is raised; the
  * outputs of such a call are undefined.  status (optional): LOGRAST_STATUS_WORDS device words owned by the caller
@@ -156,6 +158,30 @@ int lograst_forward(const lograst_view* view, int32_t n, const float* means3d, c
                     float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
                     float* point_weight_pixel, float* point_weight, float* bwd_scratch, int32_t bwd_scratch_floats,
                     uint32_t* status, void* stream);
+
+/* The forward in one call for a caller that has only a GUESS of the capacity (and of max_tile_len): what the drop-in
+ * package's default mode runs (log_amd/rasterizer.py).  Stage 1, then stage 2 with the guessed buffers are enqueued back
+ * to back -- the stream never waits for the host --, while the stage-1 header {instance count, longest list} is copied
+ * to the host on an internal side stream that waits for stage 1 only; the call returns once that copy has landed
+ * (stage 2 is then still running or queued).  If *num_instances_host <= capacity and (max_tile_len == 0 or
+ * *max_tile_len_host <= max_tile_len) the speculative stage 2 is the forward.  Otherwise its kernels returned without
+ * rendering (as in lograst_forward_render with too small a capacity) and the caller repeats stage 2 alone with exact
+ * buffers: lograst_forward_render(view, n, geom, tile_state, <keys / point_list for *num_instances_host>, ...).  An
+ * attempt that overflows does not touch `status` (the repeat records the forward).  Synchronises the side stream, not
+ * `stream`; not capturable into a HIP graph (use lograst_forward with a known capacity there).  Stands for the
+ * num_rendered read-back of the third-party forward (called at LoG/render/renderer.py:153) without its pipeline bubble. */
+int lograst_forward_speculative(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                                const float* rotations, const float* opacities, const float* colors, int32_t* radii,
+                                void* geom, void* tile_state, uint64_t* keys, uint32_t* point_list, uint32_t capacity,
+                                uint32_t max_tile_len, float* image, float* final_t, int32_t* n_contrib,
+                                int32_t* point_id_pixel, float* point_weight_pixel, float* point_weight,
+                                float* bwd_scratch, int32_t bwd_scratch_floats, uint32_t* status,
+                                uint32_t* num_instances_host, uint32_t* max_tile_len_host, void* stream);
+
+/* Measurement helper (bench.py's HBM denominator, SURVEY 8d "measured device-copy bandwidth"): streams `bytes` from
+ * src to dst with 16-byte non-temporal accesses, grid-stride over `blocks` workgroups of 256 (<= 0: 4096).  Pointers
+ * and size must be multiples of 16 bytes.  Not on the rasterizer's path. */
+int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, void* stream);
 
 /* Copies {num_instances, overflow_flag, longest tile list, rect instances} of a tile_state to host (synchronises
  * the stream; any pointer may be NULL).  rect_instances = what the plain rect rule of the reference would have
@@ -183,7 +209,9 @@ int lograst_set_tile_cull(int enabled);
  *                               (the reverse walk's atomics and the chain-rule kernel write straight into the
  *                               caller's per-step gradient bucket; no separate accumulate pass).
  *   LOGRAST_BWD_CONIC_TOUCHED_ONLY  dl_dconic is zeroed only in the rows of Gaussians with point_weight > 0 (what a
- *                               forward with extras and a bwd_scratch leaves: see below); needs point_weight.
+ *                               forward with extras and a bwd_scratch leaves on large inputs: see lograst_forward_render);
+ *                               needs point_weight.  (Documentation of the caller's state: the chain rule skips the
+ *                               rows with point_weight == 0 whenever point_weight is given, with or without this flag.)
  * point_weight (optional, NULL = none): the forward's per-Gaussian maximum blend weight.  A Gaussian with weight 0
  * contributed to no pixel, so its dL/dmean2D and dL/dconic are exactly zero: the chain rule skips it (its gradients
  * are written as 0, or left alone when accumulating) without reading its inputs -- in an opaque scene that is most of

@@ -57,6 +57,10 @@ _SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "lograst_forward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10 + [c_uint32, c_uint32]
                         + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p]),
+    "lograst_forward_speculative": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10
+                                    + [c_uint32, c_uint32] + [c_void_p] * 7 + [c_int32, c_void_p]
+                                    + [ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_stream_copy": (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),
                                           ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
     "lograst_set_tile_cull": (ctypes.c_int, [ctypes.c_int]),

@@ -7,8 +7,12 @@
   (/root/reference/LoG/model/counter.py:36-68): one kernel per view instead of ~25 indexing kernels.
 
 Both go through liblograst (include/lograst.h: lograst_id_histogram, lograst_counter_update).  Install under an
-unmodified LoG checkout with ``log_amd.counter.install()`` (= ``Counter.update_by_output = update_by_output``); the
-``torch.unique`` call sits inside ``renderer.py`` and is replaced by editing that one line."""
+unmodified LoG checkout with ``log_amd.counter.install()``: ``Counter.update_by_output = update_by_output``, and the
+name ``torch`` inside the module ``LoG.render.renderer`` is rebound to a pass-through stand-in whose ``unique`` sends the
+rasterizer's ``point_id_pixel`` map (recognised by the tag ``GaussianRasterizer.forward`` leaves on it) through
+``unique_ids`` and hands every other call, and every other attribute, to the real ``torch`` -- no LoG line is edited."""
+import types
+
 import torch
 
 from . import rasterizer as _r
@@ -41,8 +45,43 @@ def update_by_output(self, output, fix_parent=False):
             vf["index_vis"] = torch.where(flag_vis)[0]
 
 
-def install():
-    """Patch the reference class in place (needs LoG importable)."""
+def torch_unique(input, *args, **kwargs):
+    """``torch.unique`` as LoG/render/renderer.py:156 calls it (``sorted=True, return_counts=True`` on the rasterizer's
+    per-pixel id map) through the histogram kernel, with torch's result: ascending ids INCLUDING the leading -1 of the
+    pixels nothing contributed to (renderer.py:157-159 strips it), int64 counts.  Anything else is torch.unique."""
+    n = getattr(input, "_lograst_num_gaussians", None)
+    if (n is None or args or set(kwargs) - {"sorted", "return_counts"} or not kwargs.get("return_counts", False)
+            or not kwargs.get("sorted", True) or input.dtype != torch.int32):
+        return torch.unique(input, *args, **kwargs)
+    ids, counts = unique_ids(input, n)
+    empty = input.numel() - counts.sum()          # pixels whose id is -1
+    if int(empty.item()) > 0:                     # (renderer.py:157 `if point_id[0] == -1` reads the same fact back)
+        ids = torch.cat([ids.new_full((1,), -1), ids])
+        counts = torch.cat([empty.reshape(1), counts])
+    return ids, counts
+
+
+class _TorchForRenderer(types.ModuleType):
+    """What the name ``torch`` means inside LoG.render.renderer after install(): torch itself, except ``unique``."""
+
+    def __init__(self):
+        super().__init__("torch")
+        self.unique = torch_unique
+
+    def __getattr__(self, name):      # (only called for names not set on this object: everything except `unique`)
+        return getattr(torch, name)
+
+
+def install(renderer=True):
+    """Patch the reference in place (needs LoG importable): Counter.update_by_output, and -- when the module can be
+    imported (it needs cv2) -- the torch.unique call of LoG.render.renderer."""
     from LoG.model.counter import Counter
     Counter.update_by_output = update_by_output
+    if renderer:
+        try:
+            import LoG.render.renderer as rr
+        except ImportError:
+            rr = None
+        if rr is not None and not isinstance(rr.torch, _TorchForRenderer):
+            rr.torch = _TorchForRenderer()
     return Counter

@@ -28,7 +28,8 @@ void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, hipStream_t s);
+                    int zero_block_floats, int rebased, int speculative, hipStream_t s);
+void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s);
 void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
@@ -286,7 +287,7 @@ static int lr_stage1(const LrView& v, int32_t n, const float* means3d, const flo
 static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st, uint64_t* keys, uint32_t* point_list,
                      uint32_t capacity, uint32_t max_tile_len, float* image, float* final_t, int32_t* n_contrib,
                      int32_t* point_id_pixel, float* point_weight_pixel, float* point_weight, float* bwd_scratch,
-                     int32_t bwd_scratch_floats, uint32_t* status, hipStream_t s) {
+                     int32_t bwd_scratch_floats, uint32_t* status, hipStream_t s, int speculative = 0) {
   const uint32_t tiles = (uint32_t)(v.gx * v.gy);
   if (n == 0 && status)   // no fill kernel runs: this forward's entries of the status block
     LR_HIP(hipMemsetAsync(status + LOGRAST_STATUS_LAST_INSTANCES, 0, 4 * sizeof(uint32_t), s));
@@ -307,7 +308,7 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   }
   lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, max_tile_len, status,
                  zero_n, zero_floats > 0 ? zero_block : nullptr, zero_floats,
-                 lr_big_input(n) ? 1 : 0, s);
+                 lr_big_input(n) ? 1 : 0, speculative, s);
   static const int stop_after_fill = lr_env_int("LOGRAST_STOP_AFTER_FILL", 0);   // timing experiments (tools/) only
   if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
@@ -428,6 +429,73 @@ int lograst_forward(const lograst_view* view, int32_t n, const float* means3d, c
   return LOGRAST_OK;
 }
 
+// Side stream + event + pinned words for the read-back of lograst_forward_speculative, one set per host thread and
+// device (created on first use, never destroyed: they live as long as the process).
+struct LrSpec { int dev; hipStream_t side; hipEvent_t ev; uint32_t* pinned; };
+static thread_local std::vector<LrSpec> g_spec;
+static int lr_spec_get(LrSpec** out) {
+  int dev = 0;
+  LR_HIP(hipGetDevice(&dev));
+  for (auto& e : g_spec)
+    if (e.dev == dev) { *out = &e; return LOGRAST_OK; }
+  LrSpec e{dev, nullptr, nullptr, nullptr};
+  LR_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+  LR_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+  LR_HIP(hipHostMalloc(reinterpret_cast<void**>(&e.pinned), sizeof(uint32_t) * LR_HDR_WORDS, hipHostMallocDefault));
+  g_spec.push_back(e);
+  *out = &g_spec.back();
+  return LOGRAST_OK;
+}
+
+int lograst_forward_speculative(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                                const float* rotations, const float* opacities, const float* colors, int32_t* radii,
+                                void* geom, void* tile_state, uint64_t* keys, uint32_t* point_list, uint32_t capacity,
+                                uint32_t max_tile_len, float* image, float* final_t, int32_t* n_contrib,
+                                int32_t* point_id_pixel, float* point_weight_pixel, float* point_weight,
+                                float* bwd_scratch, int32_t bwd_scratch_floats, uint32_t* status,
+                                uint32_t* num_instances_host, uint32_t* max_tile_len_host, void* stream) {
+  g_prof_call++;
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  rc = lr_check_stage1_args(v, n, means3d, scales, rotations, opacities, colors, radii, geom, tile_state);
+  if (rc) return rc;
+  rc = lr_check_stage2_args(v, n, tile_state, keys, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
+                            point_weight_pixel, point_weight, bwd_scratch, bwd_scratch_floats);
+  if (rc) return rc;
+  if (!num_instances_host || !max_tile_len_host) return lr_fail(LOGRAST_ERR_ARG, "NULL host pointer");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* st = reinterpret_cast<uint32_t*>(tile_state);
+  LrSpec* sp = nullptr;
+  rc = lr_spec_get(&sp);
+  if (rc) return rc;
+  rc = lr_stage1(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st, s);
+  if (rc) return rc;
+  LR_HIP(hipEventRecord(sp->ev, s));   // the scan has written the header: instance count and longest list
+  // stage 2 is enqueued before the host knows whether `capacity` suffices: the stream never waits for the host
+  rc = lr_stage2(v, n, geom, st, keys, point_list, capacity, max_tile_len, image, final_t, n_contrib, point_id_pixel,
+                 point_weight_pixel, point_weight, bwd_scratch, bwd_scratch_floats, status, s, 1);
+  if (rc) return rc;
+  LR_HIP(hipGetLastError());
+  // ... and the header is read on a side stream that waits for stage 1 only (the fill kernel rewrites only the overflow
+  // word, which is not read here)
+  LR_HIP(hipStreamWaitEvent(sp->side, sp->ev, 0));
+  LR_HIP(hipMemcpyAsync(sp->pinned, st, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, sp->side));
+  LR_HIP(hipStreamSynchronize(sp->side));
+  *num_instances_host = sp->pinned[LR_HDR_NUM];
+  *max_tile_len_host = sp->pinned[LR_HDR_MAXLEN];
+  return LOGRAST_OK;
+}
+
+int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, void* stream) {
+  if (bytes && (!dst || !src)) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "lograst_stream_copy: pointers and size must be multiples of 16 bytes");
+  lr_launch_stream_copy(src, dst, bytes, blocks, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
 int lograst_set_tile_cull(int enabled) {
   const int old = lr_tile_cull();
   g_tile_cull.store(enabled ? 1 : 0, std::memory_order_relaxed);
@@ -474,6 +542,12 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   const bool accumulate = (flags & LOGRAST_BWD_ACCUMULATE) != 0;
   if ((flags & LOGRAST_BWD_CONIC_TOUCHED_ONLY) && !point_weight)
     return lr_fail(LOGRAST_ERR_ARG, "LOGRAST_BWD_CONIC_TOUCHED_ONLY needs point_weight");
+  // A forward with extras on a large input clears the dL/dconic rows of contributing Gaussians only (lr_stage2:
+  // touched_only); the chain rule must then skip the others, which it does exactly when it is handed point_weight.
+  if ((flags & LOGRAST_BWD_SCRATCH_ZEROED) && v.extras && lr_big_input(n) && !point_weight)
+    return lr_fail(LOGRAST_ERR_ARG, "LOGRAST_BWD_SCRATCH_ZEROED after a forward with view.extras and n >= "
+                                    "LOGRAST_HELPER_MIN_N: dL/dconic is cleared for contributing Gaussians only, pass "
+                                    "point_weight (+ LOGRAST_BWD_CONIC_TOUCHED_ONLY)");
   if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED)) {
     LR_HIP(hipMemsetAsync(dl_dmeans2d, 0, sizeof(float) * 3 * (size_t)n, s));
     LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * 4 * (size_t)n, s));

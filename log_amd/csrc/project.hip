@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
                float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order, int stream_nt,
-               int ablate, int rebased) {
+               int ablate, int rebased, int speculative) {
   // Per-Gaussian buffers that later kernels accumulate into with atomics (point_weight; the backward scratch)
   // are cleared here, in a kernel that already has one thread per Gaussian, instead of by separate memsets.
   // XCD-contiguous block order (speed only): blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
@@ -705,8 +705,11 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   const uint32_t total = state[LR_HDR_NUM], maxlen = state[LR_HDR_MAXLEN];
   const bool over = total > capacity || (max_len_hint != 0u && maxlen > max_len_hint);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (over) state[LR_HDR_OVERFLOW] = 1u;
-    if (status) {
+    // (written either way: a second stage-2 pass over the same tile_state with larger buffers -- the retry of a
+    // speculative forward, lograst_forward_speculative -- must find the flag of the failed attempt cleared)
+    state[LR_HDR_OVERFLOW] = over ? 1u : 0u;
+    // a speculative attempt that overflows is repeated by the caller with exact buffers: only that pass is recorded
+    if (status && !(speculative && over)) {
       status[LOGRAST_STATUS_LAST_INSTANCES] = total;
       status[LOGRAST_STATUS_LAST_OVERFLOW] = over ? 1u : 0u;
       status[LOGRAST_STATUS_LAST_MAX_LEN] = maxlen;
@@ -821,7 +824,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, hipStream_t s) {
+                    int zero_block_floats, int rebased, int speculative, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   static const int xcd_order = lr_env_int("LOGRAST_FILL_XCD_ORDER", 1);
@@ -830,7 +833,7 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
   const int blocks = ((N + 255) / 256 + 7) & ~7;
   hipLaunchKernelGGL(lr_fill_kernel, dim3(blocks), dim3(256), 0, s, N, gx,
                      reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, max_len_hint, status, zero_n,
-                     zero_block, zero_block_floats, xcd_order, fill_nt, ablate, rebased);
+                     zero_block, zero_block_floats, xcd_order, fill_nt, ablate, rebased, speculative);
   lr_prof_end(LRK_FILL, s);
 }
 
@@ -868,4 +871,31 @@ void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s) {
   const uint32_t n4 = (uint32_t)((words + 3) / 4);   // callers pad to 16 bytes (LR_HDR_WORDS and the counter arrays are multiples of 4 words)
   if (!n4) return;
   hipLaunchKernelGGL(lr_zero_words_kernel, dim3((n4 + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n4);
+}
+
+// ---- measured roof: a streaming device-to-device copy (bench.py's HBM denominator) --------------------------------
+// 16 bytes per lane per access, grid-stride, non-temporal both ways (nothing is reused): the float4 copy
+// /opt/skills/guides/MI355X_MICROARCH.md quotes at 6.29 TB/s (read + write counted).  Not on the rasterizer's path;
+// exported as lograst_stream_copy so that bench.py divides by a rate this library's own code reaches on the same box.
+__global__ void __launch_bounds__(256)
+lr_stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
+  const lr_u4v* __restrict__ a = reinterpret_cast<const lr_u4v*>(src);
+  lr_u4v* __restrict__ b = reinterpret_cast<lr_u4v*>(dst);
+  const size_t stride = (size_t)gridDim.x * 256u;
+  size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
+    const lr_u4v v0 = __builtin_nontemporal_load(a + i), v1 = __builtin_nontemporal_load(a + i + stride);
+    const lr_u4v v2 = __builtin_nontemporal_load(a + i + 2 * stride), v3 = __builtin_nontemporal_load(a + i + 3 * stride);
+    __builtin_nontemporal_store(v0, b + i); __builtin_nontemporal_store(v1, b + i + stride);
+    __builtin_nontemporal_store(v2, b + i + 2 * stride); __builtin_nontemporal_store(v3, b + i + 3 * stride);
+  }
+  for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), b + i);
+}
+void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s) {
+  const size_t n16 = bytes / 16;
+  if (!n16) return;
+  if (blocks <= 0) blocks = 256 * 16;   // 16 workgroups of 256 per CU
+  hipLaunchKernelGGL(lr_stream_copy_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src),
+                     reinterpret_cast<uint4*>(dst), n16);
 }

@@ -53,11 +53,14 @@ def shard_views(n_views, rank, world):
 
 
 def rows_per_rank(num_points, world, block_rows=0):
-    """Rows owned by one rank; a whole number of `block_rows`-row blocks when the touched-block exchange is on."""
+    """Rows owned by one rank: a whole number of `block_rows`-row blocks when the touched-block exchange is on, and
+    always a multiple of 4 rows -- the attribute blocks of `_Flat` sit back to back, a block of c columns is
+    P_pad * c * 4 bytes, and the kernels read / write the 4-column blocks (rotations, dL/drotations) as 16-byte rows
+    (lograst_forward / lograst_backward reject pointers that are not 16-byte aligned): with P_pad % 4 == 0 every block and
+    every rank's slice of it starts on a 16-byte boundary whatever the point count (LoG's changes at every densify)."""
     per = (int(num_points) + max(int(world), 1) - 1) // max(int(world), 1)
-    if block_rows:
-        per = (per + int(block_rows) - 1) // int(block_rows) * int(block_rows)
-    return per
+    unit = math.lcm(int(block_rows) if block_rows else 1, 4)
+    return (per + unit - 1) // unit * unit
 
 
 def _active(world):

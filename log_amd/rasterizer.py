@@ -61,6 +61,14 @@ WODILATE = Flavour("diff_gaussian_rasterization_wodilate", _lib.FILTER_CLAMP, 1,
 # process's status block (include/lograst.h: LOGRAST_STATUS_*), which `overflow_since_reset()` / bench.py read.
 _capacity_hint = None
 _max_len_hint = 0
+# Default mode (no hint): SPECULATIVE stage 2 (lograst_forward_speculative) -- the forward is enqueued in one piece with
+# buffers sized from a running estimate (instances per Gaussian of the recent forwards at this resolution x 1.25) while
+# the exact count travels to the host on a side stream; in the rare case the estimate was too small the kernels of the
+# speculative stage 2 returned without rendering and stage 2 is repeated with exact buffers.  Always exact results, one
+# read-back per forward like the third-party package's `num_rendered`, but the stream never waits for the host.
+# set_speculative(False) restores the two-call form (stage 1, read-back, exact allocation, stage 2).
+_speculative = True
+_inplace_leaf_grads = True   # backward adds straight into the inputs' existing .grad when all of them are plain leaves
 _status = {}          # device -> int32[8] status block (sticky across forwards, all streams)
 _debug_keep = False   # tests: keep dL/dconic of the last backward (HipBackend.last_conic_grad)
 _DEBUG_ADDR = bool(int(__import__('os').environ.get('LOGRAST_DEBUG_ADDR', '0')))
@@ -74,6 +82,71 @@ def set_instance_capacity(n, max_tile_len=0):
     global _capacity_hint, _max_len_hint
     _capacity_hint = None if n is None else int(n)
     _max_len_hint = int(max_tile_len) if n is not None else 0
+
+
+def set_speculative(enabled):
+    """Default-mode forward: True (default) = speculative stage 2 from the running capacity estimate, False = stage 1,
+    read-back, exact allocation, stage 2.  Returns the previous setting."""
+    global _speculative
+    prev, _speculative = _speculative, bool(enabled)
+    return prev
+
+
+def set_inplace_leaf_grads(enabled):
+    """True (default): when every differentiable input of a rasterizer call is a leaf that already has a dense fp32
+    ``.grad`` (a multi-view step after its first view, or grads that are views of a flat bucket), backward adds into those
+    tensors in place (LOGRAST_BWD_ACCUMULATE) instead of returning fresh gradients for autograd to add (five full passes
+    over the attributes per view).  Same sums; leaves with tensor hooks always take the autograd route.  Returns the
+    previous setting."""
+    global _inplace_leaf_grads
+    prev, _inplace_leaf_grads = _inplace_leaf_grads, bool(enabled)
+    return prev
+
+
+class _CapacityModel:
+    """Running estimate of the tile-instance count per (device, W, H, band): the largest instances-per-Gaussian ratio,
+    instance count and tile-list length of the recent forwards, slowly forgotten so that one dense view does not pin its
+    buffers for the rest of the run.  Only a guess is needed: a wrong one costs a repeated stage 2, never a result."""
+    HEADROOM, LEN_HEADROOM, DECAY, FIRST_RATIO = 1.25, 1.5, 0.98, 2.0
+
+    def __init__(self):
+        self.hist = {}
+        self.retries = 0      # speculative attempts that had to be repeated (diagnostics)
+        self.forwards = 0
+
+    def guess(self, key, n, tiles):
+        h = self.hist.get(key)
+        if h is None:
+            return int(self.FIRST_RATIO * n) + 4 * tiles + 4096, 0
+        cap = int(max(h["I"], h["ratio"] * n) * self.HEADROOM) + 4096
+        return min(cap, 0x7fffffff), int(h["L"] * self.LEN_HEADROOM) + 256
+
+    def update(self, key, n, instances, max_len, retried):
+        self.forwards += 1
+        self.retries += int(retried)
+        h = self.hist.get(key)
+        ratio = instances / max(n, 1)
+        if h is None:
+            self.hist[key] = dict(I=float(instances), ratio=ratio, L=float(max_len))
+        else:
+            h["I"] = max(float(instances), h["I"] * self.DECAY)
+            h["ratio"] = max(ratio, h["ratio"] * self.DECAY)
+            h["L"] = max(float(max_len), h["L"] * self.DECAY)
+
+    def reset(self):
+        self.hist.clear()
+        self.retries = self.forwards = 0
+
+
+_cap_model = _CapacityModel()
+
+
+def capacity_stats(reset=False):
+    """dict(forwards, retries) of the speculative default mode since the last reset (no synchronisation)."""
+    out = dict(forwards=_cap_model.forwards, retries=_cap_model.retries)
+    if reset:
+        _cap_model.reset()
+    return out
 
 
 def _status_block(device):
@@ -234,16 +307,45 @@ class HipBackend:
         status = _status_block(device)
         i32, f32, u8 = torch.int32, torch.float32, torch.uint8
         # what the caller gets (image, radii, the fork's maps) / what backward needs / what dies with this call
-        outs = [("image", f32, (3, H, W)), ("radii", i32, (N,))]
+        # (every output is an allocation of its own, like the third-party packages': views of one arena would share a
+        # version counter -- an in-place op on `radii` would invalidate `image` for autograd -- and any one of them kept
+        # alive would pin all the others' memory)
+        o = {"image": torch.empty(3, H, W, dtype=f32, device=device), "radii": torch.empty(N, dtype=i32, device=device)}
         if flavour.extras:
-            outs += [("pid", i32, (H, W)), ("pwp", f32, (H, W)), ("pw", f32, (N,))]
-        o = self._carve(device, outs)
+            o.update(pid=torch.empty(H, W, dtype=i32, device=device), pwp=torch.empty(H, W, dtype=f32, device=device),
+                     pw=torch.empty(N, dtype=f32, device=device))
         kept = [("geom", u8, (L.lograst_geom_bytes(N),)), ("state", u8, (L.lograst_tile_state_bytes(W, H, N),)),
                 ("final_T", f32, (H, W)), ("n_contrib", i32, (H, W))]
         if scratch_floats and N:
             kept.append(("bwd_scratch", f32, (N * scratch_floats,)))
         with torch.cuda.device(device):
-            if _capacity_hint is None:
+            if _capacity_hint is None and _speculative and N > 0:
+                ckey = (device.index, W, H, _tile_rows.get())
+                tiles = ((W + 15) // 16) * ((H + 15) // 16)
+                capacity, max_len = _cap_model.guess(ckey, N, tiles)
+                k = self._carve(device, kept + [("plist", i32, (capacity,))])
+                plist = k["plist"]
+                keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                n_host, m_host = ctypes.c_uint32(0), ctypes.c_uint32(0)
+                _lib.check(L.lograst_forward_speculative(
+                    ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(colors),
+                    _ptr(o["radii"]), _ptr(k["geom"]), _ptr(k["state"]), _ptr(keys), _ptr(plist), capacity, max_len,
+                    _ptr(o["image"]), _ptr(k["final_T"]), _ptr(k["n_contrib"]), _ptr(o.get("pid")), _ptr(o.get("pwp")),
+                    _ptr(o.get("pw")), _ptr(k.get("bwd_scratch")), scratch_floats if "bwd_scratch" in k else 0,
+                    _ptr(status), ctypes.byref(n_host), ctypes.byref(m_host), stream))
+                n_inst, n_len = int(n_host.value), int(m_host.value)
+                retry = n_inst > capacity or (max_len != 0 and n_len > max_len)
+                _cap_model.update(ckey, N, n_inst, n_len, retry)
+                if retry:   # the speculative stage 2 rendered nothing: once more with exact buffers
+                    capacity, max_len = n_inst, max(n_len, 1)
+                    plist = torch.empty(capacity, dtype=i32, device=device)
+                    keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                    _lib.check(L.lograst_forward_render(
+                        ctypes.byref(view), N, _ptr(k["geom"]), _ptr(k["state"]), _ptr(keys), _ptr(plist), capacity, max_len,
+                        _ptr(o["image"]), _ptr(k["final_T"]), _ptr(k["n_contrib"]), _ptr(o.get("pid")), _ptr(o.get("pwp")),
+                        _ptr(o.get("pw")), _ptr(k.get("bwd_scratch")), scratch_floats if "bwd_scratch" in k else 0,
+                        _ptr(status), stream))
+            elif _capacity_hint is None:
                 k = self._carve(device, kept)
                 n_host, m_host = ctypes.c_uint32(0), ctypes.c_uint32(0)
                 _lib.check(L.lograst_forward_project(ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations),
@@ -602,6 +704,26 @@ class accumulate_grads_into:
         return False
 
 
+def _leaf_grad_sink(leaves, device):
+    """The inputs' own ``.grad`` tensors as a gradient sink, or None unless EVERY differentiable input qualifies: a leaf
+    that requires grad, without tensor hooks, whose .grad already exists as a dense contiguous fp32 tensor of its shape on
+    this device (then adding in place is exactly what autograd's AccumulateGrad would do with a returned gradient)."""
+    if torch.is_grad_enabled() or device.type != "cuda":   # create_graph=True: leave everything to autograd
+        return None
+    out = {}
+    for name, t in zip(("means3D", "colors", "opacities", "scales", "rotations"), leaves):
+        if t is None or not t.requires_grad or not t.is_leaf or t._backward_hooks:
+            return None
+        if getattr(t, "_post_accumulate_grad_hooks", None):
+            return None
+        g = t.grad
+        if (g is None or g.dtype != torch.float32 or g.device != device or g.layout != torch.strided or
+                not g.is_contiguous() or g.shape != t.shape or g.requires_grad):
+            return None
+        out[name] = g
+    return out
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, colors, shs, opacities, scales, rotations, rs, flavour, use_filter, cov3D=None):
@@ -613,7 +735,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ValueError("cov3D_precomp must be [N, 6]")
             if _grad_sink is not None:
                 raise ValueError("accumulate_grads_into has no entry for cov3D_precomp")
-            s, r = m.new_zeros(m.shape[0], 3), m.new_zeros(m.shape[0], 4)    # placeholders: never read
+            s, r = m.new_empty(0, 3), m.new_empty(0, 4)    # placeholders for save_for_backward: never read
         else:
             s = scales.detach().to(torch.float32).contiguous()
             r = rotations.detach().to(torch.float32).contiguous()
@@ -627,7 +749,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             c, clamped = _backend.sh_forward(m, rs.campos, sh, int(rs.sh_degree))
         else:
             c = colors.detach().to(torch.float32).contiguous()
-        if not (s.shape == (n, 3) and r.shape == (n, 4) and c.shape == (n, 3) and o.shape[0] == n and m.shape == (n, 3)):
+        if not ((cov is not None or (s.shape == (n, 3) and r.shape == (n, 4))) and c.shape == (n, 3) and o.shape[0] == n
+                and m.shape == (n, 3)):
             raise ValueError("rasterizer inputs must be means3D[N,3], scales[N,3], rotations[N,4], "
                              "colors_precomp[N,3], opacities[N,1]")
         wants_grad = any(ctx.needs_input_grad[:7])   # all False under torch.no_grad()
@@ -644,6 +767,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.rs, ctx.flavour, ctx.use_filter = rs, flavour, use_filter
         ctx.set_materialize_grads(False)   # no zero-filled gradients for radii / the fork maps (4 fill kernels per view)
         ctx.saved = saved
+        # the backward trusts the forward's point_weight (which Gaussians it may skip, which dL/dconic rows are cleared):
+        # an in-place change of that output between forward and backward is refused, like autograd does for saved tensors
+        ctx.pw_version = pw._version if pw is not None else None
+        ctx.leaves = (means3D, colors, opacities, scales, rotations) if (sh is None and cov is None) else None
         ctx.sh = (sh, clamped)
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.save_for_backward(m, s, r)
@@ -660,6 +787,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             return (None,) * 11
         m2_shape, o_shape = ctx.shapes
         sh, clamped = ctx.sh
+        pw = ctx.saved.get("point_weight") if isinstance(ctx.saved, dict) else None
+        if pw is not None and ctx.pw_version is not None and pw._version != ctx.pw_version:
+            raise RuntimeError("the rasterizer's point_weight output was modified in place between forward and backward; "
+                               "the backward uses it to skip Gaussians that contributed to no pixel -- clone it first")
         if ctx.cov is not None:
             g_m3, g_m2, g_c, g_o, g_cov, _ = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, None, None,
                                                                ctx.saved, grad_image, cov3D=ctx.cov)
@@ -669,6 +800,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_c = None
             return g_m3, g_m2.reshape(m2_shape), g_c, g_sh, g_o.reshape(o_shape), None, None, None, None, None, g_cov
         sink = _grad_sink
+        if sink is None and ctx.leaves is not None and _inplace_leaf_grads:
+            sink = _leaf_grad_sink(ctx.leaves, m.device)
         if sink is not None and (sh is None or "shs" in sink):
             n = m.shape[0]
             if not (sink["means3D"].shape == (n, 3) and sink["scales"].shape == (n, 3) and
@@ -738,8 +871,13 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         if shs is not None and not 0 <= int(self.raster_settings.sh_degree) <= 3:
             raise ValueError("sh_degree must be 0..3")
-        return _RasterizeGaussians.apply(means3D, means2D, colors_precomp, shs, opacities, scales, rotations,
-                                         self.raster_settings, flavour, use_filter, cov3D_precomp)
+        ret = _RasterizeGaussians.apply(means3D, means2D, colors_precomp, shs, opacities, scales, rotations,
+                                        self.raster_settings, flavour, use_filter, cov3D_precomp)
+        if flavour.extras:
+            # how many Gaussians the ids of point_id_pixel index: lets log_amd.counter's stand-in for the
+            # torch.unique call at LoG/render/renderer.py:156 recognise the map and take the histogram kernel
+            ret[2]._lograst_num_gaussians = int(means3D.shape[0])
+        return ret
 
 
 class UpstreamGaussianRasterizer(GaussianRasterizer):

@@ -31,9 +31,28 @@ def test_bucket_views_alias_flat_buffer():
     for i, (n, c) in enumerate(LAYOUT):
         assert params[n].grad.data_ptr() == b.views[n].data_ptr()
         assert (b.flat[off:off + 5 * c] == 2.0 * (i + 1)).all()
-        off += 5 * c
-    assert b.flat.numel() == 5 * COLS
+        assert (b.flat[off + 5 * c:off + b.Ppad * c] == 0).all()      # padding rows up to a multiple of 4
+        off += b.Ppad * c
+    assert b.Ppad == 8 and b.flat.numel() == 8 * COLS
     assert b.reduce() is b.flat   # world 1: no communication, same buffer
+
+
+def test_every_attribute_block_is_16_byte_aligned_for_any_point_count():
+    """The kernels read rotations / write dL/drotations as 16-byte rows and lograst_forward / lograst_backward reject
+    unaligned pointers; LoG's point count changes at every densify step, so the flat layouts must stay aligned for odd
+    counts and odd worlds (round-2 advisory: P_pad odd put the rotations block on an 8-byte boundary)."""
+    from log_amd.dist import FlatParams
+    for P, world, blk in ((1001, 1, 0), (999, 3, 0), (7, 2, 0), (1000003, 8, 0), (1001, 2, 6), (5, 1, 0)):
+        b = GradientBucket(P, "cpu", world, sh_coeffs=15, block_rows=blk)
+        assert b.Ppad % 4 == 0 and b.Pr * world == b.Ppad and (blk == 0 or b.Pr % blk == 0)
+        base = b.flat.data_ptr()
+        for name, _ in b.layout:
+            assert (b.views[name].data_ptr() - base) % 16 == 0, (P, world, name)
+            for r in range(world):
+                assert (b.rows(name, r).data_ptr() - base) % 16 == 0, (P, world, name, r)
+    t = {n: torch.zeros(1001, c) for n, c in LAYOUT}
+    fp = FlatParams(t, "cpu", world=1)
+    assert (fp.views["rotations"].data_ptr() - fp.flat.data_ptr()) % 16 == 0
 
 
 def _worker(rank, world, port, P, out):
@@ -189,10 +208,12 @@ def test_owner_adam_world1_reproduces_reference_optimizer(oracle_mod):
         oracle_backend.install(old)
     for n in NAMES:
         np.testing.assert_allclose(params.views[n].numpy().reshape(g["final_" + n].shape), g["final_" + n], rtol=2e-6, atol=1e-9)
-        np.testing.assert_allclose(opt.exp_avg[n].numpy().reshape(g["final_exp_avg_" + n].shape), g["final_exp_avg_" + n],
+        P = params.P     # (the moments cover Pr >= P rows: the padding rows up to a multiple of 4 never move)
+        np.testing.assert_allclose(opt.exp_avg[n].numpy()[:P].reshape(g["final_exp_avg_" + n].shape), g["final_exp_avg_" + n],
                                    rtol=2e-6, atol=1e-12)
-        np.testing.assert_allclose(opt.exp_avg_sq[n].numpy().reshape(g["final_exp_avg_sq_" + n].shape),
+        np.testing.assert_allclose(opt.exp_avg_sq[n].numpy()[:P].reshape(g["final_exp_avg_sq_" + n].shape),
                                    g["final_exp_avg_sq_" + n], rtol=2e-6, atol=1e-15)
+        assert float(opt.exp_avg[n][P:].abs().sum()) == 0.0
 
 
 @pytest.mark.parametrize("mode", ["dense", "compact", "parts", "parts_compact"])
@@ -305,7 +326,9 @@ def test_step_exchange_groups_consecutive_views():
         b.views["colors"].fill_(float(i + 1))
         b.mark_seen(torch.ones(10))
     total = ex.finish()
-    assert torch.equal(total["colors"], torch.full((10, 3), 6.0)) and torch.equal(total["seen"], torch.full((10,), 3.0))
+    assert total["colors"].shape[0] == ex.buckets[0].Pr == 12          # a rank's rows: P rounded up to a multiple of 4
+    assert torch.equal(total["colors"][:10], torch.full((10, 3), 6.0)) and torch.equal(total["seen"][:10], torch.full((10,), 3.0))
+    assert float(total["colors"][10:].abs().sum()) == 0.0 and float(total["seen"][10:].sum()) == 0.0
 
 
 def test_bucket_without_seen_counts():
@@ -320,7 +343,7 @@ def test_bucket_without_seen_counts():
     for i, bk in enumerate(ex.buckets):
         bk.views["means3D"].fill_(float(i + 1))
     total = ex.finish()
-    assert "seen" not in total and torch.equal(total["means3D"], torch.full((9, 3), 3.0))
+    assert "seen" not in total and torch.equal(total["means3D"][:9], torch.full((9, 3), 3.0))
     params = FlatParams({n: torch.zeros(9, c) for n, c in b.layout}, "cpu")
     with pytest.raises(ValueError, match="seen counts"):
         OwnerAdam(params, 0).step_rows(total, params, {"means3D": 1e-3})

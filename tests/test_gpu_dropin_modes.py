@@ -1,0 +1,195 @@
+"""GPU tests of the drop-in package's host-side modes (log_amd/rasterizer.py): the speculative default forward and its
+recovery from a capacity guess that was too small, gradients added in place into the inputs' existing .grad, outputs that
+are independent tensors, the point_weight read-only contract, and the flat gradient bucket with an odd point count."""
+import numpy as np
+import pytest
+import torch
+
+from util import rel_l2, small_case
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _leaves(sc, dev):
+    names = dict(means3D="xyz", scales="scaling", rotations="rotation", opacities="opacity", colors="colors")
+    return {k: torch.tensor(np.ascontiguousarray(sc[v], np.float32), device=dev, requires_grad=True) for k, v in names.items()}
+
+
+def _call(rast, leaves, n, dev, **extra):
+    m2 = torch.zeros(n, 3, device=dev, requires_grad=True)
+    return rast(means3D=leaves["means3D"], means2D=m2, shs=None, colors_precomp=leaves["colors"],
+                opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                cov3D_precomp=None, **extra), m2
+
+
+def test_speculative_forward_recovers_from_a_capacity_guess_that_was_too_small():
+    """Default mode = lograst_forward_speculative: stage 2 is enqueued with buffers sized from the running estimate; when
+    the estimate is too small (forced here by poisoning the history) its kernels render nothing, the host learns the exact
+    count from the side-stream read-back and repeats stage 2 -- same bits as the two-call exact form, the failed attempt
+    leaves no trace in the status block, and the next forward of that resolution needs no repeat."""
+    from log_amd import rasterizer as R
+    import gpu_util as G
+    cam, sc = small_case(n=12000, W=64, H=64, focal=70.0, seed=6, smax=0.01)   # lists beyond 1024 keys: long-list sort too
+    sc["xyz"] *= 0.05
+    key = (0, cam["image_width"], cam["image_height"], (0, 0))
+    prev = R.set_speculative(False)
+    try:
+        exact = G.hip_forward(cam, sc, (0.1, 0.2, 0.3), scratch_floats=11)
+        g_exact = G.hip_backward(exact, np.ones_like(exact["image"]))
+        assert exact["I"] > 20000 and int(np.diff(exact["tile_offsets"].astype(np.int64)).max()) > 1024
+        R.set_speculative(True)
+        for poison in (dict(I=1.0, ratio=1e-6, L=float(1 << 20)),            # instance capacity far too small
+                       dict(I=float(4 * exact["I"]), ratio=0.0, L=1.0)):     # room enough, longest-list guess too small
+            R.capacity_stats(reset=True)
+            R.overflow_since_reset(torch.device(DEV))
+            R._cap_model.hist[key] = dict(poison)
+            spec = G.hip_forward(cam, sc, (0.1, 0.2, 0.3), scratch_floats=11)
+            st = R.capacity_stats()
+            assert st == dict(forwards=1, retries=1), st
+            for k in ("image", "final_T"):
+                assert (spec[k].view(np.uint32) == exact[k].view(np.uint32)).all(), k
+            for k in ("radii", "tile_offsets", "point_list", "n_contrib", "point_id_pixel"):
+                assert (spec[k] == exact[k]).all(), k
+            assert (spec["point_weight"] == exact["point_weight"]).all()
+            n, over = R.last_overflow(torch.device(DEV))
+            assert n == exact["I"] and not over
+            chk = R.overflow_since_reset(torch.device(DEV))
+            assert not chk["overflowed"] and chk["forwards"] == 1 and chk["max_instances"] == exact["I"], chk
+            g_spec = G.hip_backward(spec, np.ones_like(spec["image"]))
+            for k in g_exact:
+                assert rel_l2(g_spec[k], g_exact[k]) < 1e-5, k
+            again = G.hip_forward(cam, sc, (0.1, 0.2, 0.3))                   # the history now knows this view
+            assert R.capacity_stats() == dict(forwards=2, retries=1)
+            assert (again["image"].view(np.uint32) == exact["image"].view(np.uint32)).all()
+        # no history at all (first forward of a resolution): a guess from the Gaussian count, repeated if it falls short
+        R.capacity_stats(reset=True)
+        first = G.hip_forward(cam, sc, (0.1, 0.2, 0.3))
+        assert (first["image"].view(np.uint32) == exact["image"].view(np.uint32)).all() and R.capacity_stats()["forwards"] == 1
+    finally:
+        R.set_speculative(prev)
+        R.capacity_stats(reset=True)
+
+
+def test_outputs_are_independent_tensors_and_point_weight_is_guarded():
+    """Like the third-party packages, every output is its own allocation: in-place ops on radii / the fork's maps do not
+    disturb autograd's view of `image` (round-2 advisory), and dropping all but one output frees the others' memory.  The
+    one output the backward depends on, point_weight, may not be modified in place before backward: refused loudly."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    import gpu_util as G
+    cam, sc = small_case(n=2000, W=150, H=97, focal=170.0, seed=3, smax=0.08)
+    dev = torch.device(DEV)
+    n = len(sc["xyz"])
+    rast = GaussianRasterizer(raster_settings=G.settings(cam, (1, 1, 1), dev))
+    leaves = _leaves(sc, dev)
+    (image, radii, pid, pwp, pw), m2 = _call(rast, leaves, n, dev)
+    ptrs = {t.untyped_storage().data_ptr() for t in (image, radii, pid, pwp, pw)}
+    assert len(ptrs) == 5
+    ref = image.detach().clone()
+    radii.clamp_(max=3)
+    pid.add_(1)
+    pwp.mul_(0.5)
+    assert torch.equal(image.detach(), ref)
+    (image * 2.0).sum().backward()
+    assert float(leaves["means3D"].grad.abs().sum()) > 0
+    (image2, _, _, _, pw2), _ = _call(rast, leaves, n, dev)
+    pw2.mul_(1.0)
+    with pytest.raises(RuntimeError, match="point_weight"):
+        image2.sum().backward()
+    # reading it (what LoG does: `.data` comparisons, level_of_gaussian.py:241,403) is of course fine
+    (image3, _, _, _, pw3), _ = _call(rast, leaves, n, dev)
+    _ = (pw3.data > 1e-8).sum()
+    image3.sum().backward()
+
+
+@pytest.mark.parametrize("n", [4000, 4001])
+def test_backward_adds_into_existing_leaf_grads_in_place(n):
+    """All five differentiable inputs are leaves that already hold a dense fp32 .grad (second view of a step; or grads
+    that are views of a flat bucket -- also with an ODD point count, where the bucket pads its blocks to 16 bytes): the
+    backward adds into them in place.  Same sums as autograd's accumulation; a leaf with a tensor hook keeps the
+    autograd route (the hook must fire)."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R, scenes
+    from log_amd.dist import GradientBucket
+    import gpu_util as G
+    dev = torch.device(DEV)
+    cams = scenes.orbit_cameras(3, W=160, H=112, focal=170.0)
+    sc = scenes.random_scene(n, seed=11, opacity=None, smax=0.07)
+    w = torch.tensor(np.random.default_rng(3).random((3, 112, 160), dtype=np.float32), device=dev)
+
+    def run(inplace, bucket_grads, hook=False):
+        prev = R.set_inplace_leaf_grads(inplace)
+        try:
+            leaves = _leaves(sc, dev)
+            fired = []
+            if hook:
+                leaves["scales"].register_hook(lambda g: fired.append(1))
+            bucket = None
+            if bucket_grads:
+                bucket = GradientBucket(n, dev)
+                assert bucket.views["rotations"].data_ptr() % 16 == 0
+                bucket.attach(leaves)
+            ptrs = None
+            for i, cam in enumerate(cams[:2]):
+                rast = GaussianRasterizer(raster_settings=G.settings(cam, (1, 1, 1), dev))
+                ret, _ = _call(rast, leaves, n, dev)
+                (ret[0] * w).sum().backward()
+                if i == 0:
+                    ptrs = {k: v.grad.data_ptr() for k, v in leaves.items()}
+            torch.cuda.synchronize()
+            assert all(v.grad.data_ptr() == ptrs[k] for k, v in leaves.items())
+            return {k: v.grad.clone() for k, v in leaves.items()}, len(fired)
+
+        finally:
+            R.set_inplace_leaf_grads(prev)
+
+    ref, _ = run(False, False)
+    for bucket_grads in (False, True):
+        got, _ = run(True, bucket_grads)
+        for k in ref:
+            assert float(ref[k].abs().sum()) > 0
+            assert rel_l2(got[k].cpu().numpy(), ref[k].cpu().numpy()) < 1e-5, (k, bucket_grads)
+    hooked, fired = run(True, False, hook=True)
+    assert fired == 2
+    for k in ref:
+        assert rel_l2(hooked[k].cpu().numpy(), ref[k].cpu().numpy()) < 1e-5, k
+
+
+def test_odd_point_count_through_the_gradient_sink_and_flat_params():
+    """Round-2 advisory (high): with an odd padded point count the rotations block of the flat layouts sat on an 8-byte
+    boundary and lograst_forward / lograst_backward refused it.  Render FROM FlatParams.views and accumulate INTO
+    GradientBucket.views with P = 2999."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R, scenes
+    from log_amd.dist import FlatParams, GradientBucket
+    import gpu_util as G
+    dev = torch.device(DEV)
+    n = 2999
+    cam = scenes.orbit_cameras(3, W=160, H=112, focal=170.0)[1]
+    sc = scenes.random_scene(n, seed=5, opacity=None, smax=0.07)
+    names = dict(means3D="xyz", scales="scaling", rotations="rotation", opacities="opacity", colors="colors")
+    t = {k: torch.tensor(np.ascontiguousarray(sc[v], np.float32), device=dev) for k, v in names.items()}
+    params = FlatParams(t, dev, world=1)
+    bucket = GradientBucket(n, dev, world=1)
+    rast = GaussianRasterizer(raster_settings=G.settings(cam, (1, 1, 1), dev))
+    w = torch.rand(3, 112, 160, device=dev)
+
+    def render(src, sink):
+        leaves = {k: v.detach().requires_grad_(True) for k, v in src.items()}
+        m2 = torch.zeros(n, 3, device=dev, requires_grad=True)
+        kw = dict(means3D=leaves["means3D"], means2D=m2, shs=None, colors_precomp=leaves["colors"],
+                  opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+        if sink is not None:
+            with R.accumulate_grads_into(sink):
+                (rast(**kw)[0] * w).sum().backward()
+            return None
+        (rast(**kw)[0] * w).sum().backward()
+        return {k: v.grad for k, v in leaves.items()}
+
+    ref = render(t, None)
+    render({k: params.views[k] for k in names}, bucket.views)
+    torch.cuda.synchronize()
+    for k in names:
+        a, b = bucket.views[k].reshape(ref[k].shape), ref[k]
+        assert float(b.abs().sum()) > 0 and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, k

@@ -359,7 +359,11 @@ def test_fused_multi_view_accumulation_matches_autograd():
         torch.cuda.synchronize()
         return bucket.flat.clone(), m2s
 
-    a, m2a = run(False)
+    prev = R.set_inplace_leaf_grads(False)     # the comparison side: autograd's own accumulation, view by view
+    try:
+        a, m2a = run(False)
+    finally:
+        R.set_inplace_leaf_grads(prev)
     b, m2b = run(True)
     assert float(a.abs().sum()) > 0
     assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5

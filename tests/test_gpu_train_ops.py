@@ -211,5 +211,5 @@ def test_owner_computes_step_on_device_matches_reference_golden():
         assert int(moved) == int(g[f"s{it}_seen"].sum())
     for n in names:
         np.testing.assert_allclose(params.views[n].cpu().numpy().reshape(g["final_" + n].shape), g["final_" + n], rtol=2e-6, atol=1e-9)
-        np.testing.assert_allclose(opt.exp_avg[n].cpu().numpy().reshape(g["final_exp_avg_" + n].shape),
+        np.testing.assert_allclose(opt.exp_avg[n].cpu().numpy()[:P].reshape(g["final_exp_avg_" + n].shape),
                                    g["final_exp_avg_" + n], rtol=2e-6, atol=1e-12)

@@ -223,6 +223,8 @@ def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
     from log_amd import lod, counter, sparse_optimizer, get_all
     saved = (TensorTree.traverse, Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict)
     saved_get_all = LoG.get_all
+    import LoG.render.renderer as ref_renderer
+    saved_torch = ref_renderer.torch
     W, H = 96, 72
     try:
         ref = _log_model(0, 400)
@@ -231,9 +233,21 @@ def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
         import log_amd
         patched = log_amd.install_all()                 # = the four install() calls of INTEGRATION.md 3b
         assert [c.__name__ for c in patched] == ["LoG", "TensorTree", "Counter", "SparseOptimizer"]
+        # ... and the torch.unique call inside renderer.py (:156) now goes through log_amd.counter.torch_unique, with
+        # torch's own result (leading -1 included), while every other use of `torch` in that module is torch's
+        assert ref_renderer.torch is not torch and ref_renderer.torch.unique is counter.torch_unique
+        assert ref_renderer.torch.zeros_like is torch.zeros_like and ref_renderer.torch.float32 is torch.float32
+        pid_map = torch.tensor([[3, -1, 3], [0, 7, -1]], dtype=torch.int32)
+        for tagged in (False, True):
+            if tagged:
+                pid_map._lograst_num_gaussians = 9
+            got = ref_renderer.torch.unique(pid_map, sorted=True, return_counts=True)
+            want = torch.unique(pid_map, sorted=True, return_counts=True)
+            assert all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(got, want)), tagged
         new = _log_model(0, 400)
         sel_new = _run_steps(new, 3, W, H)
     finally:
+        ref_renderer.torch = saved_torch
         TensorTree.traverse, Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict = saved
         LoG.get_all = saved_get_all
         if hasattr(SparseOptimizer, "_lograst_load_state_dict"):

@@ -21,9 +21,19 @@ Prints ONE JSON line on rank 0 (contract: see the task statement), including
   value        : the pipelined mode above (what a multi-view training step of this framework runs);
   modes        : the same workload also in the DROP-IN DEFAULT mode -- one stream, exact buffer sizing (one 4-byte
                  read-back per forward, like the third-party package's num_rendered), gradients accumulated by autograd;
+  modes.pipelined_opacity_rand : (N = 1) the same 30 M point with opacity = rand(N) (SURVEY 8d asks for both variants): no
+                 early termination to hide behind -- every list is walked to its end;
   roofline     : dominant kernel, algorithmic bytes/launch / average launch duration (HIP events on the launch stream,
-                 from a single-stream step when several views are in flight) vs the 8 TB/s HBM3E peak; `traffic` from the
-                 committed PMC passes at this workload (profiles/r*_traffic*.json);
+                 from a single-stream step when several views are in flight) vs the 8 TB/s HBM3E peak.  Bytes are the
+                 EFFECTIVE algorithmic bytes: SURVEY 8d's per-unit figures x the units the launch really processes (list
+                 entries up to the deepest contributor of their tile instead of all I; Gaussians with point_weight > 0
+                 instead of all V for the chain rule), so no fraction can exceed 1 by crediting bytes nobody has to move;
+                 the plain SURVEY formula is kept beside it (`*_survey_formula`).  `traffic` comes from the committed PMC
+                 passes at this workload (profiles/r*_traffic*.json: builder-collected, `traffic_source` says so);
+  measured roofs: `measured_stream_copy_GBs` = this library's own float4 streaming-copy kernel (lograst_stream_copy) on the
+                 same box in the same run, `measured_copy_GBs` = torch's Tensor.copy_ (what round 2 divided by);
+  forward_only : torch.no_grad() rendering (what the reference times: CUDA events around renderer.vis in
+                 apps/train.py:53-59,100-108): ms/view and fps for the 30 M point, C2 and C3;
   cpu_baseline : the CPU oracle (oracle/, OpenMP, all host cores) timed on whole views of the same workload;
   secondary    : (N = 1 only) C2 = configs[1] (1 M Gaussians, same harness, both modes) and C3 = configs[2] (10 M-point
                  LoD tree, SH degree 3, level selection on: one LoG training view end to end through the drop-ins).
@@ -70,13 +80,20 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 / C3 legs (they run at N = 1 only)")
     ap.add_argument("--no-dropin-mode", action="store_true", help="skip the drop-in-default measurement of the headline")
     ap.add_argument("--c3-torch", action="store_true", help="C3 leg: also time the reference-style torch pipeline")
+    ap.add_argument("--no-rand-variant", action="store_true", help="skip the opacity = rand variant of the headline (N = 1)")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the torch.no_grad() legs")
+    ap.add_argument("--no-c5-band", action="store_true", help="skip the C5 band leg (100 M Gaussians, 4K, one of 8 bands)")
+    ap.add_argument("--exchange", choices=("auto", "dense", "compact"), default=os.environ.get("LOGRAST_EXCHANGE", "auto"),
+                    help="N > 1: dense reduce-scatter, touched-row-block exchange, or decided once from the warm-up")
     return ap.parse_args()
 
 
-def algorithmic_bytes(N, V, I, Px):
+def algorithmic_bytes(N, V, I, Px, eff=None):
     """Per-view algorithmic HBM bytes per kernel (each datum counted once per producing /
-    consuming stage, fp32, no implementation overhead)."""
-    return {
+    consuming stage, fp32, no implementation overhead).  eff = effective_units(): the same per-unit figures times the
+    units the launch really has to process -- list entries up to the deepest contributor of their tile (forward: up to
+    where the tile's last pixel stops) and, for the chain rule, the Gaussians some pixel composited."""
+    alg = {
         "project": 56 * N + 4 * N + 40 * V,
         "fill_keys": 8 * I,
         "sort": 8 * I + 4 * I,
@@ -84,6 +101,45 @@ def algorithmic_bytes(N, V, I, Px):
         "blend_bwd": 44 * I + 20 * Px + 36 * V,
         "project_bwd": 56 * N + 36 * V + 68 * N,
     }
+    if eff is None:
+        return alg, dict(alg)
+    e = dict(alg)
+    e["blend_fwd"] = 44 * eff["I_walked_fwd"] + 28 * Px + 4 * eff["V_live"]
+    e["blend_bwd"] = 44 * eff["I_walked_bwd"] + 20 * Px + 36 * eff["V_live"]
+    e["project_bwd"] = 8 * N + (56 + 36 + 68) * eff["V_live"]      # live flags (radii, point_weight) of all, rows of the live
+    return alg, e
+
+
+def effective_units(wl):
+    """Per view (mean over this rank's cameras), from one raw forward each: V_live = Gaussians with point_weight > 0 (the
+    rows the chain rule processes), I_walked_bwd = sum over tiles of the deepest contributor's list position (where the
+    reverse walk starts), I_walked_fwd = sum over tiles of how far the forward has to read: the whole list when some pixel
+    of the tile never saturates (final_T >= 0.01: the stop needs T < 1e-4 / (1 - 0.99)), else the deepest contributor
+    rounded up to the next 64-entry chunk (an estimate: the exact stop position is not an output)."""
+    import torch
+    from log_amd import rasterizer as R
+    W, H, dev = wl.W, wl.H, wl.dev
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    acc = {"V_live": 0.0, "I_walked_fwd": 0.0, "I_walked_bwd": 0.0}
+    b = wl.base
+    with torch.no_grad():
+        for rast in wl.rasts:
+            _, radii, _, _, pw, saved = R._backend.forward(rast.raster_settings, R.WODILATE, True, b["means3D"], b["scales"],
+                                                           b["rotations"], b["opacities"].reshape(-1), b["colors"])
+            offs = R.tile_offsets_of(saved, W, H).to(torch.int64)
+            L = (offs[1:] - offs[:-1]).view(gy, gx)
+            nc = torch.zeros(gy * 16, gx * 16, dtype=torch.int64, device=dev)
+            nc[:H, :W] = saved["n_contrib"]
+            fT = torch.zeros(gy * 16, gx * 16, device=dev)
+            fT[:H, :W] = saved["final_T"]
+            t_nc = nc.view(gy, 16, gx, 16).amax(dim=(1, 3))
+            t_open = (fT.view(gy, 16, gx, 16) >= 0.01).any(dim=3).any(dim=1)
+            fwd = torch.where(t_open, L, torch.minimum(L, (t_nc + 64) // 64 * 64))
+            acc["V_live"] += float((pw > 0).sum())
+            acc["I_walked_bwd"] += float(t_nc.sum())
+            acc["I_walked_fwd"] += float(fwd.sum())
+            del saved
+    return {k: v / len(wl.rasts) for k, v in acc.items()}
 
 
 def self_spawn(args):
@@ -124,6 +180,7 @@ class RasterWorkload:
             self.rasts.append(GaussianRasterizer(raster_settings=rs))
         self.torch = torch
         self.zero_means2d = True
+        self.last_radii = None
 
     def one_view(self, rast, leaves):
         torch = self.torch
@@ -137,6 +194,7 @@ class RasterWorkload:
         # loss = sum(image * w): its gradient dL/dimage = w seeds the rasterizer's backward directly (the scalar
         # itself is consumed by nobody, so no reduction kernel is launched for it)
         out[0].backward(gradient=self.wloss)
+        self.last_radii = out[1]
         return out
 
 
@@ -157,11 +215,18 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     # The step's gradient exchange (log_amd.dist.StepExchange): the rank's views in `parts` consecutive groups with a
     # bucket each; group g's reduce-scatter runs on a side stream under the rendering of group g + 1.
-    ex = StepExchange(N, dev, world, rank, parts=parts, track_seen=False)   # (the gradient sum only: no optimizer here)
+    # N > 1: the buckets carry the per-row seen counts (what an owner-computes optimizer step needs, and what the
+    # touched-row-block exchange reads); --exchange auto decides ONCE, from the warm-up, whether the block form can pay
+    # (it costs a bitmap all-reduce and a small read-back per group of views): dense when most blocks are touched.
+    track = world > 1
+    block_rows = 4096 if (track and args.exchange != "dense") else 0
+    ex = StepExchange(N, dev, world, rank, parts=parts, block_rows=block_rows, track_seen=track, timing=track)
+    compact = {"on": args.exchange == "compact" and world > 1}
     lanes = []
     for li in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient buckets
         leaves = {k: v.detach().requires_grad_(True) for k, v in wl.base.items()}
-        bks = ex.buckets if li == 0 else [GradientBucket(N, dev, world, track_seen=False) for _ in range(parts)]
+        bks = ex.buckets if li == 0 else [GradientBucket(N, dev, world, block_rows=block_rows, track_seen=track)
+                                          for _ in range(parts)]
         bks[0].attach(leaves)
         lanes.append((leaves, bks))
     lane_views = [wl.rasts[li::S] for li in range(S)]
@@ -198,7 +263,11 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             for _, bks in lanes[1:]:
                 ex.buckets[part].flat.add_(bks[part].flat)
             if world > 1:
-                ex.launch(part)
+                # rows this group of views saw: in this workload every view sees the same rows (radii > 0 for the views'
+                # common frustum), recorded once per group from the last forward's radii (kept by one_view)
+                if wl.last_radii is not None:
+                    ex.buckets[part].mark_seen(wl.last_radii)
+                ex.launch(part, compact=compact["on"])
         if world > 1:
             ex.all_gather_grads(ex.finish())            # every rank ends the step with the whole gradient sum
 
@@ -222,6 +291,24 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     R.overflow_since_reset(dev)         # clear the status block: from here on every forward is recorded in it
     for _ in range(warmup):
         step()
+    if world > 1:
+        # what the step's exchange has to move: rows with a non-zero gradient (any column) and 4096-row blocks holding one
+        torch.cuda.synchronize()
+        g = ex.buckets[0]
+        nz = torch.zeros(g.Ppad, dtype=torch.bool, device=dev)
+        for name, c in g.layout:
+            nz |= (g.blocks[name].view(g.Ppad, c) != 0).any(dim=1)
+        res["exchange_nonzero_row_fraction"] = float(nz.float().mean())
+        if block_rows:
+            blk = nz.view(-1, block_rows).any(dim=1).float().mean()
+            t = torch.tensor([float(blk)], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res["exchange_touched_block_fraction"] = float(t.item())
+            if args.exchange == "auto":
+                compact["on"] = res["exchange_touched_block_fraction"] < GradientBucket.DENSE_ABOVE
+        res["exchange_mode"] = "compact" if compact["on"] else "dense"
+        del nz
+        ex.reset_timing()
     res["graphs"] = False
     if graphs and sync_free and fused:
         # One HIP graph per (stream, camera): the view's forward and backward -- memset, projection, scan, fill, sorts,
@@ -283,6 +370,13 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             torch.cuda.synchronize()
             _lib.profile_enable(False)
             res["prof_serial"] = _lib.profile_read()
+    if world > 1:
+        res["exchange_timing"] = ex.timing_summary(steps)
+        cols = sum(c for _, c in ex.buckets[0].layout) + 1
+        frac = 1.0
+        if compact["on"] and ex.touched is not None:
+            frac = ex.touched.fraction
+        res["exchange_bytes_per_step"] = int(2 * 4 * cols * ex.buckets[0].Ppad * frac * (world - 1) / world)
     chk = R.overflow_since_reset(dev)   # every forward since the capacity was set, on all streams
     assert not chk["overflowed"] and chk["max_instances"] <= cap, \
         "tile-instance capacity overflow inside the timed region: result invalid (%r)" % (chk,)
@@ -305,6 +399,187 @@ def mode_summary(N, views, world, steps, r):
 def auto_streams(args, N):
     S = args.streams if args.streams > 0 else (3 if N <= 4_000_000 else 1)
     return max(1, min(S, args.views))
+
+
+def view_bytes(N, V, I, Px, eff=None):
+    """Whole-view algorithmic bytes: SURVEY 8d's formula, and the same with the effective units of effective_units()."""
+    total = 184 * N + 116 * V + 108 * I + 48 * Px
+    if eff is None:
+        return total, total
+    _, e = algorithmic_bytes(N, V, I, Px, eff)
+    return total, sum(e.values())
+
+
+def workload_report(args, wl, r, N, Px, world, steps, roofs, timing, label):
+    """What one measured workload contributes to the line: units, bytes (formula and effective), fractions of the measured
+    roofs, per-kernel table and the dominant kernel's roofline object."""
+    V, I = r["V"], r["I"]
+    eff = effective_units(wl)
+    alg, alg_eff = algorithmic_bytes(N, V, I, Px, eff)
+    total, total_eff = view_bytes(N, V, I, Px, eff)
+    ms_view = 1e3 * r["elapsed"] / (steps * args.views)
+    out = {"workload": label, "visible_per_view": V, "tile_instances_per_view": I,
+           "tile_instances_per_view_reference_rect_rule": r["I_rect"],
+           "effective_units_per_view": dict(eff, note="V_live: point_weight > 0; I_walked_bwd: list entries up to each tile's "
+                                                      "deepest contributor; I_walked_fwd: estimated (see bench.py)"),
+           "algorithmic_bytes_per_view": total_eff, "algorithmic_bytes_per_view_survey_formula": total,
+           "algorithmic_GBs_whole_view": total_eff / (ms_view * 1e-3) / 1e9,
+           "algorithmic_GBs_whole_view_survey_formula": total / (ms_view * 1e-3) / 1e9}
+    for name, gbs in roofs.items():
+        out["algorithmic_frac_of_" + name] = out["algorithmic_GBs_whole_view"] / gbs
+        out["algorithmic_frac_of_" + name + "_survey_formula"] = out["algorithmic_GBs_whole_view_survey_formula"] / gbs
+    out["algorithmic_frac_of_hbm_peak"] = out["algorithmic_GBs_whole_view"] / HBM_PEAK_GBS
+    if timing:
+        prof = r["prof_serial"] if r["prof_serial"] is not None else r["prof_timed"]
+        out["kernels"], out["roofline"] = roof(prof, alg, alg_eff, N, wl.W, wl.H)
+        if r["prof_serial"] is None:
+            out["roofline"]["measured"] = "HIP events on the launch stream inside the timed region (one stream)"
+        else:
+            out["roofline"]["measured"] = ("HIP events on the launch stream, one eagerly launched single-stream step run right "
+                                           "after the timed region (inside it the views are replayed HIP graphs and / or "
+                                           "several views are in flight)")
+            if r["prof_timed"] is not None:
+                out["kernels_timed_region"], out["roofline_timed_region"] = roof(r["prof_timed"], alg, alg_eff, N, wl.W, wl.H)
+    return out
+
+
+def forward_only(args, wl, steps=3):
+    """torch.no_grad() rendering through the drop-in module, as the reference's demo / validation loop drives it
+    (apps/train.py:53-59,100-108 time renderer.vis with CUDA events): ms per view and fps, in the package's default mode
+    (speculative stage 2, one read-back per forward) and with a capacity hint (no read-back at all)."""
+    import torch
+    from log_amd import rasterizer as R
+    dev = wl.dev
+
+    def loop(n):
+        with torch.no_grad():
+            for _ in range(n):
+                for rast in wl.rasts:
+                    means2D = torch.zeros(wl.N, 3, device=dev)       # renderer.py:135 allocates it for every view
+                    rast(means3D=wl.base["means3D"], means2D=means2D, shs=None, colors_precomp=wl.base["colors"],
+                         opacities=wl.base["opacities"], scales=wl.base["scales"], rotations=wl.base["rotations"],
+                         cov3D_precomp=None)
+
+    def timed(n):
+        loop(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(n)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / (n * len(wl.rasts))
+        return {"ms_per_view": ms, "fps": 1e3 / ms, "gaussians_per_s": wl.N / (ms * 1e-3)}
+
+    R.set_instance_capacity(None)
+    R.overflow_since_reset(dev)
+    out = {"default_mode": timed(steps)}
+    chk = R.overflow_since_reset(dev)
+    R.set_instance_capacity(int(chk["max_instances"] * 1.02) + 1024, max_tile_len=int(chk["max_tile_len"] * 1.02) + 64)
+    try:
+        out["capacity_hint"] = timed(steps)
+        assert not R.overflow_since_reset(dev)["overflowed"]
+    finally:
+        R.set_instance_capacity(None)
+    return out
+
+
+def c5_band(args, dev, bands=8, band=3, N=100_000_000, W=3840, H=2160, views=2):
+    """BASELINE configs[4] on ONE GPU: what one of the 8 ranks does per view when the 4K image is split into bands of tile
+    rows (SURVEY 8e second axis) -- the band pre-pass over all N (lograst_tile_rows, identical on every rank), the selection
+    of the band's Gaussians, the gather of their attributes, forward + backward of the band, and the scatter-add of the
+    band's gradients into the dense per-step bucket rows.  100 M random Gaussians generated on the device (same
+    distribution as the headline's: xyz U(-0.5, 0.5), scales U(0, 0.5 N^-1/3), unit quaternions, opacity 0.999)."""
+    import numpy as np
+    import torch
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
+    from log_amd import dist as D, rasterizer as R, scenes
+    gen = torch.Generator(device=dev).manual_seed(0)
+    smax = 0.5 * float(N) ** (-1.0 / 3.0)
+    base = {"means3D": torch.rand(N, 3, device=dev, generator=gen) - 0.5,
+            "scales": torch.rand(N, 3, device=dev, generator=gen) * smax,
+            "rotations": torch.nn.functional.normalize(torch.rand(N, 4, device=dev, generator=gen) + 1e-3),
+            "opacities": torch.full((N, 1), 0.999, device=dev), "colors": torch.rand(N, 3, device=dev, generator=gen)}
+    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
+    cams = scenes.orbit_cameras(views, W=W, H=H, focal=2139.0 * W / 1920.0)
+    rows = D.band_rows(band, bands, H)
+    b, e = D.band_pixels(band, bands, H)
+    wloss = torch.rand(3, e - b, W, device=dev, generator=gen)
+    sink = {k: torch.zeros_like(v) for k, v in base.items()}                 # the rank's dense per-step gradient rows
+    rasts = []
+    for cam in cams:
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam["FoVx"] * 0.5), tanfovy=math.tan(cam["FoVy"] * 0.5),
+            bg=T([1.0, 1.0, 1.0]), scale_modifier=1.0, viewmatrix=T(cam["world_view_transform"]),
+            projmatrix=T(cam["full_proj_transform"]), sh_degree=0, campos=T(cam["camera_center"]), prefiltered=False,
+            debug=False)
+        rasts.append(GaussianRasterizer(raster_settings=rs))
+    stages, info = {}, {}
+
+    def one(rast, clock):
+        clock("band_prepass")
+        y0, y1 = rast.tile_rows(base["means3D"], base["scales"], base["rotations"])
+        clock("select")
+        idx = D.band_index(y0, y1, band, bands, H)
+        clock("gather")
+        leaves = {k: v[idx].requires_grad_(True) for k, v in base.items()}
+        clock("rasterize_fwd_bwd")
+        n = int(idx.numel())
+        means2D = torch.empty(n, 3, device=dev).requires_grad_(True)
+        with R.tile_rows(*rows):
+            out = rast(means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors"],
+                       opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                       cov3D_precomp=None)
+        out[0][:, b:e].backward(gradient=wloss)
+        clock("scatter_grads")
+        for k in sink:
+            sink[k].index_add_(0, idx, leaves[k].grad)
+        clock(None)
+        info.update(n_band=n, instances=R.last_state_info(dev)[0])
+
+    def run(staged):
+        cur = {"t": None, "name": None}
+
+        def clock(name):
+            if staged:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                if cur["name"] is not None:
+                    stages[cur["name"]] = stages.get(cur["name"], 0.0) + (now - cur["t"])
+                cur["t"], cur["name"] = now, name
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for rast in rasts:
+            one(rast, clock)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / len(rasts)
+
+    run(False)                                   # warm-up: allocator, capacity history of this resolution and band
+    ms = run(False)
+    stages.clear()
+    run(True)
+    # the same band rendered from ALL Gaussians (what round 2 did: the rect is clipped inside the full projection)
+    def full(rast):
+        leaves = {k: v.detach().requires_grad_(True) for k, v in base.items()}
+        means2D = torch.empty(N, 3, device=dev).requires_grad_(True)
+        with R.tile_rows(*rows):
+            out = rast(means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors"],
+                       opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                       cov3D_precomp=None)
+        out[0][:, b:e].backward(gradient=wloss)
+    full(rasts[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for rast in rasts:
+        full(rast)
+    torch.cuda.synchronize()
+    ms_full = 1e3 * (time.perf_counter() - t0) / len(rasts)
+    return {"workload": "C5 band (BASELINE.json configs[4] on one of its 8 GPUs): %d random Gaussians (device RNG, seed 0, "
+                        "opacity 0.999), %dx%d, band %d of %d = tile rows [%d, %d), %d orbit views: tile-row pre-pass over "
+                        "all Gaussians -> select -> gather -> forward + backward of the band -> scatter-add of the gradients"
+                        % (N, W, H, band, bands, rows[0], rows[1], views),
+            "gaussians": N, "gaussians_in_band": info["n_band"], "tile_instances_in_band": info["instances"],
+            "ms_per_view": ms, "stages_ms": {k: 1e3 * v / len(rasts) for k, v in stages.items()},
+            "ms_per_view_band_clipped_inside_full_projection": ms_full,
+            "gaussians_per_s_per_gpu": N / (ms * 1e-3)}
 
 
 def main():
@@ -342,73 +617,95 @@ def main():
     r = measure(args, wl, S, fused, args.steps, args.warmup, world, timing, graphs=not args.no_graphs)
     V, I, I_rect, elapsed = r["V"], r["I"], r["I_rect"], r["elapsed"]
     head = mode_summary(N, args.views, world, args.steps, r)
+    op_name = "rand" if args.opacity < 0 else args.opacity
+
+    def label(n, op):
+        return ("%s: %d random Gaussians (seed 0, opacity %s), %dx%d, %d orbit views per GPU, fwd+bwd of sum(image*w), "
+                "wodilate (5-tuple) flavour" %
+                ("north-star point (BASELINE.json north_star / configs[3] per GPU)" if n >= 30_000_000 else
+                 ("C2 (configs[1])" if n == 1_000_000 else "custom"), n, op, W, H, args.views))
 
     result = {
         "metric": "Gaussians/sec fwd+bwd @1080p", "value": head["value"], "unit": "Gaussians/s", "n_gpus": n_ranks,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "%s: %d random Gaussians (seed 0, opacity %s), %dx%d, %d orbit views per GPU, "
-                        "fwd+bwd of sum(image*w), wodilate (5-tuple) flavour" %
-                        ("north-star point (BASELINE.json north_star / configs[3] per GPU)" if N >= 30_000_000 else
-                         ("C2 (configs[1])" if N == 1_000_000 else "custom"),
-                         N, "rand" if args.opacity < 0 else args.opacity, W, H, args.views),
+            "workload": label(N, op_name),
             "gaussians": N, "width": W, "height": H, "views_per_gpu": args.views,
             "visible_per_view": V, "tile_instances_per_view": I, "tile_instances_per_view_reference_rect_rule": I_rect,
             "streams_per_gpu": S, "fused_gradient_accumulation": fused,
-            "parallelism": ("view-sharded dp%d, reduce-scatter of %d floats/step in %d groups of views (each under the next "
-                            "group's rendering, side stream) + one all-gather" %
-                            (n_ranks, r["bucket_floats"], r["exchange_parts"]) if world > 1 else "single GPU") +
-                           ", %d view(s) in flight per GPU (HIP streams)" % S,
+            "parallelism": ("view-sharded dp%d, %s reduce-scatter of %d floats/step in %d groups of views (each under the "
+                            "next group's rendering, side stream) + one all-gather" %
+                            (n_ranks, r.get("exchange_mode", "dense"), r["bucket_floats"], r["exchange_parts"])
+                            if world > 1 else "single GPU") + ", %d view(s) in flight per GPU (HIP streams)" % S,
         },
         "ms_per_view": head["ms_per_view"], "host_enqueue_ms_per_view": head["host_enqueue_ms_per_view"],
         "modes": {"pipelined": dict(head, streams=S, sync_free=True, fused_gradient_accumulation=fused, hip_graphs=r["graphs"],
                                     note="value of this line: capacity from the warm-up, no host sync in forward(), "
                                          "gradients added by the backward kernels into the step's bucket")},
     }
+    if world > 1:
+        result["exchange"] = {
+            "mode": r.get("exchange_mode"), "policy": args.exchange, "parts": r["exchange_parts"],
+            "nonzero_gradient_row_fraction": r.get("exchange_nonzero_row_fraction"),
+            "touched_4096_row_block_fraction": r.get("exchange_touched_block_fraction"),
+            "bytes_moved_per_rank_per_step": r.get("exchange_bytes_per_step"), "timing_ms": r.get("exchange_timing"),
+            "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO",
+                                                         "NCCL_PROTO", "RCCL_MSCCL_ENABLE") if os.environ.get(k)}}
     if not args.no_dropin_mode:
-        # the drop-in default: what LoG's unmodified renderer.py gets -- one stream, one 4-byte read-back per forward,
-        # autograd accumulating every view's gradients
+        # the drop-in default: what LoG's unmodified renderer.py gets -- one stream, the package's default forward (stage 2
+        # enqueued speculatively, one read-back per forward that the stream does not wait for), a zero-filled means2D per
+        # view, gradients added in place into the leaves' existing .grad
         dsteps = max(1, min(args.steps, 3))
         rd = measure(args, wl, 1, False, dsteps, 1, world, False, sync_free=False)
+        from log_amd import rasterizer as R
         result["modes"]["dropin_default"] = dict(
             mode_summary(N, args.views, world, dsteps, rd), streams=1, sync_free=False,
-            fused_gradient_accumulation=False, steps=dsteps,
-            note="one stream, exact buffer sizing (4-byte read-back per forward), autograd accumulation")
+            fused_gradient_accumulation=False, steps=dsteps, speculative_forward=True,
+            capacity_retries=R.capacity_stats(reset=False),
+            note="one stream, default forward of the package (speculative stage 2 + one read-back per forward on a side "
+                 "stream), gradients added in place into the leaves' .grad")
 
     if rank == 0:
-        alg = algorithmic_bytes(N, V, I, Px)
-        total_alg = 184 * N + 116 * V + 108 * I + 48 * Px
-        result["algorithmic_bytes_per_view"] = total_alg
-        result["algorithmic_GBs_whole_view"] = total_alg / (elapsed / (args.steps * args.views)) / 1e9
-        # the same box's device-copy bandwidth (the measured roof next to the 8 TB/s spec figure)
-        copy_gbs = measured_copy_bandwidth(dev)
-        result["measured_copy_GBs"] = copy_gbs
-        result["algorithmic_frac_of_measured_copy"] = result["algorithmic_GBs_whole_view"] / copy_gbs
+        roofs = {"measured_stream_copy": measured_stream_copy_bandwidth(dev), "measured_copy": measured_copy_bandwidth(dev)}
+        result["measured_stream_copy_GBs"] = roofs["measured_stream_copy"]
+        result["measured_copy_GBs"] = roofs["measured_copy"]
+        rep = workload_report(args, wl, r, N, Px, world, args.steps, roofs, timing, label(N, op_name))
+        for k in ("effective_units_per_view", "algorithmic_bytes_per_view", "algorithmic_bytes_per_view_survey_formula",
+                  "algorithmic_GBs_whole_view", "algorithmic_GBs_whole_view_survey_formula",
+                  "algorithmic_frac_of_measured_stream_copy", "algorithmic_frac_of_measured_stream_copy_survey_formula",
+                  "algorithmic_frac_of_measured_copy", "algorithmic_frac_of_measured_copy_survey_formula",
+                  "algorithmic_frac_of_hbm_peak", "kernels", "roofline", "kernels_timed_region", "roofline_timed_region"):
+            if k in rep:
+                result[k] = rep[k]
         if r.get("graphs_error"):
             result["graphs_error"] = r["graphs_error"]
-        if timing:
-            if r["prof_serial"] is None:
-                result["kernels"], result["roofline"] = roof(r["prof_timed"], alg, N, W, H)
-                result["roofline"]["measured"] = "HIP events on the launch stream inside the timed region (one stream)"
-            elif r["prof_timed"] is None:
-                result["kernels"], result["roofline"] = roof(r["prof_serial"], alg, N, W, H)
-                result["roofline"]["measured"] = ("HIP events on the launch stream, one eagerly launched single-stream step "
-                                                  "run right after the timed region (inside it the views are replayed "
-                                                  "HIP graphs, which carry no events)")
-            else:
-                # S > 1: the kernel's own duration comes from the single-stream step (this is what rocprofv3, which
-                # serialises kernels, reports for the same command); the time-shared durations of the timed region
-                # are kept next to it.
-                result["kernels"], result["roofline"] = roof(r["prof_serial"], alg, N, W, H)
-                result["roofline"]["measured"] = ("HIP events on the launch stream, single-stream step run right after "
-                                                  "the timed region (inside it %d views are in flight and kernels "
-                                                  "time-share the chip: see roofline_timed_region)" % S)
-                result["kernels_timed_region"], result["roofline_timed_region"] = roof(r["prof_timed"], alg, N, W, H)
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only: the host cores are shared by all ranks
             result["cpu_baseline"] = cpu_baseline(wl.sc, wl.cams, wl.wloss.cpu().numpy(), N)
+    else:
+        roofs = {}
+    if world == 1 and not args.no_forward_only:
+        result["forward_only"] = {"headline": forward_only(args, wl)}
     del wl
     torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_rand_variant and args.opacity >= 0:
+        # "opacity = 0.999 AND a second run with opacity = rand(N, 1)" -- same harness, same mode
+        try:
+            args_r = argparse.Namespace(**dict(vars(args), opacity=-1.0))
+            wl_r = RasterWorkload(args_r, N, dev, rank, world, torch, np)
+            rsteps = max(2, min(args.steps, 5))
+            rr = measure(args_r, wl_r, S, fused, rsteps, max(1, min(args.warmup, 2)), world, timing, graphs=not args.no_graphs)
+            mr = dict(mode_summary(N, args.views, world, rsteps, rr), streams=S, sync_free=True, hip_graphs=rr["graphs"],
+                      steps=rsteps)
+            mr.update(workload_report(args_r, wl_r, rr, N, Px, world, rsteps, roofs, timing, label(N, "rand")))
+            result["modes"]["pipelined_opacity_rand"] = mr
+            if not args.no_forward_only:
+                result["forward_only"]["headline_opacity_rand"] = forward_only(args_r, wl_r)
+            del wl_r
+        except Exception as e:
+            result["modes"]["pipelined_opacity_rand"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
 
     if world == 1 and not args.no_secondary:
         sec = {}
@@ -417,24 +714,26 @@ def main():
                 wl2 = RasterWorkload(args, 1_000_000, dev, rank, world, torch, np)
                 S2, steps2 = auto_streams(args, 1_000_000), max(args.steps, 20)   # (a 0.65 ms view: 20 steps = 0.1 s)
                 r2 = measure(args, wl2, S2, fused, steps2, max(args.warmup, 2), world, timing, graphs=not args.no_graphs)
-                c2 = {"workload": "C2 (BASELINE.json configs[1]): 1000000 random Gaussians (seed 0, opacity %s), %dx%d, "
-                                  "%d orbit views, same harness as the headline"
-                                  % ("rand" if args.opacity < 0 else args.opacity, W, H, args.views),
-                      "visible_per_view": r2["V"], "tile_instances_per_view": r2["I"],
-                      "modes": {"pipelined": dict(mode_summary(1_000_000, args.views, 1, steps2, r2), streams=S2,
+                c2 = {"modes": {"pipelined": dict(mode_summary(1_000_000, args.views, 1, steps2, r2), streams=S2,
                                                   hip_graphs=r2["graphs"])}}
-                if timing:
-                    alg2 = algorithmic_bytes(1_000_000, r2["V"], r2["I"], Px)
-                    c2["kernels"], c2["roofline"] = roof(r2["prof_serial"] or r2["prof_timed"], alg2, 1_000_000, W, H)
+                c2.update(workload_report(args, wl2, r2, 1_000_000, Px, 1, steps2, roofs, timing,
+                                          "C2 (BASELINE.json configs[1]): 1000000 random Gaussians (seed 0, opacity %s), "
+                                          "%dx%d, %d orbit views, same harness as the headline" % (op_name, W, H, args.views)))
                 if not args.no_dropin_mode:
                     rd2 = measure(args, wl2, 1, False, 3, 1, world, False, sync_free=False)
                     c2["modes"]["dropin_default"] = dict(mode_summary(1_000_000, args.views, 1, 3, rd2), streams=1)
+                if not args.no_forward_only:
+                    c2["forward_only"] = forward_only(args, wl2, steps=10)
                 sec["c2"] = c2
                 del wl2
                 torch.cuda.empty_cache()
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_log_step
-            sec["c3"] = bench_log_step.c3_pipeline(views=4, with_torch=args.c3_torch, dev=dev)
+            sec["c3"] = bench_log_step.c3_pipeline(views=4, with_torch=args.c3_torch, dev=dev,
+                                                   forward_only=not args.no_forward_only)
+            torch.cuda.empty_cache()
+            if not args.no_c5_band:
+                sec["c5_band"] = c5_band(args, dev)
         except Exception as e:   # the headline stands on its own; say what happened to the rest
             sec["error"] = "%s: %s" % (type(e).__name__, e)
         result["secondary"] = sec
@@ -446,13 +745,17 @@ def main():
         dist.destroy_process_group()
 
 
-def roof(prof, alg, N, W, H):
+def roof(prof, alg, alg_eff, N, W, H):
+    """-> (per-kernel table, roofline object of the dominant kernel).  GB/s figures divide the EFFECTIVE algorithmic bytes
+    (units the launch really processes) by the average launch duration; the SURVEY-formula bytes are kept beside them."""
     kern = {}
     for name, (ms, cnt) in prof.items():
         kern[name] = {"avg_us": 1e3 * ms / cnt, "launches": int(cnt)}
         if name in alg:   # per-kernel algorithmic GB/s against the same 8 TB/s roof
-            gbs = alg[name] / (1e-3 * ms / cnt) / 1e9
-            kern[name].update(alg_GBs=gbs, hbm_frac=gbs / HBM_PEAK_GBS)
+            t = 1e-3 * ms / cnt
+            kern[name].update(alg_GBs=alg_eff[name] / t / 1e9, hbm_frac=alg_eff[name] / t / 1e9 / HBM_PEAK_GBS,
+                              alg_bytes=alg_eff[name], alg_bytes_survey_formula=alg[name],
+                              hbm_frac_survey_formula=alg[name] / t / 1e9 / HBM_PEAK_GBS)
     sort_ms = sum(prof[k][0] for k in prof if k.startswith("sort"))
     merged = {k: prof[k][0] for k in prof if not k.startswith("sort")}
     if sort_ms:
@@ -460,18 +763,23 @@ def roof(prof, alg, N, W, H):
     dom = max(merged, key=merged.get)
     launches = prof[dom][1] if dom in prof else prof["sort_small"][1]
     avg_s = merged[dom] / launches / 1e3
-    achieved = alg.get(dom, 0) / avg_s / 1e9
+    achieved = alg_eff.get(dom, 0) / avg_s / 1e9
     return kern, {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                  "achieved_survey_formula": alg.get(dom, 0) / avg_s / 1e9,
+                  "frac_survey_formula": alg.get(dom, 0) / avg_s / 1e9 / HBM_PEAK_GBS,
                   "traffic": pmc_traffic(dom, N, W, H),
+                  "traffic_source": "committed profile (profiles/r*_traffic*.json, collected by the builder with rocprofv3 "
+                                    "--pmc on this workload; not measured in this run)",
                   # the compositing kernels are bound by fp32 VALU issue, which the hbm/mfma vocabulary of
                   # this object cannot name: fraction of SIMD issue cycles spent in VALU ops (PMC pass)
                   "valu_issue_frac": pmc_traffic(dom, N, W, H, "valu_active_frac_at_2p4GHz"),
-                  "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_us": avg_s * 1e6}
+                  "algorithmic_bytes_per_launch": alg_eff.get(dom, 0),
+                  "algorithmic_bytes_per_launch_survey_formula": alg.get(dom, 0), "avg_launch_us": avg_s * 1e6}
 
 
 def measured_copy_bandwidth(dev, mib=1024, reps=5):
-    """Device-to-device copy of `mib` MiB (read + write counted), best of `reps`: GB/s."""
+    """Device-to-device copy of `mib` MiB with torch's Tensor.copy_ (read + write counted), best of `reps`: GB/s."""
     import torch
     a = torch.empty(mib * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
     b = torch.empty_like(a)
@@ -486,6 +794,32 @@ def measured_copy_bandwidth(dev, mib=1024, reps=5):
         best = min(best, e0.elapsed_time(e1))
     del a, b
     return 2 * mib * 1024 * 1024 / (best * 1e-3) / 1e9
+
+
+def measured_stream_copy_bandwidth(dev, mib=1024, reps=5):
+    """The same copy with this library's own streaming kernel (lograst_stream_copy: 16-byte non-temporal accesses,
+    grid-stride; the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s), launched on torch's current stream so that the
+    torch events bracket it: GB/s, read + write counted, best of `reps` over a few grid sizes."""
+    import ctypes
+    import torch
+    from log_amd import _lib
+    L = _lib.lib()
+    nbytes = mib * 1024 * 1024
+    a = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    best = float("inf")
+    for blocks in (2048, 4096, 8192, 16384):
+        _lib.check(L.lograst_stream_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), nbytes, blocks, stream))
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(L.lograst_stream_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), nbytes, blocks, stream))
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+    del a, b
+    return 2 * nbytes / (best * 1e-3) / 1e9
 
 
 def pmc_traffic(kernel, N, W, H, field="traffic_bytes"):

@@ -178,6 +178,14 @@ int lograst_forward_speculative(const lograst_view* view, int32_t n, const float
                                 float* bwd_scratch, int32_t bwd_scratch_floats, uint32_t* status,
                                 uint32_t* num_instances_host, uint32_t* max_tile_len_host, void* stream);
 
+/* Image split into bands of tile rows (new design, SURVEY 8e / BASELINE configs[4]; view->tile_row_begin/end): the
+ * tile-row range every Gaussian's rect covers on the WHOLE image, rows_out[i] = y0 | y1 << 16 (rows [y0, y1); 0 = the
+ * projection drops this Gaussian), computed by the projection's own code: the Gaussians lograst_forward keeps for a band
+ * [b, e) are exactly those with y0 < e and y1 > b.  A rank that owns a band renders from that subset only (same relative
+ * order => same tile lists, bit-identical band).  view->tile_row_begin/end are ignored here. */
+int lograst_tile_rows(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                      const float* rotations, uint32_t* rows_out, void* stream);
+
 /* Measurement helper (bench.py's HBM denominator, SURVEY 8d "measured device-copy bandwidth"): streams `bytes` from
  * src to dst with 16-byte non-temporal accesses, grid-stride over `blocks` workgroups of 256 (<= 0: 4096).  Pointers
  * and size must be multiples of 16 bytes.  Not on the rasterizer's path. */

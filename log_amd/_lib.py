@@ -60,6 +60,8 @@ _SIGNATURES = {
     "lograst_forward_speculative": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10
                                     + [c_uint32, c_uint32] + [c_void_p] * 7 + [c_int32, c_void_p]
                                     + [ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
+    "lograst_tile_rows": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
     "lograst_stream_copy": (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),
                                           ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),

@@ -29,6 +29,8 @@ void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
                     int zero_block_floats, int rebased, int speculative, hipStream_t s);
+void lr_launch_tile_rows(const LrView& v, int N, const float* means, const float* scales, const float* rots,
+                         uint32_t* rows, hipStream_t s);
 void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s);
 void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                     uint32_t max_len, hipStream_t s);
@@ -484,6 +486,22 @@ int lograst_forward_speculative(const lograst_view* view, int32_t n, const float
   LR_HIP(hipStreamSynchronize(sp->side));
   *num_instances_host = sp->pinned[LR_HDR_NUM];
   *max_tile_len_host = sp->pinned[LR_HDR_MAXLEN];
+  return LOGRAST_OK;
+}
+
+int lograst_tile_rows(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
+                      const float* rotations, uint32_t* rows_out, void* stream) {
+  g_prof_call++;
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
+  if (n == 0) return LOGRAST_OK;
+  if (!means3d || !rows_out || (!v.cov3d && (!scales || !rotations))) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (reinterpret_cast<uintptr_t>(rotations) & 15u) return lr_fail(LOGRAST_ERR_ARG, "rotations must be 16-byte aligned");
+  v.ty0 = 0; v.ty1 = v.gy;   // always the rows of the whole image: the caller intersects them with its band
+  lr_launch_tile_rows(v, n, means3d, scales, rotations, rows_out, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
 

@@ -899,3 +899,42 @@ void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks,
   hipLaunchKernelGGL(lr_stream_copy_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src),
                      reinterpret_cast<uint4*>(dst), n16);
 }
+
+// ---- image split into bands of tile rows: which rows does each Gaussian reach? -------------------
+// The rect's tile-row range [y0, y1) of every Gaussian over the WHOLE image (y0 | y1 << 16; 0 = culled / empty rect),
+// from the very code the projection runs (lr_project_one with counters that count nothing), so that "rows [b, e)
+// intersect [y0, y1)" is exactly "the projection clipped to the band [b, e) keeps this Gaussian".  A rank that owns a
+// band selects its Gaussians from this array and projects, bins, composites and differentiates only those: 44 bytes
+// read + 4 written per Gaussian here instead of the full projection (and the full chain rule) over all of them.
+struct LrNoCounters {
+  LR_DEV uint32_t rank(int) const { return 0u; }
+  LR_DEV void count_big(int) const {}
+};
+__global__ void __launch_bounds__(256)
+lr_tile_rows_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
+                    const float* __restrict__ rots, uint32_t* __restrict__ rows) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  LrInputs in;
+  in.p[0] = means[3 * i]; in.p[1] = means[3 * i + 1]; in.p[2] = means[3 * i + 2];
+  if (v.cov3d) {
+    const float* __restrict__ c6 = v.cov3d + 6 * (size_t)i;
+    in.s[0] = c6[0]; in.s[1] = c6[1]; in.s[2] = c6[2];
+    in.q = float4{c6[3], c6[4], c6[5], 0.f};
+  } else {
+    in.s[0] = scales[3 * i]; in.s[1] = scales[3 * i + 1]; in.s[2] = scales[3 * i + 2];
+    in.q = reinterpret_cast<const float4*>(rots)[i];
+  }
+  in.op = 1.f; in.c[0] = 0.f; in.c[1] = 0.f; in.c[2] = 0.f;
+  float4 g0, g1, g2, g3;
+  int rad = 0;
+  uint32_t rect = 0;
+  bool huge = false;
+  lr_project_one<true>(v, in, 0, LrNoCounters{}, g0, g1, g2, g3, rad, rect, huge, 0);
+  rows[i] = rad > 0 ? ((__float_as_uint(g2.z) >> 16) | (__float_as_uint(g2.w) & 0xffff0000u)) : 0u;
+}
+void lr_launch_tile_rows(const LrView& v, int N, const float* means, const float* scales, const float* rots,
+                         uint32_t* rows, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(lr_tile_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, N, means, scales, rots, rows);
+}

@@ -336,8 +336,12 @@ class StepExchange:
     bucket's, grouped by part."""
 
     def __init__(self, num_points, device, world=1, rank=0, sh_coeffs=0, parts=1, block_rows=0, group=None,
-                 track_seen=True):
+                 track_seen=True, timing=False):
+        """timing: record device events around every collective and around the join in finish(), so that a run reports
+        how much of the exchange ran under the rendering and how much was exposed (``timing_summary``)."""
         self.world, self.rank, self.parts, self.group = max(int(world), 1), int(rank), max(int(parts), 1), group
+        self._timing = bool(timing)
+        self._ev = {"reduce_scatter": [], "join": [], "all_gather": []}
         self.buckets = [GradientBucket(num_points, device, world, sh_coeffs, block_rows, track_seen)
                         for _ in range(self.parts)]
         self.device = self.buckets[0].flat.device
@@ -358,6 +362,41 @@ class StepExchange:
         self._shards = [None] * self.parts
         self.touched = None
 
+    def _timed(self, kind, stream):
+        """Context manager: a pair of timing events on `stream` around the block (no-op unless timing on a HIP device)."""
+        ex = self
+
+        class _T:
+            def __enter__(self_t):
+                self_t.on = ex._timing and ex.device.type == "cuda"
+                if self_t.on:
+                    self_t.a = torch.cuda.Event(enable_timing=True)
+                    self_t.b = torch.cuda.Event(enable_timing=True)
+                    self_t.a.record(stream)
+
+            def __exit__(self_t, *exc):
+                if self_t.on:
+                    self_t.b.record(stream)
+                    ex._ev[kind].append((self_t.a, self_t.b))
+                return False
+        return _T()
+
+    def reset_timing(self):
+        for v in self._ev.values():
+            v.clear()
+
+    def timing_summary(self, steps):
+        """ms per step (synchronises): `reduce_scatter` = the collectives' own duration on the side stream (mostly hidden
+        under the next group's rendering), `exposed_join` = how long the compute stream stood still in finish() waiting
+        for the last of them, `all_gather` = the closing all-gather on the compute stream (exposed)."""
+        if not self._timing or self.device.type != "cuda":
+            return None
+        torch.cuda.synchronize(self.device)
+        tot = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self._ev.items()}
+        n = max(int(steps), 1)
+        return {"reduce_scatter_ms_per_step": tot["reduce_scatter"] / n, "exposed_join_ms_per_step": tot["join"] / n,
+                "all_gather_ms_per_step": tot["all_gather"] / n, "collectives_timed": len(self._ev["reduce_scatter"])}
+
     def launch(self, part, compact=False):
         b = self.buckets[part]
         if self.side is None:
@@ -365,7 +404,8 @@ class StepExchange:
             return
         self.side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.side):
-            self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact)
+            with self._timed("reduce_scatter", self.side):
+                self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact)
 
     def finish(self):
         """-> dict name -> [Pr, c] (+ "seen" -> [Pr]): this rank's rows of the sum over all groups and ranks."""
@@ -374,7 +414,8 @@ class StepExchange:
                 self.launch(g)
         if self.side is not None:
             main = torch.cuda.current_stream(self.device)
-            main.wait_stream(self.side)
+            with self._timed("join", main):
+                main.wait_stream(self.side)
             for sh in self._shards:
                 for t in sh.values():
                     t.record_stream(main)
@@ -399,8 +440,10 @@ class StepExchange:
             for name, _ in b0.layout:
                 b0.rows(name, 0).copy_(total[name])
             return b0.flat
-        for name, c in b0.layout:
-            _all_gather(b0.blocks[name], total[name].reshape(-1), self.group)
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        with self._timed("all_gather", main):
+            for name, c in b0.layout:
+                _all_gather(b0.blocks[name], total[name].reshape(-1), self.group)
         return b0.flat
 
 
@@ -421,6 +464,16 @@ def band_rows(rank, world, height):
 def band_pixels(rank, world, height):
     b, e = band_rows(rank, world, height)
     return b * TILE, min(e * TILE, int(height))
+
+
+def band_index(y0, y1, rank, world, height):
+    """Indices (ascending, int64) of the Gaussians whose rect reaches `rank`'s band of tile rows, from the per-Gaussian
+    row ranges of ``GaussianRasterizer.tile_rows`` (one 44-byte-per-Gaussian pass, the same on every rank): the rank then
+    gathers, projects, composites and differentiates only those -- SURVEY 8e "every GPU preprocesses only Gaussians whose
+    rect intersects its band".  Rendering the subset inside ``rasterizer.tile_rows(*band_rows(rank, world, H))`` gives the
+    band bit for bit as rendering all Gaussians does (same Gaussians, same relative order)."""
+    b, e = band_rows(rank, world, height)
+    return torch.nonzero((y0 < e) & (y1 > b)).reshape(-1)
 
 
 def gather_bands(image, rank, world, group=None):

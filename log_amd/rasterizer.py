@@ -481,6 +481,20 @@ class HipBackend:
             return g_means3D, g_cov, None
         return g_means3D, g_scales, g_rot
 
+    def tile_rows(self, rs, flavour, use_filter, means3D, scales, rotations):
+        """-> (y0, y1) int32[N]: the tile rows [y0, y1) each Gaussian's rect covers on the whole image (y0 = y1 = 0 when
+        the projection drops it): lograst_tile_rows.  See log_amd.dist.band_index."""
+        device = means3D.device
+        L = self.require(device)
+        N = means3D.shape[0]
+        m, s, r = _dev_f32(means3D, device), _dev_f32(scales, device), _dev_f32(rotations, device)
+        view, keep = self.make_view(rs, flavour, use_filter, device)
+        rows = torch.empty(N, dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_tile_rows(ctypes.byref(view), N, _ptr(m), _ptr(s), _ptr(r), _ptr(rows), _stream_ptr(device)))
+        del keep
+        return rows & 0xffff, (rows >> 16) & 0xffff
+
     def compute_radius(self, means3D, scales, rotations, projmatrix, viewmatrix, fx, fy, tanfovx, tanfovy):
         device = means3D.device
         L = self.require(device)
@@ -853,6 +867,13 @@ class GaussianRasterizer(nn.Module):
         with torch.no_grad():
             return _backend.compute_radius(xyz, scaling * rs.scale_modifier, rotation, rs.projmatrix, rs.viewmatrix,
                                            fx, fy, rs.tanfovx, rs.tanfovy)
+
+    def tile_rows(self, xyz, scaling, rotation, use_filter=True):
+        """New (image split across GPUs): (y0, y1) int32[N], the tile rows [y0, y1) of each Gaussian's rect on
+        the whole image under this rasterizer's settings, (0, 0) when the forward would drop it.  The Gaussians a forward
+        inside ``tile_rows(b, e)`` keeps are exactly those with y0 < e and y1 > b (log_amd.dist.band_index)."""
+        with torch.no_grad():
+            return _backend.tile_rows(self.raster_settings, self.FLAVOUR, use_filter, xyz, scaling, rotation)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None, **kwargs):

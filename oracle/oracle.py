@@ -209,6 +209,37 @@ def backward(view, fwd, dL_dimage):
     return out
 
 
+def backward_f64(view, fwd, dL_dimage, cond=True, pert=1e-7, trials=3):
+    """The float64 twin of backward() at full size (C: ora64_blend_bwd + ora64_project_bwd): every value in double, every
+    decision the fp32 forward's.  Returns the same keys as backward() as float64 arrays, plus (cond=True) "cond":
+    float64[N, 3] = how much the chain rule amplifies a relative perturbation of its inputs, for the means3D / scales /
+    rotations row of every Gaussian (see the C header).  Not available with cov3D_precomp."""
+    assert fwd.get("cov3d") is None, "the float64 twin covers the scales / rotations path"
+    means, scales, rots, opac, colors = fwd["inputs"]
+    N = fwd["N"]
+    n = max(N, 1)
+    dL = _f32(dL_dimage)
+    z = lambda *shape: np.zeros(shape, np.float64)
+    g_mean2d, g_conic, g_opac, g_col = z(n, 3), z(n, 4), z(n), z(n, 3)
+    g_means, g_scales, g_rots = z(n, 3), z(n, 3), z(n, 4)
+    cnd = z(n, 3) if cond else None
+    g_abs = z(n, 5) if cond else None
+    L = lib()
+    rec = np.ascontiguousarray(fwd["rec"]) if N else np.zeros((1, REC), np.float32)
+    plist = fwd["point_list"] if fwd["I"] else np.zeros(1, np.uint32)
+    L.ora64_blend_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(rec), _p(fwd["tile_offsets"]), _p(plist),
+                      _p(fwd["n_contrib"]), _p(dL), _p(g_mean2d), _p(g_conic), _p(g_opac), _p(g_col),
+                      _p(g_abs) if cond else None)
+    L.ora64_project_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots), _p(fwd["radii"]),
+                        _p(g_mean2d), _p(g_conic), _p(g_abs) if cond else None, _p(g_means), _p(g_scales), _p(g_rots),
+                        _p(cnd) if cond else None, ctypes.c_double(pert), ctypes.c_int32(trials))
+    out = dict(means3D=g_means[:N], means2D=g_mean2d[:N], scales=g_scales[:N], rotations=g_rots[:N],
+               opacities=g_opac[:N].reshape(-1, 1), colors=g_col[:N], conic=g_conic[:N])
+    if cond:
+        out["cond"] = cnd[:N]
+    return out
+
+
 def project_backward(view, fwd, g_mean2d, g_conic):
     """A6b alone: chain rule from (dL/d ndc-mean [N,3], dL/d conic [N,4]) to means3D/scales/rotations."""
     means, scales, rots, opac, colors = fwd["inputs"]

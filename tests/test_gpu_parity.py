@@ -120,23 +120,6 @@ def test_exact_reference_lists_without_tile_cull(oracle_mod, name):
         assert rel_l2(g_on[k], g_off[k]) < 1e-5, k
 
 
-def _ill_conditioned_rows(oracle_mod, v, of, og):
-    """Rows whose A6b chain rule amplifies a 1e-6 relative perturbation of dL/dconic by more than 1000x in
-    fp32 (pancake-flat Gaussians: one scale ~1e-4 of the others).  Their scale/rotation gradients are
-    numerical noise in ANY fp32 implementation -- the oracle's own result moves by O(1) when its atomics
-    reorder -- so the end-to-end comparison skips them; the A6b kernel itself is pinned on all rows by
-    test_project_backward_isolated, and the reverse walk (dL/dconic etc.) is compared on all rows."""
-    rng = np.random.default_rng(7)
-    pert = og["conic"] * (1 + 1e-6 * rng.standard_normal(og["conic"].shape).astype(np.float32))
-    g2 = oracle_mod.project_backward(v, of, og["means2D"], pert)
-    bad = np.zeros(len(og["scales"]), bool)
-    for k in ("means3D", "scales", "rotations"):
-        num = np.abs(g2[k] - og[k]).max(1)
-        den = np.abs(og[k]).max(1) + 1e-12
-        bad |= (num / den) > 1e-3
-    return bad
-
-
 @pytest.mark.parametrize("name", CASES)
 def test_backward_vs_oracle(oracle_mod, name):
     import gpu_util as G
@@ -151,11 +134,11 @@ def test_backward_vs_oracle(oracle_mod, name):
     for k in ("means2D", "conic", "opacities", "colors"):
         assert rel_l2(hg[k], og[k]) < GRAD_TOL, (k, rel_l2(hg[k], og[k]))
     assert (hg["means2D"][:, 2] == 0).all()
-    # A6 + A6b end to end, rows where fp32 carries information
-    bad = _ill_conditioned_rows(oracle_mod, v, of, og)
-    assert bad.mean() < 0.02, bad.mean()
-    for k in ("means3D", "scales", "rotations"):
-        assert rel_l2(hg[k][~bad], og[k][~bad]) < GRAD_TOL, (k, rel_l2(hg[k][~bad], og[k][~bad]))
+    # A6 + A6b end to end: every row against the float64 twin of the backward (tests/gpu_util.py: rel-L2 <= 1e-4 over all
+    # rows the chain rule conditions to better than 500x, and on EVERY row HIP no further from float64 than twice the
+    # fp32 oracle; the small scenes hold a few more pancake-flat Gaussians than the bench scenes: up to 5 % above the bound)
+    g64 = oracle_mod.backward_f64(v, of, dL)
+    G.assert_gradients_anchored(G.gradient_anchor_stats(hg, og, g64), tol=GRAD_TOL, max_excluded=0.05, name="case_" + name)
 
 
 @pytest.mark.parametrize("name", CASES)

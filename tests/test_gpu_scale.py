@@ -66,7 +66,7 @@ def test_c2_full_size_vs_oracle(oracle_mod):
         assert rel_l2(hp[k], og[k]) < 1e-6, k
 
 
-def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True):
+def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_name=None):
     """Forward bit-exact (lists: exact, or the oracle's lists minus provably invisible entries), backward <= 1e-4 rel-L2
     on every output of the reverse walk, chain rule <= 1e-6 on identical inputs.  The forward prepares the backward's
     accumulators as the autograd path does (touched-only dL/dconic on large inputs)."""
@@ -92,15 +92,11 @@ def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True):
     hp = G.hip_project_backward(hf, og["means2D"], og["conic"])    # the chain rule on identical inputs: every row
     for k in ("means3D", "scales", "rotations"):
         assert rel_l2(hp[k], og[k]) < 1e-6, k
-    # end to end the chain rule amplifies the (atomic-order) noise of dL/dconic on near-degenerate rows by orders of
-    # magnitude: row by row, the bulk must agree tightly and the tail must stay small
-    for k in ("means3D", "scales", "rotations"):
-        d = np.linalg.norm((hg[k] - og[k]).astype(np.float64), axis=1)
-        ref = np.linalg.norm(og[k].astype(np.float64), axis=1)
-        live = ref > 1e-6 * ref.max()
-        rel = d[live] / ref[live]
-        assert np.median(rel) < 1e-5 and np.quantile(rel, 0.97) < 1e-3, (k, float(np.median(rel)), float(np.quantile(rel, 0.97)))
-        assert (hg[k][~(og[k] != 0).any(axis=1)] == 0).all(), k     # rows the oracle leaves at zero (culled / untouched) are zero
+    # end to end, every row, anchored on the float64 twin of the backward (tests/gpu_util.py: the four tested claims --
+    # 1e-4 rel-L2 over all rows the chain rule conditions to better than 500x, HIP no further from float64 than twice the
+    # fp32 oracle on EVERY row, exact zeros where the gradient is zero); no masked or quantile criterion
+    g64 = oracle_mod.backward_f64(v, of, dL)
+    G.assert_gradients_anchored(G.gradient_anchor_stats(hg, og, g64), name=stats_name)
     return of
 
 
@@ -111,18 +107,22 @@ def test_c2_every_view_vs_oracle(oracle_mod, opacity):
     cams = scenes.orbit_cameras(8, W=1920, H=1080, focal=2139.0)
     sc = scenes.random_scene(1_000_000, seed=0, opacity=opacity)
     for v, cam in enumerate(cams):
-        of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), dL_seed=1 + v, check_lists=(v in (0, 5)))
+        of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), dL_seed=1 + v, check_lists=(v in (0, 5)),
+                          stats_name="c2_%s_view%d" % ("opaque" if opacity else "rand", v))
         assert of["I"] > 2_000_000
 
 
-@pytest.mark.parametrize("n,opacity,view", [(10_000_000, None, 3), (30_000_000, 0.999, 0)],
-                         ids=["10M_opacity_rand", "30M_north_star"])
-def test_full_size_vs_oracle(oracle_mod, n, opacity, view):
-    """The bench workloads at full size against the oracle: 10 M (C3 scale) and the 30 M north-star point -- lists
-    (every tile's list = the oracle's minus provably invisible entries, same order), image / final_T / fork maps bit for
-    bit, every gradient of the reverse walk, the chain rule on identical inputs."""
-    cam, sc = _scene(n, 1920, 1080, opacity=opacity, view=view)
-    of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0))
+@pytest.mark.parametrize("n,opacity,view,W,H", [(10_000_000, None, 3, 1920, 1080), (30_000_000, 0.999, 0, 1920, 1080),
+                                                (30_000_000, None, 5, 1920, 1080), (10_000_000, None, 2, 3840, 2160)],
+                         ids=["10M_opacity_rand", "30M_north_star", "30M_opacity_rand", "4K_10M_opacity_rand"])
+def test_full_size_vs_oracle(oracle_mod, n, opacity, view, W, H):
+    """The bench workloads at full size against the oracle: 10 M (C3 scale), the 30 M north-star point with opacity 0.999
+    and with random opacities (every list walked to its end), and 10 M Gaussians on the 4K tile grid of C5 -- lists (every
+    tile's list = the oracle's minus provably invisible entries, same order), image / final_T / fork maps bit for bit,
+    every gradient of the reverse walk, the chain rule on identical inputs, and end to end against the float64 twin."""
+    cam, sc = _scene(n, W, H, opacity=opacity, view=view)
+    of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0),
+                      stats_name="full_%dM_%s_%dx%d" % (n // 1_000_000, "opaque" if opacity else "rand", W, H))
     assert of["I"] > n
 
 
@@ -151,7 +151,7 @@ def test_tree_ordered_heavy_tailed_vs_oracle(oracle_mod):
               rotation=(q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)).astype(np.float32),
               opacity=(1.0 / (1.0 + np.exp(-(rng.standard_normal((sel.shape[0], 1)) + 1.0)))).astype(np.float32),
               colors=rng.random((sel.shape[0], 3), dtype=np.float32))
-    of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0))
+    of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), stats_name="tree_ordered_heavy_tailed")
     radii = of["radii"]
     assert (radii > 16).mean() > 0.01 and of["I"] > 2 * sel.shape[0]
 
@@ -211,7 +211,7 @@ def test_properties_at_scale(n, W, H):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_image_split_into_tile_row_bands(world):
+def test_image_split_into_tile_row_bands(oracle_mod, world):
     """SURVEY 8e second axis ("per-GPU tile ownership"), on one GPU: rendering the bands of tile rows one after the
     other (log_amd.rasterizer.tile_rows, as each rank of a node would) gives the single-GPU image bit for bit, the
     same arg-max map, radii / point_weight as the max over bands, and gradients that sum to the single-GPU ones."""
@@ -273,11 +273,78 @@ def test_image_split_into_tile_row_bands(world):
     for k in ("means2D", "opacity", "colors"):
         err = float((g_sum[k] - g_full[k]).norm() / g_full[k].norm())
         assert err < 1e-5, (k, err)
-    # behind the per-Gaussian chain rule a few near-degenerate rows amplify the (non-deterministic) atomic summation
-    # order by orders of magnitude and dominate a norm (bit-exactness contract): compare row by row
-    for k in ("xyz", "scaling", "rotation"):
-        d = (g_sum[k] - g_full[k]).reshape(N, -1).norm(dim=1)
-        ref = g_full[k].reshape(N, -1).norm(dim=1)
-        live = ref > 1e-6 * ref.max()
-        rel = d[live] / ref[live]
-        assert float(torch.quantile(rel.float().cpu(), 0.97)) < 1e-3 and float(rel.median()) < 1e-5, (k, float(rel.median()))
+    # behind the per-Gaussian chain rule: the bands' sum and the single render are two fp32 summation orders of the same
+    # gradient -- on EVERY row they differ by no more than the summation-order noise the row's conditioning allows
+    # (tests/gpu_util.py: ROW_FLOOR units of amplified round-off each, conditioning from the float64 twin)
+    import gpu_util as G
+    v64, of = G.oracle_forward(oracle_mod, cam, sc, (0.2, 0.4, 0.6))
+    g64 = oracle_mod.backward_f64(v64, of, w.cpu().numpy())
+    for j, (k, k64) in enumerate((("xyz", "means3D"), ("scaling", "scales"), ("rotation", "rotations"))):
+        d = (g_sum[k] - g_full[k]).reshape(N, -1).double().norm(dim=1).cpu().numpy()
+        y = np.linalg.norm(g64[k64], axis=1)
+        unit = G.EPS32 * np.maximum(g64["cond"][:, j], 1.0) * y
+        assert (d <= 2.0 * G.ROW_FLOOR * unit).all(), (k, float((d / np.maximum(unit, 1e-300))[y > 0].max()))
+        assert rel_l2(g_full[k].cpu().numpy().astype(np.float64)[g64["cond"][:, j] <= G.COND_BOUND],
+                      g64[k64][g64["cond"][:, j] <= G.COND_BOUND]) < 1e-4, k
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_band_prepass_selects_exactly_the_gaussians_the_band_keeps(world):
+    """"every GPU preprocesses only Gaussians whose rect intersects its band".  lograst_tile_rows gives
+    every Gaussian's tile-row range from the projection's own code; for every band of `world`: the selected set is exactly
+    the set a full-input forward clipped to the band keeps (radii > 0), and rendering FROM THE SUBSET gives that band bit
+    for bit (image, arg-max map through the index, point_weight) with gradients equal to the full-input render's rows."""
+    import math
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizationSettings, GaussianRasterizer
+    from log_amd import dist as D, rasterizer as R, scenes
+    dev = torch.device("cuda:0")
+    N, W, H = 150_000, 1280, 720
+    sc = scenes.random_scene(N, seed=9, opacity=None, smax=0.03)
+    sc["xyz"][:2000] *= 4.0                                   # some Gaussians outside the frustum / behind the camera
+    cam = scenes.orbit_cameras(4, W=W, H=H, focal=1400.0)[2]
+    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam["FoVx"] * 0.5), tanfovy=math.tan(cam["FoVy"] * 0.5),
+        bg=T([0.2, 0.4, 0.6]), scale_modifier=1.0, viewmatrix=T(cam["world_view_transform"]),
+        projmatrix=T(cam["full_proj_transform"]), sh_degree=0, campos=T(cam["camera_center"]), prefiltered=False,
+        debug=False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    w = torch.rand(3, H, W, device=dev)
+    keys = ("xyz", "scaling", "rotation", "opacity", "colors")
+    base = {k: T(sc[k]) for k in keys}
+    y0, y1 = rast.tile_rows(base["xyz"], base["scaling"], base["rotation"])
+    gy = (H + 15) // 16
+    assert int(y1.max()) <= gy and bool(((y1 > y0) | ((y0 == 0) & (y1 == 0))).all())
+
+    def render(index, rows):
+        leaves = {k: (base[k] if index is None else base[k][index]).clone().requires_grad_(True) for k in keys}
+        n = leaves["xyz"].shape[0]
+        m2 = torch.zeros(n, 3, device=dev, requires_grad=True)
+        with R.tile_rows(*rows):
+            out = rast(means3D=leaves["xyz"], means2D=m2, shs=None, colors_precomp=leaves["colors"],
+                       opacities=leaves["opacity"], scales=leaves["scaling"], rotations=leaves["rotation"],
+                       cov3D_precomp=None)
+        b, e = rows[0] * 16, min(rows[1] * 16, H)
+        (out[0][:, b:e] * w[:, b:e]).sum().backward()
+        return out, {**{k: leaves[k].grad for k in keys}, "means2D": m2.grad}
+
+    total = 0
+    for r in range(world):
+        rows = D.band_rows(r, world, H)
+        b, e = D.band_pixels(r, world, H)
+        idx = D.band_index(y0, y1, r, world, H)
+        full, g_full = render(None, rows)
+        assert torch.equal(idx, torch.nonzero(full[1] > 0).reshape(-1)), r      # exactly what the clipped projection keeps
+        total += int(idx.numel())
+        sub, g_sub = render(idx, rows)
+        assert torch.equal(sub[0][:, b:e], full[0][:, b:e])
+        assert torch.equal(sub[1], full[1][idx]) and torch.equal(sub[4], full[4][idx])
+        pid = sub[2][b:e]
+        assert torch.equal(torch.where(pid >= 0, idx[pid.clamp(min=0).long()], pid.long()), full[2][b:e].long())
+        for k in ("means2D", "opacity", "colors"):
+            ref = g_full[k][idx]
+            assert float((g_sub[k] - ref).norm()) <= 1e-5 * float(ref.norm()) + 1e-12, (r, k)
+            rest = torch.ones(N, dtype=torch.bool, device=dev)
+            rest[idx] = False
+            assert float(g_full[k][rest].abs().sum()) == 0.0, (r, k)               # nobody else has a gradient in this band
+    assert total >= int(((y1 > y0)).sum())                                        # bands overlap where a rect straddles them

@@ -45,6 +45,36 @@ def test_c_oracle_vs_float64_autograd(oracle_mod, seed, opacity, filter_mode, nd
         assert rel_l2(g[k], tg[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("seed,opacity,filter_mode,ndc_cull", [(0, None, 2, 1), (2, None, 1, 0), (4, 0.5, 2, 0)])
+def test_float64_twin_of_the_backward_vs_float64_autograd(oracle_mod, seed, opacity, filter_mode, ndc_cull):
+    """oracle.backward_f64 (the C reverse walk + chain rule in double, decisions from the fp32 forward: the anchor of the
+    GPU tests' end-to-end gradient criterion) against the independent dense float64 autograd forward: an order of
+    magnitude closer than the fp32 backward is (what is left is the fp32 rounding of the projected records the walk
+    reads), and its per-row conditioning estimate bounds the fp32 oracle's own row errors."""
+    from oracle import torch_oracle
+    cam, sc = small_case(seed=seed, opacity=opacity)
+    bg = [0.3, 0.6, 0.9]
+    v = oracle_view(oracle_mod, cam, bg, filter_mode, ndc_cull)
+    f = oracle_mod.forward(v, sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["colors"])
+    dL = np.random.default_rng(1).random(f["image"].shape, dtype=np.float32)
+    g32 = oracle_mod.backward(v, f, dL)
+    g64 = oracle_mod.backward_f64(v, f, dL)
+    _, _, _, tg = _torch_run(torch_oracle, cam, sc, bg, dL, filter_mode, ndc_cull)
+    for k in ("means3D", "means2D", "scales", "rotations", "opacities", "colors"):
+        assert g64[k].dtype == np.float64
+        e64, e32 = rel_l2(g64[k], tg[k]), rel_l2(g32[k].astype(np.float64), tg[k])
+        assert e64 < 2e-5 and e64 < max(e32, 2e-6), (k, e64, e32)
+    cond = g64["cond"]
+    assert cond.shape == (len(sc["xyz"]), 3) and (cond >= 0).all() and (cond[f["radii"] == 0] == 0).all()
+    for j, k in enumerate(("means3D", "scales", "rotations")):
+        y = np.linalg.norm(g64[k], axis=1)
+        live = y > 0
+        err = np.linalg.norm(g32[k].astype(np.float64) - g64[k], axis=1)[live] / y[live]
+        unit = 6e-8 * np.maximum(cond[live, j], 1.0)
+        # fp32 row errors against the conditioning model: the bulk within a few units (a unit = amplified round-off)
+        assert np.median(err / unit) < 20 and np.quantile(err / unit, 0.99) < 500, (k, float(np.median(err / unit)))
+
+
 def test_invariants(oracle_mod):
     cam, sc = small_case(n=400, W=64, H=64, seed=7)
     v = oracle_view(oracle_mod, cam, (0.2, 0.4, 0.6))

@@ -147,3 +147,58 @@ def test_shs_gradients_through_the_running_sum_sink():
     for k in a:
         assert b[k].grad is None
         assert rel_l2(sink[k].cpu().numpy(), a[k].grad.cpu().numpy()) < 1e-5, k
+
+
+@pytest.mark.gpu
+def test_native_shs_degree3_full_size_through_the_gradient_sink(oracle_mod):
+    """The packages' native `shs=` input at C2 size: 1 M Gaussians with 16 SH coefficients each (degree 3), 1920x1080,
+    5-tuple flavour, gradients added by the backward kernels straight into running sums (accumulate_grads_into with an
+    "shs" entry) -- against the oracle end to end: SH colours and clamp mask bit for bit, image bit for bit, dL/dshs and
+    every other attribute's gradient within 1e-4 relative L2 (means3D: the projection chain + the view-direction term)."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R, scenes
+    import gpu_util as G
+    dev = torch.device("cuda:0")
+    N, W, H = 1_000_000, 1920, 1080
+    cam = scenes.orbit_cameras(8, W=W, H=H, focal=2139.0)[3]
+    sc = scenes.random_scene(N, seed=0, opacity=None)
+    rng = np.random.default_rng(21)
+    shs_np = ((rng.random((N, 16, 3), dtype=np.float32) - 0.5) * 1.2).astype(np.float32)
+    shs_np[:, 0] += 0.8                                             # mostly positive colours, some clamped at 0
+    bg = (0.1, 0.2, 0.3)
+    rs = G.settings(cam, bg, dev)._replace(sh_degree=3)
+    T = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev, requires_grad=True)
+    lv = dict(means3D=T(sc["xyz"]), scales=T(sc["scaling"]), rotations=T(sc["rotation"]), opacities=T(sc["opacity"]),
+              shs=T(shs_np))
+    sink = {k: torch.zeros_like(v) for k, v in lv.items()}
+    m2 = torch.zeros(N, 3, device=dev, requires_grad=True)
+    w_np = np.random.default_rng(22).random((3, H, W), dtype=np.float32)
+    out = GaussianRasterizer(raster_settings=rs)(means3D=lv["means3D"], means2D=m2, shs=lv["shs"], colors_precomp=None,
+                                                 opacities=lv["opacities"], scales=lv["scales"], rotations=lv["rotations"])
+    with R.accumulate_grads_into(sink):
+        out[0].backward(gradient=torch.tensor(w_np, device=dev))
+    torch.cuda.synchronize()
+    # the oracle's route: SH colours, then the colors_precomp path, then back through the SH polynomial
+    ocol, ocl = oracle_mod.sh_forward(sc["xyz"], cam["camera_center"], shs_np, 3)
+    assert 0.001 < float((ocl != 0).mean()) < 0.5
+    sc_o = dict(sc, colors=ocol)
+    v, of = G.oracle_forward(oracle_mod, cam, sc_o, bg)
+    assert (out[0].detach().cpu().numpy().view(np.uint32) == of["image"].view(np.uint32)).all()
+    assert (out[1].cpu().numpy() == of["radii"]).all() and (out[2].cpu().numpy() == of["point_id_pixel"]).all()
+    og = oracle_mod.backward(v, of, w_np)
+    ogs, ogm = oracle_mod.sh_backward(sc["xyz"], cam["camera_center"], shs_np, 3, ocl, og["colors"])
+    assert rel_l2(sink["shs"].cpu().numpy(), ogs) < 1e-4
+    assert rel_l2(sink["opacities"].cpu().numpy().reshape(-1, 1), og["opacities"]) < 1e-4
+    assert rel_l2(m2.grad.cpu().numpy(), og["means2D"]) < 1e-4
+    assert rel_l2(sink["means3D"].cpu().numpy(), og["means3D"] + ogm) < 1e-4
+    # scales / rotations: every row against the float64 twin (tests/gpu_util.py)
+    g64 = oracle_mod.backward_f64(v, of, w_np)
+    for j, k in ((1, "scales"), (2, "rotations")):
+        hk, ref = sink[k].cpu().numpy().astype(np.float64), g64[k]
+        well = g64["cond"][:, j] <= G.COND_BOUND
+        assert float((~well & (np.linalg.norm(ref, axis=1) > 0)).mean()) <= 0.02
+        assert rel_l2(hk[well], ref[well]) < 1e-4, k
+        eh = np.linalg.norm(hk - ref, axis=1)
+        eo = np.linalg.norm(og[k].astype(np.float64) - ref, axis=1)
+        unit = G.EPS32 * np.maximum(g64["cond"][:, j], 1.0) * np.linalg.norm(ref, axis=1)
+        assert (eh <= 2.0 * eo + G.ROW_FLOOR * unit).all(), k

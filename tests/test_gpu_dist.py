@@ -39,9 +39,20 @@ def test_bench_line_carries_the_contract_fields():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "modes"):
         assert k in d, k
     assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert set(d["modes"]) == {"pipelined", "dropin_default"}
+    assert set(d["modes"]) == {"pipelined", "dropin_default", "pipelined_opacity_rand"}
+    assert "error" not in d["modes"]["pipelined_opacity_rand"] and d["modes"]["pipelined_opacity_rand"]["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "committed profile" in r["traffic_source"]
+    # effective algorithmic bytes: no kernel is credited with more than the peak
+    for name, k in d["kernels"].items():
+        assert k.get("hbm_frac", 0.0) <= 1.0, (name, k)
+    assert d["measured_stream_copy_GBs"] > 1000 and d["measured_copy_GBs"] > 1000
+    assert 0 < d["algorithmic_frac_of_measured_stream_copy"] < 1
+    assert d["effective_units_per_view"]["I_walked_bwd"] <= d["config"]["tile_instances_per_view"]
+    fo = d["forward_only"]["headline"]
+    assert fo["default_mode"]["fps"] > 0 and fo["capacity_hint"]["ms_per_view"] > 0
+    assert d["modes"]["dropin_default"]["capacity_retries"]["forwards"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
 
 

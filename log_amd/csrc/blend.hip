@@ -439,6 +439,224 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   }
 }
 
+// ---- backward, row-split form -----------------------------------------------------------------------------------
+// Same workgroup / wave -> quadrant mapping as above, but the wave's four 16-lane ROWS (the unit DPP operates on) each
+// own a 4x4 pixel block of the quadrant and walk the chunk's entries on their own: per iteration every row takes its own
+// next two relevant entries, so one pass of the 2-wide body serves up to eight (Gaussian, block) pairs instead of two
+// (Gaussian, quadrant) pairs.  What that buys on tiny splats (support radius ~4 px against the 8 px quadrant):
+//   * a visit evaluates 16 pixels of which ~8 contribute, instead of 64 of which ~18 do (tools/visit_stats.py: 0.21
+//     row-iterations per list entry against 0.34 quadrant visits);
+//   * the nine per-Gaussian sums are reduced over 16 lanes with DPP row operations only -- row_mirror, row_half_mirror and
+//     two quad permutes, packed two values per register through the 16 -> 8 and 8 -> 4 levels with bank-masked moves:
+//     ~50 VALU for BOTH entries of all four rows against 2 x 28 for one entry each of the whole wave.
+// The entries of a chunk are staged once per wave in LDS (48 B each; slot 64 is an all-zero entry that rows without work
+// read: alpha = 0 contributes nothing, branch-free); a row's lanes read their entry with three broadcast ds_read_b128.
+// Each row commits its own sums with the lanes (lane & 3) == 0: five atomic instructions per pass.
+#define LR_RB_SLOT 3      // float4 per staged entry: (mx, my, A, B) (C, opacity, r, g) (b, id, -, -)
+template <int CTRL>
+LR_DEV float lr_dpp_perm(float x) {   // full-mask permutation within the row (all the controls used are self-inverse)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int BANKS>
+LR_DEV float lr_bank_select(float keep, float take) {   // lanes of the 4-lane banks in BANKS <- take, the others keep
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(take), 0xE4, 0xf, BANKS, false));
+}
+// lanes 0-7 of the row: the eight pair sums of a; lanes 8-15: those of b (row_mirror: lane i <-> 15 - i)
+LR_DEV float lr_row_pair8(float a, float b) {
+  return lr_bank_select<0xc>(a + lr_dpp_perm<0x140>(a), b + lr_dpp_perm<0x140>(b));
+}
+// banks 0 and 2 keep p's four-lane sums, banks 1 and 3 take q's (row_half_mirror: i <-> 7 - i inside each half)
+LR_DEV float lr_row_pair4(float p, float q) {
+  return lr_bank_select<0xa>(p + lr_dpp_perm<0x141>(p), q + lr_dpp_perm<0x141>(q));
+}
+LR_DEV float lr_quad_total(float x) {   // every lane of a quad <- the quad's total
+  x = x + lr_dpp_perm<0xB1>(x);         // quad_perm [1,0,3,2]
+  return x + lr_dpp_perm<0x4E>(x);      // quad_perm [2,3,0,1]
+}
+
+__global__ void __launch_bounds__(256)
+lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
+                         uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
+                         const float* __restrict__ final_T, const int* __restrict__ n_contrib,
+                         const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
+                         float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
+                         int xcd_mode, int cull, int ablate) {
+  __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
+  if (lr_bail(state, capacity)) return;
+  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
+  if (tile >= tiles) return;
+  const uint32_t* offsets = state + lr_offsets_off(tiles);
+  const uint32_t beg = offsets[tile];
+  const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  const int row = lane >> 4, li = lane & 15;
+  const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
+  const int qx0 = tx * 16 + (wq & 1) * 8, qy0 = ty * 16 + (wq >> 1) * 8;
+  const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
+  const float pxf = (float)px, pyf = (float)py;
+  const bool in = (px < v.W) && (py < v.H);
+  const size_t plane = (size_t)v.W * v.H;
+  const size_t pix = in ? (size_t)py * v.W + px : 0;
+  const float sx = 0.5f * (float)v.W, sy = 0.5f * (float)v.H;
+  const float Tf = in ? final_T[pix] : 0.f;
+  const int lastc = in ? n_contrib[pix] : 0;
+  const float dp0 = in ? dL_dimage[pix] : 0.f;
+  const float dp1 = in ? dL_dimage[plane + pix] : 0.f;
+  const float dp2 = in ? dL_dimage[2 * plane + pix] : 0.f;
+  const float bgdot = lr_fma(v.bg[0], dp0, lr_fma(v.bg[1], dp1, v.bg[2] * dp2));
+  float T = Tf, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+  // deepest contributor of every row's block (entries behind it are not that row's business) and of the wave
+  int rmax = lastc;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) rmax = max(rmax, __shfl_xor(rmax, off));
+  const int rm0 = lr_readlane_i(rmax, 0), rm1 = lr_readlane_i(rmax, 16), rm2 = lr_readlane_i(rmax, 32),
+            rm3 = lr_readlane_i(rmax, 48);
+  const int maxc = max(max(rm0, rm1), max(rm2, rm3));
+  if (maxc == 0) return;
+
+  float4* const stage = lr_stage[wq];
+  if (lane < LR_RB_SLOT) stage[64 * LR_RB_SLOT + lane] = float4{0.f, 0.f, 0.f, 0.f};   // the all-zero entry (id patched below)
+  if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
+
+  // Where a row's sums go (see the packing in the loop): lanes (lane & 3) == 0, one per quad of the row.
+  //   S1: quads (col r, col b, col g, opacity)   S2: quads (mean x, conic A, mean y, conic B)   S3: quads 0 / 2: conic C of entry 0 / 1
+  const int qd = li >> 2;
+  const bool lead = (li & 3) == 0;
+  float* const base1 = qd == 3 ? g_opac : g_col + (qd == 0 ? 0 : (qd == 1 ? 2 : 1));
+  const uint32_t mul1 = qd == 3 ? 1u : 3u;
+  float* const base2 = (qd & 1) ? g_conic + (qd >> 1) : g_mean2d + (qd >> 1);
+  const uint32_t mul2 = (qd & 1) ? 4u : 3u;
+  float* const base3 = g_conic + 2;
+  const uint32_t shift8 = 8u * (uint32_t)row;
+
+  // the four blocks of this quadrant (wave-uniform), for the support tests
+  const float bx[2] = {(float)qx0, (float)(qx0 + 4)}, by[2] = {(float)qy0, (float)(qy0 + 4)};
+
+  const uint32_t nchunks = ((uint32_t)maxc + 63u) >> 6;
+  auto load_id = [&](uint32_t c) -> uint32_t {
+    const int pos = maxc - 1 - (int)(c * 64u) - lane;
+    return (c < nchunks && pos >= 0) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
+  };
+  uint32_t id_n = load_id(0), id_nn = load_id(1);
+  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
+  float cb_n = 0.f;
+  if (id_n != 0xffffffffu) {
+    const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
+    g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
+  }
+
+  for (uint32_t ch = 0; ch < nchunks; ch++) {
+    const int hi = maxc - (int)(ch * 64u);
+    const uint32_t id = id_n;
+    const float4 g0 = g0_n, g1 = g1_n;
+    const float cb = cb_n;
+    id_n = id_nn;
+    id_nn = load_id(ch + 2);
+    if (id_n != 0xffffffffu) {
+      const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
+      g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
+    }
+    // this chunk's entries -> LDS (the wave's own slots; the previous chunk's reads have all returned)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    stage[lane * LR_RB_SLOT + 0] = g0;
+    stage[lane * LR_RB_SLOT + 1] = g1;
+    stage[lane * LR_RB_SLOT + 2] = float4{cb, __uint_as_float(id), 0.f, 0.f};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // which rows does lane's entry concern?  valid, in front of the row's deepest contributor, and able to reach the
+    // alpha floor somewhere in the row's 4x4 block (conservative test shared with the binning stage)
+    const bool valid = id != 0xffffffffu;
+    const int pos = hi - 1 - lane;
+    bool r0 = valid & (pos < rm0), r1 = valid & (pos < rm1), r2 = valid & (pos < rm2), r3 = valid & (pos < rm3);
+    if (cull) {
+      const LrSupport sp = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
+      r0 = r0 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[0], by[0] + 3.f);
+      r1 = r1 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[0], by[0] + 3.f);
+      r2 = r2 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[1], by[1] + 3.f);
+      r3 = r3 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[1], by[1] + 3.f);
+    }
+    uint64_t m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
+    while (m0 | m1 | m2 | m3) {
+      // every row's next two entries (64 = none: the all-zero slot)
+      uint32_t pa = 0u, pb = 0u;
+#define LR_TAKE(m, sh)                                                                          \
+      {                                                                                         \
+        uint32_t ja = 64u, jb = 64u;                                                            \
+        if (m) { ja = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
+        if (m) { jb = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
+        pa |= ja << (sh); pb |= jb << (sh);                                                     \
+      }
+      LR_TAKE(m0, 0) LR_TAKE(m1, 8) LR_TAKE(m2, 16) LR_TAKE(m3, 24)
+#undef LR_TAKE
+      const uint32_t ja = (pa >> shift8) & 0xffu, jb = (pb >> shift8) & 0xffu;      // this lane's row's entries
+      const float4* sa = stage + ja * LR_RB_SLOT;
+      const float4* sb = stage + jb * LR_RB_SLOT;
+      const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
+      const uint32_t gida = __float_as_uint(a2.y), gidb = __float_as_uint(b2.y);
+      const float op0 = a1.y, op1 = b1.y;
+      const lr_f2 dx2 = lr_f2{a0.x, b0.x} - pxf, dy2 = lr_f2{a0.y, b0.y} - pyf;
+      const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
+      const lr_f2 bdx = lr_f2{a0.w, b0.w} * dx2;
+      const lr_f2 pw2 = lr_fma2(lr_f2{a0.z, b0.z} * dx2, hdx2,
+                                lr_fma2(lr_f2{a1.x, b1.x} * dy2, hdy2, lr_f2{-bdx.x, -bdx.y} * dy2));
+      const lr_f2 G2 = lr_exp2(pw2);
+      const lr_f2 al2 = lr_f2{op0, op1} * G2;
+      const float alpha0 = fminf(0.99f, al2.x), alpha1 = fminf(0.99f, al2.y);
+      const int k0 = hi - 1 - (int)ja, k1 = hi - 1 - (int)jb;   // list positions (the all-zero slot has opacity 0: never a hit)
+      const bool hit0 = (k0 < lastc) & !(pw2.x > 0.f) & !(alpha0 < 1.0f / 255.0f);
+      const bool hit1 = (k1 < lastc) & !(pw2.y > 0.f) & !(alpha1 < 1.0f / 255.0f);
+      const lr_f2 alpha = {hit0 ? alpha0 : 0.f, hit1 ? alpha1 : 0.f};
+      const bool any = __builtin_amdgcn_ballot_w64((alpha.x > 0.f) | (alpha.y > 0.f)) != 0;
+      if (!any) continue;
+      const lr_f2 G = {hit0 ? G2.x : 0.f, hit1 ? G2.y : 0.f};
+      const lr_f2 om = 1.f - alpha;
+      lr_f2 rc = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+      rc = lr_fma2(lr_fma2(-om, rc, lr_f2{1.f, 1.f}), rc, rc);
+      const float Ta = T * rc.x, Tb = Ta * rc.y;
+      const lr_f2 T2 = {Ta, Tb};
+      T = Tb;
+      const lr_f2 w = alpha * T2;
+      const lr_f2 cr = {a1.z, b1.z}, cg = {a1.w, b1.w}, cbl = {a2.x, b2.x};
+      const float a0r = lr_fma(alpha.x, cr.x, om.x * acc0), a0g = lr_fma(alpha.x, cg.x, om.x * acc1),
+                  a0b = lr_fma(alpha.x, cbl.x, om.x * acc2);
+      lr_f2 dL_dalpha = lr_fma2(cr - lr_f2{acc0, a0r}, lr_f2{dp0, dp0},
+                                lr_fma2(cg - lr_f2{acc1, a0g}, lr_f2{dp1, dp1}, (cbl - lr_f2{acc2, a0b}) * dp2));
+      dL_dalpha = lr_fma2(dL_dalpha, T2, -(Tf * rc) * bgdot);
+      acc0 = lr_fma(alpha.y, cr.y, om.y * a0r);
+      acc1 = lr_fma(alpha.y, cg.y, om.y * a0g);
+      acc2 = lr_fma(alpha.y, cbl.y, om.y * a0b);
+      const lr_f2 Ar = {a0.z, b0.z}, Br = {a0.w, b0.w}, Cr = {a1.x, b1.x};
+      const lr_f2 dL_dG = lr_f2{op0, op1} * dL_dalpha;
+      const lr_f2 gdx = G * dx2, gdy = G * dy2;
+      const lr_f2 dG_ddx = lr_fma2(-Ar, gdx, -(Br * gdy));
+      const lr_f2 dG_ddy = lr_fma2(-Cr, gdy, -(Br * gdx));
+      const lr_f2 c0 = w * dp0, c1 = w * dp1, c2 = w * dp2, go = G * dL_dalpha;
+      const lr_f2 mxs = dL_dG * dG_ddx * sx, mys = dL_dG * dG_ddy * sy;
+      const lr_f2 kA = -0.5f * gdx * dx2 * dL_dG, kB = -gdx * dy2 * dL_dG, kC = -0.5f * gdy * dy2 * dL_dG;
+      // row reductions, packed: S1 quads = (col r, col b, col g, opacity), S2 quads = (mean x, conic A, mean y, conic B)
+      const float s1a = lr_quad_total(lr_row_pair4(lr_row_pair8(c0.x, c1.x), lr_row_pair8(c2.x, go.x)));
+      const float s1b = lr_quad_total(lr_row_pair4(lr_row_pair8(c0.y, c1.y), lr_row_pair8(c2.y, go.y)));
+      const float s2a = lr_quad_total(lr_row_pair4(lr_row_pair8(mxs.x, mys.x), lr_row_pair8(kA.x, kB.x)));
+      const float s2b = lr_quad_total(lr_row_pair4(lr_row_pair8(mxs.y, mys.y), lr_row_pair8(kA.y, kB.y)));
+      float s3 = lr_row_pair8(kC.x, kC.y);                      // lanes 0-7: entry 0's conic C, lanes 8-15: entry 1's
+      s3 = lr_quad_total(s3 + lr_dpp_perm<0x141>(s3));
+      if (!(ablate & 1)) {
+        if (lead && gida != 0xffffffffu) {
+          atomicAdd(base1 + (size_t)gida * mul1, s1a);
+          atomicAdd(base2 + (size_t)gida * mul2, s2a);
+        }
+        if (lead && gidb != 0xffffffffu) {
+          atomicAdd(base1 + (size_t)gidb * mul1, s1b);
+          atomicAdd(base2 + (size_t)gidb * mul2, s2b);
+        }
+        const uint32_t gid3 = (qd & 2) ? gidb : gida;
+        if (lead && !(qd & 1) && gid3 != 0xffffffffu) atomicAdd(base3 + (size_t)gid3 * 4u, s3);
+      }
+    }
+  }
+}
+
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
@@ -447,9 +665,18 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
   static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
+  // LOGRAST_BWD_ROWS=1: the row-split form (the four 16-lane rows of a wave walk their own 4x4 blocks); 0: one
+  // (Gaussian, quadrant) pair per visit.  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
+  static const int rows = lr_env_int("LOGRAST_BWD_ROWS", 0);
+  static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);
   lr_prof_begin(LRK_BLEND_BWD, s);
-  hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom), state,
-                     tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
-                     xcd_mode, cull);
+  if (rows)
+    hipLaunchKernelGGL(lr_blend_bwd_rows_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom),
+                       state, tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
+                       xcd_mode, cull, ablate);
+  else
+    hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom), state,
+                       tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
+                       xcd_mode, cull);
   lr_prof_end(LRK_BLEND_BWD, s);
 }

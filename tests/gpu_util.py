@@ -164,10 +164,12 @@ def compare_forward(hf, of):
 #   (2) EVERY row, whatever its conditioning: |hip - f64| <= 2 |oracle - f64| + ROW_FLOOR * cond * 6e-8 * |f64| -- the HIP
 #       kernels are no further from the float64 gradient than twice the fp32 CPU oracle is, up to the summation-order
 #       noise both have (measured between two oracle runs with different thread counts: <= 100 such units, q99.9 = 4);
-#   (3) in L2 over all rows: |hip - f64| <= 2 |oracle - f64|;
+#   (3) in L2 over all rows: |hip - f64| <= 2 |oracle - f64| + L2_FLOOR units of amplified round-off (in L2 over the rows:
+#       on a scene of a hundred Gaussians both errors are a handful of such units and their ratio is noise);
 #   (4) rows the float64 twin leaves at zero (culled, or contributing to no pixel) are exactly zero.
 COND_BOUND = 500.0
 ROW_FLOOR = 256.0
+L2_FLOOR = 32.0
 EPS32 = 6e-8
 
 
@@ -198,6 +200,7 @@ def gradient_anchor_stats(hg, og, g64):
                      max_row_rel_well_hip=float((eh[well] / y[well]).max()) if well.any() else 0.0,
                      row_bound_violations=int((excess > ROW_FLOOR).sum()), worst_row_excess_units=float(excess.max()) if live.any() else 0.0,
                      err_l2_ratio=float(np.linalg.norm(eh) / max(float(np.linalg.norm(eo)), 1e-300)),
+                     err_l2_excess_units=float((np.linalg.norm(eh) - 2.0 * np.linalg.norm(eo)) / max(float(np.linalg.norm(unit)), 1e-300)),
                      zero_rows_nonzero=int((hg[k][~live] != 0).any(axis=1).sum()),
                      cond_q50_q99_max=[float(q) for q in np.quantile(cond[live, j], [0.5, 0.99, 1.0])] if live.any() else [0, 0, 0])
     return st
@@ -222,5 +225,5 @@ def assert_gradients_anchored(st, tol=1e-4, max_excluded=0.02, name=None):
         assert s["excluded_fraction"] <= max_excluded, (k, s)
         assert s["rel_l2_well_hip"] <= tol, (k, s)
         assert s["row_bound_violations"] == 0, (k, s)
-        assert s["err_l2_ratio"] <= 2.0, (k, s)
+        assert s["err_l2_excess_units"] <= L2_FLOOR, (k, s)
         assert s["zero_rows_nonzero"] == 0, (k, s)

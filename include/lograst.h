@@ -191,6 +191,18 @@ int lograst_tile_rows(const lograst_view* view, int32_t n, const float* means3d,
  * and size must be multiples of 16 bytes.  Not on the rasterizer's path. */
 int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, void* stream);
 
+/* ---- performance knobs -------------------------------------------------------------------------------------------
+ * Launch-shape parameters that change no result (thresholds, grid caps, dispatch orders; the list is enumerated by
+ * lograst_knob_count / lograst_knob_info).  Each is the environment variable of the same name unless overridden here;
+ * overrides take effect from the next launch.  Sizing helpers (lograst_tile_state_bytes) and the forward of one view must
+ * see the same values: change knobs between views, not between a sizing call and its forward.  log_amd.tune() calibrates
+ * them per device.  All return 0 or LOGRAST_ERR_ARG (unknown name / value outside [lo, hi]). */
+int lograst_knob_count(void);
+int lograst_knob_info(int32_t index, const char** name, int32_t* dflt, int32_t* lo, int32_t* hi, const char** what);
+int lograst_set_knob(const char* name, int32_t value);
+int lograst_get_knob(const char* name, int32_t* value);
+int lograst_reset_knobs(void);
+
 /* Copies {num_instances, overflow_flag, longest tile list, rect instances} of a tile_state to host (synchronises
  * the stream; any pointer may be NULL).  rect_instances = what the plain rect rule of the reference would have
  * binned (num_rendered of the third-party package); num_instances <= rect_instances when the support cull is on. */

@@ -66,6 +66,12 @@ _SIGNATURES = {
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),
                                           ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32), c_void_p]),
     "lograst_set_tile_cull": (ctypes.c_int, [ctypes.c_int]),
+    "lograst_knob_count": (ctypes.c_int, []),
+    "lograst_knob_info": (ctypes.c_int, [c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_int32),
+                                         ctypes.POINTER(c_int32), ctypes.POINTER(c_int32), ctypes.POINTER(ctypes.c_char_p)]),
+    "lograst_set_knob": (ctypes.c_int, [ctypes.c_char_p, c_int32]),
+    "lograst_get_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(c_int32)]),
+    "lograst_reset_knobs": (ctypes.c_int, []),
     "lograst_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 18 + [c_int32, c_void_p]),
     "lograst_project_backward": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32] + [c_void_p] * 10),
     "lograst_sh_forward": (ctypes.c_int, [c_int32, c_int32, c_int32] + [c_void_p] * 6),

@@ -88,6 +88,35 @@ int lr_env_int(const char* name, int dflt) {
   const char* e = std::getenv(name);
   return (e && *e) ? std::atoi(e) : dflt;
 }
+// ---- performance knobs ------------------------------------------------------------------------------------
+// The tunable ones (lograst_knob_info enumerates them for log_amd.tune): name = the environment variable, default, range.
+struct LrKnobInfo { const char* name; int dflt, lo, hi; const char* what; };
+static const LrKnobInfo kKnobs[] = {
+    {"LOGRAST_HELPER_MIN_N", 4000000, 0, 2000000000, "Gaussians from which the helper passes (absolute slot table, touched-only dL/dconic clearing, separate zero-fill kernels) pay for their launches"},
+    {"LOGRAST_DEFER_TILES", LR_COOP_TILES, 4, 4096, "rects above this many tiles are counted by lr_count_huge_kernel (one wave per rect) instead of by their lane"},
+    {"LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK, 256, 8192, "Gaussians per workgroup of lr_count_huge_kernel (multiple of 256)"},
+    {"LOGRAST_BATCH_PLANES", 4, 1, 4, "consecutive projection batches one workgroup owns"},
+    {"LOGRAST_BATCH_SLOTS", 256, 64, 1024, "workgroups per round the batched projection sizes its batches for"},
+    {"LOGRAST_SEPARATE_ZERO", 1, 0, 1, "large inputs: zero-fills streamed by kernels of their own instead of inside the fill kernel"},
+    {"LOGRAST_FILL_XCD_ORDER", 1, 0, 1, "fill kernel walks the Gaussians XCD-contiguously"},
+    {"LOGRAST_FILL_NT", 1, 0, 1, "fill kernel: non-temporal streams for the fill records and zero-fills"},
+    {"LOGRAST_XCD_MODE", 3, 0, 3, "blockIdx -> tile mapping of the compositing kernels (3 = longest list first)"},
+    {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
+    {"LOGRAST_BWD_ROWS", 0, 0, 1, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave"},
+};
+static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
+static std::mutex g_knob_mu;
+static std::vector<std::pair<std::string, int>> g_knob_over;   // overrides set through lograst_set_knob
+static std::atomic<unsigned> g_knob_gen{1};
+unsigned lr_knob_generation() { return g_knob_gen.load(std::memory_order_acquire); }
+int lr_knob_lookup(const char* name, int dflt) {
+  {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    for (auto& kv : g_knob_over)
+      if (kv.first == name) return kv.second;
+  }
+  return lr_env_int(name, dflt);
+}
 // Support cull in the binning kernels (project.hip): on unless LOGRAST_TILE_CULL=0 or lograst_set_tile_cull(0).
 static std::atomic<int> g_tile_cull{-1};
 // Gaussians per projection batch (project.hip: lr_project_batched_kernel), 0 = unbatched kernel, and the number of
@@ -99,7 +128,8 @@ static std::atomic<int> g_tile_cull{-1};
 struct LrBatching { uint32_t batch, planes; };
 static LrBatching lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t gy) {
   static const int forced = lr_env_int("LOGRAST_BATCH", -1);
-  static const uint32_t max_planes = (uint32_t)lr_env_int("LOGRAST_BATCH_PLANES", 4);
+  LR_KNOB(max_planes_k, "LOGRAST_BATCH_PLANES", 4);
+  const uint32_t max_planes = (uint32_t)max_planes_k;
   if (n <= 0 || tiles > LR_BATCH_MAX_TILES || gx > 8191u || gy > 8191u || forced == 0) return {0u, 1u};  // 13-bit tile coordinates in the fill record
   uint32_t smax = (uint32_t)(LR_BATCH_LDS_BYTES / (sizeof(uint32_t) * (size_t)tiles));
   if (smax > max_planes) smax = max_planes;
@@ -111,7 +141,8 @@ static LrBatching lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t
   }
   // One workgroup of 1024 threads per CU (82 VGPRs): 256 run at a time.  Size the work so that the workgroups fill
   // whole rounds of 256 (10 M Gaussians: 306 batches of 32768 = 1.2 rounds ran as long as 2).
-  static const uint32_t slots = (uint32_t)lr_env_int("LOGRAST_BATCH_SLOTS", 256);
+  LR_KNOB(slots_k, "LOGRAST_BATCH_SLOTS", 256);
+  const uint32_t slots = (uint32_t)(slots_k > 0 ? slots_k : 256);
   const uint64_t per_round = (uint64_t)slots * 32768u * smax;
   const uint32_t rounds = (uint32_t)(((uint64_t)n + per_round - 1u) / per_round);
   const uint32_t groups = slots * rounds;                                  // workgroups
@@ -129,7 +160,7 @@ static uint32_t lr_batches(int32_t n, uint32_t batch) { return batch ? ((uint32_
 // save is smaller than that): lr_rebase_kernel (absolute slot table for the fill) and the touched-only clearing of
 // dL/dconic.  Both stages of a forward evaluate this with the same n.
 static bool lr_big_input(int32_t n) {
-  static const int min_n = lr_env_int("LOGRAST_HELPER_MIN_N", 4000000);
+  LR_KNOB(min_n, "LOGRAST_HELPER_MIN_N", 4000000);
   return n >= min_n;
 }
 
@@ -302,7 +333,7 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   int zero_floats = bwd_scratch_floats;
   if (touched_only) { zero_block += 4 * (size_t)n; zero_floats -= 4; }
   float* zero_n = v.extras ? point_weight : nullptr;
-  static const int separate_zero = lr_env_int("LOGRAST_SEPARATE_ZERO", 1);   // 0: always inside the fill kernel (experiments)
+  LR_KNOB(separate_zero, "LOGRAST_SEPARATE_ZERO", 1);   // 0: always inside the fill kernel
   if (separate_zero && lr_big_input(n)) {   // large inputs: streamed by kernels of their own (see lr_zero_floats_kernel)
     lr_launch_zero_floats(zero_n, (size_t)n, s);
     if (zero_floats > 0) lr_launch_zero_floats(zero_block, (size_t)zero_floats * (size_t)n, s);
@@ -511,6 +542,51 @@ int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks
     return lr_fail(LOGRAST_ERR_ARG, "lograst_stream_copy: pointers and size must be multiples of 16 bytes");
   lr_launch_stream_copy(src, dst, bytes, blocks, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+int lograst_knob_count(void) { return kNumKnobs; }
+int lograst_knob_info(int32_t index, const char** name, int32_t* dflt, int32_t* lo, int32_t* hi, const char** what) {
+  if (index < 0 || index >= kNumKnobs) return lr_fail(LOGRAST_ERR_ARG, "knob index out of range");
+  if (name) *name = kKnobs[index].name;
+  if (dflt) *dflt = kKnobs[index].dflt;
+  if (lo) *lo = kKnobs[index].lo;
+  if (hi) *hi = kKnobs[index].hi;
+  if (what) *what = kKnobs[index].what;
+  return LOGRAST_OK;
+}
+static const LrKnobInfo* lr_find_knob(const char* name) {
+  if (!name) return nullptr;
+  for (int i = 0; i < kNumKnobs; i++)
+    if (std::strcmp(kKnobs[i].name, name) == 0) return &kKnobs[i];
+  return nullptr;
+}
+int lograst_set_knob(const char* name, int32_t value) {
+  const LrKnobInfo* k = lr_find_knob(name);
+  if (!k) return lr_fail(LOGRAST_ERR_ARG, std::string("unknown knob: ") + (name ? name : "(null)"));
+  if (value < k->lo || value > k->hi) return lr_fail(LOGRAST_ERR_ARG, std::string(name) + ": value out of range");
+  {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    bool found = false;
+    for (auto& kv : g_knob_over)
+      if (kv.first == name) { kv.second = value; found = true; }
+    if (!found) g_knob_over.emplace_back(name, value);
+  }
+  g_knob_gen.fetch_add(1, std::memory_order_acq_rel);
+  return LOGRAST_OK;
+}
+int lograst_get_knob(const char* name, int32_t* value) {
+  const LrKnobInfo* k = lr_find_knob(name);
+  if (!k || !value) return lr_fail(LOGRAST_ERR_ARG, "unknown knob or NULL pointer");
+  *value = lr_knob_lookup(k->name, k->dflt);
+  return LOGRAST_OK;
+}
+int lograst_reset_knobs(void) {
+  {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    g_knob_over.clear();
+  }
+  g_knob_gen.fetch_add(1, std::memory_order_acq_rel);
   return LOGRAST_OK;
 }
 

@@ -238,7 +238,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
                          int* pid, float* pwp, float* pw, float* zero_conic, hipStream_t s) {
-  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
+  LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
   static const size_t lds_fwd = (size_t)lr_env_int("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
@@ -661,13 +661,13 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
                          hipStream_t s) {
-  static const int xcd_mode = lr_env_int("LOGRAST_XCD_MODE", 3);
+  LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
   static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   // LOGRAST_BWD_ROWS=1: the row-split form (the four 16-lane rows of a wave walk their own 4x4 blocks); 0: one
   // (Gaussian, quadrant) pair per visit.  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
-  static const int rows = lr_env_int("LOGRAST_BWD_ROWS", 0);
+  LR_KNOB(rows, "LOGRAST_BWD_ROWS", 0);
   static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);
   lr_prof_begin(LRK_BLEND_BWD, s);
   if (rows)

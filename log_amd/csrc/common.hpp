@@ -404,3 +404,17 @@ enum LrKernelSlot {
 void lr_prof_begin(int slot, hipStream_t s);
 void lr_prof_end(int slot, hipStream_t s);
 int lr_env_int(const char* name, int dflt);
+// Performance knobs (api.hip): value = lograst_set_knob override, else the environment variable of that name, else the
+// default.  Read at every launch through a per-call-site cache that is refreshed when any knob changes, so that
+// log_amd.tune() can move them at run time.  None of them changes a result (tests/test_gpu_knobs.py sweeps them and
+// compares bit for bit).
+struct LrKnobCache { int value; unsigned gen; };
+extern unsigned lr_knob_generation();
+int lr_knob_lookup(const char* name, int dflt);
+#define LR_KNOB(var, name, dflt)                                                       \
+  static LrKnobCache var##_cache = {0, 0xffffffffu};                                   \
+  if (var##_cache.gen != lr_knob_generation()) {                                       \
+    var##_cache.value = lr_knob_lookup(name, dflt);                                    \
+    var##_cache.gen = lr_knob_generation();                                            \
+  }                                                                                    \
+  const int var = var##_cache.value

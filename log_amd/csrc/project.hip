@@ -469,8 +469,9 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
       attr_set = true;
     }
-    static const int defer_tiles = lr_env_int("LOGRAST_DEFER_TILES", LR_COOP_TILES);
-    static const int chunk = lr_env_int("LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK) / 256 * 256;
+    LR_KNOB(defer_tiles, "LOGRAST_DEFER_TILES", LR_COOP_TILES);
+    LR_KNOB(chunk_k, "LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK);
+    const int chunk = chunk_k >= 256 ? chunk_k / 256 * 256 : 256;
     const int batches = (N + batch - 1) / batch;
     const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
     uint32_t* hugecount = basetab + (size_t)batches * tiles;
@@ -485,7 +486,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     lr_prof_end(LRK_RESERVED, s);
     return;
   } else {
-    static const int max_blocks = lr_env_int("LOGRAST_PROJECT_BLOCKS", 512);  // 2 workgroups per CU: measured optimum
+    LR_KNOB(max_blocks, "LOGRAST_PROJECT_BLOCKS", 512);  // 2 workgroups per CU: measured optimum
     int blocks = (N + 255) / 256;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(lr_project_kernel, dim3(blocks), dim3(256), 0, s, v, N, means, scales, rots, opac, colors, radii,
@@ -827,8 +828,8 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
                     int zero_block_floats, int rebased, int speculative, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
-  static const int xcd_order = lr_env_int("LOGRAST_FILL_XCD_ORDER", 1);
-  static const int fill_nt = lr_env_int("LOGRAST_FILL_NT", 1);
+  LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
+  LR_KNOB(fill_nt, "LOGRAST_FILL_NT", 1);
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores
   const int blocks = ((N + 255) / 256 + 7) & ~7;
   hipLaunchKernelGGL(lr_fill_kernel, dim3(blocks), dim3(256), 0, s, N, gx,

@@ -67,3 +67,53 @@ def test_product_path_refuses_cpu_tensors():
     model, camera = U.log_like(g, "cpu")
     with pytest.raises(_lib.LograstError):
         get_all.get_all(model, camera, None)
+
+
+def test_a_training_view_leaves_no_tensor_in_a_reference_cycle(double):
+    """What a view allocates must die with the view's last reference, not at the next run of Python's cyclic collector:
+    an autograd Function whose ctx can reach one of its own output tensors (output -> grad_fn -> ctx -> output) keeps the
+    gathered rows, the AccumulateGrad nodes and through them the parameters' .grad alive -- GBs per C3 view, each a fresh
+    hipMalloc (round-2 verdict, weak #7).  One get_all + rasterizer forward / backward through the drop-ins, then every
+    reference dropped: the collector must find no tensor and no autograd node."""
+    import gc
+    import weakref
+    from log_amd import get_all, rasterizer as R
+    from log_amd import scenes
+    from util import cam_tan
+    g = np.load(U.GOLDEN[1])
+    cam = scenes.orbit_cameras(2, W=64, H=48, focal=60.0)[0]
+    tfx, tfy = cam_tan(cam)
+    T = lambda a: torch.tensor(np.asarray(a, np.float32))
+    rs = R.GaussianRasterizationSettings(48, 64, tfx, tfy, T([1, 1, 1]), 1.0, T(cam["world_view_transform"]),
+                                         T(cam["full_proj_transform"]), 0, T(cam["camera_center"]), False, False)
+    rast = R.GaussianRasterizer(raster_settings=rs)
+    watch = []
+
+    model, camera = U.log_like(g, "cpu")       # long-lived, like LoG's model (the stand-in is itself a cycle: keep it alive)
+    flags0 = dict(model.gaussian.visibility_flag)
+
+    def view():
+        model.gaussian.visibility_flag = dict(flags0)
+        act = get_all.get_all(model, camera, rast)
+        m2 = torch.zeros_like(act["xyz"], requires_grad=True)
+        out = rast(means3D=act["xyz"], means2D=m2, shs=None, colors_precomp=act["colors"], opacities=act["opacity"],
+                   scales=act["scaling"], rotations=act["rotation"], cov3D_precomp=None)
+        out[0].sum().backward()
+        params = model.gaussian.visibility_flag["params"]
+        assert params["scaling"].grad is not None
+        watch.extend(weakref.ref(t) for t in (act["colors"], act["xyz"], params["scaling"], params["scaling"].grad, out[0], out[4]))
+        model.gaussian.visibility_flag = None     # (LoG replaces it at the next view)
+
+    gc.collect()
+    gc.disable()
+    try:
+        view()
+        assert [w() is None for w in watch] == [True] * len(watch)        # freed by reference counting alone
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        bad = [type(o).__name__ for o in gc.garbage if isinstance(o, torch.Tensor) or type(o).__name__.endswith("Backward")]
+        assert not bad, bad
+    finally:
+        gc.set_debug(0)
+        gc.garbage.clear()
+        gc.enable()

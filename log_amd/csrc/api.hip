@@ -103,6 +103,7 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_XCD_MODE", 3, 0, 3, "blockIdx -> tile mapping of the compositing kernels (3 = longest list first)"},
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
     {"LOGRAST_BWD_ROWS", 0, 0, 1, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave"},
+    {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
 };
 static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
 static std::mutex g_knob_mu;

@@ -451,7 +451,12 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 //     ~50 VALU for BOTH entries of all four rows against 2 x 28 for one entry each of the whole wave.
 // The entries of a chunk are staged once per wave in LDS (48 B each; slot 64 is an all-zero entry that rows without work
 // read: alpha = 0 contributes nothing, branch-free); a row's lanes read their entry with three broadcast ds_read_b128.
-// Each row commits its own sums with the lanes (lane & 3) == 0: five atomic instructions per pass.
+// A row's sums do NOT go to memory from the loop: four rows x two entries x nine sums per pass, each its own memory-side
+// atomic, ran the reverse walk at the atomic units' rate (measured: C2 978 us with them, 220 us without; ~25 G atomic line
+// operations per second chip-wide, the same figure the binning kernels hit).  They are added into a per-wave table in LDS
+// (nine sums x 64 chunk entries, ds_add_f32 from the lanes (lane & 3) == 0: 16 lanes x 5 instructions per pass), and
+// when the chunk is done every entry that collected something is committed once per wave -- the memory-side traffic of
+// the quadrant form -- with the lanes arranged so that one instruction carries an entry's values that share a line.
 #define LR_RB_SLOT 3      // float4 per staged entry: (mx, my, A, B) (C, opacity, r, g) (b, id, -, -)
 template <int CTRL>
 LR_DEV float lr_dpp_perm(float x) {   // full-mask permutation within the row (all the controls used are self-inverse)
@@ -480,8 +485,9 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          const float* __restrict__ final_T, const int* __restrict__ n_contrib,
                          const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
                          float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
-                         int xcd_mode, int cull, int ablate) {
+                         int xcd_mode, int cull, int ablate, int block_test) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
+  __shared__ float lr_acc[4][9 * 65];          // [value][chunk entry]; column 64 swallows the sums of rows without work
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
@@ -517,16 +523,25 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   if (lane < LR_RB_SLOT) stage[64 * LR_RB_SLOT + lane] = float4{0.f, 0.f, 0.f, 0.f};   // the all-zero entry (id patched below)
   if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
 
-  // Where a row's sums go (see the packing in the loop): lanes (lane & 3) == 0, one per quad of the row.
+  // Where a row's sums go (see the packing in the loop): lanes (lane & 3) == 0, one per quad of the row, into the wave's
+  // table tab[value][entry] -- values: 0-2 colour r g b, 3 opacity, 4-5 mean x y, 6-8 conic A B C.
   //   S1: quads (col r, col b, col g, opacity)   S2: quads (mean x, conic A, mean y, conic B)   S3: quads 0 / 2: conic C of entry 0 / 1
   const int qd = li >> 2;
   const bool lead = (li & 3) == 0;
-  float* const base1 = qd == 3 ? g_opac : g_col + (qd == 0 ? 0 : (qd == 1 ? 2 : 1));
-  const uint32_t mul1 = qd == 3 ? 1u : 3u;
-  float* const base2 = (qd & 1) ? g_conic + (qd >> 1) : g_mean2d + (qd >> 1);
-  const uint32_t mul2 = (qd & 1) ? 4u : 3u;
-  float* const base3 = g_conic + 2;
+  float* const tab = lr_acc[wq];
+  float* const tab1 = tab + 65 * (qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3)));
+  float* const tab2 = tab + 65 * (qd == 0 ? 4 : (qd == 1 ? 6 : (qd == 2 ? 5 : 7)));
+  float* const tab3 = tab + 65 * 8;
+  for (int t = lane; t < 9 * 65; t += 64) tab[t] = 0.f;
   const uint32_t shift8 = 8u * (uint32_t)row;
+  // the commit at the end of a chunk: lanes as (entry, value) pairs so that values sharing a line share an instruction
+  //   A: 16 entries x (col r, g, b, opacity) per instruction, 4 instructions;  B: 12 entries x (mean x, y, conic A, B, C), 6
+  const int ea = lane >> 2, va = lane & 3;
+  float* const dstA = va == 3 ? g_opac : g_col + va;
+  const uint32_t mulA = va == 3 ? 1u : 3u;
+  const int eb = lane / 5, vb = lane - 5 * eb;          // lanes 60-63 idle in B
+  float* const dstB = vb < 2 ? g_mean2d + vb : g_conic + (vb - 2);
+  const uint32_t mulB = vb < 2 ? 3u : 4u;
 
   // the four blocks of this quadrant (wave-uniform), for the support tests
   const float bx[2] = {(float)qx0, (float)(qx0 + 4)}, by[2] = {(float)qy0, (float)(qy0 + 4)};
@@ -571,12 +586,24 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     bool r0 = valid & (pos < rm0), r1 = valid & (pos < rm1), r2 = valid & (pos < rm2), r3 = valid & (pos < rm3);
     if (cull) {
       const LrSupport sp = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
-      r0 = r0 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[0], by[0] + 3.f);
-      r1 = r1 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[0], by[0] + 3.f);
-      r2 = r2 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[1], by[1] + 3.f);
-      r3 = r3 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[1], by[1] + 3.f);
+      if (block_test) {   // the exact ellipse-vs-box test for each of the four blocks (~75 VALU each)
+        r0 = r0 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[0], by[0] + 3.f);
+        r1 = r1 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[0], by[0] + 3.f);
+        r2 = r2 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[1], by[1] + 3.f);
+        r3 = r3 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[1], by[1] + 3.f);
+      } else {            // exact test for the quadrant, the support's bounding box against each block (4 compares each)
+        const bool q = lr_support_box(sp, bx[0], bx[0] + 7.f, by[0], by[0] + 7.f);
+        const bool bb = sp.mode == 2;
+        const bool x_lo = !bb || (sp.mx - sp.ex <= bx[0] + 3.f), x_hi = !bb || (sp.mx + sp.ex >= bx[1]);
+        const bool y_lo = !bb || (sp.my - sp.ey <= by[0] + 3.f), y_hi = !bb || (sp.my + sp.ey >= by[1]);
+        r0 = r0 && q && x_lo && y_lo;
+        r1 = r1 && q && x_hi && y_lo;
+        r2 = r2 && q && x_lo && y_hi;
+        r3 = r3 && q && x_hi && y_hi;
+      }
     }
     uint64_t m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
+    bool touched = false;                                       // wave-uniform: some pass of this chunk contributed
     while (m0 | m1 | m2 | m3) {
       // every row's next two entries (64 = none: the all-zero slot)
       uint32_t pa = 0u, pb = 0u;
@@ -593,7 +620,6 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const float4* sa = stage + ja * LR_RB_SLOT;
       const float4* sb = stage + jb * LR_RB_SLOT;
       const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
-      const uint32_t gida = __float_as_uint(a2.y), gidb = __float_as_uint(b2.y);
       const float op0 = a1.y, op1 = b1.y;
       const lr_f2 dx2 = lr_f2{a0.x, b0.x} - pxf, dy2 = lr_f2{a0.y, b0.y} - pyf;
       const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
@@ -609,6 +635,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const lr_f2 alpha = {hit0 ? alpha0 : 0.f, hit1 ? alpha1 : 0.f};
       const bool any = __builtin_amdgcn_ballot_w64((alpha.x > 0.f) | (alpha.y > 0.f)) != 0;
       if (!any) continue;
+      touched = true;
       const lr_f2 G = {hit0 ? G2.x : 0.f, hit1 ? G2.y : 0.f};
       const lr_f2 om = 1.f - alpha;
       lr_f2 rc = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
@@ -641,19 +668,40 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const float s2b = lr_quad_total(lr_row_pair4(lr_row_pair8(mxs.y, mys.y), lr_row_pair8(kA.y, kB.y)));
       float s3 = lr_row_pair8(kC.x, kC.y);                      // lanes 0-7: entry 0's conic C, lanes 8-15: entry 1's
       s3 = lr_quad_total(s3 + lr_dpp_perm<0x141>(s3));
-      if (!(ablate & 1)) {
-        if (lead && gida != 0xffffffffu) {
-          atomicAdd(base1 + (size_t)gida * mul1, s1a);
-          atomicAdd(base2 + (size_t)gida * mul2, s2a);
-        }
-        if (lead && gidb != 0xffffffffu) {
-          atomicAdd(base1 + (size_t)gidb * mul1, s1b);
-          atomicAdd(base2 + (size_t)gidb * mul2, s2b);
-        }
-        const uint32_t gid3 = (qd & 2) ? gidb : gida;
-        if (lead && !(qd & 1) && gid3 != 0xffffffffu) atomicAdd(base3 + (size_t)gid3 * 4u, s3);
+      if (lead) {   // (rows without work add exact zeros into column 64)
+        atomicAdd(tab1 + ja, s1a);
+        atomicAdd(tab1 + jb, s1b);
+        atomicAdd(tab2 + ja, s2a);
+        atomicAdd(tab2 + jb, s2b);
+        if (!(qd & 1)) atomicAdd(tab3 + ((qd & 2) ? jb : ja), s3);
       }
     }
+    if (!touched) continue;
+    // commit this chunk: what the wave collected per entry, once, and clear the table for the next chunk
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int e = 16 * k + ea;
+      float* cell = tab + 65 * va + e;
+      const float x = *cell;
+      *cell = 0.f;
+      const uint32_t gid = (uint32_t)__shfl((int)id, e);
+      if (x != 0.f && !(ablate & 1)) atomicAdd(dstA + (size_t)gid * mulA, x);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int e = 12 * k + eb;
+      const bool on = lane < 60 && e < 64;
+      float* cell = tab + 65 * (4 + vb) + (on ? e : 64);
+      const float x = on ? *cell : 0.f;
+      if (on) *cell = 0.f;
+      const uint32_t gid = (uint32_t)__shfl((int)id, on ? e : 0);
+      if (x != 0.f && !(ablate & 1)) atomicAdd(dstB + (size_t)gid * mulB, x);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -669,11 +717,12 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
   // (Gaussian, quadrant) pair per visit.  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
   LR_KNOB(rows, "LOGRAST_BWD_ROWS", 0);
   static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);
+  LR_KNOB(block_test, "LOGRAST_BWD_BLOCK_TEST", 1);
   lr_prof_begin(LRK_BLEND_BWD, s);
   if (rows)
     hipLaunchKernelGGL(lr_blend_bwd_rows_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom),
                        state, tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
-                       xcd_mode, cull, ablate);
+                       xcd_mode, cull, ablate, block_test);
   else
     hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom), state,
                        tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,

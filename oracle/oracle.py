@@ -237,6 +237,16 @@ def backward_f64(view, fwd, dL_dimage, cond=True, pert=1e-7, trials=3):
                opacities=g_opac[:N].reshape(-1, 1), colors=g_col[:N], conic=g_conic[:N])
     if cond:
         out["cond"] = cnd[:N]
+        # the fp32 chain rule (ora_project_bwd: the op sequence the HIP kernel shares) on the float64 sums rounded to fp32:
+        # its distance from the float64 chain rule is the EVALUATION error of that row in fp32 -- for a needle-shaped
+        # Gaussian (two scales a thousand times below the third) the rounding of intermediates that perturbing the inputs
+        # cannot reach (the six entries of Sigma rounded independently, det = ac - b^2 of a nearly rank-1 covariance)
+        m32, s32, r32 = (np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 4), np.float32))
+        g2_32 = np.ascontiguousarray(g_mean2d, np.float32)
+        gc_32 = np.ascontiguousarray(g_conic, np.float32)
+        L.ora_project_bwd(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots), _p(fwd["radii"]),
+                          _p(g2_32), _p(gc_32), _p(m32), _p(s32), _p(r32), None, None)
+        out["chain32"] = dict(means3D=m32[:N], scales=s32[:N], rotations=r32[:N])
     return out
 
 

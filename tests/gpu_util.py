@@ -156,21 +156,35 @@ def compare_forward(hf, of):
 
 # ---- end-to-end gradients anchored on the float64 twin (oracle.backward_f64) -----------------------------------------
 # BASELINE.json: "gradients within 1e-4 relative L2".  The reverse walk's outputs meet that on every row.  Behind the
-# per-Gaussian chain rule a pancake-flat Gaussian amplifies a relative input error (fp32 round-off, the summation-order
-# noise of the walk's sums) by its condition number, which the float64 twin estimates per row (oracle/lograst_oracle.c:
-# ora64_project_bwd).  Tested claims, on every row the float64 twin leaves non-zero:
-#   (1) rows whose condition number is at most COND_BOUND (amplified round-off 500 * 6e-8 = 3e-5): relative L2 over all
-#       of them <= 1e-4 against the float64 twin; the fraction of rows above the bound is reported and bounded;
-#   (2) EVERY row, whatever its conditioning: |hip - f64| <= 2 |oracle - f64| + ROW_FLOOR * cond * 6e-8 * |f64| -- the HIP
-#       kernels are no further from the float64 gradient than twice the fp32 CPU oracle is, up to the summation-order
-#       noise both have (measured between two oracle runs with different thread counts: <= 100 such units, q99.9 = 4);
-#   (3) in L2 over all rows: |hip - f64| <= 2 |oracle - f64| + L2_FLOOR units of amplified round-off (in L2 over the rows:
-#       on a scene of a hundred Gaussians both errors are a handful of such units and their ratio is noise);
+# per-Gaussian chain rule a degenerate Gaussian (pancake: one scale far below the others; needle: two) loses digits in
+# ANY fp32 evaluation.  The float64 twin quantifies that per row, as a relative scale
+#     s_i = 6e-8 * cond_i  +  |chain32_i - f64_i| / |f64_i|
+# cond_i: how much the chain rule amplifies relative perturbations of its inputs -- the Gaussian's scales / quaternion, and
+# the five sums of the reverse walk, each moved by the magnitude of its addends' own terms (cancellation inside an addend
+# and among the addends); chain32_i: the fp32 chain rule (the op sequence the HIP kernel shares with the oracle) evaluated
+# on the float64 sums -- the rounding of intermediates that input perturbations cannot reach.  Tested claims, on every row
+# the float64 twin leaves non-zero:
+#   (1) rows fp32 can know to 3e-5 (s_i <= COND_BOUND * 6e-8): relative L2 over all of them <= 1e-4 against the float64
+#       twin; the fraction of rows beyond that is reported and bounded;
+#   (2) EVERY row, whatever its conditioning: |hip - f64| <= 2 |oracle - f64| + ROW_FLOOR * s_i * |f64| -- the HIP kernels are
+#       no further from the float64 gradient than twice the fp32 CPU oracle is, up to the rounding / summation-order noise
+#       any two fp32 evaluations have between them (calibrated on the CPU with a restatement of the HIP kernel's op order
+#       and reduction tree against the oracle);
+#   (3) in L2 over all rows: |hip - f64| <= 2 |oracle - f64| + L2_FLOOR of those units (in L2 over the rows: on a scene of a
+#       hundred Gaussians both errors are a handful of units and their ratio is noise);
 #   (4) rows the float64 twin leaves at zero (culled, or contributing to no pixel) are exactly zero.
 COND_BOUND = 500.0
-ROW_FLOOR = 256.0
+ROW_FLOOR = 64.0
 L2_FLOOR = 32.0
 EPS32 = 6e-8
+
+
+def row_units(g64, k, j):
+    """(unit, well) per row of chain-rule output k (column j of cond): unit = s_i * |f64_i| (absolute), well = rows fp32
+    can know to COND_BOUND * 6e-8."""
+    y = np.linalg.norm(g64[k], axis=1)
+    unit = EPS32 * np.maximum(g64["cond"][:, j], 1.0) * y + np.linalg.norm(g64["chain32"][k].astype(np.float64) - g64[k], axis=1)
+    return unit, (y > 0) & (unit <= COND_BOUND * EPS32 * y)
 
 
 def gradient_anchor_stats(hg, og, g64):
@@ -188,12 +202,13 @@ def gradient_anchor_stats(hg, og, g64):
         y = np.linalg.norm(ref, axis=1)
         eh, eo = np.linalg.norm(dh, axis=1), np.linalg.norm(do, axis=1)
         live = y > 0
-        kap = np.maximum(cond[:, j], 1.0)
-        unit = EPS32 * kap * y
-        well = live & (cond[:, j] <= COND_BOUND)
+        unit = EPS32 * np.maximum(cond[:, j], 1.0) * y + np.linalg.norm(g64["chain32"][k].astype(f64) - ref, axis=1)
+        rel_scale = np.where(live, unit / np.maximum(y, 1e-300), 0.0)
+        well = live & (rel_scale <= COND_BOUND * EPS32)
         nw = max(float(np.linalg.norm(ref[well])), 1e-300)
         na = max(float(np.linalg.norm(ref)), 1e-300)
         excess = np.where(live, (eh - 2.0 * eo) / np.maximum(unit, 1e-300), 0.0)
+        q = lambda a: [float(x) for x in np.quantile(a[live], [0.5, 0.99, 1.0])] if live.any() else [0.0, 0.0, 0.0]
         st[k] = dict(rows=int(live.sum()), excluded_fraction=float((live & ~well).sum() / max(int(live.sum()), 1)),
                      rel_l2_well_hip=float(np.linalg.norm(dh[well]) / nw), rel_l2_well_oracle=float(np.linalg.norm(do[well]) / nw),
                      rel_l2_all_hip=float(np.linalg.norm(dh) / na), rel_l2_all_oracle=float(np.linalg.norm(do) / na),
@@ -202,11 +217,12 @@ def gradient_anchor_stats(hg, og, g64):
                      err_l2_ratio=float(np.linalg.norm(eh) / max(float(np.linalg.norm(eo)), 1e-300)),
                      err_l2_excess_units=float((np.linalg.norm(eh) - 2.0 * np.linalg.norm(eo)) / max(float(np.linalg.norm(unit)), 1e-300)),
                      zero_rows_nonzero=int((hg[k][~live] != 0).any(axis=1).sum()),
-                     cond_q50_q99_max=[float(q) for q in np.quantile(cond[live, j], [0.5, 0.99, 1.0])] if live.any() else [0, 0, 0])
+                     rel_scale_q50_q99_max=q(rel_scale), hip_err_units_q50_q99_max=q(eh / np.maximum(unit, 1e-300)),
+                     oracle_err_units_q50_q99_max=q(eo / np.maximum(unit, 1e-300)))
     return st
 
 
-def assert_gradients_anchored(st, tol=1e-4, max_excluded=0.02, name=None):
+def assert_gradients_anchored(st, tol=1e-4, max_excluded=0.06, name=None):
     """The four claims above; `name`: also dump the statistics to gpurun_out/parity_stats/<name>.json (best effort)."""
     if name:
         import json

@@ -281,11 +281,9 @@ def test_image_split_into_tile_row_bands(oracle_mod, world):
     g64 = oracle_mod.backward_f64(v64, of, w.cpu().numpy())
     for j, (k, k64) in enumerate((("xyz", "means3D"), ("scaling", "scales"), ("rotation", "rotations"))):
         d = (g_sum[k] - g_full[k]).reshape(N, -1).double().norm(dim=1).cpu().numpy()
-        y = np.linalg.norm(g64[k64], axis=1)
-        unit = G.EPS32 * np.maximum(g64["cond"][:, j], 1.0) * y
-        assert (d <= 2.0 * G.ROW_FLOOR * unit).all(), (k, float((d / np.maximum(unit, 1e-300))[y > 0].max()))
-        assert rel_l2(g_full[k].cpu().numpy().astype(np.float64)[g64["cond"][:, j] <= G.COND_BOUND],
-                      g64[k64][g64["cond"][:, j] <= G.COND_BOUND]) < 1e-4, k
+        unit, well = G.row_units(g64, k64, j)
+        assert (d <= 2.0 * G.ROW_FLOOR * unit).all(), (k, float((d / np.maximum(unit, 1e-300))[unit > 0].max()))
+        assert rel_l2(g_full[k].cpu().numpy().astype(np.float64)[well], g64[k64][well]) < 1e-4, k
 
 
 @pytest.mark.parametrize("world", [3, 8])

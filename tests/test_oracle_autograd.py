@@ -69,10 +69,12 @@ def test_float64_twin_of_the_backward_vs_float64_autograd(oracle_mod, seed, opac
     for j, k in enumerate(("means3D", "scales", "rotations")):
         y = np.linalg.norm(g64[k], axis=1)
         live = y > 0
-        err = np.linalg.norm(g32[k].astype(np.float64) - g64[k], axis=1)[live] / y[live]
-        unit = 6e-8 * np.maximum(cond[live, j], 1.0)
-        # fp32 row errors against the conditioning model: the bulk within a few units (a unit = amplified round-off)
-        assert np.median(err / unit) < 20 and np.quantile(err / unit, 0.99) < 500, (k, float(np.median(err / unit)))
+        err = np.linalg.norm(g32[k].astype(np.float64) - g64[k], axis=1)[live]
+        # the per-row error scale of the GPU tests (tests/gpu_util.py: amplified round-off of the inputs + the fp32
+        # evaluation error of the chain rule itself): the fp32 oracle's own row errors are a few such units
+        unit = (6e-8 * np.maximum(cond[:, j], 1.0) * y + np.linalg.norm(g64["chain32"][k].astype(np.float64) - g64[k], axis=1))[live]
+        assert np.median(err / unit) < 5 and np.quantile(err / unit, 0.99) < 64 and (err / unit).max() < 512, \
+            (k, float(np.median(err / unit)), float((err / unit).max()))
 
 
 def test_invariants(oracle_mod):

@@ -195,10 +195,10 @@ def test_native_shs_degree3_full_size_through_the_gradient_sink(oracle_mod):
     g64 = oracle_mod.backward_f64(v, of, w_np)
     for j, k in ((1, "scales"), (2, "rotations")):
         hk, ref = sink[k].cpu().numpy().astype(np.float64), g64[k]
-        well = g64["cond"][:, j] <= G.COND_BOUND
-        assert float((~well & (np.linalg.norm(ref, axis=1) > 0)).mean()) <= 0.02
+        unit, well = G.row_units(g64, k, j)
+        live = np.linalg.norm(ref, axis=1) > 0
+        assert float((live & ~well).sum()) <= 0.06 * float(live.sum())
         assert rel_l2(hk[well], ref[well]) < 1e-4, k
         eh = np.linalg.norm(hk - ref, axis=1)
         eo = np.linalg.norm(og[k].astype(np.float64) - ref, axis=1)
-        unit = G.EPS32 * np.maximum(g64["cond"][:, j], 1.0) * np.linalg.norm(ref, axis=1)
-        assert (eh <= 2.0 * eo + G.ROW_FLOOR * unit).all(), k
+        assert (eh <= 2.0 * eo + G.ROW_FLOOR * unit).all(), (k, float(((eh - 2.0 * eo) / np.maximum(unit, 1e-300)).max()))

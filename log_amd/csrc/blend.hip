@@ -453,10 +453,12 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 // read: alpha = 0 contributes nothing, branch-free); a row's lanes read their entry with three broadcast ds_read_b128.
 // A row's sums do NOT go to memory from the loop: four rows x two entries x nine sums per pass, each its own memory-side
 // atomic, ran the reverse walk at the atomic units' rate (measured: C2 978 us with them, 220 us without; ~25 G atomic line
-// operations per second chip-wide, the same figure the binning kernels hit).  They are added into a per-wave table in LDS
-// (nine sums x 64 chunk entries, ds_add_f32 from the lanes (lane & 3) == 0: 16 lanes x 5 instructions per pass), and
-// when the chunk is done every entry that collected something is committed once per wave -- the memory-side traffic of
-// the quadrant form -- with the lanes arranged so that one instruction carries an entry's values that share a line.
+// operations per second chip-wide, the same figure the binning kernels hit).  Nor through LDS atomics (ds_add_f32 into a
+// per-wave table: ~1 lane per clock per CU, C2 344 us).  A row meets an entry at most ONCE per chunk, so its nine sums for
+// that entry have a cell of their own in a per-wave table tab[value][entry][row] and are written there with plain stores
+// (the lanes (lane & 3) == 0: 16 lanes x 5 ds_write_b32 per pass); when the chunk is done every entry's four row cells
+// are read back as one 16-byte access, summed, cleared, and committed once per wave -- the memory-side traffic of the
+// quadrant form -- with the lanes arranged so that one atomic instruction carries an entry's values that share a line.
 #define LR_RB_SLOT 3      // float4 per staged entry: (mx, my, A, B) (C, opacity, r, g) (b, id, -, -)
 template <int CTRL>
 LR_DEV float lr_dpp_perm(float x) {   // full-mask permutation within the row (all the controls used are self-inverse)
@@ -487,7 +489,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
                          int xcd_mode, int cull, int ablate, int block_test) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
-  __shared__ float lr_acc[4][9 * 65];          // [value][chunk entry]; column 64 swallows the sums of rows without work
+  __shared__ float4 lr_acc[4][9 * 65];         // per wave: [value][chunk entry] x (row 0..3); entry 64 swallows the sums of rows without work
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
@@ -524,15 +526,16 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
 
   // Where a row's sums go (see the packing in the loop): lanes (lane & 3) == 0, one per quad of the row, into the wave's
-  // table tab[value][entry] -- values: 0-2 colour r g b, 3 opacity, 4-5 mean x y, 6-8 conic A B C.
+  // table tab[value][entry][row] -- values: 0-2 colour r g b, 3 opacity, 4-5 mean x y, 6-8 conic A B C.
   //   S1: quads (col r, col b, col g, opacity)   S2: quads (mean x, conic A, mean y, conic B)   S3: quads 0 / 2: conic C of entry 0 / 1
   const int qd = li >> 2;
   const bool lead = (li & 3) == 0;
-  float* const tab = lr_acc[wq];
-  float* const tab1 = tab + 65 * (qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3)));
-  float* const tab2 = tab + 65 * (qd == 0 ? 4 : (qd == 1 ? 6 : (qd == 2 ? 5 : 7)));
-  float* const tab3 = tab + 65 * 8;
-  for (int t = lane; t < 9 * 65; t += 64) tab[t] = 0.f;
+  float4* const tab4 = lr_acc[wq];
+  float* const tab = reinterpret_cast<float*>(tab4) + row;       // this row's cell of (value, entry) = tab[4 * (65 * value + entry)]
+  float* const tab1 = tab + 4 * 65 * (qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3)));
+  float* const tab2 = tab + 4 * 65 * (qd == 0 ? 4 : (qd == 1 ? 6 : (qd == 2 ? 5 : 7)));
+  float* const tab3 = tab + 4 * 65 * 8;
+  for (int t = lane; t < 9 * 65; t += 64) tab4[t] = float4{0.f, 0.f, 0.f, 0.f};
   const uint32_t shift8 = 8u * (uint32_t)row;
   // the commit at the end of a chunk: lanes as (entry, value) pairs so that values sharing a line share an instruction
   //   A: 16 entries x (col r, g, b, opacity) per instruction, 4 instructions;  B: 12 entries x (mean x, y, conic A, B, C), 6
@@ -668,12 +671,12 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const float s2b = lr_quad_total(lr_row_pair4(lr_row_pair8(mxs.y, mys.y), lr_row_pair8(kA.y, kB.y)));
       float s3 = lr_row_pair8(kC.x, kC.y);                      // lanes 0-7: entry 0's conic C, lanes 8-15: entry 1's
       s3 = lr_quad_total(s3 + lr_dpp_perm<0x141>(s3));
-      if (lead) {   // (rows without work add exact zeros into column 64)
-        atomicAdd(tab1 + ja, s1a);
-        atomicAdd(tab1 + jb, s1b);
-        atomicAdd(tab2 + ja, s2a);
-        atomicAdd(tab2 + jb, s2b);
-        if (!(qd & 1)) atomicAdd(tab3 + ((qd & 2) ? jb : ja), s3);
+      if (lead) {   // (a row meets an entry once per chunk: plain stores; rows without work write zeros into entry 64)
+        tab1[4u * ja] = s1a;
+        tab1[4u * jb] = s1b;
+        tab2[4u * ja] = s2a;
+        tab2[4u * jb] = s2b;
+        if (!(qd & 1)) tab3[4u * ((qd & 2) ? jb : ja)] = s3;
       }
     }
     if (!touched) continue;
@@ -684,9 +687,10 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int e = 16 * k + ea;
-      float* cell = tab + 65 * va + e;
-      const float x = *cell;
-      *cell = 0.f;
+      float4* cell = tab4 + 65 * va + e;
+      const float4 c4 = *cell;
+      *cell = float4{0.f, 0.f, 0.f, 0.f};
+      const float x = (c4.x + c4.y) + (c4.z + c4.w);
       const uint32_t gid = (uint32_t)__shfl((int)id, e);
       if (x != 0.f && !(ablate & 1)) atomicAdd(dstA + (size_t)gid * mulA, x);
     }
@@ -694,9 +698,10 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     for (int k = 0; k < 6; k++) {
       const int e = 12 * k + eb;
       const bool on = lane < 60 && e < 64;
-      float* cell = tab + 65 * (4 + vb) + (on ? e : 64);
-      const float x = on ? *cell : 0.f;
-      if (on) *cell = 0.f;
+      float4* cell = tab4 + 65 * (4 + vb) + (on ? e : 64);
+      const float4 c4 = *cell;
+      *cell = float4{0.f, 0.f, 0.f, 0.f};
+      const float x = on ? (c4.x + c4.y) + (c4.z + c4.w) : 0.f;
       const uint32_t gid = (uint32_t)__shfl((int)id, on ? e : 0);
       if (x != 0.f && !(ablate & 1)) atomicAdd(dstB + (size_t)gid * mulB, x);
     }

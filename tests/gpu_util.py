@@ -234,8 +234,12 @@ def assert_gradients_anchored(st, tol=1e-4, max_excluded=0.06, name=None):
                 json.dump(st, f, indent=1)
         except OSError:
             pass
+    # the reverse walk's outputs against the float64 twin: within the tolerance, or -- where the fp32 forward's own
+    # evaluation error (alpha of a sharp splat; 1 / (1 - alpha) of a near-opaque one) already separates ANY fp32 reverse walk
+    # from the float64 one by more than that (one C2 view with random opacities: 1.7e-4 for HIP and oracle alike) -- no
+    # further from it than the fp32 oracle is; HIP against the oracle itself is asserted at 1e-4 by the callers
     for k in ("means2D", "conic", "opacities", "colors"):
-        assert st[k]["rel_l2_hip"] <= tol, (k, st[k])
+        assert st[k]["rel_l2_hip"] <= max(tol, 1.25 * st[k]["rel_l2_oracle"]), (k, st[k])
     for k in ("means3D", "scales", "rotations"):
         s = st[k]
         assert s["excluded_fraction"] <= max_excluded, (k, s)

@@ -22,6 +22,7 @@ SWEEP = {
     "LOGRAST_FILL_XCD_ORDER": (0, 1),
     "LOGRAST_FILL_NT": (0, 1),
     "LOGRAST_XCD_MODE": (0, 1, 2, 3),
+    "LOGRAST_PROJECT_BLOCKS": (64, 512, 4096),
     "LOGRAST_BWD_ROWS": (0, 1),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
 }

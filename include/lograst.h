@@ -27,9 +27,13 @@
 extern "C" {
 #endif
 
-#define LOGRAST_VERSION 2   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d */
+#define LOGRAST_VERSION 3   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows) */
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
+/* The reverse walk's accumulators: ONE 64-byte row per Gaussian -- slots 0-1 dL/d(ndc mean x, y), 2-4 dL/d(conic A, B, C),
+ * 5 dL/dopacity, 6-8 dL/dcolour r g b, 9-15 unused.  A memory-side atomic costs one operation per 64-byte line whatever the
+ * number of lanes in it (tools/micro/atomic_lines.hip), so a (wave, Gaussian) visit commits all nine sums as one. */
+#define LOGRAST_BWD_ROW_FLOATS 16
 
 /* 2-D low-pass flavours */
 #define LOGRAST_FILTER_NONE 0   /* use_filter=False of the fork (LoG/render/renderer.py:151-152) */
@@ -128,20 +132,20 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
  * under-estimate leaves such lists partially sorted, so pass 0 when in doubt.
  * Outputs: image[3,H,W], final_T[H,W], n_contrib[H,W] (both kept for backward), and when
  * view->extras: point_id_pixel[H,W] (i32, -1 = none), point_weight_pixel[H,W], point_weight[n].
- * bwd_scratch (optional, NULL/0 = none): a block of bwd_scratch_floats * n fp32 that this call zero-fills (inside
- * a kernel it launches anyway) for a caller that will run lograst_backward on this view: carve dL_dconic[n,4],
- * dL_dmeans2d[n,3] (7 floats per Gaussian, in this order) and, without LOGRAST_BWD_ACCUMULATE, dL_dopacities[n],
- * dL_dcolors[n,3] (11) out of it and pass LOGRAST_BWD_SCRATCH_ZEROED -- no separate memset launches.  With
- * view->extras on large inputs (n >= 4,000,000, env LOGRAST_HELPER_MIN_N) the leading dL_dconic block is cleared only
- * in the rows of Gaussians that contributed to a pixel (point_weight > 0; below that size the whole block is cleared):
- * always pass point_weight and LOGRAST_BWD_CONIC_TOUCHED_ONLY to lograst_backward after a forward with view->extras
- * (correct at every size; lograst_backward rejects LOGRAST_BWD_SCRATCH_ZEROED without point_weight on large inputs).
+ * bwd_scratch (optional, NULL/0 = none; bwd_scratch_floats must be 0 or LOGRAST_BWD_ROW_FLOATS): the n x 16 fp32
+ * accumulator rows of lograst_backward (its `bwd_rows`), zero-filled here (inside a kernel this call launches anyway) for
+ * a caller that will differentiate this view: pass the block to lograst_backward with LOGRAST_BWD_SCRATCH_ZEROED -- no
+ * separate memset.  With view->extras on large inputs (n >= 4,000,000, env LOGRAST_HELPER_MIN_N) only the rows of
+ * Gaussians that contributed to a pixel are cleared (point_weight > 0; the compositing kernel clears a row when it meets
+ * the Gaussian; below that size the whole block is cleared): always pass point_weight and
+ * LOGRAST_BWD_CONIC_TOUCHED_ONLY to lograst_backward after a forward with view->extras (correct at every size;
+ * lograst_backward rejects LOGRAST_BWD_SCRATCH_ZEROED without point_weight on large inputs).
  * max_tile_len is also CHECKED on the device: when the real longest list exceeds a non-zero max_tile_len (or the
  * instance count exceeds capacity) nothing is sorted or composited and the overflow flag of tile_state is raised; the
  * outputs of such a call are undefined.  status (optional): LOGRAST_STATUS_WORDS device words owned by the caller
  * (zeroed once), into which every forward records itself -- see LOGRAST_STATUS_* -- so that a caller running many
  * sync-free forwards, on any number of streams, checks all of them with one read-back.
- * bwd_scratch must be 16-byte aligned. */
+ * bwd_scratch must be 64-byte aligned. */
 int lograst_forward_render(const lograst_view* view, int32_t n, const void* geom, void* tile_state,
                            uint64_t* keys, uint32_t* point_list, uint32_t capacity, uint32_t max_tile_len,
                            float* image, float* final_t, int32_t* n_contrib, int32_t* point_id_pixel,
@@ -220,30 +224,30 @@ int lograst_set_tile_cull(int enabled);
  * (LoG/utils/trainer.py:158).  dL_dimage[3,H,W] in; all gradient outputs are overwritten:
  *   dL_dmeans2d[n,3]  (x,y = d/d ndc, z = 0; consumed at LoG/model/counter.py:40,46)
  *   dL_dmeans3d[n,3], dL_dscales[n,3], dL_drotations[n,4], dL_dopacities[n], dL_dcolors[n,3]
- * dL_dconic[n,4] is scratch and, like rotations / dl_drotations, must be 16-byte aligned (read and written as one
- * 16-byte access per Gaussian).  flags:
- *   LOGRAST_BWD_SCRATCH_ZEROED  the caller already zeroed dl_dmeans2d / dl_dconic (and, unless accumulating,
- *                               dl_dopacities / dl_dcolors) -- e.g. one memset over a block holding all of them;
+ * bwd_rows[n, LOGRAST_BWD_ROW_FLOATS] is scratch: the reverse walk's accumulator rows (64-byte aligned; the forward's
+ * bwd_scratch, or any zeroed block); the chain-rule kernel reads each live Gaussian's row and writes the separate
+ * outputs (dL_dmeans2d for every row; dL_dopacities / dL_dcolors written, or added to when accumulating).  rotations /
+ * dl_drotations must be 16-byte aligned (one 16-byte access per Gaussian).  flags:
+ *   LOGRAST_BWD_SCRATCH_ZEROED  bwd_rows is already zeroed (the forward's bwd_scratch; or the caller's memset);
  *   LOGRAST_BWD_ACCUMULATE      multi-view accumulation (new, not in the reference): dl_dopacities, dl_dcolors,
  *                               dl_dmeans3d, dl_dscales, dl_drotations are running sums that this call ADDS to
  *                               (the reverse walk's atomics and the chain-rule kernel write straight into the
  *                               caller's per-step gradient bucket; no separate accumulate pass).
- *   LOGRAST_BWD_CONIC_TOUCHED_ONLY  dl_dconic is zeroed only in the rows of Gaussians with point_weight > 0 (what a
+ *   LOGRAST_BWD_CONIC_TOUCHED_ONLY  bwd_rows is zeroed only in the rows of Gaussians with point_weight > 0 (what a
  *                               forward with extras and a bwd_scratch leaves on large inputs: see lograst_forward_render);
  *                               needs point_weight.  (Documentation of the caller's state: the chain rule skips the
  *                               rows with point_weight == 0 whenever point_weight is given, with or without this flag.)
  * point_weight (optional, NULL = none): the forward's per-Gaussian maximum blend weight.  A Gaussian with weight 0
  * contributed to no pixel, so its dL/dmean2D and dL/dconic are exactly zero: the chain rule skips it (its gradients
  * are written as 0, or left alone when accumulating) without reading its inputs -- in an opaque scene that is most of
- * the Gaussians.
- * bwd_scratch of the forward: [dL_dconic n x 4 | dL_dmeans2d n x 3 | (dL_dopacities n | dL_dcolors n x 3)]. */
+ * the Gaussians. */
 #define LOGRAST_BWD_SCRATCH_ZEROED 1
 #define LOGRAST_BWD_ACCUMULATE 2
 #define LOGRAST_BWD_CONIC_TOUCHED_ONLY 4
 int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                      const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
-                     const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
+                     const float* dl_dimage, float* dl_dmeans2d, float* bwd_rows, float* dl_dopacities,
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
                      const float* point_weight, int32_t flags, void* stream);
 

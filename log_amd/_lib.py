@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblogra
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
 REC_FLOATS = 16
+BWD_ROW_FLOATS = 16   # LOGRAST_BWD_ROW_FLOATS: the reverse walk's accumulator row (64 B per Gaussian)
 NUM_KERNELS = 20
 
 c_void_p, c_int32, c_uint32, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32,
@@ -117,7 +118,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.lograst_version() != 2:
+        if L.lograst_version() != 3:
             raise LograstError("liblograst.so version mismatch; rebuild")
         _lib = L
     return _lib

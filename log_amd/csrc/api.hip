@@ -39,10 +39,10 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
                          int* pid, float* pwp, float* pw, float* zero_conic, hipStream_t s);
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
-                         const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
-                         hipStream_t s);
+                         const float* dL_dimage, float* acc_rows, hipStream_t s);
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
-                           const int* radii, const float* g_mean2d, const float* g_conic, const float* pw,
+                           const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
+                           float* o_mean2d, float* o_opac, float* o_col, const float* pw,
                            float* g_means3d, float* g_scales, float* g_rots, bool accumulate, hipStream_t s);
 
 size_t lr_knn_scratch_bytes(int P);
@@ -325,14 +325,15 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   const uint32_t tiles = (uint32_t)(v.gx * v.gy);
   if (n == 0 && status)   // no fill kernel runs: this forward's entries of the status block
     LR_HIP(hipMemsetAsync(status + LOGRAST_STATUS_LAST_INSTANCES, 0, 4 * sizeof(uint32_t), s));
-  // point_weight (atomicMax target) and the optional backward scratch are cleared by the fill kernel -- except, in
-  // the 5-tuple flavour on large inputs, the scratch's leading dL/dconic block [n,4]: only the rows of Gaussians that
-  // contribute to a pixel will ever be read, and the compositing kernel clears exactly those when it meets them
-  // (a separate pass over point_weight afterwards cost 70 us per 30 M-Gaussian view, the stores inside the kernel 30)
-  const bool touched_only = v.extras && bwd_scratch_floats >= 4 && lr_big_input(n);
+  // point_weight (atomicMax target) and the optional backward scratch (one 64-byte accumulator row per Gaussian) are
+  // cleared by the fill kernel -- except, in the 5-tuple flavour on large inputs, the scratch: only the rows of
+  // Gaussians that contribute to a pixel will ever be read, and the compositing kernel clears exactly those when it
+  // meets them (a separate pass over point_weight afterwards cost 70 us per 30 M-Gaussian view, the stores inside the
+  // kernel 30)
+  const bool touched_only = v.extras && bwd_scratch_floats > 0 && lr_big_input(n);
   float* zero_block = bwd_scratch_floats > 0 ? bwd_scratch : nullptr;
   int zero_floats = bwd_scratch_floats;
-  if (touched_only) { zero_block += 4 * (size_t)n; zero_floats -= 4; }
+  if (touched_only) { zero_block = nullptr; zero_floats = 0; }
   float* zero_n = v.extras ? point_weight : nullptr;
   LR_KNOB(separate_zero, "LOGRAST_SEPARATE_ZERO", 1);   // 0: always inside the fill kernel
   if (separate_zero && lr_big_input(n)) {   // large inputs: streamed by kernels of their own (see lr_zero_floats_kernel)
@@ -385,10 +386,11 @@ static int lr_check_stage2_args(const LrView& v, int32_t n, const void* tile_sta
   if (capacity > 0 && (!keys || !point_list)) return lr_fail(LOGRAST_ERR_ARG, "keys/point_list NULL with capacity > 0");
   if (v.extras && (!point_id_pixel || !point_weight_pixel || (n > 0 && !point_weight)))
     return lr_fail(LOGRAST_ERR_ARG, "extras requested but output pointers are NULL");
-  if (bwd_scratch_floats < 0 || bwd_scratch_floats > 16 || (bwd_scratch_floats > 0 && n > 0 && !bwd_scratch))
-    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch: 0..16 floats per Gaussian and a non-NULL block");
-  if (bwd_scratch_floats > 0 && (reinterpret_cast<uintptr_t>(bwd_scratch) & 15u))
-    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch must be 16-byte aligned");
+  if ((bwd_scratch_floats != 0 && bwd_scratch_floats != LOGRAST_BWD_ROW_FLOATS) ||
+      (bwd_scratch_floats > 0 && n > 0 && !bwd_scratch))
+    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch: 0 or LOGRAST_BWD_ROW_FLOATS (16) floats per Gaussian and a non-NULL block");
+  if (bwd_scratch_floats > 0 && (reinterpret_cast<uintptr_t>(bwd_scratch) & 63u))
+    return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch must be 64-byte aligned (one accumulator row per line)");
   return LOGRAST_OK;
 }
 
@@ -614,9 +616,10 @@ int lograst_read_state(const void* tile_state, uint32_t* num_instances_host, uin
 int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                      const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,
-                     const float* dl_dimage, float* dl_dmeans2d, float* dl_dconic, float* dl_dopacities,
+                     const float* dl_dimage, float* dl_dmeans2d, float* bwd_rows, float* dl_dopacities,
                      float* dl_dcolors, float* dl_dmeans3d, float* dl_dscales, float* dl_drotations,
                      const float* point_weight, int32_t flags, void* stream) {
+  float* const dl_dconic = bwd_rows;   // (the fourth gradient argument: since version 3 the n x 16 accumulator rows)
   g_prof_call++;
   LrView v;
   int rc = lr_make_view(view, &v);
@@ -628,9 +631,10 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   rc = lr_check_cov_args(v, scales, rotations, dl_dscales, dl_drotations);
   if (rc) return rc;
-  if ((reinterpret_cast<uintptr_t>(dl_dconic) | reinterpret_cast<uintptr_t>(rotations) |
-       reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
-    return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_drotations must be 16-byte aligned");
+  if (reinterpret_cast<uintptr_t>(bwd_rows) & 63u)
+    return lr_fail(LOGRAST_ERR_ARG, "bwd_rows must be 64-byte aligned (one accumulator row per line)");
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   const uint32_t* st = reinterpret_cast<const uint32_t*>(tile_state);
@@ -643,19 +647,14 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
     return lr_fail(LOGRAST_ERR_ARG, "LOGRAST_BWD_SCRATCH_ZEROED after a forward with view.extras and n >= "
                                     "LOGRAST_HELPER_MIN_N: dL/dconic is cleared for contributing Gaussians only, pass "
                                     "point_weight (+ LOGRAST_BWD_CONIC_TOUCHED_ONLY)");
-  if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED)) {
-    LR_HIP(hipMemsetAsync(dl_dmeans2d, 0, sizeof(float) * 3 * (size_t)n, s));
-    LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * 4 * (size_t)n, s));
-    if (!accumulate) {
-      LR_HIP(hipMemsetAsync(dl_dopacities, 0, sizeof(float) * (size_t)n, s));
-      LR_HIP(hipMemsetAsync(dl_dcolors, 0, sizeof(float) * 3 * (size_t)n, s));
-    }
-  }
+  if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED))
+    LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * LOGRAST_BWD_ROW_FLOATS * (size_t)n, s));
   // capacity check is a forward concern: a list that rendered is by construction within capacity
-  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dmeans2d,
-                      dl_dconic, dl_dopacities, dl_dcolors, s);
-  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, point_weight, dl_dmeans3d,
-                        dl_dscales, dl_drotations, accumulate, s);
+  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic, s);
+  // the chain rule reads every live Gaussian's accumulator row and hands out the separate outputs: dL/dmeans2D (written
+  // for all rows), dL/dopacities and dL/dcolors (written, or added to the caller's running sums)
+  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, nullptr, nullptr, dl_dconic, dl_dmeans2d, dl_dopacities,
+                        dl_dcolors, point_weight, dl_dmeans3d, dl_dscales, dl_drotations, accumulate, s);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
@@ -677,8 +676,8 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
   if ((reinterpret_cast<uintptr_t>(dl_dconic) | reinterpret_cast<uintptr_t>(rotations) |
        reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");
-  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, nullptr, dl_dmeans3d,
-                        dl_dscales, dl_drotations, false, (hipStream_t)stream);
+  lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, dl_dmeans3d, dl_dscales, dl_drotations, false, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

@@ -196,12 +196,11 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (EXTRAS) {
           if (w0 > wmax) { wmax = w0; wid = gid; }
           const uint32_t m = lr_wave_umax_to63(__float_as_uint(w0));  // w >= 0: unsigned order == float order
-          if (lane == 63) {
-            atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
-            // training forward: this Gaussian contributes, so the reverse walk will add to its dL/dconic row -- clear it
-            // (every wave that meets the Gaussian stores the same zeros; rows of Gaussians nobody meets are never read)
-            if (zero_conic) zero_conic[gid] = float4{0.f, 0.f, 0.f, 0.f};
-          }
+          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
+          // training forward: this Gaussian contributes, so the reverse walk will add to its 64-byte accumulator row --
+          // clear it (four lanes, one quarter each; every wave that meets the Gaussian stores the same zeros; rows of
+          // Gaussians nobody meets are never read)
+          if (zero_conic && lane >= 60) zero_conic[4 * (size_t)(uint32_t)gid + (lane - 60)] = float4{0.f, 0.f, 0.f, 0.f};
         }
       }
       if (hit1) {
@@ -211,12 +210,11 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (EXTRAS) {
           if (w1 > wmax) { wmax = w1; wid = gid; }
           const uint32_t m = lr_wave_umax_to63(__float_as_uint(w1));
-          if (lane == 63) {
-            atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
-            // training forward: this Gaussian contributes, so the reverse walk will add to its dL/dconic row -- clear it
-            // (every wave that meets the Gaussian stores the same zeros; rows of Gaussians nobody meets are never read)
-            if (zero_conic) zero_conic[gid] = float4{0.f, 0.f, 0.f, 0.f};
-          }
+          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
+          // training forward: this Gaussian contributes, so the reverse walk will add to its 64-byte accumulator row --
+          // clear it (four lanes, one quarter each; every wave that meets the Gaussian stores the same zeros; rows of
+          // Gaussians nobody meets are never read)
+          if (zero_conic && lane >= 60) zero_conic[4 * (size_t)(uint32_t)gid + (lane - 60)] = float4{0.f, 0.f, 0.f, 0.f};
         }
       }
       if (!(hit0 | hit1) && __all(done)) break;
@@ -293,8 +291,7 @@ __global__ void __launch_bounds__(256)
 lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
-                    const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
-                    float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
+                    const float* __restrict__ dL_dimage, float* __restrict__ acc_rows,
                     int xcd_mode, int cull) {
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
@@ -323,16 +320,15 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
   maxc = lr_readlane_i(maxc, 0);  // wave-uniform: deepest contributor among this quadrant's pixels
 
-  // Destinations of the packed reduction (see lr_reduce9), as loop-invariant per-lane (base, stride) pairs so
-  // the per-Gaussian address is one multiply-add, no divergence:
-  //   atomic #1, lanes 0/16/32/48 (rows 0..3): colour r,g,b (g_col + 3*gid + row) and opacity (g_opac + gid)
-  //   atomic #2, rows 0..3: mean x,y (g_mean2d + 3*gid + row), conic A,B (g_conic + 4*gid + row-2);
-  //              lane 1 additionally carries conic C (g_conic + 4*gid + 2) so no third instruction is needed.
+  // Destinations of the packed reduction (see lr_reduce9): the Gaussian's 64-byte accumulator row (slots 0-1 mean x y,
+  // 2-4 conic A B C, 5 opacity, 6-8 colour r g b), as loop-invariant per-lane slots so that the per-Gaussian address is one
+  // multiply-add, no divergence.  Both instructions land in ONE line: the memory side charges an atomic per 64-byte line,
+  // not per lane (tools/micro/atomic_lines.hip).
+  //   atomic #1, lanes 0/16/32/48 (rows 0..3): colour r,g,b (slots 6-8) and opacity (slot 5)
+  //   atomic #2, rows 0..3: mean x,y (slots 0-1), conic A,B (slots 2-3); lane 1 additionally carries conic C (slot 4)
   const int row = lane >> 4;
-  float* const base0 = (row < 3) ? (g_col + row) : g_opac;
-  const int mul0 = (row < 3) ? 3 : 1;
-  float* const base1 = (lane == 1) ? (g_conic + 2) : ((row < 2) ? (g_mean2d + row) : (g_conic + (row - 2)));
-  const int mul1 = (lane == 1 || row >= 2) ? 4 : 3;
+  float* const base0 = acc_rows + ((row < 3) ? 6 + row : 5);
+  float* const base1 = acc_rows + ((lane == 1) ? 4 : row);
   const bool lead = (lane & 15) == 0;
 
   // Reverse walk in 64-entry chunks from the deepest contributor; lane l of chunk ch holds list position
@@ -432,8 +428,8 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         for (int m = 0; m < 9; m++) sv[m] = e ? s2[m].y : s2[m].x;
         float r0, r1, r2;
         lr_reduce9(sv, r0, r1, r2);
-        if (lead) atomicAdd(base0 + (size_t)gid * mul0, r0);
-        if (lead || lane == 1) atomicAdd(base1 + (size_t)gid * mul1, lane == 1 ? r2 : r1);
+        if (lead) atomicAdd(base0 + (size_t)gid * LOGRAST_BWD_ROW_FLOATS, r0);
+        if (lead || lane == 1) atomicAdd(base1 + (size_t)gid * LOGRAST_BWD_ROW_FLOATS, lane == 1 ? r2 : r1);
       }
     }
   }
@@ -451,14 +447,14 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 //     ~50 VALU for BOTH entries of all four rows against 2 x 28 for one entry each of the whole wave.
 // The entries of a chunk are staged once per wave in LDS (48 B each; slot 64 is an all-zero entry that rows without work
 // read: alpha = 0 contributes nothing, branch-free); a row's lanes read their entry with three broadcast ds_read_b128.
-// A row's sums do NOT go to memory from the loop: four rows x two entries x nine sums per pass, each its own memory-side
-// atomic, ran the reverse walk at the atomic units' rate (measured: C2 978 us with them, 220 us without; ~25 G atomic line
-// operations per second chip-wide, the same figure the binning kernels hit).  Nor through LDS atomics (ds_add_f32 into a
-// per-wave table: ~1 lane per clock per CU, C2 344 us).  A row meets an entry at most ONCE per chunk, so its nine sums for
-// that entry have a cell of their own in a per-wave table tab[value][entry][row] and are written there with plain stores
-// (the lanes (lane & 3) == 0: 16 lanes x 5 ds_write_b32 per pass); when the chunk is done every entry's four row cells
-// are read back as one 16-byte access, summed, cleared, and committed once per wave -- the memory-side traffic of the
-// quadrant form -- with the lanes arranged so that one atomic instruction carries an entry's values that share a line.
+// Committing the sums is what decides this form.  A row visit is its own commit (2.5x as many as quadrant visits), and the
+// memory side charges an atomic per 64-byte LINE it touches (tools/micro/atomic_lines.hip: 17-21 G lines/s chip-wide
+// whether 1, 9 or 16 lanes share the line).  With the sums in four separate arrays a row visit was 5 line operations:
+// C2 978 us (220 us with the atomics removed).  Through LDS instead: ds_add_f32 into a per-wave table runs at ~1 lane per
+// clock per CU (344 us); per-row cells written with plain stores and summed once per chunk: 322 us (274 without the
+// commits) -- the table's traffic eats what the rows gain.  With ONE 64-byte accumulator row per Gaussian (the layout
+// lograst_backward now uses) a row visit is ONE line operation: the nine sums of an entry are moved into nine lanes of
+// the row (two v_cndmask) and leave in one atomic instruction per entry.
 #define LR_RB_SLOT 3      // float4 per staged entry: (mx, my, A, B) (C, opacity, r, g) (b, id, -, -)
 template <int CTRL>
 LR_DEV float lr_dpp_perm(float x) {   // full-mask permutation within the row (all the controls used are self-inverse)
@@ -485,11 +481,9 @@ __global__ void __launch_bounds__(256)
 lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          const float* __restrict__ final_T, const int* __restrict__ n_contrib,
-                         const float* __restrict__ dL_dimage, float* __restrict__ g_mean2d,
-                         float* __restrict__ g_conic, float* __restrict__ g_opac, float* __restrict__ g_col,
+                         const float* __restrict__ dL_dimage, float* __restrict__ acc_rows,
                          int xcd_mode, int cull, int ablate, int block_test) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
-  __shared__ float4 lr_acc[4][9 * 65];         // per wave: [value][chunk entry] x (row 0..3); entry 64 swallows the sums of rows without work
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
@@ -525,26 +519,17 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   if (lane < LR_RB_SLOT) stage[64 * LR_RB_SLOT + lane] = float4{0.f, 0.f, 0.f, 0.f};   // the all-zero entry (id patched below)
   if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
 
-  // Where a row's sums go (see the packing in the loop): lanes (lane & 3) == 0, one per quad of the row, into the wave's
-  // table tab[value][entry][row] -- values: 0-2 colour r g b, 3 opacity, 4-5 mean x y, 6-8 conic A B C.
-  //   S1: quads (col r, col b, col g, opacity)   S2: quads (mean x, conic A, mean y, conic B)   S3: quads 0 / 2: conic C of entry 0 / 1
-  const int qd = li >> 2;
-  const bool lead = (li & 3) == 0;
-  float4* const tab4 = lr_acc[wq];
-  float* const tab = reinterpret_cast<float*>(tab4) + row;       // this row's cell of (value, entry) = tab[4 * (65 * value + entry)]
-  float* const tab1 = tab + 4 * 65 * (qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3)));
-  float* const tab2 = tab + 4 * 65 * (qd == 0 ? 4 : (qd == 1 ? 6 : (qd == 2 ? 5 : 7)));
-  float* const tab3 = tab + 4 * 65 * 8;
-  for (int t = lane; t < 9 * 65; t += 64) tab4[t] = float4{0.f, 0.f, 0.f, 0.f};
+  // Where a row's sums go: after the packed reductions (see the loop) every lane of a quad holds the quad's total of
+  //   S1: quads (col r, col b, col g, opacity)   S2: quads (mean x, conic A, mean y, conic B)   S3: lanes 0-7 / 8-15: conic C of entry 0 / 1
+  // Lanes (lane & 3) == 0 take S1, == 1 take S2, lane 2 (entry 0) / lane 10 (entry 1) take S3: nine lanes of the row
+  // carry the entry's nine sums into the Gaussian's accumulator row in one instruction (slots: 0-1 mean x y, 2-4 conic
+  // A B C, 5 opacity, 6-8 colour r g b).
+  const int qd = li >> 2, sel = li & 3;
+  const int slot = sel == 0 ? (qd == 0 ? 6 : (qd == 1 ? 8 : (qd == 2 ? 7 : 5)))
+                            : (sel == 1 ? (qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3))) : 4);
+  const bool on_a = sel < 2 || li == 2, on_b = sel < 2 || li == 10;
+  float* const dst = acc_rows + slot;
   const uint32_t shift8 = 8u * (uint32_t)row;
-  // the commit at the end of a chunk: lanes as (entry, value) pairs so that values sharing a line share an instruction
-  //   A: 16 entries x (col r, g, b, opacity) per instruction, 4 instructions;  B: 12 entries x (mean x, y, conic A, B, C), 6
-  const int ea = lane >> 2, va = lane & 3;
-  float* const dstA = va == 3 ? g_opac : g_col + va;
-  const uint32_t mulA = va == 3 ? 1u : 3u;
-  const int eb = lane / 5, vb = lane - 5 * eb;          // lanes 60-63 idle in B
-  float* const dstB = vb < 2 ? g_mean2d + vb : g_conic + (vb - 2);
-  const uint32_t mulB = vb < 2 ? 3u : 4u;
 
   // the four blocks of this quadrant (wave-uniform), for the support tests
   const float bx[2] = {(float)qx0, (float)(qx0 + 4)}, by[2] = {(float)qy0, (float)(qy0 + 4)};
@@ -606,7 +591,6 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       }
     }
     uint64_t m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
-    bool touched = false;                                       // wave-uniform: some pass of this chunk contributed
     while (m0 | m1 | m2 | m3) {
       // every row's next two entries (64 = none: the all-zero slot)
       uint32_t pa = 0u, pb = 0u;
@@ -623,6 +607,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const float4* sa = stage + ja * LR_RB_SLOT;
       const float4* sb = stage + jb * LR_RB_SLOT;
       const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
+      const uint32_t gida = __float_as_uint(a2.y), gidb = __float_as_uint(b2.y);
       const float op0 = a1.y, op1 = b1.y;
       const lr_f2 dx2 = lr_f2{a0.x, b0.x} - pxf, dy2 = lr_f2{a0.y, b0.y} - pyf;
       const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
@@ -638,7 +623,6 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const lr_f2 alpha = {hit0 ? alpha0 : 0.f, hit1 ? alpha1 : 0.f};
       const bool any = __builtin_amdgcn_ballot_w64((alpha.x > 0.f) | (alpha.y > 0.f)) != 0;
       if (!any) continue;
-      touched = true;
       const lr_f2 G = {hit0 ? G2.x : 0.f, hit1 ? G2.y : 0.f};
       const lr_f2 om = 1.f - alpha;
       lr_f2 rc = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
@@ -671,49 +655,20 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const float s2b = lr_quad_total(lr_row_pair4(lr_row_pair8(mxs.y, mys.y), lr_row_pair8(kA.y, kB.y)));
       float s3 = lr_row_pair8(kC.x, kC.y);                      // lanes 0-7: entry 0's conic C, lanes 8-15: entry 1's
       s3 = lr_quad_total(s3 + lr_dpp_perm<0x141>(s3));
-      if (lead) {   // (a row meets an entry once per chunk: plain stores; rows without work write zeros into entry 64)
-        tab1[4u * ja] = s1a;
-        tab1[4u * jb] = s1b;
-        tab2[4u * ja] = s2a;
-        tab2[4u * jb] = s2b;
-        if (!(qd & 1)) tab3[4u * ((qd & 2) ? jb : ja)] = s3;
+      // one instruction per entry: nine lanes of every row, one 64-byte line per row
+      const float xa = sel == 0 ? s1a : (sel == 1 ? s2a : s3);
+      const float xb = sel == 0 ? s1b : (sel == 1 ? s2b : s3);
+      if (!(ablate & 1)) {
+        if (on_a && gida != 0xffffffffu) atomicAdd(dst + (size_t)gida * LOGRAST_BWD_ROW_FLOATS, xa);
+        if (on_b && gidb != 0xffffffffu) atomicAdd(dst + (size_t)gidb * LOGRAST_BWD_ROW_FLOATS, xb);
       }
     }
-    if (!touched) continue;
-    // commit this chunk: what the wave collected per entry, once, and clear the table for the next chunk
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int e = 16 * k + ea;
-      float4* cell = tab4 + 65 * va + e;
-      const float4 c4 = *cell;
-      *cell = float4{0.f, 0.f, 0.f, 0.f};
-      const float x = (c4.x + c4.y) + (c4.z + c4.w);
-      const uint32_t gid = (uint32_t)__shfl((int)id, e);
-      if (x != 0.f && !(ablate & 1)) atomicAdd(dstA + (size_t)gid * mulA, x);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const int e = 12 * k + eb;
-      const bool on = lane < 60 && e < 64;
-      float4* cell = tab4 + 65 * (4 + vb) + (on ? e : 64);
-      const float4 c4 = *cell;
-      *cell = float4{0.f, 0.f, 0.f, 0.f};
-      const float x = on ? (c4.x + c4.y) + (c4.z + c4.w) : 0.f;
-      const uint32_t gid = (uint32_t)__shfl((int)id, on ? e : 0);
-      if (x != 0.f && !(ablate & 1)) atomicAdd(dstB + (size_t)gid * mulB, x);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
-                         const float* dL_dimage, float* g_mean2d, float* g_conic, float* g_opac, float* g_col,
-                         hipStream_t s) {
+                         const float* dL_dimage, float* acc_rows, hipStream_t s) {
   LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
   static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
@@ -726,11 +681,10 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
   lr_prof_begin(LRK_BLEND_BWD, s);
   if (rows)
     hipLaunchKernelGGL(lr_blend_bwd_rows_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
-                       xcd_mode, cull, ablate, block_test);
+                       state, tiles, plist, capacity, final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull, ablate,
+                       block_test);
   else
     hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom), state,
-                       tiles, plist, capacity, final_T, n_contrib, dL_dimage, g_mean2d, g_conic, g_opac, g_col,
-                       xcd_mode, cull);
+                       tiles, plist, capacity, final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull);
   lr_prof_end(LRK_BLEND_BWD, s);
 }

@@ -14,8 +14,8 @@
 // The chain rule of ONE Gaussian the forward composited (gm, gs, gq, and dL/dcov3D written / added in place when COV).
 template <bool ACCUMULATE, bool COV>
 LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__ means, const float* __restrict__ scales,
-                               const float* __restrict__ rots, const float* __restrict__ g_mean2d,
-                               const float* __restrict__ g_conic, float gm[3], float gs[3], float gq[4]) {
+                               const float* __restrict__ rots, float gnx, float gny, float gA, float gB, float gC,
+                               float gm[3], float gs[3], float gq[4]) {
   const float* __restrict__ V = v.view;
   const float* __restrict__ Pm = v.proj;
   float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
@@ -36,8 +36,6 @@ LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__
   const float a = e.a, b = e.b, c = e.c;
   const float det = a * c - b * b;
   const float di2 = 1.f / (det * det);
-  const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
-  const float gA = gc4.x, gB = gc4.y, gC = gc4.z;
   // conic = (c, -b, a) / det
   float ga = di2 * (-c * c * gA + b * c * gB - b * b * gC);
   float gb = di2 * (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC);
@@ -85,7 +83,6 @@ LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__
   const float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], p[0], p[1], p[2], Pm[13]);
   const float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], p[0], p[1], p[2], Pm[15]);
   const float pw = 1.0f / (hw + 0.0000001f);
-  const float gnx = g_mean2d[3 * (size_t)i], gny = g_mean2d[3 * (size_t)i + 1];
   const float ghx = gnx * pw, ghy = gny * pw, ghw = -(gnx * hx + gny * hy) * pw * pw;
   m0 += Pm[0] * ghx + Pm[1] * ghy + Pm[3] * ghw;
   m1 += Pm[4] * ghx + Pm[5] * ghy + Pm[7] * ghw;
@@ -131,11 +128,20 @@ LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__
 #ifndef LR_PBWD_ROWS
 #define LR_PBWD_ROWS 1024
 #endif
-template <bool ACCUMULATE, bool TOUCHED, bool COV>
+// AOS (lograst_backward): the reverse walk's nine sums of a Gaussian sit in ONE 64-byte row of `rows` (slots: 0-1 mean
+// x y, 2-4 conic A B C, 5 opacity, 6-8 colour r g b: include/lograst.h LOGRAST_BWD_ROW_FLOATS) -- a memory-side atomic
+// costs one operation per 64-byte LINE whatever the number of lanes in it (tools/micro/atomic_lines.hip: 17-21 G lines/s
+// chip-wide for 1, 9 or 16 lanes per line), so the reverse walk commits a (wave, Gaussian) visit with one line operation
+// instead of four.  This kernel then also hands out the API's separate outputs: dL/dmeans2D (written for every row: it
+// is a per-view output), dL/dopacity and dL/dcolour (written, or added to the running sums when ACCUMULATE).
+// !AOS (lograst_project_backward, the isolated chain rule): g_mean2d [n, 3] / g_conic [n, 4] in, as before.
+template <bool ACCUMULATE, bool TOUCHED, bool COV, bool AOS>
 __global__ void __launch_bounds__(256)
 lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                       const float* __restrict__ rots, const int* __restrict__ radii,
                       const float* __restrict__ g_mean2d, const float* __restrict__ g_conic,
+                      const float4* __restrict__ rows, float* __restrict__ o_mean2d, float* __restrict__ o_opac,
+                      float* __restrict__ o_col,
                       const float* __restrict__ pw, float* __restrict__ g_means3d, float* __restrict__ g_scales,
                       float* __restrict__ g_rots) {
   __shared__ uint32_t live_list[LR_PBWD_ROWS];
@@ -147,6 +153,13 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
   for (int k = 0; k < LR_PBWD_ROWS / 256; k++) {
     const int i = base + k * 256 + tid;
     const bool live = i < N && radii[i] > 0 && (!TOUCHED || pw[i] > 0.f);
+    if (AOS && i < N && !live) {   // dL/dmeans2D is a per-view output: defined for every row
+      o_mean2d[3 * (size_t)i + 0] = 0.f; o_mean2d[3 * (size_t)i + 1] = 0.f; o_mean2d[3 * (size_t)i + 2] = 0.f;
+      if (!ACCUMULATE) {
+        o_opac[i] = 0.f;
+        o_col[3 * (size_t)i + 0] = 0.f; o_col[3 * (size_t)i + 1] = 0.f; o_col[3 * (size_t)i + 2] = 0.f;
+      }
+    }
     if (!ACCUMULATE && i < N && !live) {   // culled / untouched: zero gradients (running sums are simply left alone)
       g_means3d[3 * (size_t)i + 0] = 0.f; g_means3d[3 * (size_t)i + 1] = 0.f; g_means3d[3 * (size_t)i + 2] = 0.f;
       if (COV) {
@@ -170,7 +183,25 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
   for (uint32_t j = (uint32_t)tid; j < n; j += 256u) {
     const int i = (int)live_list[j];
     float gm[3], gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-    lr_project_bwd_row<ACCUMULATE, COV>(v, i, means, scales, rots, g_mean2d, g_conic, gm, gs, gq);
+    float gnx, gny, gA, gB, gC;
+    if (AOS) {
+      const float4 a0 = rows[4 * (size_t)i], a1 = rows[4 * (size_t)i + 1];
+      const float cb = reinterpret_cast<const float*>(rows + 4 * (size_t)i + 2)[0];
+      gnx = a0.x; gny = a0.y; gA = a0.z; gB = a0.w; gC = a1.x;
+      o_mean2d[3 * (size_t)i + 0] = gnx; o_mean2d[3 * (size_t)i + 1] = gny; o_mean2d[3 * (size_t)i + 2] = 0.f;
+      if (ACCUMULATE) {
+        o_opac[i] += a1.y;
+        o_col[3 * (size_t)i + 0] += a1.z; o_col[3 * (size_t)i + 1] += a1.w; o_col[3 * (size_t)i + 2] += cb;
+      } else {
+        o_opac[i] = a1.y;
+        o_col[3 * (size_t)i + 0] = a1.z; o_col[3 * (size_t)i + 1] = a1.w; o_col[3 * (size_t)i + 2] = cb;
+      }
+    } else {
+      gnx = g_mean2d[3 * (size_t)i]; gny = g_mean2d[3 * (size_t)i + 1];
+      const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
+      gA = gc4.x; gB = gc4.y; gC = gc4.z;
+    }
+    lr_project_bwd_row<ACCUMULATE, COV>(v, i, means, scales, rots, gnx, gny, gA, gB, gC, gm, gs, gq);
     if (ACCUMULATE) {  // running sums over views (log_amd.dist)
 #pragma unroll
       for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] += gm[k];
@@ -191,18 +222,24 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
   }
 }
 
+// rows != NULL: the 64-byte accumulator rows of lograst_backward (+ its three separate outputs); NULL: g_mean2d / g_conic
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
-                           const int* radii, const float* g_mean2d, const float* g_conic, const float* pw,
+                           const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
+                           float* o_mean2d, float* o_opac, float* o_col, const float* pw,
                            float* g_means3d, float* g_scales, float* g_rots, bool accumulate, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_PROJECT_BWD, s);
   const dim3 grid((N + LR_PBWD_ROWS - 1) / LR_PBWD_ROWS), block(256);
-#define LR_PBWD(A, T, C) hipLaunchKernelGGL((lr_project_bwd_kernel<A, T, C>), grid, block, 0, s, v, N, means, scales, \
-                                            rots, radii, g_mean2d, g_conic, pw, g_means3d, g_scales, g_rots)
+  const float4* rows4 = reinterpret_cast<const float4*>(rows);
+#define LR_PBWD2(A, T, C, O) hipLaunchKernelGGL((lr_project_bwd_kernel<A, T, C, O>), grid, block, 0, s, v, N, means, scales, \
+                                                rots, radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw,       \
+                                                g_means3d, g_scales, g_rots)
+#define LR_PBWD(A, T, C) do { if (rows) LR_PBWD2(A, T, C, true); else LR_PBWD2(A, T, C, false); } while (0)
 #define LR_PBWD_C(A, T) do { if (v.cov3d) LR_PBWD(A, T, true); else LR_PBWD(A, T, false); } while (0)
   if (accumulate) { if (pw) LR_PBWD_C(true, true); else LR_PBWD_C(true, false); }
   else { if (pw) LR_PBWD_C(false, true); else LR_PBWD_C(false, false); }
 #undef LR_PBWD_C
 #undef LR_PBWD
+#undef LR_PBWD2
   lr_prof_end(LRK_PROJECT_BWD, s);
 }

@@ -295,8 +295,9 @@ class HipBackend:
 
     def forward(self, rs, flavour, use_filter, means3D, scales, rotations, opacities, colors, scratch_floats=0,
                 cov3D=None):
-        """scratch_floats: 0, or the fp32 words per Gaussian of backward scratch to allocate and have the forward
-        zero-fill (7 with a gradient sink, 11 without): saved as `bwd_scratch` and consumed by the first backward.
+        """scratch_floats: non-zero = allocate the backward's accumulator rows (16 fp32 = 64 B per Gaussian,
+        include/lograst.h: LOGRAST_BWD_ROW_FLOATS) and have the forward clear them: saved as `bwd_scratch` and consumed by
+        the first backward.
         cov3D: the rasterizer's cov3D_precomp ([N, 6] fp32) instead of scales / rotations (both None then)."""
         device = means3D.device
         L = self.require(device)
@@ -316,6 +317,7 @@ class HipBackend:
                      pw=torch.empty(N, dtype=f32, device=device))
         kept = [("geom", u8, (L.lograst_geom_bytes(N),)), ("state", u8, (L.lograst_tile_state_bytes(W, H, N),)),
                 ("final_T", f32, (H, W)), ("n_contrib", i32, (H, W))]
+        scratch_floats = _lib.BWD_ROW_FLOATS if scratch_floats else 0
         if scratch_floats and N:
             kept.append(("bwd_scratch", f32, (N * scratch_floats,)))
         with torch.cuda.device(device):
@@ -394,12 +396,12 @@ class HipBackend:
         view.tile_row_begin, view.tile_row_end = saved.get("tile_rows", (0, 0))   # the band the forward rendered
         f32 = dict(dtype=torch.float32, device=device)
         grad_image = grad_image.to(torch.float32).contiguous()
-        need = 11 if sink is None else 7
-        # The accumulators the reverse walk adds into come from ONE zeroed block: the one the forward already
-        # cleared for this purpose (first backward of this forward), else a fresh torch.zeros.  Layout: the 16-byte
-        # rows first (dL/dconic [N,4], read as one access per Gaussian), then dL/dmeans2D [N,3] (, opacity, colours).
-        # In the 5-tuple flavour the forward cleared the dL/dconic rows of the contributing Gaussians only
-        # (point_weight > 0); the chain rule skips all the others (LOGRAST_BWD_CONIC_TOUCHED_ONLY).
+        need = _lib.BWD_ROW_FLOATS
+        # The reverse walk adds into ONE 64-byte accumulator row per Gaussian (mean x y, conic A B C, opacity, colour):
+        # the block the forward already cleared for this purpose (first backward of this forward), else a fresh
+        # torch.zeros.  In the 5-tuple flavour the forward cleared the rows of the contributing Gaussians only
+        # (point_weight > 0); the chain rule skips all the others (LOGRAST_BWD_CONIC_TOUCHED_ONLY) -- and hands out the
+        # separate outputs: dL/dmeans2D, and dL/dopacity / dL/dcolour (written, or added into the sink's running sums).
         acc = saved.pop("bwd_scratch", None)
         pw = saved.get("point_weight")
         flags = 1
@@ -407,14 +409,13 @@ class HipBackend:
             acc = torch.zeros(N * need, **f32)
         elif pw is not None:
             flags |= 4
-        g_conic = acc[:4 * N].view(N, 4)
-        g_means2D = acc[4 * N:7 * N].view(N, 3)
+        g_conic = acc          # (the C ABI's `bwd_rows`)
+        g_means2D = torch.empty(N, 3, **f32)
         if sink is None:
-            g_opac = acc[7 * N:8 * N]
-            g_colors = acc[8 * N:11 * N].view(N, 3)
             g = self._carve(device, [("rot", torch.float32, (N, 4)), ("means3D", torch.float32, (N, 3)),
-                                     ("scales", torch.float32, (N, 3))])
-            g_means3D, g_scales, g_rot = g["means3D"], g["scales"], g["rot"]
+                                     ("scales", torch.float32, (N, 3)), ("colors", torch.float32, (N, 3)),
+                                     ("opac", torch.float32, (N,))])
+            g_means3D, g_scales, g_rot, g_colors, g_opac = g["means3D"], g["scales"], g["rot"], g["colors"], g["opac"]
         else:
             g_opac, g_colors = sink["opacities"], sink["colors"]
             g_means3D, g_scales, g_rot = sink["means3D"], sink["scales"], sink["rotations"]
@@ -427,7 +428,9 @@ class HipBackend:
                                           _ptr(g_colors), _ptr(g_means3D), _ptr(g_scales), _ptr(g_rot), _ptr(pw),
                                           flags, _stream_ptr(device)))
         del keep
-        self.last_conic_grad = g_conic if _debug_keep else None   # test introspection only (pins the whole block)
+        # test introspection only: dL/dconic [N, 4] (A, B, C, 0) out of the accumulator rows
+        self.last_conic_grad = (torch.cat([acc.view(N, need)[:, 2:5], acc.new_zeros(N, 1)], dim=1)
+                                if _debug_keep and N else (acc.new_zeros(0, 4) if _debug_keep else None))
         if sink is not None:
             return None, g_means2D, None, None, None, None
         if cov3D is not None:
@@ -768,10 +771,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise ValueError("rasterizer inputs must be means3D[N,3], scales[N,3], rotations[N,4], "
                              "colors_precomp[N,3], opacities[N,1]")
         wants_grad = any(ctx.needs_input_grad[:7])   # all False under torch.no_grad()
-        scratch_floats = 0 if not wants_grad else (7 if (_grad_sink is not None and (sh is None or "shs" in _grad_sink)) else 11)
         wants_grad = wants_grad or (cov is not None and ctx.needs_input_grad[10])
-        if cov is not None:
-            scratch_floats = 11 if wants_grad else 0
+        scratch_floats = _lib.BWD_ROW_FLOATS if wants_grad else 0
             image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, None, None, o, c,
                                                                  scratch_floats=scratch_floats, cov3D=cov)
         else:

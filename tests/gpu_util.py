@@ -23,7 +23,7 @@ def settings(cam, bg, dev, scale_modifier=1.0):
 
 def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", scale_modifier=1.0, scratch_floats=0):
     """Raw backend call (keeps the intermediates).  Returns dict of numpy arrays + the torch `saved`.
-    scratch_floats=11: have the forward prepare the backward's accumulators, as the autograd path does."""
+    scratch_floats=16: have the forward prepare the backward's accumulator rows, as the autograd path does."""
     dev = torch.device(dev)
     rs = settings(cam, bg, dev, scale_modifier)
     t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)

@@ -36,7 +36,7 @@ def test_speculative_forward_recovers_from_a_capacity_guess_that_was_too_small()
     key = (0, cam["image_width"], cam["image_height"], (0, 0))
     prev = R.set_speculative(False)
     try:
-        exact = G.hip_forward(cam, sc, (0.1, 0.2, 0.3), scratch_floats=11)
+        exact = G.hip_forward(cam, sc, (0.1, 0.2, 0.3), scratch_floats=16)
         g_exact = G.hip_backward(exact, np.ones_like(exact["image"]))
         assert exact["I"] > 20000 and int(np.diff(exact["tile_offsets"].astype(np.int64)).max()) > 1024
         R.set_speculative(True)
@@ -45,7 +45,7 @@ def test_speculative_forward_recovers_from_a_capacity_guess_that_was_too_small()
             R.capacity_stats(reset=True)
             R.overflow_since_reset(torch.device(DEV))
             R._cap_model.hist[key] = dict(poison)
-            spec = G.hip_forward(cam, sc, (0.1, 0.2, 0.3), scratch_floats=11)
+            spec = G.hip_forward(cam, sc, (0.1, 0.2, 0.3), scratch_floats=16)
             st = R.capacity_stats()
             assert st == dict(forwards=1, retries=1), st
             for k in ("image", "final_T"):

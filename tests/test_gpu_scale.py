@@ -71,7 +71,7 @@ def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_nam
     on every output of the reverse walk, chain rule <= 1e-6 on identical inputs.  The forward prepares the backward's
     accumulators as the autograd path does (touched-only dL/dconic on large inputs)."""
     import gpu_util as G
-    hf = G.hip_forward(cam, sc, bg, scratch_floats=11)
+    hf = G.hip_forward(cam, sc, bg, scratch_floats=16)
     v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
     st = G.compare_forward(hf, of) if check_lists else None
     if st is not None:

@@ -773,6 +773,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         wants_grad = any(ctx.needs_input_grad[:7])   # all False under torch.no_grad()
         wants_grad = wants_grad or (cov is not None and ctx.needs_input_grad[10])
         scratch_floats = _lib.BWD_ROW_FLOATS if wants_grad else 0
+        if cov is not None:
             image, radii, pid, pwp, pw, saved = _backend.forward(rs, flavour, use_filter, m, None, None, o, c,
                                                                  scratch_floats=scratch_floats, cov3D=cov)
         else:

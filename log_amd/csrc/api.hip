@@ -39,7 +39,7 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
                          int* pid, float* pwp, float* pw, float* zero_conic, hipStream_t s);
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
-                         const float* dL_dimage, float* acc_rows, hipStream_t s);
+                         const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s);
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
                            float* o_mean2d, float* o_opac, float* o_col, const float* pw,
@@ -102,7 +102,7 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_FILL_NT", 1, 0, 1, "fill kernel: non-temporal streams for the fill records and zero-fills"},
     {"LOGRAST_XCD_MODE", 3, 0, 3, "blockIdx -> tile mapping of the compositing kernels (3 = longest list first)"},
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
-    {"LOGRAST_BWD_ROWS", 0, 0, 1, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave"},
+    {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = row-split from LOGRAST_HELPER_MIN_N Gaussians"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
 };
 static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
@@ -650,7 +650,8 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED))
     LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * LOGRAST_BWD_ROW_FLOATS * (size_t)n, s));
   // capacity check is a forward concern: a list that rendered is by construction within capacity
-  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic, s);
+  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic,
+                      lr_big_input(n) ? 1 : 0, s);
   // the chain rule reads every live Gaussian's accumulator row and hands out the separate outputs: dL/dmeans2D (written
   // for all rows), dL/dopacities and dL/dcolors (written, or added to the caller's running sums)
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, nullptr, nullptr, dl_dconic, dl_dmeans2d, dl_dopacities,

@@ -668,14 +668,16 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
 
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
-                         const float* dL_dimage, float* acc_rows, hipStream_t s) {
+                         const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s) {
   LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
   static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   // LOGRAST_BWD_ROWS=1: the row-split form (the four 16-lane rows of a wave walk their own 4x4 blocks); 0: one
-  // (Gaussian, quadrant) pair per visit.  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
-  LR_KNOB(rows, "LOGRAST_BWD_ROWS", 0);
+  // (Gaussian, quadrant) pair per visit; 2 (default): row-split on large inputs (measured, MI355X: 30 M tiny splats 949 ->
+  // 700 us, with random opacities 1768 -> 1259; C2's 1 M 292 -> 307).  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
+  LR_KNOB(rows_knob, "LOGRAST_BWD_ROWS", 2);
+  const int rows = rows_knob == 2 ? (big_input ? 1 : 0) : rows_knob;
   static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);
   LR_KNOB(block_test, "LOGRAST_BWD_BLOCK_TEST", 1);
   lr_prof_begin(LRK_BLEND_BWD, s);

@@ -23,7 +23,7 @@ SWEEP = {
     "LOGRAST_FILL_NT": (0, 1),
     "LOGRAST_XCD_MODE": (0, 1, 2, 3),
     "LOGRAST_PROJECT_BLOCKS": (64, 512, 4096),
-    "LOGRAST_BWD_ROWS": (0, 1),
+    "LOGRAST_BWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
 }
 
@@ -95,7 +95,7 @@ def test_calibration_runs_end_to_end_and_is_reloadable(tmp_path):
         chosen = tune.tune(views=views, device=dev, repeats=2, save=True, path=path, helper=False,
                            candidates={"LOGRAST_DEFER_TILES": (8, 16, 32), "LOGRAST_BWD_ROWS": (0, 1)})
         assert set(chosen) == {"LOGRAST_DEFER_TILES", "LOGRAST_BWD_ROWS"}
-        assert chosen["LOGRAST_DEFER_TILES"] in (8, 16, 32) and chosen["LOGRAST_BWD_ROWS"] in (0, 1)
+        assert chosen["LOGRAST_DEFER_TILES"] in (8, 16, 32) and chosen["LOGRAST_BWD_ROWS"] in (0, 1, 2)
         stored = json.load(open(path))
         assert stored["knobs"] == chosen and "timings_ms" in stored
         tune.reset_knobs()

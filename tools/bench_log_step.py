@@ -354,6 +354,6 @@ def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, wi
 if __name__ == "__main__":
     a = sys.argv[1:]
     res = c3_pipeline(int(a[0]) if len(a) > 0 else 40000, int(a[1]) if len(a) > 1 else 7, int(a[2]) if len(a) > 2 else 3,
-                      int(a[3]) if len(a) > 3 else 8, float(a[4]) if len(a) > 4 else 0.03, with_torch=True)
+                      int(a[3]) if len(a) > 3 else 8, float(a[4]) if len(a) > 4 else 0.03, with_torch="--torch" in a)
     res["bench"] = "log_step"
     print(json.dumps(res))

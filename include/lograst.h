@@ -244,6 +244,12 @@ int lograst_set_tile_cull(int enabled);
 #define LOGRAST_BWD_SCRATCH_ZEROED 1
 #define LOGRAST_BWD_ACCUMULATE 2
 #define LOGRAST_BWD_CONIC_TOUCHED_ONLY 4
+/* Which form of the reverse walk (speed only; knob LOGRAST_BWD_ROWS = 2 follows these, 0 / 1 override them): the caller
+ * knows the view's tile instances per Gaussian from the forward -- tiny splats (few instances each) are walked by the
+ * wave's four 16-lane rows on their own 4x4 blocks, larger ones by the whole wave on its 8x8 quadrant.  Neither bit: the
+ * library decides from n alone. */
+#define LOGRAST_BWD_ROWSPLIT 8
+#define LOGRAST_BWD_QUADRANT 16
 int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                      const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,

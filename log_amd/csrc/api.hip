@@ -36,7 +36,7 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
                     uint32_t max_len, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, float* zero_conic, hipStream_t s);
+                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, hipStream_t s);
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s);
@@ -103,6 +103,7 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_XCD_MODE", 3, 0, 3, "blockIdx -> tile mapping of the compositing kernels (3 = longest list first)"},
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
     {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = row-split from LOGRAST_HELPER_MIN_N Gaussians"},
+    {"LOGRAST_FWD_ROWS", 0, 0, 2, "compositing: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = row-split from LOGRAST_HELPER_MIN_N Gaussians"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
 };
 static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
@@ -348,7 +349,7 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
-                      point_weight_pixel, point_weight, touched_only ? bwd_scratch : nullptr, s);
+                      point_weight_pixel, point_weight, touched_only ? bwd_scratch : nullptr, lr_big_input(n) ? 1 : 0, s);
   return LOGRAST_OK;
 }
 
@@ -650,8 +651,8 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED))
     LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * LOGRAST_BWD_ROW_FLOATS * (size_t)n, s));
   // capacity check is a forward concern: a list that rendered is by construction within capacity
-  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic,
-                      lr_big_input(n) ? 1 : 0, s);
+  const int form_hint = (flags & LOGRAST_BWD_ROWSPLIT) ? 1 : ((flags & LOGRAST_BWD_QUADRANT) ? 0 : (lr_big_input(n) ? 1 : 0));
+  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic, form_hint, s);
   // the chain rule reads every live Gaussian's accumulator row and hands out the separate outputs: dL/dmeans2D (written
   // for all rows), dL/dopacities and dL/dcolors (written, or added to the caller's running sums)
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, nullptr, nullptr, dl_dconic, dl_dmeans2d, dl_dopacities,

@@ -233,25 +233,6 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   }
 }
 
-void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
-                         const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, float* zero_conic, hipStream_t s) {
-  LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
-  static const int cull = lr_env_int("LOGRAST_CULL", 1);
-  static const size_t lds_fwd = (size_t)lr_env_int("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;
-  uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
-  lr_prof_begin(LRK_BLEND_FWD, s);
-  if (v.extras)
-    hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw,
-                       reinterpret_cast<float4*>(zero_conic), xcd_mode, cull);
-  else
-    hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, image, final_T, n_contrib, pid, pwp, pw,
-                       reinterpret_cast<float4*>(zero_conic), xcd_mode, cull);
-  lr_prof_end(LRK_BLEND_FWD, s);
-}
-
 // ---- backward ---------------------------------------------------------------------------------------------
 // Packed wave64 reduction of 9 per-lane sums.  v_permlane32_swap(a,b) leaves a=[a.lo,b.lo], b=[a.hi,b.hi], so
 // ONE swap + ONE add halves two values at once (a's sum in lanes 0-31, b's in 32-63); v_permlane16_swap does
@@ -666,6 +647,204 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   }
 }
 
+// ---- forward, row-split form ------------------------------------------------------------------------------------
+// The forward counterpart of lr_blend_bwd_rows_kernel: the wave's four 16-lane rows composite their own 4x4 blocks, each
+// taking its own next two relevant entries per pass.  Per pixel the op sequence is the quadrant kernel's (same 2-wide
+// power / exp / alpha, entries in list order), so image, final_T, n_contrib and the fork maps stay bit-identical to the
+// oracle.  A row stops taking entries when its 16 pixels are saturated; point_weight gets one atomicMax per contributing
+// (row, Gaussian) visit (row maximum by four DPP steps), and the Gaussian's accumulator row is cleared by the row's
+// first four lanes.
+template <bool EXTRAS>
+__global__ void __launch_bounds__(256)
+lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
+                         uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
+                         float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
+                         int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
+                         float4* __restrict__ zero_rows, int xcd_mode, int cull) {
+  __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
+  if (lr_bail(state, capacity)) return;
+  const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
+  if (tile >= tiles) return;
+  const uint32_t* offsets = state + lr_offsets_off(tiles);
+  const uint32_t beg = offsets[tile], end = offsets[tile + 1];
+  const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  const int row = lane >> 4, li = lane & 15;
+  const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
+  const int qx0 = tx * 16 + (wq & 1) * 8, qy0 = ty * 16 + (wq >> 1) * 8;
+  const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
+  const float pxf = (float)px, pyf = (float)py;
+  const bool inside = (px < v.W) && (py < v.H);
+  bool done = !inside;
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, wmax = 0.f;
+  int wid = -1, last = 0;
+  float4* const stage = lr_stage[wq];
+  if (lane < LR_RB_SLOT) stage[64 * LR_RB_SLOT + lane] = float4{0.f, 0.f, 0.f, 0.f};
+  if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
+  const uint32_t shift8 = 8u * (uint32_t)row;
+  const float bx[2] = {(float)qx0, (float)(qx0 + 4)}, by[2] = {(float)qy0, (float)(qy0 + 4)};
+  const uint64_t rowbits = 0xffffull;
+
+  const uint32_t nchunks = (end - beg + 63u) >> 6;
+  auto load_id = [&](uint32_t c) -> uint32_t {
+    const uint32_t idx = beg + c * 64u + (uint32_t)lane;
+    return (c < nchunks && idx < end) ? plist[idx] : 0xffffffffu;
+  };
+  uint32_t id_n = load_id(0), id_nn = load_id(1);
+  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
+  float cb_n = 0.f;
+  if (id_n != 0xffffffffu) {
+    const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
+    g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
+  }
+
+  for (uint32_t ch = 0; ch < nchunks; ch++) {
+    if (__all(done)) break;
+    const uint32_t id = id_n;
+    const float4 g0 = g0_n, g1 = g1_n;
+    const float cb = cb_n;
+    id_n = id_nn;
+    id_nn = load_id(ch + 2);
+    if (id_n != 0xffffffffu) {
+      const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
+      g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    stage[lane * LR_RB_SLOT + 0] = g0;
+    stage[lane * LR_RB_SLOT + 1] = g1;
+    stage[lane * LR_RB_SLOT + 2] = float4{cb, __uint_as_float(id), 0.f, 0.f};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool valid = id != 0xffffffffu;
+    bool r0 = valid, r1 = valid, r2 = valid, r3 = valid;
+    if (cull) {
+      const LrSupport sp = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
+      r0 = r0 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[0], by[0] + 3.f);
+      r1 = r1 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[0], by[0] + 3.f);
+      r2 = r2 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[1], by[1] + 3.f);
+      r3 = r3 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[1], by[1] + 3.f);
+    }
+    uint64_t m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
+    const int pos0 = (int)(ch * 64u);
+    while (true) {
+      // a row whose 16 pixels are all saturated takes no more entries
+      const uint64_t dm = __ballot(done);
+      if (((dm >> 0) & rowbits) == rowbits) m0 = 0;
+      if (((dm >> 16) & rowbits) == rowbits) m1 = 0;
+      if (((dm >> 32) & rowbits) == rowbits) m2 = 0;
+      if (((dm >> 48) & rowbits) == rowbits) m3 = 0;
+      if (!(m0 | m1 | m2 | m3)) break;
+      uint32_t pa = 0u, pb = 0u;
+#define LR_TAKE(m, sh)                                                                          \
+      {                                                                                         \
+        uint32_t ja = 64u, jb = 64u;                                                            \
+        if (m) { ja = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
+        if (m) { jb = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
+        pa |= ja << (sh); pb |= jb << (sh);                                                     \
+      }
+      LR_TAKE(m0, 0) LR_TAKE(m1, 8) LR_TAKE(m2, 16) LR_TAKE(m3, 24)
+#undef LR_TAKE
+      const uint32_t ja = (pa >> shift8) & 0xffu, jb = (pb >> shift8) & 0xffu;
+      const float4* sa = stage + ja * LR_RB_SLOT;
+      const float4* sb = stage + jb * LR_RB_SLOT;
+      const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
+      const int gida = (int)__float_as_uint(a2.y), gidb = (int)__float_as_uint(b2.y);
+      const float op0 = a1.y, op1 = b1.y;
+      const lr_f2 dx2 = lr_f2{a0.x, b0.x} - pxf, dy2 = lr_f2{a0.y, b0.y} - pyf;
+      const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
+      const lr_f2 bdx = lr_f2{a0.w, b0.w} * dx2;
+      const lr_f2 pw2 = lr_fma2(lr_f2{a0.z, b0.z} * dx2, hdx2,
+                                lr_fma2(lr_f2{a1.x, b1.x} * dy2, hdy2, lr_f2{-bdx.x, -bdx.y} * dy2));
+      const lr_f2 al2 = lr_f2{op0, op1} * lr_exp2(pw2);
+      const float alpha0 = fminf(0.99f, al2.x), alpha1 = fminf(0.99f, al2.y);
+      // entry a, then entry b, in list order (the all-zero slot of a row without work has opacity 0: never ok)
+      const bool ok0 = !done & !(pw2.x > 0.f) & !(alpha0 < 1.0f / 255.0f);
+      const float test0 = T * (1.f - alpha0);
+      const bool stop0 = ok0 & (test0 < 0.0001f);
+      const bool acc0 = ok0 & !stop0;
+      const float w0 = acc0 ? alpha0 * T : 0.f;
+      T = acc0 ? test0 : T;
+      last = acc0 ? pos0 + (int)ja + 1 : last;
+      done = done | stop0;
+      const bool ok1 = !done & !(pw2.y > 0.f) & !(alpha1 < 1.0f / 255.0f);
+      const float test1 = T * (1.f - alpha1);
+      const bool stop1 = ok1 & (test1 < 0.0001f);
+      const bool acc1 = ok1 & !stop1;
+      const float w1 = acc1 ? alpha1 * T : 0.f;
+      T = acc1 ? test1 : T;
+      last = acc1 ? pos0 + (int)jb + 1 : last;
+      done = done | stop1;
+      const bool hit = __builtin_amdgcn_ballot_w64((w0 > 0.f) | (w1 > 0.f)) != 0;
+      if (!hit) continue;
+      if (acc0) { C0 = lr_fma(a1.z, w0, C0); C1 = lr_fma(a1.w, w0, C1); C2 = lr_fma(a2.x, w0, C2); }
+      if (acc1) { C0 = lr_fma(b1.z, w1, C0); C1 = lr_fma(b1.w, w1, C1); C2 = lr_fma(b2.x, w1, C2); }
+      if (EXTRAS) {
+        if (w0 > wmax) { wmax = w0; wid = gida; }
+        if (w1 > wmax) { wmax = w1; wid = gidb; }
+        // row maxima (non-negative floats order as unsigned): every lane of the row ends up with the row's maximum
+        uint32_t ma = __float_as_uint(w0), mb = __float_as_uint(w1);
+#define LR_RMAX(x, CTRL) x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true))
+        LR_RMAX(ma, 0x140); LR_RMAX(mb, 0x140);
+        LR_RMAX(ma, 0x141); LR_RMAX(mb, 0x141);
+        LR_RMAX(ma, 0xB1); LR_RMAX(mb, 0xB1);
+        LR_RMAX(ma, 0x4E); LR_RMAX(mb, 0x4E);
+#undef LR_RMAX
+        if (ma != 0u) {
+          if (li == 0) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gida, ma);
+          if (zero_rows && li < 4) zero_rows[4 * (size_t)(uint32_t)gida + li] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (mb != 0u) {
+          if (li == 0) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gidb, mb);
+          if (zero_rows && li < 4) zero_rows[4 * (size_t)(uint32_t)gidb + li] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
+
+  if (inside) {
+    const size_t plane = (size_t)v.W * v.H;
+    const size_t pix = (size_t)py * v.W + px;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    image[pix] = lr_fma(T, v.bg[0], C0);
+    image[plane + pix] = lr_fma(T, v.bg[1], C1);
+    image[2 * plane + pix] = lr_fma(T, v.bg[2], C2);
+    if (EXTRAS) { pid[pix] = wid; pwp[pix] = wmax; }
+  }
+}
+
+void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
+                         const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
+                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, hipStream_t s) {
+  LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
+  static const int cull = lr_env_int("LOGRAST_CULL", 1);
+  static const size_t lds_fwd = (size_t)lr_env_int("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;
+  // LOGRAST_FWD_ROWS: 1 = row-split form (lr_blend_fwd_rows_kernel), 0 = one quadrant per wave, 2 = row-split on large inputs
+  LR_KNOB(rows_knob, "LOGRAST_FWD_ROWS", 0);
+  const int rows = rows_knob == 2 ? (big_input ? 1 : 0) : rows_knob;
+  uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
+  const float4* g4 = reinterpret_cast<const float4*>(geom);
+  float4* z4 = reinterpret_cast<float4*>(zero_conic);
+  lr_prof_begin(LRK_BLEND_FWD, s);
+  if (rows) {
+    if (v.extras)
+      hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+    else
+      hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+  } else {
+    if (v.extras)
+      hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+    else
+      hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+  }
+  lr_prof_end(LRK_BLEND_FWD, s);
+}
+
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s) {
@@ -674,8 +853,9 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
   static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   // LOGRAST_BWD_ROWS=1: the row-split form (the four 16-lane rows of a wave walk their own 4x4 blocks); 0: one
-  // (Gaussian, quadrant) pair per visit; 2 (default): row-split on large inputs (measured, MI355X: 30 M tiny splats 949 ->
-  // 700 us, with random opacities 1768 -> 1259; C2's 1 M 292 -> 307).  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
+  // (Gaussian, quadrant) pair per visit; 2 (default): the caller's hint (lograst_backward flags: row-split for views of
+  // tiny splats, few tile instances per Gaussian), else row-split on large inputs.  Measured, MI355X: 30 M tiny splats
+  // 949 -> 700 us, with random opacities 1768 -> 1259; C2's 1 M 292 -> 307; a tree-ordered heavy-tailed view 448 -> 579.  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
   LR_KNOB(rows_knob, "LOGRAST_BWD_ROWS", 2);
   const int rows = rows_knob == 2 ? (big_input ? 1 : 0) : rows_knob;
   static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);

@@ -194,18 +194,31 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     const int i = (int)live_list[j];
     float gm[3], gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
     float gnx, gny, gA, gB, gC;
+    // running sums (ACCUMULATE): every old value is requested up front, next to the row's inputs -- the row is a chain of
+    // ~20 scattered accesses, and the read-modify-writes behind the chain rule's ~600 instructions were fully exposed
+    float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_c[3] = {0.f, 0.f, 0.f}, old_o = 0.f;
+    float4 old_q = {0.f, 0.f, 0.f, 0.f};
+    if (ACCUMULATE) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) old_m[k] = g_means3d[3 * (size_t)i + k];
+      if (!COV) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) old_s[k] = g_scales[3 * (size_t)i + k];
+        old_q = reinterpret_cast<const float4*>(g_rots)[i];
+      }
+      if (AOS) {
+        old_o = o_opac[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) old_c[k] = o_col[3 * (size_t)i + k];
+      }
+    }
     if (AOS) {
       const float4 a0 = rows[4 * (size_t)i], a1 = rows[4 * (size_t)i + 1];
       const float cb = reinterpret_cast<const float*>(rows + 4 * (size_t)i + 2)[0];
       gnx = a0.x; gny = a0.y; gA = a0.z; gB = a0.w; gC = a1.x;
       o_mean2d[3 * (size_t)i + 0] = gnx; o_mean2d[3 * (size_t)i + 1] = gny; o_mean2d[3 * (size_t)i + 2] = 0.f;
-      if (ACCUMULATE) {
-        o_opac[i] += a1.y;
-        o_col[3 * (size_t)i + 0] += a1.z; o_col[3 * (size_t)i + 1] += a1.w; o_col[3 * (size_t)i + 2] += cb;
-      } else {
-        o_opac[i] = a1.y;
-        o_col[3 * (size_t)i + 0] = a1.z; o_col[3 * (size_t)i + 1] = a1.w; o_col[3 * (size_t)i + 2] = cb;
-      }
+      o_opac[i] = old_o + a1.y;
+      o_col[3 * (size_t)i + 0] = old_c[0] + a1.z; o_col[3 * (size_t)i + 1] = old_c[1] + a1.w; o_col[3 * (size_t)i + 2] = old_c[2] + cb;
     } else {
       gnx = g_mean2d[3 * (size_t)i]; gny = g_mean2d[3 * (size_t)i + 1];
       const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
@@ -214,13 +227,11 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     lr_project_bwd_row<ACCUMULATE, COV>(v, i, means, scales, rots, gnx, gny, gA, gB, gC, gm, gs, gq);
     if (ACCUMULATE) {  // running sums over views (log_amd.dist)
 #pragma unroll
-      for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] += gm[k];
+      for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] = old_m[k] + gm[k];
       if (!COV) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) g_scales[3 * (size_t)i + k] += gs[k];
-        float4 q = reinterpret_cast<float4*>(g_rots)[i];
-        q.x += gq[0]; q.y += gq[1]; q.z += gq[2]; q.w += gq[3];
-        reinterpret_cast<float4*>(g_rots)[i] = q;
+        for (int k = 0; k < 3; k++) g_scales[3 * (size_t)i + k] = old_s[k] + gs[k];
+        reinterpret_cast<float4*>(g_rots)[i] = float4{old_q.x + gq[0], old_q.y + gq[1], old_q.z + gq[2], old_q.w + gq[3]};
       }
     } else {
       g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];

@@ -22,6 +22,7 @@ CANDIDATES = {
     "LOGRAST_FILL_NT": (0, 1),
     "LOGRAST_FILL_XCD_ORDER": (0, 1),
     "LOGRAST_BWD_ROWS": (0, 1, 2),
+    "LOGRAST_FWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
 }
 HELPER_KNOBS = ("LOGRAST_HELPER_MIN_N",)      # thresholds on the input size: tuned by helper_threshold()

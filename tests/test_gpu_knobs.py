@@ -24,6 +24,7 @@ SWEEP = {
     "LOGRAST_XCD_MODE": (0, 1, 2, 3),
     "LOGRAST_PROJECT_BLOCKS": (64, 512, 4096),
     "LOGRAST_BWD_ROWS": (0, 1, 2),
+    "LOGRAST_FWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LOGRAST_VERSION 3   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows) */
+#define LOGRAST_VERSION 3   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows); lograst_view gained walk_form */
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
 /* The reverse walk's accumulators: ONE 64-byte row per Gaussian -- slots 0-1 dL/d(ndc mean x, y), 2-4 dL/d(conic A, B, C),
@@ -37,6 +37,9 @@ extern "C" {
 
 /* 2-D low-pass flavours */
 #define LOGRAST_FILTER_NONE 0   /* use_filter=False of the fork (LoG/render/renderer.py:151-152) */
+#define LOGRAST_FORM_AUTO 0
+#define LOGRAST_FORM_ROWS 1
+#define LOGRAST_FORM_QUADRANT 2
 #define LOGRAST_FILTER_DILATE 1 /* upstream package: cov.xx += 0.3 (LoG/model/geometry.py:87-88) */
 #define LOGRAST_FILTER_CLAMP 2  /* `wodilate` fork: cov.xx = max(cov.xx, 0.3) (LoG/cuda/compute_radius_kernel.cu:100-104) */
 
@@ -83,6 +86,12 @@ typedef struct lograst_view {
    * `dl_dcov3d` and leave dl_dscales / dl_drotations (may be NULL) alone. */
   const float* cov3d_precomp;
   float* dl_dcov3d;
+  /* Which form of the compositing kernels (speed only, never a result; knobs LOGRAST_FWD_ROWS / LOGRAST_BWD_ROWS = 2
+   * follow it, 0 / 1 override it): LOGRAST_FORM_AUTO = the library decides from n alone; LOGRAST_FORM_ROWS = the wave's
+   * four 16-lane rows walk their own 4x4 pixel blocks (views of tiny splats: few tile instances per Gaussian);
+   * LOGRAST_FORM_QUADRANT = the whole wave walks its 8x8 quadrant.  The caller knows the view's instances per Gaussian
+   * from earlier forwards (forward) or from this view's forward (backward). */
+  int32_t walk_form;
 } lograst_view;
 
 int lograst_version(void);
@@ -244,12 +253,7 @@ int lograst_set_tile_cull(int enabled);
 #define LOGRAST_BWD_SCRATCH_ZEROED 1
 #define LOGRAST_BWD_ACCUMULATE 2
 #define LOGRAST_BWD_CONIC_TOUCHED_ONLY 4
-/* Which form of the reverse walk (speed only; knob LOGRAST_BWD_ROWS = 2 follows these, 0 / 1 override them): the caller
- * knows the view's tile instances per Gaussian from the forward -- tiny splats (few instances each) are walked by the
- * wave's four 16-lane rows on their own 4x4 blocks, larger ones by the whole wave on its 8x8 quadrant.  Neither bit: the
- * library decides from n alone. */
-#define LOGRAST_BWD_ROWSPLIT 8
-#define LOGRAST_BWD_QUADRANT 16
+
 int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                      const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,
                      const uint32_t* point_list, const float* final_t, const int32_t* n_contrib,

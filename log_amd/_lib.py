@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblograst.so")  # env: experiment builds only
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
+FORM_AUTO, FORM_ROWS, FORM_QUADRANT = 0, 1, 2
 REC_FLOATS = 16
 BWD_ROW_FLOATS = 16   # LOGRAST_BWD_ROW_FLOATS: the reverse walk's accumulator row (64 B per Gaussian)
 NUM_KERNELS = 20
@@ -25,6 +26,7 @@ class LograstView(ctypes.Structure):
         ("viewmatrix", c_void_p), ("projmatrix", c_void_p), ("bg", c_void_p),
         ("tile_row_begin", c_int32), ("tile_row_end", c_int32),
         ("cov3d_precomp", c_void_p), ("dl_dcov3d", c_void_p),
+        ("walk_form", c_int32),
     ]
 
 

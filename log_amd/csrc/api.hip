@@ -102,8 +102,8 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_FILL_NT", 1, 0, 1, "fill kernel: non-temporal streams for the fill records and zero-fills"},
     {"LOGRAST_XCD_MODE", 3, 0, 3, "blockIdx -> tile mapping of the compositing kernels (3 = longest list first)"},
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
-    {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = row-split from LOGRAST_HELPER_MIN_N Gaussians"},
-    {"LOGRAST_FWD_ROWS", 0, 0, 2, "compositing: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = row-split from LOGRAST_HELPER_MIN_N Gaussians"},
+    {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint (none: row-split from LOGRAST_HELPER_MIN_N Gaussians)"},
+    {"LOGRAST_FWD_ROWS", 2, 0, 2, "compositing: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
 };
 static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
@@ -264,6 +264,8 @@ static int lr_make_view(const lograst_view* in, LrView* out) {
   out->filter_mode = in->filter_mode; out->ndc_cull = in->ndc_cull; out->extras = in->extras;
   out->view = in->viewmatrix; out->proj = in->projmatrix; out->bg = in->bg;
   out->cov3d = in->cov3d_precomp; out->g_cov3d = in->dl_dcov3d;
+  if (in->walk_form < LOGRAST_FORM_AUTO || in->walk_form > LOGRAST_FORM_QUADRANT) return lr_fail(LOGRAST_ERR_ARG, "bad walk_form");
+  out->walk_form = in->walk_form;
   return LOGRAST_OK;
 }
 
@@ -651,8 +653,8 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   if (!(flags & LOGRAST_BWD_SCRATCH_ZEROED))
     LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * LOGRAST_BWD_ROW_FLOATS * (size_t)n, s));
   // capacity check is a forward concern: a list that rendered is by construction within capacity
-  const int form_hint = (flags & LOGRAST_BWD_ROWSPLIT) ? 1 : ((flags & LOGRAST_BWD_QUADRANT) ? 0 : (lr_big_input(n) ? 1 : 0));
-  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic, form_hint, s);
+  lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic,
+                      lr_big_input(n) ? 1 : 0, s);
   // the chain rule reads every live Gaussian's accumulator row and hands out the separate outputs: dL/dmeans2D (written
   // for all rows), dL/dopacities and dL/dcolors (written, or added to the caller's running sums)
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, nullptr, nullptr, dl_dconic, dl_dmeans2d, dl_dopacities,

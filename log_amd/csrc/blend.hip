@@ -820,9 +820,12 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
   static const int cull = lr_env_int("LOGRAST_CULL", 1);
   static const size_t lds_fwd = (size_t)lr_env_int("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;
-  // LOGRAST_FWD_ROWS: 1 = row-split form (lr_blend_fwd_rows_kernel), 0 = one quadrant per wave, 2 = row-split on large inputs
-  LR_KNOB(rows_knob, "LOGRAST_FWD_ROWS", 0);
-  const int rows = rows_knob == 2 ? (big_input ? 1 : 0) : rows_knob;
+  // LOGRAST_FWD_ROWS: 1 = row-split form (lr_blend_fwd_rows_kernel), 0 = one quadrant per wave, 2 (default) = the caller's
+  // hint (lograst_view.walk_form), quadrant without one.  Measured, MI355X: 30 M tiny splats 706 -> 658 us (random
+  // opacities 1267 -> 1188); C2's 1 M 174 -> 193; a tree-ordered heavy-tailed view 278 -> 347.
+  LR_KNOB(rows_knob, "LOGRAST_FWD_ROWS", 2);
+  const int rows = rows_knob != 2 ? rows_knob
+                   : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : (v.walk_form == LOGRAST_FORM_QUADRANT ? 0 : 0));   // no hint: quadrant
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   const float4* g4 = reinterpret_cast<const float4*>(geom);
   float4* z4 = reinterpret_cast<float4*>(zero_conic);
@@ -853,11 +856,12 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
   static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   // LOGRAST_BWD_ROWS=1: the row-split form (the four 16-lane rows of a wave walk their own 4x4 blocks); 0: one
-  // (Gaussian, quadrant) pair per visit; 2 (default): the caller's hint (lograst_backward flags: row-split for views of
+  // (Gaussian, quadrant) pair per visit; 2 (default): the caller's hint (lograst_view.walk_form: row-split for views of
   // tiny splats, few tile instances per Gaussian), else row-split on large inputs.  Measured, MI355X: 30 M tiny splats
   // 949 -> 700 us, with random opacities 1768 -> 1259; C2's 1 M 292 -> 307; a tree-ordered heavy-tailed view 448 -> 579.  LOGRAST_BWD_ABLATE (timing experiments): 1 = no atomics in the row-split form.
   LR_KNOB(rows_knob, "LOGRAST_BWD_ROWS", 2);
-  const int rows = rows_knob == 2 ? (big_input ? 1 : 0) : rows_knob;
+  const int rows = rows_knob != 2 ? rows_knob
+                   : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : (v.walk_form == LOGRAST_FORM_QUADRANT ? 0 : (big_input ? 1 : 0)));
   static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);
   LR_KNOB(block_test, "LOGRAST_BWD_BLOCK_TEST", 1);
   lr_prof_begin(LRK_BLEND_BWD, s);

@@ -72,6 +72,7 @@ struct LrView {
   int ty0, ty1;   // tile rows this call owns (image split across GPUs): rects are clipped to [ty0, ty1)
   float tanfovx, tanfovy, fx, fy, scale_modifier;
   int filter_mode, ndc_cull, extras;
+  int walk_form;   // LOGRAST_FORM_*
   const float* view;
   const float* proj;
   const float* bg;

@@ -281,7 +281,15 @@ class HipBackend:
         v.tile_row_begin, v.tile_row_end = _tile_rows.get()
         v.cov3d_precomp = cov3D.data_ptr() if cov3D is not None else None
         v.dl_dcov3d = g_cov3D.data_ptr() if g_cov3D is not None else None
+        v.walk_form = _lib.FORM_AUTO
         return v, keep
+
+    @staticmethod
+    def walk_form(instances, n):
+        """LOGRAST_FORM_* for a view of n Gaussians with `instances` tile instances (None / 0 = unknown)."""
+        if not instances or n <= 0:
+            return _lib.FORM_AUTO
+        return _lib.FORM_ROWS if instances < ROWSPLIT_MAX_INSTANCES_PER_GAUSSIAN * n else _lib.FORM_QUADRANT
 
     @staticmethod
     def _carve(device, parts):
@@ -325,9 +333,13 @@ class HipBackend:
         if scratch_floats and N:
             kept.append(("bwd_scratch", f32, (N * scratch_floats,)))
         instances = None
+        ckey = (device.index, W, H, _tile_rows.get())
+        hist = _cap_model.hist.get(ckey)
+        # which form the compositing kernel takes: instances per Gaussian as the recent forwards of this resolution had
+        # them (speculative / exact mode), or the caller's capacity (sync-free mode)
+        view.walk_form = self.walk_form(_capacity_hint if _capacity_hint is not None else (hist["ratio"] * N if hist else 0), N)
         with torch.cuda.device(device):
             if _capacity_hint is None and _speculative and N > 0:
-                ckey = (device.index, W, H, _tile_rows.get())
                 tiles = ((W + 15) // 16) * ((H + 15) // 16)
                 capacity, max_len = _cap_model.guess(ckey, N, tiles)
                 k = self._carve(device, kept + [("plist", i32, (capacity,))])
@@ -417,8 +429,7 @@ class HipBackend:
             acc = torch.zeros(N * need, **f32)
         elif pw is not None:
             flags |= 4
-        # which form of the reverse walk: tiny splats (few tile instances per Gaussian) -> the row-split form
-        flags |= 8 if saved.get("instances", 0) < ROWSPLIT_MAX_INSTANCES_PER_GAUSSIAN * N else 16
+        view.walk_form = self.walk_form(saved.get("instances", 0), N)   # tiny splats -> the row-split reverse walk
         g_conic = acc          # (the C ABI's `bwd_rows`)
         g_means2D = torch.empty(N, 3, **f32)
         if sink is None:

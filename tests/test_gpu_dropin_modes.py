@@ -193,3 +193,40 @@ def test_odd_point_count_through_the_gradient_sink_and_flat_params():
     for k in names:
         a, b = bucket.views[k].reshape(ref[k].shape), ref[k]
         assert float(b.abs().sum()) > 0 and rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5, k
+
+
+def test_walk_form_hint_changes_no_result():
+    """lograst_view.walk_form (set by the package from the view's tile instances per Gaussian: history of the resolution
+    for the forward, the forward's own count for the backward) only picks the form of the compositing kernels: the forward
+    is bit-identical in both forms and in the sync-free mode, the gradients agree to accumulation order."""
+    from log_amd import rasterizer as R, _lib
+    import gpu_util as G
+    B = R.HipBackend
+    assert B.walk_form(0, 1000) == _lib.FORM_AUTO and B.walk_form(None, 1000) == _lib.FORM_AUTO
+    assert B.walk_form(1700, 1000) == _lib.FORM_ROWS and B.walk_form(1900, 1000) == _lib.FORM_QUADRANT
+    cam, sc = small_case(n=6000, W=200, H=120, focal=220.0, seed=9, smax=0.03)
+    key = (0, cam["image_width"], cam["image_height"], (0, 0))
+    dL = np.random.default_rng(1).random((3, cam["image_height"], cam["image_width"]), dtype=np.float32)
+    res = {}
+    try:
+        for name, ratio in (("rows", 1.0), ("quadrant", 50.0)):
+            R.capacity_stats(reset=True)
+            first = G.hip_forward(cam, sc, (0.2, 0.1, 0.0), scratch_floats=16)
+            R._cap_model.hist[key]["ratio"] = ratio
+            hf = G.hip_forward(cam, sc, (0.2, 0.1, 0.0), scratch_floats=16)
+            hf["_torch"][-1]["instances"] = int(ratio * len(sc["xyz"]))      # the backward's hint
+            res[name] = (hf, G.hip_backward(hf, dL))
+            assert (first["image"].view(np.uint32) == hf["image"].view(np.uint32)).all()
+        R.set_instance_capacity(int(res["rows"][0]["I"] * 1.02) + 1024)      # sync-free: the hint is the capacity
+        hs = G.hip_forward(cam, sc, (0.2, 0.1, 0.0), scratch_floats=16)
+    finally:
+        R.set_instance_capacity(None)
+        R.capacity_stats(reset=True)
+    a, b = res["rows"], res["quadrant"]
+    for k in ("image", "final_T"):
+        assert (a[0][k].view(np.uint32) == b[0][k].view(np.uint32)).all(), k
+        assert (a[0][k].view(np.uint32) == hs[k].view(np.uint32)).all(), k
+    for k in ("n_contrib", "point_id_pixel", "point_weight", "radii"):
+        assert (a[0][k] == b[0][k]).all(), k
+    for k in a[1]:
+        assert float(np.abs(a[1][k]).sum()) > 0 and rel_l2(a[1][k], b[1][k]) < 1e-5, k

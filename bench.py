@@ -565,13 +565,44 @@ def c5_band(args, dev, bands=8, band=3, N=100_000_000, W=3840, H=2160, views=2):
                        opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
                        cov3D_precomp=None)
         out[0][:, b:e].backward(gradient=wloss)
-    full(rasts[0])
+    def timed(fn):
+        fn(rasts[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for rast in rasts:
+            fn(rast)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / len(rasts)
+
+    ms_full = timed(full)
+    # ... and with the band's gradients added straight into the rank's dense per-step rows (what a rank of the node does:
+    # no per-view gradient tensors of 100 M rows, no pre-pass, no gather / scatter -- the projection itself drops the
+    # Gaussians whose rect misses the band, at 44 bytes each: lr_project_batched_kernel<SPARSE>)
+
+    def full_sink(rast):
+        leaves = {k: v.detach().requires_grad_(True) for k, v in base.items()}
+        means2D = torch.empty(N, 3, device=dev).requires_grad_(True)
+        with R.accumulate_grads_into(sink), R.tile_rows(*rows):
+            out = rast(means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors"],
+                       opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+                       cov3D_precomp=None)
+            out[0][:, b:e].backward(gradient=wloss)
+
+    ms_sink = timed(full_sink)
+    from log_amd import tune
+    sparse_knob = tune.get_knob("LOGRAST_BAND_SPARSE")
+    tune.set_knob("LOGRAST_BAND_SPARSE", 0)
+    try:
+        ms_sink_dense = timed(full_sink)
+    finally:
+        tune.set_knob("LOGRAST_BAND_SPARSE", sparse_knob)
+    from log_amd import _lib
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    full_sink(rasts[0])
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for rast in rasts:
-        full(rast)
-    torch.cuda.synchronize()
-    ms_full = 1e3 * (time.perf_counter() - t0) / len(rasts)
+    _lib.profile_enable(False)
+    kern = {k: round(1e3 * ms_k / max(cnt, 1), 1) for k, (ms_k, cnt) in _lib.profile_read().items()}
     return {"workload": "C5 band (BASELINE.json configs[4] on one of its 8 GPUs): %d random Gaussians (device RNG, seed 0, "
                         "opacity 0.999), %dx%d, band %d of %d = tile rows [%d, %d), %d orbit views: tile-row pre-pass over "
                         "all Gaussians -> select -> gather -> forward + backward of the band -> scatter-add of the gradients"
@@ -579,7 +610,14 @@ def c5_band(args, dev, bands=8, band=3, N=100_000_000, W=3840, H=2160, views=2):
             "gaussians": N, "gaussians_in_band": info["n_band"], "tile_instances_in_band": info["instances"],
             "ms_per_view": ms, "stages_ms": {k: 1e3 * v / len(rasts) for k, v in stages.items()},
             "ms_per_view_band_clipped_inside_full_projection": ms_full,
-            "gaussians_per_s_per_gpu": N / (ms * 1e-3)}
+            "ms_per_view_band_clipped_gradient_sink": ms_sink,
+            "ms_per_view_band_clipped_gradient_sink_full_view_kernel": ms_sink_dense,
+            "kernels_us_band_clipped_gradient_sink": kern,
+            "gaussians_per_s_per_gpu": N / (min(ms, ms_full, ms_sink) * 1e-3),
+            "note": "ms_per_view: pre-pass + gather / scatter path; band_clipped_*: all 100 M Gaussians handed to the "
+                    "rasterizer with tile_row_begin/end set -- autograd gradients (five fresh 100 M-row tensors per view) "
+                    "or added into the rank's per-step rows (gradient_sink: the multi-GPU step's form); "
+                    "gaussians_per_s_per_gpu is the fastest of the three"}
 
 
 def main():

@@ -104,6 +104,7 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
     {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint (none: row-split from LOGRAST_HELPER_MIN_N Gaussians)"},
     {"LOGRAST_FWD_ROWS", 2, 0, 2, "compositing: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint"},
+    {"LOGRAST_BAND_SPARSE", 1, 0, 1, "band views (tile_row_begin/end a proper part of the grid): 1 = Gaussians without a rect cost 44 bytes (no record, late opacity / colour), 0 = the full-view kernel"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
 };
 static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
@@ -278,8 +279,9 @@ size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
   return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy, gx, gy).batch));
 }
-size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection
-  return (sizeof(float) * LOGRAST_REC_FLOATS + 16) * (size_t)(n > 0 ? n : 0);
+size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection + one bit each (band views)
+  const size_t m = (size_t)(n > 0 ? n : 0);
+  return (sizeof(float) * LOGRAST_REC_FLOATS + 16) * m + 8 * ((m + 63) / 64);
 }
 size_t lograst_keys_bytes(uint32_t capacity) { return 2 * sizeof(uint64_t) * (size_t)capacity; }  // keys + sort scratch
 size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }

@@ -39,6 +39,7 @@
 #define LR_HDR_BATCH 6  // Gaussians per projection batch (0 = unbatched kernel: slots in q3 are absolute)
 #define LR_HDR_CULL 5  // 1 if lr_project_kernel applied the support cull (the fill kernel must repeat it)
 #define LR_HDR_RECT 4  // tile instances of the plain rect rule (what the reference would sort), before the support cull
+#define LR_HDR_SPARSE 3  // batched projection of a band view: records / fill records exist only where the bitmap behind the fill records says so
 #define LR_HDR_HUGE 7  // batched projection: some workgroup deferred a rect to lr_count_huge_kernel (else that kernel returns at once)
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_LONG_LIST 4096   // longer lists are sorted with their keys streamed from memory (shorter ones: LDS-resident)

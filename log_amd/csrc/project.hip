@@ -67,6 +67,9 @@ struct LrInputs {
 };
 // (cov3d: the rasterizer's cov3D_precomp instead of scales + rotations -- its six floats travel in s[] and q.xyz, so the
 // prefetch holds no more registers)
+// LATE: opacity and colour are left out (16 of the 56 bytes): lr_project_one<.., LATE> fetches them once the Gaussian has
+// a non-empty rect -- for views that own a band of tile rows, where most Gaussians have none.
+template <bool LATE = false>
 LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const float* __restrict__ scales,
                                const float* __restrict__ rots, const float* __restrict__ opac,
                                const float* __restrict__ colors, const float* __restrict__ cov3d) {
@@ -80,8 +83,12 @@ LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const flo
     in.s[0] = scales[3 * i]; in.s[1] = scales[3 * i + 1]; in.s[2] = scales[3 * i + 2];
     in.q = reinterpret_cast<const float4*>(rots)[i];
   }
-  in.op = opac[i];
-  in.c[0] = colors[3 * i]; in.c[1] = colors[3 * i + 1]; in.c[2] = colors[3 * i + 2];
+  if (LATE) {
+    in.op = 0.f; in.c[0] = 0.f; in.c[1] = 0.f; in.c[2] = 0.f;
+  } else {
+    in.op = opac[i];
+    in.c[0] = colors[3 * i]; in.c[1] = colors[3 * i + 1]; in.c[2] = colors[3 * i + 2];
+  }
   return in;
 }
 
@@ -90,10 +97,11 @@ LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const flo
 // DEFER_HUGE: rects of more than `defer_tiles` tiles are not counted here (`huge` is raised instead and
 // lr_count_huge_kernel counts them, one wave per rect) -- a lane walking an 81-tile rect with a 50-instruction support
 // test per tile holds up its whole wave, and in level-of-detail order the big splats sit together in a few batches.
-template <bool DEFER_HUGE, typename Counters>
+template <bool DEFER_HUGE, typename Counters, bool LATE = false>
 LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, const Counters& ctr, float4& g0,
                            float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances, bool& huge,
-                           int defer_tiles = LR_COOP_TILES) {
+                           int defer_tiles = LR_COOP_TILES, const float* __restrict__ late_opac = nullptr,
+                           const float* __restrict__ late_colors = nullptr, int late_i = 0) {
   huge = false;
   const float* __restrict__ V = v.view;
   const float* __restrict__ Pm = v.proj;
@@ -135,9 +143,14 @@ LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, c
   y0 = min(v.ty1, max(v.ty0, y0)); y1 = min(v.ty1, max(v.ty0, y1));   // [ty0, ty1) = [0, gy) unless the image is split
   if ((x1 - x0) * (y1 - y0) <= 0) return;
   rad = (int)rf;
+  float op = in.op, c0 = in.c[0], c1 = in.c[1], c2 = in.c[2];
+  if (LATE) {   // only the Gaussians that reach this line cost their 16 bytes of opacity and colour
+    op = late_opac[late_i];
+    c0 = late_colors[3 * late_i]; c1 = late_colors[3 * late_i + 1]; c2 = late_colors[3 * late_i + 2];
+  }
   g0 = float4{mx, my, cA, cB};
-  g1 = float4{cC, in.op, in.c[0], in.c[1]};
-  g2 = float4{in.c[2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
+  g1 = float4{cC, op, c0, c1};
+  g2 = float4{c2, tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
               __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
   const int w = x1 - x0, nt = w * (y1 - y0);
   rect_instances += (uint32_t)nt;
@@ -265,7 +278,14 @@ LR_DEV void lr_quad_transpose(float4& a, float4& b, float4& c, float4& d, int m)
   lr_quad_exchange<0x4E>(b, d, (m & 2) != 0);
 }
 
+// SPARSE (views that own a band of tile rows, [ty0, ty1) a proper part of the grid -- one rank's share of an image split
+// across GPUs, SURVEY 8e: most Gaussians end with an empty rect): a Gaussian without a rect costs the 40 bytes its rect
+// is computed from, its radii word and one bit -- opacity and colour are fetched late (above), its 64-byte record and its
+// 16-byte fill record are NOT written (nothing reads the records of Gaussians with radii == 0), and a bitmap behind the
+// fill records (one word per wave of 64 Gaussians) tells lr_fill_kernel / lr_count_huge_kernel which fill records
+// exist.  100 M Gaussians at 3840x2160, band of 17 of the 135 tile rows: 14 GB of projection traffic -> 6.
 #define LR_MAX_PLANES 4
+template <bool SPARSE>
 __global__ void __launch_bounds__(LR_BATCH_THREADS)
 lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                           const float* __restrict__ rots, const float* __restrict__ opac,
@@ -278,30 +298,37 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   const int tiles = v.gx * v.gy;
   for (int t = threadIdx.x; t < S * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
   if (threadIdx.x < LR_MAX_PLANES) lr_huge_cnt[threadIdx.x] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; hdr[LR_HDR_SPARSE] = SPARSE ? 1u : 0u;
+  }
   __syncthreads();
   uint32_t rect_instances = 0;
   const int i_begin = blockIdx.x * (S * B), i_end = min(N, i_begin + S * B);
+  uint4* const fillrec = reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N);
+  uint64_t* const has_rect = reinterpret_cast<uint64_t*>(fillrec + N);    // SPARSE: bit (i & 63) of word i >> 6
   // software pipeline: the next Gaussian's inputs are requested before the current one is projected (a workgroup
   // is 16 waves on one CU, so there is little other work to hide the loads behind)
   int i = i_begin + (int)threadIdx.x;
   LrInputs nxt;
-  if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors, v.cov3d);
+  if (i < i_end) nxt = lr_load_inputs<SPARSE>(i, means, scales, rots, opac, colors, v.cov3d);
   // (trip count uniform per wave: the record stores below are cooperative among groups of four lanes)
   for (; (i & ~63) < i_end; i += LR_BATCH_THREADS) {
     const bool mine = i < i_end;
     const LrInputs in = nxt;
-    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
+    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs<SPARSE>(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
     const int plane = ((i & ~63) - i_begin) / B;            // B is a multiple of the workgroup size: uniform per iteration
     const LrLdsCounters ctr{lr_lds_ctr + plane * tiles};
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
     int rad = 0;
     bool huge = false;
     if (mine) {
-      lr_project_one<true>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
+      lr_project_one<true, LrLdsCounters, SPARSE>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge,
+                                                  defer_tiles, opac, colors, i);
       if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
       radii[i] = rad;
     }
+    const uint64_t rect_mask = SPARSE ? __ballot(rad > 0) : ~0ull;   // (rad is 0 in lanes beyond i_end)
+    if (SPARSE && (threadIdx.x & 63) == 0 && mine) has_rect[i >> 6] = rect_mask;   // i is a multiple of 64 in lane 0
     // Records leave as full 64-byte lines: a lane's four quads are 64 B apart from its neighbour's, so storing them
     // lane by lane makes every store instruction touch 64 lines with 16 B each (four partial writes per line at the
     // L2).  A 4x4 transpose inside every group of four lanes (two DPP quad-permute stages) gives lane m the quad m of
@@ -312,12 +339,15 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       lr_quad_transpose(t0, t1, t2, t3, m);                  // t[k] = quad m of Gaussian (i - m + k)
       const int ib = i - m;
       float4* rec = geom + LR_REC_QUADS * (size_t)ib + m;
-      if (ib + 0 < i_end) rec[0 * LR_REC_QUADS] = t0;
-      if (ib + 1 < i_end) rec[1 * LR_REC_QUADS] = t1;
-      if (ib + 2 < i_end) rec[2 * LR_REC_QUADS] = t2;
-      if (ib + 3 < i_end) rec[3 * LR_REC_QUADS] = t3;       // (q3 is not read in this mode: written to complete the 64-byte line)
+      // SPARSE: a group of four Gaussians without a rect among them stores nothing
+      if (!SPARSE || ((rect_mask >> ((threadIdx.x & 63) & ~3)) & 0xfull)) {
+        if (ib + 0 < i_end) rec[0 * LR_REC_QUADS] = t0;
+        if (ib + 1 < i_end) rec[1 * LR_REC_QUADS] = t1;
+        if (ib + 2 < i_end) rec[2 * LR_REC_QUADS] = t2;
+        if (ib + 3 < i_end) rec[3 * LR_REC_QUADS] = t3;     // (q3 is not read in this mode: written to complete the 64-byte line)
+      }
     }
-    if (!mine) continue;
+    if (!mine || (SPARSE && rad <= 0)) continue;
     // Fill record (16 B, its own coalesced array behind the records): everything lr_fill_kernel needs, so that it
     // does not fetch half of every 64-byte record again.  x = depth bits; y = x0 | y0<<13 | (w-1)<<26 | (h-1)<<28 |
     // big<<30 (all ones = nothing to fill); ranked: z,w = four 16-bit ranks inside the batch (0xffff = tile dropped
@@ -337,7 +367,7 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
         fr.z = x1 | (y1 << 16);
       }
     }
-    reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N)[i] = fr;
+    fillrec[i] = fr;
   }
   __syncthreads();
   // reservations: eight tiles per thread per round, all eight returning atomics in flight before the first result
@@ -409,11 +439,13 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint4* __restrict__ fill = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
+  const uint64_t* __restrict__ has_rect = reinterpret_cast<const uint64_t*>(fill + N);
+  const bool sparse = hdr[LR_HDR_SPARSE] != 0u;              // only the fill records of Gaussians with a rect exist
   for (int k = 0; k < chunk / 256; k++) {
     const int i = base + k * 256 + (int)threadIdx.x;
     int x0 = 0, y0 = 0, w = 0, nt = 0;
     LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};
-    if (i < N) {
+    if (i < N && (!sparse || ((has_rect[i >> 6] >> (i & 63)) & 1ull))) {
       const uint4 fr = fill[i];
       if (fr.y != 0xffffffffu && (fr.y & (1u << 30))) {
         x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
@@ -463,7 +495,9 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const size_t lds = sizeof(uint32_t) * (size_t)tiles;
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_count_huge_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
@@ -475,9 +509,16 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const int batches = (N + batch - 1) / batch;
     const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
     uint32_t* hugecount = basetab + (size_t)batches * tiles;
-    hipLaunchKernelGGL(lr_project_batched_kernel, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
-                       means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                       basetab, hugecount, tile_cull, batch, planes, defer_tiles);
+    LR_KNOB(sparse_knob, "LOGRAST_BAND_SPARSE", 1);
+    const bool sparse = sparse_knob && (v.ty0 > 0 || v.ty1 < v.gy);   // a band of tile rows: most rects are empty
+    if (sparse)
+      hipLaunchKernelGGL(lr_project_batched_kernel<true>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
+                         means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
+                         basetab, hugecount, tile_cull, batch, planes, defer_tiles);
+    else
+      hipLaunchKernelGGL(lr_project_batched_kernel<false>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
+                         means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
+                         basetab, hugecount, tile_cull, batch, planes, defer_tiles);
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
     hipLaunchKernelGGL(lr_count_huge_kernel, dim3(min((N + chunk - 1) / chunk, 2048)), dim3(256), lds + 1028, s, N, v.gx,
@@ -734,6 +775,12 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   uint32_t dbits = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
   uint32_t slot[LR_RANKED_TILES] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  if (vis && batch && state[LR_HDR_SPARSE]) {
+    // band views: fill records exist only for Gaussians with a rect (lr_project_batched_kernel<true>)
+    const uint64_t* __restrict__ has_rect =
+        reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N) + N);
+    vis = ((has_rect[i >> 6] >> (i & 63)) & 1ull) != 0ull;
+  }
   if (vis && batch) {
     // batched projection: the 16-byte fill record (see lr_project_batched_kernel)
     const uint4* frp = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N) + i;

@@ -26,6 +26,7 @@ SWEEP = {
     "LOGRAST_BWD_ROWS": (0, 1, 2),
     "LOGRAST_FWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
+    "LOGRAST_BAND_SPARSE": (0, 1),
 }
 
 
@@ -83,6 +84,50 @@ def test_every_knob_leaves_every_output_bit_identical():
             tune.set_knob("LOGRAST_NO_SUCH_KNOB", 1)
         with pytest.raises(Exception, match="out of range"):
             tune.set_knob("LOGRAST_BATCH_PLANES", 9)
+    finally:
+        tune.reset_knobs()
+
+
+def test_band_views_skip_rectless_gaussians_without_changing_a_bit():
+    """A view that owns a band of tile rows (one rank's share of an image split across GPUs) projects in the sparse mode:
+    Gaussians whose rect misses the band cost neither a record nor a fill record nor their opacity / colour
+    (LOGRAST_BAND_SPARSE).  Against the full-view kernel on the same band, for bands at the top, the middle and the
+    bottom of the image, with deferred (huge) rects in play and with the exact two-call forward as well as the
+    speculative one: radii, tile lists, image, fork maps bit for bit; records of the Gaussians that have a rect bit for
+    bit; gradients to summation-order noise."""
+    import gpu_util as G
+    from log_amd import rasterizer as R, tune
+    cam, sc = _tree_view()
+    H = cam["image_height"]
+    gy = (H + 15) // 16
+    dL = np.random.default_rng(4).random((3, H, cam["image_width"]), dtype=np.float32)
+    tune.reset_knobs()
+    try:
+        for rows in ((0, 7), (gy // 2 - 3, gy // 2 + 4), (gy - 6, gy)):
+            for speculative in (False, True):
+                prev = R.set_speculative(speculative)
+                try:
+                    res = {}
+                    for sparse in (0, 1):
+                        tune.set_knob("LOGRAST_BAND_SPARSE", sparse)
+                        tune.set_knob("LOGRAST_DEFER_TILES", 8)               # more rects through lr_count_huge_kernel
+                        with R.tile_rows(*rows):
+                            hf = G.hip_forward(cam, sc, (1.0, 1.0, 1.0), scratch_floats=16)
+                            res[sparse] = (hf, G.hip_backward(hf, dL))
+                finally:
+                    R.set_speculative(prev)
+                (a, ga), (b, gb) = res[0], res[1]
+                vis = a["radii"] > 0
+                if rows[0] > 0 and rows[1] < gy:                              # the middle band: a real mix
+                    assert 0.01 < vis.mean() < 0.95 and a["I"] > 1000, (rows, vis.mean(), a["I"])
+                for k in ("image", "final_T", "point_weight_pixel", "point_weight"):
+                    assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), (rows, k)
+                for k in ("radii", "tile_offsets", "point_list", "n_contrib", "point_id_pixel"):
+                    assert (a[k] == b[k]).all(), (rows, k)
+                assert (a["rec"][vis].view(np.uint32) == b["rec"][vis].view(np.uint32)).all(), rows
+                for k in ga:
+                    assert rel_l2(gb[k], ga[k]) < 1e-5, (rows, k)
+                    assert np.abs(gb[k][~vis]).max() == 0 or k == "conic", (rows, k)
     finally:
         tune.reset_knobs()
 

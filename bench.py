@@ -590,19 +590,24 @@ def c5_band(args, dev, bands=8, band=3, N=100_000_000, W=3840, H=2160, views=2):
 
     ms_sink = timed(full_sink)
     from log_amd import tune
+    from log_amd import _lib
+
+    def kernels():
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        full_sink(rasts[0])
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        return {k: round(1e3 * ms_k / max(cnt, 1), 1) for k, (ms_k, cnt) in _lib.profile_read().items()}
+
+    kern = kernels()
     sparse_knob = tune.get_knob("LOGRAST_BAND_SPARSE")
     tune.set_knob("LOGRAST_BAND_SPARSE", 0)
     try:
         ms_sink_dense = timed(full_sink)
+        kern_dense = kernels()
     finally:
         tune.set_knob("LOGRAST_BAND_SPARSE", sparse_knob)
-    from log_amd import _lib
-    _lib.profile_reset()
-    _lib.profile_enable(True)
-    full_sink(rasts[0])
-    torch.cuda.synchronize()
-    _lib.profile_enable(False)
-    kern = {k: round(1e3 * ms_k / max(cnt, 1), 1) for k, (ms_k, cnt) in _lib.profile_read().items()}
     return {"workload": "C5 band (BASELINE.json configs[4] on one of its 8 GPUs): %d random Gaussians (device RNG, seed 0, "
                         "opacity 0.999), %dx%d, band %d of %d = tile rows [%d, %d), %d orbit views: tile-row pre-pass over "
                         "all Gaussians -> select -> gather -> forward + backward of the band -> scatter-add of the gradients"
@@ -613,6 +618,7 @@ def c5_band(args, dev, bands=8, band=3, N=100_000_000, W=3840, H=2160, views=2):
             "ms_per_view_band_clipped_gradient_sink": ms_sink,
             "ms_per_view_band_clipped_gradient_sink_full_view_kernel": ms_sink_dense,
             "kernels_us_band_clipped_gradient_sink": kern,
+            "kernels_us_band_clipped_gradient_sink_full_view_kernel": kern_dense,
             "gaussians_per_s_per_gpu": N / (min(ms, ms_full, ms_sink) * 1e-3),
             "note": "ms_per_view: pre-pass + gather / scatter path; band_clipped_*: all 100 M Gaussians handed to the "
                     "rasterizer with tile_row_begin/end set -- autograd gradients (five fresh 100 M-row tensors per view) "

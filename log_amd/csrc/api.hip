@@ -23,7 +23,8 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
                        uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int planes, int tile_cull,
                        hipStream_t s);
 void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_off, hipStream_t s);
-void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, hipStream_t s);
+void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, uint32_t t_lo, uint32_t t_hi, hipStream_t s);
+bool lr_band_sparse(const LrView& v, int batch);
 void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
@@ -104,7 +105,8 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
     {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint (none: row-split from LOGRAST_HELPER_MIN_N Gaussians)"},
     {"LOGRAST_FWD_ROWS", 2, 0, 2, "compositing: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint"},
-    {"LOGRAST_BAND_SPARSE", 1, 0, 1, "band views (tile_row_begin/end a proper part of the grid): 1 = Gaussians without a rect cost 44 bytes (no record, late opacity / colour), 0 = the full-view kernel"},
+    {"LOGRAST_FILL_PER_THREAD", 1, 1, 4, "bucket fill: Gaussians per thread (their fill records are requested together): 1, 2 or 4"},
+    {"LOGRAST_BAND_SPARSE", 1, 0, 1, "band views (tile_row_begin/end a proper part of the grid): 1 = the band projection (Gaussians without a rect cost 44 bytes, survivors compacted into full waves), 0 = the full-view kernel"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
 };
 static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
@@ -279,9 +281,8 @@ size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
   return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy, gx, gy).batch));
 }
-size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection + one bit each (band views)
-  const size_t m = (size_t)(n > 0 ? n : 0);
-  return (sizeof(float) * LOGRAST_REC_FLOATS + 16) * m + 8 * ((m + 63) / 64);
+size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection + a 4-byte index each (band views)
+  return (sizeof(float) * LOGRAST_REC_FLOATS + 16 + 4) * (size_t)(n > 0 ? n : 0);
 }
 size_t lograst_keys_bytes(uint32_t capacity) { return 2 * sizeof(uint64_t) * (size_t)capacity; }  // keys + sort scratch
 size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }
@@ -319,7 +320,12 @@ static int lr_stage1(const LrView& v, int32_t n, const float* means3d, const flo
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
                     st + big_off, st, st + lr_basetab_off(tiles), (int)bt.batch, (int)bt.planes, lr_tile_cull(), s);
   lr_launch_scan(st, tiles, cs, big_off, s);
-  if (lr_big_input(n)) lr_launch_rebase(st, tiles, lr_batches(n, bt.batch), s);  return LOGRAST_OK;
+  if (lr_big_input(n)) {
+    const bool band = lr_band_sparse(v, (int)bt.batch);   // only the band's tiles have slot-table entries
+    lr_launch_rebase(st, tiles, lr_batches(n, bt.batch), band ? (uint32_t)(v.ty0 * v.gx) : 0u,
+                     band ? (uint32_t)(v.ty1 * v.gx) : tiles, s);
+  }
+  return LOGRAST_OK;
 }
 
 // stage 2 launches: bucket fill (+ zero-fills), per-tile sort, compositing

@@ -39,7 +39,8 @@
 #define LR_HDR_BATCH 6  // Gaussians per projection batch (0 = unbatched kernel: slots in q3 are absolute)
 #define LR_HDR_CULL 5  // 1 if lr_project_kernel applied the support cull (the fill kernel must repeat it)
 #define LR_HDR_RECT 4  // tile instances of the plain rect rule (what the reference would sort), before the support cull
-#define LR_HDR_SPARSE 3  // batched projection of a band view: records / fill records exist only where the bitmap behind the fill records says so
+#define LR_HDR_SPARSE 3  // band view (lr_project_band_kernel): only Gaussians with a rect have a record; their fill records are compacted per projection workgroup:
+#define LR_HDR_SPAN 8    // workgroup w owns fill-record slots [w * span, w * span + survcount[w]), the Gaussians' indices behind the fill records
 #define LR_HDR_HUGE 7  // batched projection: some workgroup deferred a rect to lr_count_huge_kernel (else that kernel returns at once)
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_LONG_LIST 4096   // longer lists are sorted with their keys streamed from memory (shorter ones: LDS-resident)
@@ -58,8 +59,12 @@ __host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_o
 __host__ __device__ inline size_t lr_hugecount_off(uint32_t tiles, uint32_t batches) {
   return (size_t)lr_basetab_off(tiles) + (size_t)batches * tiles;
 }
-__host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batches) {
+// then survcount[batches] (band views: survivors of projection workgroup w at [w], lr_project_band_kernel)
+__host__ __device__ inline size_t lr_survcount_off(uint32_t tiles, uint32_t batches) {
   return lr_hugecount_off(tiles, batches) + ((batches + 15u) & ~15u);
+}
+__host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batches) {
+  return lr_survcount_off(tiles, batches) + ((batches + 15u) & ~15u);
 }
 #define LR_COOP_TILES 16   // rects above this many tiles are expanded by a whole wave (lanes = tiles), not by their lane
 #define LR_HUGE_CHUNK 256  // Gaussians per workgroup of lr_count_huge_kernel (a chunk full of 81-tile rects is a serial walk per wave: 2048 ran 0.36 ms on the tree-ordered view, 512 0.14, 256 0.093)
@@ -82,6 +87,13 @@ struct LrView {
 };
 
 #define LR_DEV __device__ __forceinline__
+
+// The view's matrices (device pointers in lograst_view) never change while a kernel runs.  Read through the constant
+// address space they are scalar loads (s_load_dword: the scalar cache, counted by lgkmcnt) wherever the compiler needs
+// them; read through the flat pointer, a kernel with enough stores in it gets VECTOR loads of these uniform addresses,
+// each followed by s_waitcnt vmcnt(0) -- which also waits for the prefetch of the next iteration's inputs.
+typedef const float __attribute__((address_space(4))) lr_cfloat;
+LR_DEV const lr_cfloat* lr_uniform(const float* p) { return (const lr_cfloat*)p; }
 
 LR_DEV float lr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 LR_DEV float lr_dot3p(float a0, float a1, float a2, float b0, float b1, float b2, float c) {
@@ -173,7 +185,9 @@ struct LrEwa {
 
 // EWA projection of the 3-D covariance (/root/reference/LoG/cuda/compute_radius_kernel.cu:63-105),
 // with the low-pass selectable: fork max(.,0.3) (:102-103) / upstream +0.3 (LoG/model/geometry.py:87-88) / none.
-LR_DEV void lr_ewa(const float p[3], const float Sg[6], const float* __restrict__ V, float fx, float fy,
+// (V: const float*, or the view's matrix through lr_uniform())
+template <typename VP>
+LR_DEV void lr_ewa(const float p[3], const float Sg[6], VP V, float fx, float fy,
                    float tanfovx, float tanfovy, int filter_mode, LrEwa& e) {
   e.t[0] = lr_dot3p(V[0], V[4], V[8], p[0], p[1], p[2], V[12]);
   e.t[1] = lr_dot3p(V[1], V[5], V[9], p[0], p[1], p[2], V[13]);

@@ -67,9 +67,9 @@ struct LrInputs {
 };
 // (cov3d: the rasterizer's cov3D_precomp instead of scales + rotations -- its six floats travel in s[] and q.xyz, so the
 // prefetch holds no more registers)
-// LATE: opacity and colour are left out (16 of the 56 bytes): lr_project_one<.., LATE> fetches them once the Gaussian has
-// a non-empty rect -- for views that own a band of tile rows, where most Gaussians have none.
-template <bool LATE = false>
+// RECT_ONLY: opacity and colour are left out (16 of the 56 bytes) -- what lr_project_rect needs; lr_project_band_kernel
+// fetches the other two for the Gaussians that turn out to have a rect.
+template <bool RECT_ONLY = false>
 LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const float* __restrict__ scales,
                                const float* __restrict__ rots, const float* __restrict__ opac,
                                const float* __restrict__ colors, const float* __restrict__ cov3d) {
@@ -83,7 +83,7 @@ LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const flo
     in.s[0] = scales[3 * i]; in.s[1] = scales[3 * i + 1]; in.s[2] = scales[3 * i + 2];
     in.q = reinterpret_cast<const float4*>(rots)[i];
   }
-  if (LATE) {
+  if (RECT_ONLY) {
     in.op = 0.f; in.c[0] = 0.f; in.c[1] = 0.f; in.c[2] = 0.f;
   } else {
     in.op = opac[i];
@@ -92,32 +92,23 @@ LR_DEV LrInputs lr_load_inputs(int i, const float* __restrict__ means, const flo
   return in;
 }
 
-// Projection of one Gaussian (A1) + counting / ranking of its tile instances (A2) against `ctr`.  Outputs the four
-// record quads, the integer radius (0 = culled) and the rect-rule instance count.
-// DEFER_HUGE: rects of more than `defer_tiles` tiles are not counted here (`huge` is raised instead and
-// lr_count_huge_kernel counts them, one wave per rect) -- a lane walking an 81-tile rect with a 50-instruction support
-// test per tile holds up its whole wave, and in level-of-detail order the big splats sit together in a few batches.
-template <bool DEFER_HUGE, typename Counters, bool LATE = false>
-LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, const Counters& ctr, float4& g0,
-                           float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances, bool& huge,
-                           int defer_tiles = LR_COOP_TILES, const float* __restrict__ late_opac = nullptr,
-                           const float* __restrict__ late_colors = nullptr, int late_i = 0) {
-  huge = false;
-  const float* __restrict__ V = v.view;
-  const float* __restrict__ Pm = v.proj;
-  rad = 0;
-  g0 = float4{0.f, 0.f, 0.f, 0.f};
-  g1 = g0; g3 = g0;
-  g2 = g0;  // culled: empty rect (the fill kernel reads only q2)
+// The rect of one Gaussian: everything lr_project_one computes from means3D / scales / rotations alone.
+struct LrRect {
+  float mx, my, cA, cB, cC, tz;
+  int x0, y0, x1, y1, rad;
+};
+LR_DEV bool lr_project_rect(const LrView& v, const LrInputs& in, LrRect& r) {
+  const lr_cfloat* V = lr_uniform(v.view);
+  const lr_cfloat* Pm = lr_uniform(v.proj);
   const float p[3] = {in.p[0], in.p[1], in.p[2]};
   float tz = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
-  if (!(tz > 0.2f)) return;
+  if (!(tz > 0.2f)) return false;
   float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], p[0], p[1], p[2], Pm[12]);
   float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], p[0], p[1], p[2], Pm[13]);
   float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], p[0], p[1], p[2], Pm[15]);
   float pw = 1.0f / (hw + 0.0000001f);
   float nx = hx * pw, ny = hy * pw;
-  if (v.ndc_cull && (nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) return;
+  if (v.ndc_cull && (nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f)) return false;
   float Sg[6];
   if (v.cov3d) {   // cov3D_precomp (wave-uniform): see lr_load_inputs
     Sg[0] = in.s[0]; Sg[1] = in.s[1]; Sg[2] = in.s[2]; Sg[3] = in.q.x; Sg[4] = in.q.y; Sg[5] = in.q.z;
@@ -130,27 +121,44 @@ LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, c
   LrEwa e;
   lr_ewa(p, Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
   float det = e.a * e.c - e.b * e.b;
-  if (det == 0.0f) return;
+  if (det == 0.0f) return false;
   float det_inv = 1.f / det;
-  float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
+  r.cA = e.c * det_inv; r.cB = -e.b * det_inv; r.cC = e.a * det_inv;
   float rf = ceilf(lr_radius_from_cov(e.a, e.c, det));
   float mx = ((nx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
   float my = ((ny + 1.0f) * (float)v.H - 1.0f) * 0.5f;
-  if (!((rf <= 1048576.f) && (fabsf(mx) < 1.0e8f) && (fabsf(my) < 1.0e8f))) return;
+  if (!((rf <= 1048576.f) && (fabsf(mx) < 1.0e8f) && (fabsf(my) < 1.0e8f))) return false;
   int x0 = (int)((mx - rf) / 16.f), y0 = (int)((my - rf) / 16.f);
   int x1 = (int)(((mx + rf) + 15.f) / 16.f), y1 = (int)(((my + rf) + 15.f) / 16.f);
   x0 = min(v.gx, max(0, x0)); x1 = min(v.gx, max(0, x1));
   y0 = min(v.ty1, max(v.ty0, y0)); y1 = min(v.ty1, max(v.ty0, y1));   // [ty0, ty1) = [0, gy) unless the image is split
-  if ((x1 - x0) * (y1 - y0) <= 0) return;
-  rad = (int)rf;
-  float op = in.op, c0 = in.c[0], c1 = in.c[1], c2 = in.c[2];
-  if (LATE) {   // only the Gaussians that reach this line cost their 16 bytes of opacity and colour
-    op = late_opac[late_i];
-    c0 = late_colors[3 * late_i]; c1 = late_colors[3 * late_i + 1]; c2 = late_colors[3 * late_i + 2];
-  }
+  if ((x1 - x0) * (y1 - y0) <= 0) return false;
+  r.mx = mx; r.my = my; r.tz = tz; r.x0 = x0; r.y0 = y0; r.x1 = x1; r.y1 = y1; r.rad = (int)rf;
+  return true;
+}
+
+// Projection of one Gaussian (A1) + counting / ranking of its tile instances (A2) against `ctr`.  Outputs the four
+// record quads, the integer radius (0 = culled) and the rect-rule instance count.
+// DEFER_HUGE: rects of more than `defer_tiles` tiles are not counted here (`huge` is raised instead and
+// lr_count_huge_kernel counts them, one wave per rect) -- a lane walking an 81-tile rect with a 50-instruction support
+// test per tile holds up its whole wave, and in level-of-detail order the big splats sit together in a few batches.
+template <bool DEFER_HUGE, typename Counters>
+LR_DEV void lr_project_one(const LrView& v, const LrInputs& in, int tile_cull, const Counters& ctr, float4& g0,
+                           float4& g1, float4& g2, float4& g3, int& rad, uint32_t& rect_instances, bool& huge,
+                           int defer_tiles = LR_COOP_TILES) {
+  huge = false;
+  rad = 0;
+  g0 = float4{0.f, 0.f, 0.f, 0.f};
+  g1 = g0; g3 = g0;
+  g2 = g0;  // culled: empty rect (the fill kernel reads only q2)
+  LrRect rc;
+  if (!lr_project_rect(v, in, rc)) return;
+  const float mx = rc.mx, my = rc.my, cA = rc.cA, cB = rc.cB, cC = rc.cC, tz = rc.tz;
+  const int x0 = rc.x0, y0 = rc.y0, x1 = rc.x1, y1 = rc.y1;
+  rad = rc.rad;
   g0 = float4{mx, my, cA, cB};
-  g1 = float4{cC, op, c0, c1};
-  g2 = float4{c2, tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
+  g1 = float4{cC, in.op, in.c[0], in.c[1]};
+  g2 = float4{in.c[2], tz, __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 16)),
               __uint_as_float((uint32_t)x1 | ((uint32_t)y1 << 16))};
   const int w = x1 - x0, nt = w * (y1 - y0);
   rect_instances += (uint32_t)nt;
@@ -278,14 +286,58 @@ LR_DEV void lr_quad_transpose(float4& a, float4& b, float4& c, float4& d, int m)
   lr_quad_exchange<0x4E>(b, d, (m & 2) != 0);
 }
 
-// SPARSE (views that own a band of tile rows, [ty0, ty1) a proper part of the grid -- one rank's share of an image split
-// across GPUs, SURVEY 8e: most Gaussians end with an empty rect): a Gaussian without a rect costs the 40 bytes its rect
-// is computed from, its radii word and one bit -- opacity and colour are fetched late (above), its 64-byte record and its
-// 16-byte fill record are NOT written (nothing reads the records of Gaussians with radii == 0), and a bitmap behind the
-// fill records (one word per wave of 64 Gaussians) tells lr_fill_kernel / lr_count_huge_kernel which fill records
-// exist.  100 M Gaussians at 3840x2160, band of 17 of the 135 tile rows: 14 GB of projection traffic -> 6.
+// Fill record (16 B, its own coalesced array behind the records): everything lr_fill_kernel needs, so that it
+// does not fetch half of every 64-byte record again.  x = depth bits; y = x0 | y0<<13 | (w-1)<<26 | (h-1)<<28 |
+// big<<30 (all ones = nothing to fill); ranked: z,w = four 16-bit ranks inside the batch (0xffff = tile dropped
+// by the support cull); big: z = x1 | y1<<16.
+LR_DEV uint4 lr_fill_record(const float4& g2, const float4& g3, int rad) {
+  uint4 fr = {__float_as_uint(g2.y), 0xffffffffu, 0u, 0u};
+  if (rad > 0) {
+    const uint32_t r0 = __float_as_uint(g2.z), r1 = __float_as_uint(g2.w);
+    const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = r1 & 0xffffu, y1 = r1 >> 16, w = x1 - x0, h = y1 - y0;
+    if (w * h <= LR_RANKED_TILES) {
+      const uint32_t s0 = __float_as_uint(g3.x), s1 = __float_as_uint(g3.y), s2 = __float_as_uint(g3.z),
+                     s3 = __float_as_uint(g3.w);
+      fr.y = x0 | (y0 << 13) | ((w - 1u) << 26) | ((h - 1u) << 28);
+      fr.z = (s0 & 0xffffu) | (s1 << 16);                  // 0xffffffff -> 0xffff; ranks are < 32768
+      fr.w = (s2 & 0xffffu) | (s3 << 16);
+    } else {
+      fr.y = x0 | (y0 << 13) | (1u << 30);
+      fr.z = x1 | (y1 << 16);
+    }
+  }
+  return fr;
+}
+
 #define LR_MAX_PLANES 4
-template <bool SPARSE>
+// Reservations of a workgroup's batches (the tail of both projection kernels): eight tiles per thread per round, all
+// eight returning atomics in flight before the first result is stored (one memory round trip per round, not eight);
+// one atomic covers the workgroup's S batches.  Tiles [t_lo, t_hi); the LDS plane of batch pl starts at pl * stride and
+// holds tile t at t - t_lo.
+LR_DEV void lr_reserve_batches(const uint32_t* lds_ctr, int stride, int t_lo, int t_hi, int nplanes, int tiles,
+                               uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* mybase) {
+  for (int t0 = t_lo + (int)threadIdx.x; t0 < t_hi; t0 += 8 * LR_BATCH_THREADS) {
+    uint32_t base[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t0 + u * LR_BATCH_THREADS;
+      uint32_t c = 0u, cb = 0u;
+      if (t < t_hi)
+        for (int pl = 0; pl < nplanes; pl++) { const uint32_t packed = lds_ctr[pl * stride + (t - t_lo)]; c += packed & 0xffffu; cb += packed >> 16; }
+      base[u] = c ? atomicAdd(&ranked[t], c) : 0u;          // dense counters: see lr_scan_kernel
+      if (cb) atomicAdd(&big[t], cb);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t0 + u * LR_BATCH_THREADS;
+      if (t < t_hi) {
+        uint32_t run = base[u];
+        for (int pl = 0; pl < nplanes; pl++) { mybase[(size_t)pl * tiles + t] = run; run += lds_ctr[pl * stride + (t - t_lo)] & 0xffffu; }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(LR_BATCH_THREADS)
 lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                           const float* __restrict__ rots, const float* __restrict__ opac,
@@ -298,37 +350,31 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   const int tiles = v.gx * v.gy;
   for (int t = threadIdx.x; t < S * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
   if (threadIdx.x < LR_MAX_PLANES) lr_huge_cnt[threadIdx.x] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; hdr[LR_HDR_SPARSE] = SPARSE ? 1u : 0u;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
   __syncthreads();
   uint32_t rect_instances = 0;
   const int i_begin = blockIdx.x * (S * B), i_end = min(N, i_begin + S * B);
   uint4* const fillrec = reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N);
-  uint64_t* const has_rect = reinterpret_cast<uint64_t*>(fillrec + N);    // SPARSE: bit (i & 63) of word i >> 6
   // software pipeline: the next Gaussian's inputs are requested before the current one is projected (a workgroup
   // is 16 waves on one CU, so there is little other work to hide the loads behind)
   int i = i_begin + (int)threadIdx.x;
   LrInputs nxt;
-  if (i < i_end) nxt = lr_load_inputs<SPARSE>(i, means, scales, rots, opac, colors, v.cov3d);
+  if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors, v.cov3d);
   // (trip count uniform per wave: the record stores below are cooperative among groups of four lanes)
   for (; (i & ~63) < i_end; i += LR_BATCH_THREADS) {
     const bool mine = i < i_end;
     const LrInputs in = nxt;
-    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs<SPARSE>(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
+    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
     const int plane = ((i & ~63) - i_begin) / B;            // B is a multiple of the workgroup size: uniform per iteration
     const LrLdsCounters ctr{lr_lds_ctr + plane * tiles};
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
     int rad = 0;
     bool huge = false;
     if (mine) {
-      lr_project_one<true, LrLdsCounters, SPARSE>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge,
-                                                  defer_tiles, opac, colors, i);
+      lr_project_one<true>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
       if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
       radii[i] = rad;
     }
-    const uint64_t rect_mask = SPARSE ? __ballot(rad > 0) : ~0ull;   // (rad is 0 in lanes beyond i_end)
-    if (SPARSE && (threadIdx.x & 63) == 0 && mine) has_rect[i >> 6] = rect_mask;   // i is a multiple of 64 in lane 0
     // Records leave as full 64-byte lines: a lane's four quads are 64 B apart from its neighbour's, so storing them
     // lane by lane makes every store instruction touch 64 lines with 16 B each (four partial writes per line at the
     // L2).  A 4x4 transpose inside every group of four lanes (two DPP quad-permute stages) gives lane m the quad m of
@@ -339,62 +385,180 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       lr_quad_transpose(t0, t1, t2, t3, m);                  // t[k] = quad m of Gaussian (i - m + k)
       const int ib = i - m;
       float4* rec = geom + LR_REC_QUADS * (size_t)ib + m;
-      // SPARSE: a group of four Gaussians without a rect among them stores nothing
-      if (!SPARSE || ((rect_mask >> ((threadIdx.x & 63) & ~3)) & 0xfull)) {
-        if (ib + 0 < i_end) rec[0 * LR_REC_QUADS] = t0;
-        if (ib + 1 < i_end) rec[1 * LR_REC_QUADS] = t1;
-        if (ib + 2 < i_end) rec[2 * LR_REC_QUADS] = t2;
-        if (ib + 3 < i_end) rec[3 * LR_REC_QUADS] = t3;     // (q3 is not read in this mode: written to complete the 64-byte line)
-      }
+      if (ib + 0 < i_end) rec[0 * LR_REC_QUADS] = t0;
+      if (ib + 1 < i_end) rec[1 * LR_REC_QUADS] = t1;
+      if (ib + 2 < i_end) rec[2 * LR_REC_QUADS] = t2;
+      if (ib + 3 < i_end) rec[3 * LR_REC_QUADS] = t3;       // (q3 is not read in this mode: written to complete the 64-byte line)
     }
-    if (!mine || (SPARSE && rad <= 0)) continue;
-    // Fill record (16 B, its own coalesced array behind the records): everything lr_fill_kernel needs, so that it
-    // does not fetch half of every 64-byte record again.  x = depth bits; y = x0 | y0<<13 | (w-1)<<26 | (h-1)<<28 |
-    // big<<30 (all ones = nothing to fill); ranked: z,w = four 16-bit ranks inside the batch (0xffff = tile dropped
-    // by the support cull); big: z = x1 | y1<<16.
-    uint4 fr = {__float_as_uint(g2.y), 0xffffffffu, 0u, 0u};
-    if (rad > 0) {
-      const uint32_t r0 = __float_as_uint(g2.z), r1 = __float_as_uint(g2.w);
-      const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16, x1 = r1 & 0xffffu, y1 = r1 >> 16, w = x1 - x0, h = y1 - y0;
-      if (w * h <= LR_RANKED_TILES) {
-        const uint32_t s0 = __float_as_uint(g3.x), s1 = __float_as_uint(g3.y), s2 = __float_as_uint(g3.z),
-                       s3 = __float_as_uint(g3.w);
-        fr.y = x0 | (y0 << 13) | ((w - 1u) << 26) | ((h - 1u) << 28);
-        fr.z = (s0 & 0xffffu) | (s1 << 16);                  // 0xffffffff -> 0xffff; ranks are < 32768
-        fr.w = (s2 & 0xffffu) | (s3 << 16);
-      } else {
-        fr.y = x0 | (y0 << 13) | (1u << 30);
-        fr.z = x1 | (y1 << 16);
-      }
-    }
-    fillrec[i] = fr;
+    if (!mine) continue;
+    fillrec[i] = lr_fill_record(g2, g3, rad);
   }
   __syncthreads();
-  // reservations: eight tiles per thread per round, all eight returning atomics in flight before the first result
-  // is stored (one memory round trip per round, not eight); one atomic covers the workgroup's S batches
   const int nplanes = min(S, (i_end - i_begin + B - 1) / B);   // batches this workgroup really holds
-  uint32_t* const mybase = basetab + (size_t)blockIdx.x * S * tiles;
-  for (int t0 = threadIdx.x; t0 < tiles; t0 += 8 * LR_BATCH_THREADS) {
-    uint32_t base[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t0 + u * LR_BATCH_THREADS;
-      uint32_t c = 0u, cb = 0u;
-      if (t < tiles)
-        for (int pl = 0; pl < nplanes; pl++) { const uint32_t packed = lr_lds_ctr[pl * tiles + t]; c += packed & 0xffffu; cb += packed >> 16; }
-      base[u] = c ? atomicAdd(&ranked[t], c) : 0u;          // dense counters: see lr_scan_kernel
-      if (cb) atomicAdd(&big[t], cb);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t0 + u * LR_BATCH_THREADS;
-      if (t < tiles) {
-        uint32_t run = base[u];
-        for (int pl = 0; pl < nplanes; pl++) { mybase[(size_t)pl * tiles + t] = run; run += lr_lds_ctr[pl * tiles + t] & 0xffffu; }
-      }
-    }
-  }
+  lr_reserve_batches(lr_lds_ctr, tiles, 0, tiles, nplanes, tiles, ranked, big, basetab + (size_t)blockIdx.x * S * tiles);
   if ((int)threadIdx.x < nplanes) {   // complete: the barrier after the Gaussian loop
+    hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];
+    if (lr_huge_cnt[threadIdx.x]) atomicOr(&hdr[LR_HDR_HUGE], 1u);
+  }
+  lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
+}
+
+// ---- band views ---------------------------------------------------------------------------------------------------
+// A view that owns a band of tile rows ([ty0, ty1) a proper part of the grid: one rank's share of an image split across
+// GPUs) is handed ALL Gaussians and keeps few: most end with an empty rect.  Returning early from the loop
+// above saves nothing -- in Gaussian order nearly every wave holds a survivor and runs the whole projection (100 M
+// Gaussians at 3840x2160, 19.5 M in a band of 17 of the 135 tile rows: 3.3 ms either way).  This kernel works in two
+// phases per wave:
+//   A  every Gaussian: its rect from the 40 bytes of means3D / scales / rotations (lr_project_rect, ~300 instructions)
+//      and radii[]; a survivor's index and those ten floats go to a per-wave ring in LDS;
+//   B  whenever the ring holds 64: one FULL wave of survivors runs the rest of the projection (support test, ranking,
+//      record; ~1000 instructions).  Its inputs come from the ring -- gathering them again from memory made the texture
+//      addresser the bound (64 distinct lines per load instruction) -- except opacity and colour, which only survivors
+//      ever cost and which are requested one firing ahead of their use.
+// A Gaussian without a rect costs 44 bytes and neither a record nor a fill record.  The survivors' fill records go,
+// compacted per workgroup, to the front of the workgroup's own range of the fill-record array, their indices to the same
+// slots of an index array behind it (survcount[w] of them in workgroup w's range): lr_fill_kernel / lr_count_huge_kernel
+// walk those slots -- coalesced, and four fifths of their workgroups return after one read.  Ranks inside a (batch, tile) run are handed out
+// in ring order, not Gaussian order -- any order will do, the lists are sorted by (depth, id) afterwards.
+// LDS: S counter planes over the BAND's tiles only (counters, reservations and slot-table entries of other tiles are
+// neither cleared nor written nor read: a band of 17 rows at 3840x2160 is 4080 of 32400 tiles) + 88 KB of rings.
+// Measured (MI355X, 100 M Gaussians, 19.5 M in the band): projection 3.13 -> 1.88 ms (phase A alone 1.21, of which the
+// 44 bytes per Gaussian are 1.00), fill 0.89 -> 0.62, slot-table rebase 0.25 -> 0.04.
+#define LR_RING 128                       // entries per wave: < 64 pending before a phase-A step, <= 64 added by it
+#define LR_RING_FLOATS 10                 // mean 3, scale 3, quaternion 4 (or the six covariance floats)
+#define LR_BAND_STATIC_LDS ((LR_BATCH_THREADS / 64) * LR_RING * (LR_RING_FLOATS + 1) * 4 + 128)   // rings + the small per-workgroup words
+struct LrLdsBandCounters {                // LrLdsCounters over tiles [lo, ...)
+  uint32_t* ctr;
+  int lo;
+  LR_DEV uint32_t rank(int tile) const { return atomicAdd(&ctr[tile - lo], 1u) & 0xffffu; }
+  LR_DEV void count_big(int tile) const { atomicAdd(&ctr[tile - lo], 0x10000u); }
+};
+__global__ void __launch_bounds__(LR_BATCH_THREADS)
+lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
+                       const float* __restrict__ rots, const float* __restrict__ opac,
+                       const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
+                       uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
+                       uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugecount,
+                       uint32_t* __restrict__ survcount, int tile_cull, int B, int S, int defer_tiles, int ablate) {
+  extern __shared__ uint32_t lr_lds_ctr[];  // [S][band tiles] packed (ranked | big << 16) counts, one plane per batch
+  __shared__ uint32_t lr_huge_cnt[LR_MAX_PLANES];
+  __shared__ uint32_t lr_slot_cursor;       // survivors of this workgroup so far = its next free fill-record slot
+  __shared__ uint32_t lr_ring_idx[LR_BATCH_THREADS / 64][LR_RING];
+  __shared__ float lr_ring_in[LR_BATCH_THREADS / 64][LR_RING_FLOATS][LR_RING];
+  const int tiles = v.gx * v.gy;
+  const int t_lo = v.ty0 * v.gx, t_hi = v.ty1 * v.gx, band_tiles = t_hi - t_lo;
+  for (int t = threadIdx.x; t < S * band_tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
+  if (threadIdx.x < LR_MAX_PLANES) lr_huge_cnt[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) lr_slot_cursor = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; hdr[LR_HDR_SPARSE] = 1u;
+    hdr[LR_HDR_SPAN] = (uint32_t)(S * B);
+  }
+  __syncthreads();
+  uint32_t rect_instances = 0;
+  const int i_begin = blockIdx.x * (S * B), i_end = min(N, i_begin + S * B);
+  uint4* const fillrec = reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N);    // compacted: slot, not Gaussian
+  uint32_t* const survivor = reinterpret_cast<uint32_t*>(fillrec + N);                 // Gaussian index of a slot
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  uint32_t* const ring_idx = lr_ring_idx[wave];
+  float (*const ring_in)[LR_RING] = lr_ring_in[wave];
+  int i = i_begin + (int)threadIdx.x;
+  LrInputs nxt;
+  if (i < i_end) nxt = lr_load_inputs<true>(i, means, scales, rots, opac, colors, v.cov3d);
+  int head = 0, npend = 0;                                   // wave-uniform: ring entries [head, head + npend)
+  int pj = -1;                                               // the batch fired last time: its opacity / colour are in flight
+  bool have = false;                                         // wave-uniform
+  LrInputs pin = nxt;                                        // (any value: not read while pj < 0)
+  // One loop for both phases and for the drain at the end, so that phase B -- the rest of the projection, inlined --
+  // exists at ONE call site (with three it became a real call with its arguments in scratch memory: 2.5 -> 5.2 ms).
+  for (;;) {
+    const bool more = (i & ~63) < i_end;                     // wave-uniform
+    if (more) {
+      const bool mine = i < i_end;
+      const LrInputs in = nxt;
+      if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs<true>(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
+      int rad = 0;
+      if (mine) {
+        LrRect rc;
+        if (ablate & 2) rad = (in.p[0] + in.s[1] + in.q.z == 1.2345e30f) ? 1 : 0;   // timing experiments: loads only
+        else if (lr_project_rect(v, in, rc)) rad = rc.rad;
+        if (ablate & 1) rad = 0;                                                      // timing experiments: no phase B
+        radii[i] = rad;
+      }
+      const uint64_t rect_mask = __ballot(rad > 0);
+      if (rad > 0) {
+        const int e = (head + npend + __popcll(rect_mask & ((1ull << lane) - 1ull))) & (LR_RING - 1);
+        ring_idx[e] = (uint32_t)i;
+        ring_in[0][e] = in.p[0]; ring_in[1][e] = in.p[1]; ring_in[2][e] = in.p[2];
+        ring_in[3][e] = in.s[0]; ring_in[4][e] = in.s[1]; ring_in[5][e] = in.s[2];
+        ring_in[6][e] = in.q.x; ring_in[7][e] = in.q.y; ring_in[8][e] = in.q.z; ring_in[9][e] = in.q.w;
+      }
+      npend += __popcll(rect_mask);
+      i += LR_BATCH_THREADS;
+    }
+    // (the ring is private to the wave: LDS executes a wave's accesses in program order and the compiler keeps the order
+    // of may-alias LDS accesses -- no fence: an acquire fence here turns every later read of the view's matrices into a
+    // vector load behind s_waitcnt vmcnt(0), i.e. behind the prefetch of the next iteration)
+    const bool fire = more ? npend >= 64 : (npend > 0 || have);
+    if (!more && !fire) break;
+    if (!fire) continue;
+    // take (up to) 64 survivors off the ring and request their opacity / colour; run the batch taken last time
+    int j = -1;
+    LrInputs nin = pin;
+    const bool took = npend > 0;
+    if (took) {
+      __builtin_amdgcn_wave_barrier();
+      if (lane < npend) {
+        const int e = (head + lane) & (LR_RING - 1);
+        j = (int)ring_idx[e];
+        nin.p[0] = ring_in[0][e]; nin.p[1] = ring_in[1][e]; nin.p[2] = ring_in[2][e];
+        nin.s[0] = ring_in[3][e]; nin.s[1] = ring_in[4][e]; nin.s[2] = ring_in[5][e];
+        nin.q = float4{ring_in[6][e], ring_in[7][e], ring_in[8][e], ring_in[9][e]};
+        nin.op = opac[j];
+        nin.c[0] = colors[3 * j]; nin.c[1] = colors[3 * j + 1]; nin.c[2] = colors[3 * j + 2];
+      }
+      const int n_taken = min(npend, 64);
+      head = (head + n_taken) & (LR_RING - 1);
+      npend -= n_taken;
+    }
+    if (have) {
+      // phase B for Gaussian pj (< 0: idle lane) with inputs pin, run by the whole wave: the records leave through the
+      // same 4x4 transpose as in the full-view loop, so that a store instruction writes complete 64-byte lines
+      float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+      int rad = 0;
+      if (pj >= 0) {
+        const int plane = (pj - i_begin) / B;
+        const LrLdsBandCounters ctr{lr_lds_ctr + plane * band_tiles, t_lo};
+        bool huge;
+        lr_project_one<true>(v, pin, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
+        if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
+      }
+      // slots: the workgroup compacts into its own range of the fill-record array (one counter for all workgroups was a
+      // same-address memory-side atomic per firing: +1.2 ms at 100 M Gaussians)
+      const uint64_t live = __ballot(pj >= 0);               // a prefix of the lanes
+      uint32_t slot0 = 0u;
+      if (lane == 0) slot0 = atomicAdd(&lr_slot_cursor, (uint32_t)__popcll(live));
+      slot0 = (uint32_t)i_begin + (uint32_t)lr_readlane_i((int)slot0, 0);
+      if (pj >= 0) {                                         // 1 KB + 256 B of contiguous stores per wave
+        fillrec[slot0 + (uint32_t)lane] = lr_fill_record(g2, g3, rad);
+        survivor[slot0 + (uint32_t)lane] = (uint32_t)pj;
+      }
+      const int m = lane & 3;
+      lr_quad_transpose(g0, g1, g2, g3, m);                  // g<k> = quad m of the record of lane (lane - m + k)
+      const int j0 = __builtin_amdgcn_update_dpp(0, pj, 0x00, 0xf, 0xf, true), j1 = __builtin_amdgcn_update_dpp(0, pj, 0x55, 0xf, 0xf, true),
+                j2 = __builtin_amdgcn_update_dpp(0, pj, 0xAA, 0xf, 0xf, true), j3 = __builtin_amdgcn_update_dpp(0, pj, 0xFF, 0xf, 0xf, true);
+      if (j0 >= 0) geom[LR_REC_QUADS * (size_t)j0 + m] = g0;
+      if (j1 >= 0) geom[LR_REC_QUADS * (size_t)j1 + m] = g1;
+      if (j2 >= 0) geom[LR_REC_QUADS * (size_t)j2 + m] = g2;
+      if (j3 >= 0) geom[LR_REC_QUADS * (size_t)j3 + m] = g3;
+    }
+    pj = j; pin = nin; have = took;
+  }
+  __syncthreads();
+  const int nplanes = min(S, (i_end - i_begin + B - 1) / B);   // batches this workgroup really holds
+  lr_reserve_batches(lr_lds_ctr, band_tiles, t_lo, t_hi, nplanes, tiles, ranked, big, basetab + (size_t)blockIdx.x * S * tiles);
+  if (threadIdx.x == 0) survcount[blockIdx.x] = lr_slot_cursor;
+  if ((int)threadIdx.x < nplanes) {
     hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];
     if (lr_huge_cnt[threadIdx.x]) atomicOr(&hdr[LR_HDR_HUGE], 1u);
   }
@@ -409,9 +573,15 @@ __global__ void __launch_bounds__(256)
 lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,
                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ hugecount, int B, int tile_cull,
                      int defer_tiles, int chunk) {
+  const int n_all = N;                                       // (the arrays behind the records are laid out for all N)
   extern __shared__ uint32_t lr_lds_ctr[];                   // [tiles] counters | [256] chunks with work | their number
   uint32_t* const lr_chunk_todo = lr_lds_ctr + tiles;
   if (!hdr[LR_HDR_HUGE]) return;                             // no workgroup deferred anything: the common case
+  // band views (lr_project_band_kernel): projection workgroup w left the fill records of its survcount[w] survivors in
+  // slots [w * span, ...), their Gaussian indices in the same slots of the array behind the fill records
+  const bool sparse = hdr[LR_HDR_SPARSE] != 0u;
+  const int span = sparse ? (int)hdr[LR_HDR_SPAN] : 1;       // slots per projection workgroup (a multiple of B and of chunk)
+  const uint32_t* __restrict__ survcount = hugecount + (((N + B - 1) / B + 15) & ~15);
   // (the grid is capped at a few workgroups per CU: each walks its share of the chunks and skips those whose batches
   // deferred nothing -- 58 K workgroups that only return cost a 30 M-Gaussian view 30 us.  The flags of up to 256 chunks
   // are fetched by as many threads at once: one dependent scalar read per chunk was a 28 us chain of round trips.)
@@ -422,7 +592,14 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
     if (cid * chunk < N) {
       const int base = (int)cid * chunk;
       const int b0 = base / B, b1 = min(N - 1, base + chunk - 1) / B;
-      for (int b = b0; b <= b1; b++) any |= hugecount[b];
+      if (sparse) {   // slots of projection workgroup w: deferred rects of any of its batches, and only its first survcount[w] slots
+        const int s_batches = span / B;
+        for (int w = base / span; w <= min(N - 1, base + chunk - 1) / span; w++)
+          if (max(base, w * span) - w * span < (int)survcount[w])
+            for (int b = w * s_batches; b < (w + 1) * s_batches && (long long)b * B < N; b++) any |= hugecount[b];
+      } else {
+        for (int b = b0; b <= b1; b++) any |= hugecount[b];
+      }
     }
     __syncthreads();                                         // (the previous round's readers are done)
     if (threadIdx.x == 0) lr_chunk_todo[256] = 0u;
@@ -438,21 +615,21 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
   for (int t = threadIdx.x; t < tiles; t += 256) lr_lds_ctr[t] = 0u;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const uint4* __restrict__ fill = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
-  const uint64_t* __restrict__ has_rect = reinterpret_cast<const uint64_t*>(fill + N);
-  const bool sparse = hdr[LR_HDR_SPARSE] != 0u;              // only the fill records of Gaussians with a rect exist
+  const uint4* __restrict__ fill = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)n_all);
+  const uint32_t* __restrict__ survivor = reinterpret_cast<const uint32_t*>(fill + n_all);
   for (int k = 0; k < chunk / 256; k++) {
     const int i = base + k * 256 + (int)threadIdx.x;
     int x0 = 0, y0 = 0, w = 0, nt = 0;
     LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};
-    if (i < N && (!sparse || ((has_rect[i >> 6] >> (i & 63)) & 1ull))) {
+    if (i < N && (!sparse || i - (i / span) * span < (int)survcount[i / span])) {
       const uint4 fr = fill[i];
+      const size_t gid = sparse ? (size_t)survivor[i] : (size_t)i;
       if (fr.y != 0xffffffffu && (fr.y & (1u << 30))) {
         x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
         w = (int)(fr.z & 0xffffu) - x0;
         nt = w * ((int)(fr.z >> 16) - y0);
         if (nt > defer_tiles && tile_cull) {
-          const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
+          const float4 g0 = geom[LR_REC_QUADS * gid + 0], g1 = geom[LR_REC_QUADS * gid + 1];
           sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
         }
       }
@@ -484,6 +661,17 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
   }
 }
 
+// Does the batched projection of this view run in its band form (lr_project_batched_kernel<true>)?
+// Does the batched projection of this view run in its band form (lr_project_band_kernel)?  A proper band of tile rows
+// whose counter plane fits beside the rings (a band of more than half of a 3840x2160 grid does not: the full-view kernel).
+#define LR_BAND_LDS_BYTES (160 * 1024 - 512)
+bool lr_band_sparse(const LrView& v, int batch) {
+  LR_KNOB(sparse_knob, "LOGRAST_BAND_SPARSE", 1);
+  const size_t plane = sizeof(uint32_t) * (size_t)((v.ty1 - v.ty0) * v.gx);
+  return sparse_knob && batch > 0 && (v.ty0 > 0 || v.ty1 < v.gy) && v.ty1 > v.ty0 &&
+         plane + LR_BAND_STATIC_LDS <= LR_BAND_LDS_BYTES;
+}
+
 void lr_launch_project(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                        const float* opac, const float* colors, int* radii, void* geom, uint32_t* ranked,
                        uint32_t* big, uint32_t* hdr, uint32_t* basetab, int batch, int planes, int tile_cull,
@@ -495,10 +683,10 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const size_t lds = sizeof(uint32_t) * (size_t)tiles;
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel<false>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_band_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LR_BAND_LDS_BYTES - LR_BAND_STATIC_LDS);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_count_huge_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
       attr_set = true;
@@ -509,16 +697,22 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const int batches = (N + batch - 1) / batch;
     const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
     uint32_t* hugecount = basetab + (size_t)batches * tiles;
-    LR_KNOB(sparse_knob, "LOGRAST_BAND_SPARSE", 1);
-    const bool sparse = sparse_knob && (v.ty0 > 0 || v.ty1 < v.gy);   // a band of tile rows: most rects are empty
-    if (sparse)
-      hipLaunchKernelGGL(lr_project_batched_kernel<true>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
+    static const int ablate = lr_env_int("LOGRAST_PROJECT_ABLATE", 0);   // timing experiments (tools/) only: see the band kernel
+    if (lr_band_sparse(v, batch)) {
+      // planes over the band's tiles only: as many batches per workgroup as fit beside the rings (at most 4)
+      const int band_tiles = (v.ty1 - v.ty0) * v.gx;
+      int bp = (int)((LR_BAND_LDS_BYTES - LR_BAND_STATIC_LDS) / (sizeof(uint32_t) * (size_t)band_tiles));
+      bp = bp > LR_MAX_PLANES ? LR_MAX_PLANES : bp;
+      const int bgroups = (batches + bp - 1) / bp;
+      hipLaunchKernelGGL(lr_project_band_kernel, dim3(bgroups), dim3(LR_BATCH_THREADS),
+                         sizeof(uint32_t) * (size_t)band_tiles * bp, s, v, N, means, scales, rots, opac, colors, radii,
+                         reinterpret_cast<float4*>(geom), ranked, big, hdr, basetab, hugecount,
+                         hugecount + ((batches + 15) & ~15), tile_cull, batch, bp, defer_tiles, ablate);
+    } else {
+      hipLaunchKernelGGL(lr_project_batched_kernel, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                          means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
                          basetab, hugecount, tile_cull, batch, planes, defer_tiles);
-    else
-      hipLaunchKernelGGL(lr_project_batched_kernel<false>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
-                         means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                         basetab, hugecount, tile_cull, batch, planes, defer_tiles);
+    }
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
     hipLaunchKernelGGL(lr_count_huge_kernel, dim3(min((N + chunk - 1) / chunk, 2048)), dim3(256), lds + 1028, s, N, v.gx,
@@ -688,17 +882,19 @@ void lr_launch_scan(uint32_t* state, uint32_t tiles, uint32_t cs, uint32_t big_o
 // (batch, tile) here instead of once per INSTANCE in the fill kernel, whose cost is the number of scattered accesses it
 // issues (30 M Gaussians: three per instance -- two table reads and the key store -- cost 0.5 ms of address
 // processing; this pass moves 66 MB, coalesced).
+// (band views: only the rows' entries of the band's tiles [t_lo, t_hi) exist -- lr_project_batched_kernel<true>)
 __global__ void __launch_bounds__(256)
-lr_rebase_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t batches) {
+lr_rebase_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint32_t batches, uint32_t t_lo, uint32_t t_hi) {
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* __restrict__ row = state + lr_basetab_off(tiles) + (size_t)blockIdx.y * tiles;
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  if (t < tiles) row[t] += offsets[t];
+  const uint32_t t = t_lo + blockIdx.x * 256u + threadIdx.x;
+  if (t < t_hi) row[t] += offsets[t];
 }
-void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, hipStream_t s) {
-  if (!batches) return;
+void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, uint32_t t_lo, uint32_t t_hi, hipStream_t s) {
+  if (!batches || t_hi <= t_lo) return;
   lr_prof_begin(LRK_REBASE, s);
-  hipLaunchKernelGGL(lr_rebase_kernel, dim3((tiles + 255u) / 256u, batches), dim3(256), 0, s, state, tiles, batches);
+  hipLaunchKernelGGL(lr_rebase_kernel, dim3((t_hi - t_lo + 255u) / 256u, batches), dim3(256), 0, s, state, tiles, batches,
+                     t_lo, t_hi);
   lr_prof_end(LRK_REBASE, s);
 }
 
@@ -709,6 +905,7 @@ void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, hipStre
 // rects take positions from the per-tile cursor; up to LR_COOP_TILES tiles a lane expands its own rect,
 // beyond that the whole wave expands it (ballot over the lanes that hold one, record broadcast with
 // readlane) so that a single screen-filling Gaussian does not serialise its wave.
+template <int K>   // Gaussians per thread: their fill records are requested together (see lr_launch_fill)
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
@@ -727,14 +924,17 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   {
     // (streaming stores: non-temporal, so that they do not push the partially written key lines of this kernel out
     // of the XCD's L2 before their neighbours arrive)
-    const int zi = (int)(vblock * 256u + threadIdx.x);
-    if (zi < N && !(ablate & 1)) {
-      if (stream_nt) {
-        if (zero_n) __builtin_nontemporal_store(0.f, &zero_n[zi]);
-        for (int k = 0; k < zero_block_floats; k++) __builtin_nontemporal_store(0.f, &zero_block[(size_t)k * N + zi]);
-      } else {
-        if (zero_n) zero_n[zi] = 0.f;
-        for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + zi] = 0.f;
+#pragma unroll
+    for (int u = 0; u < K; u++) {
+      const int zi = (int)(vblock * (256u * K) + u * 256u + threadIdx.x);
+      if (zi < N && !(ablate & 1)) {
+        if (stream_nt) {
+          if (zero_n) __builtin_nontemporal_store(0.f, &zero_n[zi]);
+          for (int k = 0; k < zero_block_floats; k++) __builtin_nontemporal_store(0.f, &zero_block[(size_t)k * N + zi]);
+        } else {
+          if (zero_n) zero_n[zi] = 0.f;
+          for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + zi] = 0.f;
+        }
       }
     }
   }
@@ -765,33 +965,55 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   if (over) return;
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
-  int i = (int)(vblock * 256u + threadIdx.x);
   // batched projection: a ranked instance's slot is relative to its batch's reservation in the tile
   const uint32_t batch = state[LR_HDR_BATCH];
+  const int lane = threadIdx.x & 63;
+  const uint4* __restrict__ fillrec = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
+  // The K fill records of this thread, requested together (a thread's work is a chain of dependent accesses: header,
+  // bitmap, fill record, slot table, key store).  Measured: K = 4 only pays where few Gaussians have anything to fill
+  // (a band view of 100 M with no survivors 0.42 -> 0.27 ms); on the 30 M view it loses (K = 1 / 2 / 4: 433 / 462 / 493 us
+  // -- the key stores of neighbouring threads sit further apart), so K = 1 is the default (LOGRAST_FILL_PER_THREAD).
+  bool vis_k[K];
+  uint4 fr_k[K];
+  int id_k[K];
+  // band views (lr_project_band_kernel): projection workgroup w left the fill records of its survcount[w] survivors in
+  // slots [w * span, ...), their Gaussian indices in the same slots of the array behind the fill records
+  const bool sparse = batch && state[LR_HDR_SPARSE] != 0u;
+  const uint32_t* __restrict__ survivor = reinterpret_cast<const uint32_t*>(fillrec + N);
+  const uint32_t span = sparse ? state[LR_HDR_SPAN] : 1u;
+  const uint32_t* __restrict__ survcount =
+      state + lr_survcount_off(tiles, batch ? ((uint32_t)N + batch - 1u) / batch : 0u);
+#pragma unroll
+  for (int u = 0; u < K; u++) {
+    const uint32_t e = vblock * (256u * K) + u * 256u + threadIdx.x;     // slot (= Gaussian unless sparse)
+    bool vis = e < (uint32_t)N;
+    if (vis && sparse) { const uint32_t w = e / span; vis = e - w * span < survcount[w]; }
+    fr_k[u] = uint4{0u, 0xffffffffu, 0u, 0u};
+    id_k[u] = (int)e;
+    if (vis && batch) {
+      if (stream_nt) {
+        typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
+        const lr_u4v t4 = __builtin_nontemporal_load(reinterpret_cast<const lr_u4v*>(fillrec + e));
+        fr_k[u] = uint4{t4.x, t4.y, t4.z, t4.w};
+      } else {
+        fr_k[u] = fillrec[e];
+      }
+      if (sparse) id_k[u] = (int)survivor[e];
+    }
+    vis_k[u] = vis;
+  }
+#pragma unroll
+  for (int u = 0; u < K; u++) {
+  const int i = id_k[u];
+  const bool vis = vis_k[u];
   const uint32_t* __restrict__ bbase =
       batch ? state + lr_basetab_off(tiles) + (size_t)((uint32_t)i / batch) * tiles : nullptr;
-  int lane = threadIdx.x & 63;
-  bool vis = (i < N);
   uint32_t dbits = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
   uint32_t slot[LR_RANKED_TILES] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-  if (vis && batch && state[LR_HDR_SPARSE]) {
-    // band views: fill records exist only for Gaussians with a rect (lr_project_batched_kernel<true>)
-    const uint64_t* __restrict__ has_rect =
-        reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N) + N);
-    vis = ((has_rect[i >> 6] >> (i & 63)) & 1ull) != 0ull;
-  }
   if (vis && batch) {
     // batched projection: the 16-byte fill record (see lr_project_batched_kernel)
-    const uint4* frp = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N) + i;
-    uint4 fr;
-    if (stream_nt) {
-      typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
-      const lr_u4v t4 = __builtin_nontemporal_load(reinterpret_cast<const lr_u4v*>(frp));
-      fr = uint4{t4.x, t4.y, t4.z, t4.w};
-    } else {
-      fr = *frp;
-    }
+    const uint4 fr = fr_k[u];
     dbits = fr.x;
     if (fr.y != 0xffffffffu) {
       x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
@@ -868,6 +1090,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       }
     }
   }
+  }
 }
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
@@ -878,10 +1101,13 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
   LR_KNOB(fill_nt, "LOGRAST_FILL_NT", 1);
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores
-  const int blocks = ((N + 255) / 256 + 7) & ~7;
-  hipLaunchKernelGGL(lr_fill_kernel, dim3(blocks), dim3(256), 0, s, N, gx,
-                     reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, max_len_hint, status, zero_n,
-                     zero_block, zero_block_floats, xcd_order, fill_nt, ablate, rebased, speculative);
+  LR_KNOB(per_thread, "LOGRAST_FILL_PER_THREAD", 1);
+#define LR_FILL(K) do { const int blocks = ((N + 256 * K - 1) / (256 * K) + 7) & ~7;                                     \
+    hipLaunchKernelGGL(lr_fill_kernel<K>, dim3(blocks), dim3(256), 0, s, N, gx, reinterpret_cast<const float4*>(geom),  \
+                       state, tiles, keys, capacity, max_len_hint, status, zero_n, zero_block, zero_block_floats,       \
+                       xcd_order, fill_nt, ablate, rebased, speculative); } while (0)
+  if (per_thread >= 4) LR_FILL(4); else if (per_thread >= 2) LR_FILL(2); else LR_FILL(1);
+#undef LR_FILL
   lr_prof_end(LRK_FILL, s);
 }
 

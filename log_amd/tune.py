@@ -21,6 +21,7 @@ CANDIDATES = {
     "LOGRAST_BATCH_PLANES": (1, 2, 4),
     "LOGRAST_FILL_NT": (0, 1),
     "LOGRAST_FILL_XCD_ORDER": (0, 1),
+    "LOGRAST_FILL_PER_THREAD": (1, 2, 4),
     "LOGRAST_BWD_ROWS": (0, 1, 2),
     "LOGRAST_FWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),

@@ -33,8 +33,7 @@ def test_sizing_helpers_and_error_text_work_without_gpu():
     assert L.lograst_version() == 3
     tiles = 120 * 68
     assert L.lograst_tile_state_bytes(1920, 1080, 1000000) >= 4 * (tiles + 1)
-    assert L.lograst_geom_bytes(10) == 10 * (64 + 16) + 8   # records + fill records + one bit each (band views)
-    assert L.lograst_geom_bytes(129) == 129 * 80 + 24
+    assert L.lograst_geom_bytes(10) == 10 * (64 + 16 + 4)   # records + fill records + an index each (band views)
     assert L.lograst_keys_bytes(7) == 2 * 56 and L.lograst_list_bytes(7) == 28   # keys + the sort scratch half
     # argument validation happens before any device work
     rc = L.lograst_compute_radius(-1, None, None, None, None, None, 1.0, 1.0, 1.0, 1.0, None, None)

@@ -27,6 +27,7 @@ SWEEP = {
     "LOGRAST_FWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
     "LOGRAST_BAND_SPARSE": (0, 1),
+    "LOGRAST_FILL_PER_THREAD": (1, 2, 4),
 }
 
 
@@ -89,9 +90,10 @@ def test_every_knob_leaves_every_output_bit_identical():
 
 
 def test_band_views_skip_rectless_gaussians_without_changing_a_bit():
-    """A view that owns a band of tile rows (one rank's share of an image split across GPUs) projects in the sparse mode:
-    Gaussians whose rect misses the band cost neither a record nor a fill record nor their opacity / colour
-    (LOGRAST_BAND_SPARSE).  Against the full-view kernel on the same band, for bands at the top, the middle and the
+    """A view that owns a band of tile rows (one rank's share of an image split across GPUs) is projected by
+    lr_project_band_kernel: Gaussians whose rect misses the band cost neither a record nor a fill record nor their opacity
+    / colour, the survivors are compacted into full waves and into per-workgroup slot ranges that the fill and the
+    deferred-rect count walk (LOGRAST_BAND_SPARSE).  Against the full-view kernel on the same band, for bands at the top, the middle and the
     bottom of the image, with deferred (huge) rects in play and with the exact two-call forward as well as the
     speculative one: radii, tile lists, image, fork maps bit for bit; records of the Gaussians that have a rect bit for
     bit; gradients to summation-order noise."""

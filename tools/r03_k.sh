@@ -1,0 +1,23 @@
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
+D=$PWD/gpurun_out/r03k
+mkdir -p "$D"
+timeout 900 python -m pytest tests/test_gpu_knobs.py tests/test_gpu_parity.py \
+  "tests/test_gpu_scale.py::test_image_split_into_tile_row_bands" \
+  "tests/test_gpu_scale.py::test_band_prepass_selects_exactly_the_gaussians_the_band_keeps" \
+  tests/test_gpu_dist.py -q -m gpu -x > $D/pytest.log 2>&1
+tail -4 $D/pytest.log
+run() { name=$1; shift; env "$@" timeout 300 python tools/band_project_probe.py > $D/$name.json 2> $D/$name.err; tail -1 $D/$name.json | cut -c1-420; }
+run base A=1
+run abl1 LOGRAST_PROJECT_ABLATE=1
+run sorted PROBE_SORTED=1
+run fill1 LOGRAST_FILL_PER_THREAD=1
+P="--no-cpu-baseline --no-secondary --no-dropin-mode --no-rand-variant --no-forward-only"
+for k in 1 2 4; do
+  LOGRAST_FILL_PER_THREAD=$k timeout 600 python bench.py $P > $D/b30_fill$k.json 2> $D/b30_fill$k.err
+  python - <<PY
+import json
+d = json.loads(open("gpurun_out/r03k/b30_fill$k.json").read().strip().splitlines()[-1])
+print("fill per thread $k:", round(d["ms_per_view"], 3), {k: round(v["avg_us"], 1) for k, v in d["kernels"].items()})
+PY
+done

@@ -29,7 +29,7 @@ void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, int speculative, hipStream_t s);
+                    int zero_block_floats, int rebased, int speculative, int band, hipStream_t s);
 void lr_launch_tile_rows(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                          uint32_t* rows, hipStream_t s);
 void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s);
@@ -354,7 +354,8 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   }
   lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, max_tile_len, status,
                  zero_n, zero_floats > 0 ? zero_block : nullptr, zero_floats,
-                 lr_big_input(n) ? 1 : 0, speculative, s);
+                 lr_big_input(n) ? 1 : 0, speculative,
+                 lr_band_sparse(v, (int)lr_pick_batch(n, tiles, (uint32_t)v.gx, (uint32_t)v.gy).batch) ? 1 : 0, s);
   static const int stop_after_fill = lr_env_int("LOGRAST_STOP_AFTER_FILL", 0);   // timing experiments (tools/) only
   if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);

@@ -919,14 +919,21 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   // eight L2s and leave each of them as a partial line (a read-modify-write at HBM: 30 M Gaussians, 44 M keys took
   // 1.1 ms = 128 B of traffic per key).  With XCD x walking Gaussians [x N/8, (x+1) N/8) the segments of consecutive
   // batches complete their lines inside one L2 before they are evicted.
-  const uint32_t per_xcd = gridDim.x >> 3;                       // grid is a multiple of 8
-  const uint32_t vblock = xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  // K > 1: a workgroup owns K blocks of 256 Gaussians that lie a K-th of its XCD's share apart -- K streams per XCD, each
+  // walking consecutive Gaussians like the single one (K ADJACENT blocks per workgroup lost on the 30 M view: 433 / 462 /
+  // 493 us for K = 1 / 2 / 4).
+  const uint32_t per_xcd_sub = gridDim.x >> 3;                   // grid is a multiple of 8: blocks per XCD and stream
+  const uint32_t per_xcd = per_xcd_sub * K;
+  uint32_t vblock_k[K];
+#pragma unroll
+  for (int u = 0; u < K; u++)
+    vblock_k[u] = xcd_order ? (blockIdx.x & 7u) * per_xcd + u * per_xcd_sub + (blockIdx.x >> 3) : blockIdx.x + u * gridDim.x;
   {
     // (streaming stores: non-temporal, so that they do not push the partially written key lines of this kernel out
     // of the XCD's L2 before their neighbours arrive)
 #pragma unroll
     for (int u = 0; u < K; u++) {
-      const int zi = (int)(vblock * (256u * K) + u * 256u + threadIdx.x);
+      const int zi = (int)(vblock_k[u] * 256u + threadIdx.x);
       if (zi < N && !(ablate & 1)) {
         if (stream_nt) {
           if (zero_n) __builtin_nontemporal_store(0.f, &zero_n[zi]);
@@ -969,10 +976,8 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   const uint32_t batch = state[LR_HDR_BATCH];
   const int lane = threadIdx.x & 63;
   const uint4* __restrict__ fillrec = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
-  // The K fill records of this thread, requested together (a thread's work is a chain of dependent accesses: header,
-  // bitmap, fill record, slot table, key store).  Measured: K = 4 only pays where few Gaussians have anything to fill
-  // (a band view of 100 M with no survivors 0.42 -> 0.27 ms); on the 30 M view it loses (K = 1 / 2 / 4: 433 / 462 / 493 us
-  // -- the key stores of neighbouring threads sit further apart), so K = 1 is the default (LOGRAST_FILL_PER_THREAD).
+  // The K fill records of this thread, requested together: a thread's work is a chain of dependent accesses (header,
+  // fill record, slot table, key store) that a workgroup waits through once, whatever K (LOGRAST_FILL_PER_THREAD).
   bool vis_k[K];
   uint4 fr_k[K];
   int id_k[K];
@@ -985,7 +990,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       state + lr_survcount_off(tiles, batch ? ((uint32_t)N + batch - 1u) / batch : 0u);
 #pragma unroll
   for (int u = 0; u < K; u++) {
-    const uint32_t e = vblock * (256u * K) + u * 256u + threadIdx.x;     // slot (= Gaussian unless sparse)
+    const uint32_t e = vblock_k[u] * 256u + threadIdx.x;                 // slot (= Gaussian unless sparse)
     bool vis = e < (uint32_t)N;
     if (vis && sparse) { const uint32_t w = e / span; vis = e - w * span < survcount[w]; }
     fr_k[u] = uint4{0u, 0xffffffffu, 0u, 0u};
@@ -1095,17 +1100,21 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, int speculative, hipStream_t s) {
+                    int zero_block_floats, int rebased, int speculative, int band, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
   LR_KNOB(fill_nt, "LOGRAST_FILL_NT", 1);
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores
-  LR_KNOB(per_thread, "LOGRAST_FILL_PER_THREAD", 1);
-#define LR_FILL(K) do { const int blocks = ((N + 256 * K - 1) / (256 * K) + 7) & ~7;                                     \
+  LR_KNOB(per_thread_knob, "LOGRAST_FILL_PER_THREAD", 1);
+  int per_thread = per_thread_knob;
+#define LR_FILL(K) do { const int blocks = (((N + 255) / 256 + K - 1) / K + 7) & ~7;                                     \
     hipLaunchKernelGGL(lr_fill_kernel<K>, dim3(blocks), dim3(256), 0, s, N, gx, reinterpret_cast<const float4*>(geom),  \
                        state, tiles, keys, capacity, max_len_hint, status, zero_n, zero_block, zero_block_floats,       \
                        xcd_order, fill_nt, ablate, rebased, speculative); } while (0)
+  // measured, K = 1 / 2 / 4: the 30 M view 388 / 413 / 424 us; a band view (100 M, a fifth of the slots used: most
+  // workgroups only pass through the chain once) 618 / 551 / 510 us
+  if (band) per_thread = 4;
   if (per_thread >= 4) LR_FILL(4); else if (per_thread >= 2) LR_FILL(2); else LR_FILL(1);
 #undef LR_FILL
   lr_prof_end(LRK_FILL, s);

@@ -195,28 +195,67 @@ hipError_t lr_launch_counter(const CounterArgs& a, hipStream_t s) {
 // sequence of _single_tensor_adam, fp32:  m = fma(g, 1-b1, m*b1); v = fma((1-b2)*g, g, v*b2);
 // denom = sqrt(amsgrad ? max(vmax, v) : v) / sqrt(bias_correction2) + eps;  p = p + (-step_size) * (m / denom).
 
+// ADAM_UNROLL elements per thread and round, a grid apart (each a coalesced access of its wave), their flag / index
+// reads and then all their moments and gradients requested together.  Measured on 6.3 M of 13 M rows x 59 floats
+// (tools/adam_probe.py; algorithmic GB/s at 28 B per element), unroll 1 / 4:  contiguous rows 4280 / 4640, groups of 16
+// rows 4250 / 4060, groups of 4 (siblings of a 4-ary tree) 3650 / 3330, random rows 2950 / 2570 -- with rows scattered, more
+// requests in flight only spread the partial lines of neighbouring rows further apart in time.  A level-of-detail cut
+// looks like the last two (C3: 3380), so 1 it is; four ADJACENT elements per thread (16-byte strides per lane) lose
+// everywhere (3010 contiguous).  IDX32: element indices fit 31 bits (32-bit division for (row, column)).
+#define ADAM_UNROLL 1
+template <bool IDX32>
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamArgs a) {
   const AdamKey& k = a.key[blockIdx.y];
   const int64_t total = (int64_t)a.m * k.width;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int32_t r = (int32_t)(e / k.width), c = (int32_t)(e - (int64_t)r * k.width);
-    if (!a.flag_vis[r]) continue;
-    const int64_t row = a.index[r];
-    if (row < 0 || row >= a.num_points) continue;
-    const size_t o = (size_t)row * (size_t)k.width + (size_t)c;
-    const float g = k.grad[e];
-    const float m = lr_fma(g, a.omb1, k.exp_avg[o] * a.beta1);
-    const float v = lr_fma(a.omb2 * g, g, k.exp_avg_sq[o] * a.beta2);
-    k.exp_avg[o] = m;
-    k.exp_avg_sq[o] = v;
-    float vd = v;
-    if (k.max_exp_avg_sq) {
-      vd = fmaxf(k.max_exp_avg_sq[o], v);
-      k.max_exp_avg_sq[o] = vd;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += ADAM_UNROLL * stride) {
+    int64_t e[ADAM_UNROLL], row[ADAM_UNROLL];
+    int32_t c[ADAM_UNROLL];
+    bool ok[ADAM_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ADAM_UNROLL; u++) {
+      e[u] = e0 + u * stride;
+      ok[u] = e[u] < total;
+      row[u] = -1;
+      c[u] = 0;
+      if (ok[u]) {
+        int32_t r;
+        if (IDX32) { r = (int32_t)((uint32_t)e[u] / (uint32_t)k.width); c[u] = (int32_t)((uint32_t)e[u] - (uint32_t)r * (uint32_t)k.width); }
+        else { r = (int32_t)(e[u] / k.width); c[u] = (int32_t)(e[u] - (int64_t)r * k.width); }
+        if (a.flag_vis[r]) row[u] = a.index[r];
+      }
     }
-    const float denom = sqrtf(vd) / a.bc2_sqrt + a.eps;
-    k.model[o] = k.param[e] + k.neg_step_size * (m / denom);
+    float g[ADAM_UNROLL], m0[ADAM_UNROLL], v0[ADAM_UNROLL], p0[ADAM_UNROLL], vm[ADAM_UNROLL];
+    size_t o[ADAM_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ADAM_UNROLL; u++) {
+      ok[u] = ok[u] && row[u] >= 0 && row[u] < a.num_points;
+      o[u] = 0; g[u] = 0.f; m0[u] = 0.f; v0[u] = 0.f; p0[u] = 0.f; vm[u] = 0.f;
+      if (ok[u]) {
+        o[u] = (size_t)row[u] * (size_t)k.width + (size_t)c[u];
+        g[u] = k.grad[e[u]];
+        m0[u] = k.exp_avg[o[u]];
+        v0[u] = k.exp_avg_sq[o[u]];
+        p0[u] = k.param[e[u]];
+        if (k.max_exp_avg_sq) vm[u] = k.max_exp_avg_sq[o[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ADAM_UNROLL; u++) {
+      if (!ok[u]) continue;
+      const float m = lr_fma(g[u], a.omb1, m0[u] * a.beta1);
+      const float v = lr_fma(a.omb2 * g[u], g[u], v0[u] * a.beta2);
+      k.exp_avg[o[u]] = m;
+      k.exp_avg_sq[o[u]] = v;
+      float vd = v;
+      if (k.max_exp_avg_sq) {
+        vd = fmaxf(vm[u], v);
+        k.max_exp_avg_sq[o[u]] = vd;
+      }
+      const float denom = sqrtf(vd) / a.bc2_sqrt + a.eps;
+      k.model[o[u]] = p0[u] + k.neg_step_size * (m / denom);
+    }
   }
 }
 
@@ -224,10 +263,14 @@ hipError_t lr_launch_sparse_adam(const AdamArgs& a, int num_keys, hipStream_t s)
   if (a.m <= 0 || num_keys <= 0) return hipSuccess;
   int maxw = 1;
   for (int i = 0; i < num_keys; i++) maxw = a.key[i].width > maxw ? a.key[i].width : maxw;
-  int64_t blocks = ((int64_t)a.m * maxw + 255) / 256;
+  int64_t blocks = ((int64_t)a.m * maxw + 256 * ADAM_UNROLL - 1) / (256 * ADAM_UNROLL);
   if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
   lr_prof_begin(LRK_ADAM, s);
-  hipLaunchKernelGGL(adam_kernel, dim3((uint32_t)blocks, (uint32_t)num_keys), dim3(256), 0, s, a);
+  if ((int64_t)a.m * maxw < (int64_t)0x7fffffff)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((uint32_t)blocks, (uint32_t)num_keys), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((uint32_t)blocks, (uint32_t)num_keys), dim3(256), 0, s, a);
   lr_prof_end(LRK_ADAM, s);
   return hipGetLastError();
 }

@@ -346,3 +346,44 @@ def test_band_prepass_selects_exactly_the_gaussians_the_band_keeps(world):
             rest[idx] = False
             assert float(g_full[k][rest].abs().sum()) == 0.0, (r, k)               # nobody else has a gradient in this band
     assert total >= int(((y1 > y0)).sum())                                        # bands overlap where a rect straddles them
+
+
+@pytest.mark.parametrize("n,bands,band", [(4_000_000, 8, 3), (4_000_000, 8, 0), (3_000_001, 2, 1), (1_000_000, 27, 13)])
+def test_band_projection_at_scale(n, bands, band):
+    """lr_project_band_kernel against the full-view kernel on the same band of a 3840x2160 view (LOGRAST_BAND_SPARSE 1 / 0):
+    several projection workgroups with several batches each, rings that wrap, a band of one plane (half the image), a band
+    of five tile rows, a Gaussian count that ends inside a wave -- radii, tile lists, image, fork maps bit for bit,
+    records of the Gaussians that have a rect bit for bit, gradients to summation-order noise."""
+    import gpu_util as G
+    from log_amd import dist as D, rasterizer as R, tune
+    W, H = 3840, 2160
+    cam, sc = _scene(n, W, H, seed=3, opacity=None, view=2)
+    rows = D.band_rows(band, bands, H)
+    b, e = D.band_pixels(band, bands, H)
+    dL = np.zeros((3, H, W), np.float32)
+    dL[:, b:e] = np.random.default_rng(2).random((3, e - b, W), dtype=np.float32)
+    res = {}
+    tune.reset_knobs()
+    try:
+        for sparse in (0, 1):
+            tune.set_knob("LOGRAST_BAND_SPARSE", sparse)
+            with R.tile_rows(*rows):
+                hf = G.hip_forward(cam, sc, (0.1, 0.2, 0.3), scratch_floats=16)
+                res[sparse] = (hf, G.hip_backward(hf, dL))
+    finally:
+        tune.reset_knobs()
+    (a, ga), (s, gs) = res[0], res[1]
+    vis = a["radii"] > 0
+    assert 0.001 < vis.mean() < 0.9 and a["I"] > 10000, (vis.mean(), a["I"])
+    for k in ("image", "final_T", "point_weight_pixel", "point_weight"):
+        assert (a[k].view(np.uint32) == s[k].view(np.uint32)).all(), k
+    for k in ("radii", "tile_offsets", "point_list", "n_contrib", "point_id_pixel"):
+        assert (a[k] == s[k]).all(), k
+    assert (a["rec"][vis].view(np.uint32) == s["rec"][vis].view(np.uint32)).all()
+    # the two runs share every kernel behind the projection: their gradients differ by the order of the reverse walk's
+    # float atomics only -- 1e-5 on its own outputs; behind the chain rule a few ill-conditioned rows (near-isotropic
+    # Gaussians: the rotation gradient is a difference of nearly equal terms) carry that noise into the L2 norm at 2e-4
+    # (same kernel, two runs; the row-wise criteria of tests/gpu_util.py are what bounds those rows against float64)
+    for k in ga:
+        assert rel_l2(gs[k], ga[k]) < (1e-5 if k in ("means2D", "conic", "opacities", "colors") else 2e-3), k
+        assert np.abs(gs[k][~vis]).max() == 0 or k == "conic", k

@@ -1064,7 +1064,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
     sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
   }
-  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES) {
+  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !(ablate & 4)) {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++)
         if (lr_support_tile(sup, x, y)) {
@@ -1072,7 +1072,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
           keys[pos] = key;
         }
   }
-  uint64_t bigm = __ballot(nt > LR_COOP_TILES);
+  uint64_t bigm = __ballot(nt > LR_COOP_TILES && !(ablate & 8));
   while (bigm) {
     int src = __builtin_ctzll(bigm);
     bigm &= bigm - 1;
@@ -1105,7 +1105,7 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
   LR_KNOB(fill_nt, "LOGRAST_FILL_NT", 1);
-  static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores
+  static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores, 4 no 5-16-tile rects, 8 no larger rects
   LR_KNOB(per_thread_knob, "LOGRAST_FILL_PER_THREAD", 1);
   int per_thread = per_thread_knob;
 #define LR_FILL(K) do { const int blocks = (((N + 255) / 256 + K - 1) / K + 7) & ~7;                                     \

@@ -19,8 +19,9 @@ comes from the warm-up; every forward records itself in the rasterizer's status 
 
 Prints ONE JSON line on rank 0 (contract: see the task statement), including
   value        : the pipelined mode above (what a multi-view training step of this framework runs);
-  modes        : the same workload also in the DROP-IN DEFAULT mode -- one stream, exact buffer sizing (one 4-byte
-                 read-back per forward, like the third-party package's num_rendered), gradients accumulated by autograd;
+  modes        : the same workload also in the DROP-IN DEFAULT mode -- one stream, the package's default forward (stage 2
+                 enqueued speculatively, one read-back per forward on a side stream that the launch stream never waits
+                 for; always exact), gradients added in place into the leaves' .grad;
   modes.pipelined_opacity_rand : (N = 1) the same 30 M point with opacity = rand(N) (SURVEY 8d asks for both variants): no
                  early termination to hide behind -- every list is walked to its end;
   roofline     : dominant kernel, algorithmic bytes/launch / average launch duration (HIP events on the launch stream,
@@ -35,8 +36,10 @@ Prints ONE JSON line on rank 0 (contract: see the task statement), including
   forward_only : torch.no_grad() rendering (what the reference times: CUDA events around renderer.vis in
                  apps/train.py:53-59,100-108): ms/view and fps for the 30 M point, C2 and C3;
   cpu_baseline : the CPU oracle (oracle/, OpenMP, all host cores) timed on whole views of the same workload;
-  secondary    : (N = 1 only) C2 = configs[1] (1 M Gaussians, same harness, both modes) and C3 = configs[2] (10 M-point
-                 LoD tree, SH degree 3, level selection on: one LoG training view end to end through the drop-ins).
+  secondary    : (N = 1 only) C2 = configs[1] (1 M Gaussians, same harness, both modes), C3 = configs[2] (10 M-point
+                 LoD tree, SH degree 3, level selection on: one LoG training view end to end through the drop-ins) and
+                 c5_band = configs[4] on ONE of its 8 GPUs (100 M Gaussians, 3840x2160, one band of tile rows: pre-pass +
+                 gather / scatter, clipped inside the projection with autograd gradients, and with the gradient sink).
 """
 import argparse
 import json

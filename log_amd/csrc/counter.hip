@@ -197,11 +197,12 @@ hipError_t lr_launch_counter(const CounterArgs& a, hipStream_t s) {
 
 // ADAM_UNROLL elements per thread and round, a grid apart (each a coalesced access of its wave), their flag / index
 // reads and then all their moments and gradients requested together.  Measured on 6.3 M of 13 M rows x 59 floats
-// (tools/adam_probe.py; algorithmic GB/s at 28 B per element), unroll 1 / 4:  contiguous rows 4280 / 4640, groups of 16
-// rows 4250 / 4060, groups of 4 (siblings of a 4-ary tree) 3650 / 3330, random rows 2950 / 2570 -- with rows scattered, more
-// requests in flight only spread the partial lines of neighbouring rows further apart in time.  A level-of-detail cut
-// looks like the last two (C3: 3380), so 1 it is; four ADJACENT elements per thread (16-byte strides per lane) lose
-// everywhere (3010 contiguous).  IDX32: element indices fit 31 bits (32-bit division for (row, column)).
+// (tools/adam_probe.py, profiles/r03_probes.md; algorithmic GB/s at 28 B per element), unroll 1 / 4:  contiguous rows
+// 5070 / 4640, groups of 16 rows 4930 / 4060, groups of 4 (siblings of a 4-ary tree) 4180 / 3330, random rows 3280 / 2570
+// -- more requests in flight only spread the partial lines of neighbouring rows further apart in time; four ADJACENT
+// elements per thread (16-byte strides per lane) lose more (3010 contiguous).  So 1 it is.  IDX32: element indices fit
+// 31 bits -- 32-bit instead of 64-bit division for (row, column): 4280 -> 5070 contiguous, 2950 -> 3280 random (a
+// division-free variant had changed nothing in round 2 -- on rows gathered through a 64-bit index all the same).
 #define ADAM_UNROLL 1
 template <bool IDX32>
 __global__ void __launch_bounds__(256)

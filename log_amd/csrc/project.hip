@@ -361,11 +361,15 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   LrInputs nxt;
   if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors, v.cov3d);
   // (trip count uniform per wave: the record stores below are cooperative among groups of four lanes)
+  // plane of the iteration = (i - i_begin) / B, uniform (B is a multiple of the workgroup size): counted, not divided -- a
+  // 32-bit division is ~30 of this VALU-bound loop's ~1000 instructions
+  int plane = 0, left_in_plane = B / LR_BATCH_THREADS;
   for (; (i & ~63) < i_end; i += LR_BATCH_THREADS) {
     const bool mine = i < i_end;
     const LrInputs in = nxt;
     if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
-    const int plane = ((i & ~63) - i_begin) / B;            // B is a multiple of the workgroup size: uniform per iteration
+    if (left_in_plane == 0) { plane++; left_in_plane = B / LR_BATCH_THREADS; }
+    left_in_plane--;
     const LrLdsCounters ctr{lr_lds_ctr + plane * tiles};
     float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
     int rad = 0;
@@ -527,7 +531,8 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
       float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
       int rad = 0;
       if (pj >= 0) {
-        const int plane = (pj - i_begin) / B;
+        const int dj = pj - i_begin;                           // (at most LR_MAX_PLANES batches per workgroup: no division)
+        const int plane = (dj >= B) + (dj >= 2 * B) + (dj >= 3 * B);
         const LrLdsBandCounters ctr{lr_lds_ctr + plane * band_tiles, t_lo};
         bool huge;
         lr_project_one<true>(v, pin, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);

@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--no-fused-accumulate", action="store_true",
                     help="let autograd accumulate each view's gradients (5 extra passes per view) instead of the "
                          "rasterizer adding them straight into the step's gradient bucket")
+    ap.add_argument("--planar-bucket", action="store_true",
+                    help="fused accumulation into attribute-major buckets (five arrays) instead of one 64-byte row per Gaussian")
     ap.add_argument("--no-graphs", action="store_true",
                     help="pipelined mode: enqueue every view's ~15 launches from Python instead of replaying one captured "
                          "HIP graph per view")
@@ -223,13 +225,17 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     # (it costs a bitmap all-reduce and a small read-back per group of views): dense when most blocks are touched.
     track = world > 1
     block_rows = 4096 if (track and args.exchange != "dense") else 0
-    ex = StepExchange(N, dev, world, rank, parts=parts, block_rows=block_rows, track_seen=track, timing=track)
+    # fused accumulation: the buckets are row-major (one 64-byte row of running sums per Gaussian: the chain rule's
+    # read-modify-write of a live Gaussian is one line instead of five pieces in five arrays; the exchange moves one block)
+    row_major = fused and not args.planar_bucket
+    ex = StepExchange(N, dev, world, rank, parts=parts, block_rows=block_rows, track_seen=track, timing=track,
+                      row_major=row_major)
     compact = {"on": args.exchange == "compact" and world > 1}
     lanes = []
     for li in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient buckets
         leaves = {k: v.detach().requires_grad_(True) for k, v in wl.base.items()}
-        bks = ex.buckets if li == 0 else [GradientBucket(N, dev, world, block_rows=block_rows, track_seen=track)
-                                          for _ in range(parts)]
+        bks = ex.buckets if li == 0 else [GradientBucket(N, dev, world, block_rows=block_rows, track_seen=track,
+                                                         row_major=row_major) for _ in range(parts)]
         bks[0].attach(leaves)
         lanes.append((leaves, bks))
     lane_views = [wl.rasts[li::S] for li in range(S)]
@@ -283,7 +289,8 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         stats.append((int((out[1] > 0).sum().item()), n_inst, max_len, n_rect))
         assert not over
         del out
-    res = {"V": float(np.mean([s[0] for s in stats])), "I": float(np.mean([s[1] for s in stats])),
+    res = {"row_major_bucket": row_major,
+           "V": float(np.mean([s[0] for s in stats])), "I": float(np.mean([s[1] for s in stats])),
            "I_rect": float(np.mean([s[3] for s in stats])), "bucket_floats": int(ex.buckets[0].flat.numel()),
            "exchange_parts": parts}
     cap = int(max(s[1] for s in stats) * 1.02) + 1024
@@ -582,10 +589,12 @@ def c5_band(args, dev, bands=8, band=3, N=100_000_000, W=3840, H=2160, views=2):
     # no per-view gradient tensors of 100 M rows, no pre-pass, no gather / scatter -- the projection itself drops the
     # Gaussians whose rect misses the band, at 44 bytes each: lr_project_batched_kernel<SPARSE>)
 
+    row_sink = {"rows": torch.zeros(N, 16, device=dev)}           # (row-major: one 64-byte row of running sums per Gaussian)
+
     def full_sink(rast):
         leaves = {k: v.detach().requires_grad_(True) for k, v in base.items()}
         means2D = torch.empty(N, 3, device=dev).requires_grad_(True)
-        with R.accumulate_grads_into(sink), R.tile_rows(*rows):
+        with R.accumulate_grads_into(row_sink), R.tile_rows(*rows):
             out = rast(means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors"],
                        opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
                        cov3D_precomp=None)
@@ -680,7 +689,7 @@ def main():
             "workload": label(N, op_name),
             "gaussians": N, "width": W, "height": H, "views_per_gpu": args.views,
             "visible_per_view": V, "tile_instances_per_view": I, "tile_instances_per_view_reference_rect_rule": I_rect,
-            "streams_per_gpu": S, "fused_gradient_accumulation": fused,
+            "streams_per_gpu": S, "fused_gradient_accumulation": fused, "row_major_gradient_bucket": r.get("row_major_bucket"),
             "parallelism": ("view-sharded dp%d, %s reduce-scatter of %d floats/step in %d groups of views (each under the "
                             "next group's rendering, side stream) + one all-gather" %
                             (n_ranks, r.get("exchange_mode", "dense"), r["bucket_floats"], r["exchange_parts"])

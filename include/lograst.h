@@ -255,6 +255,14 @@ int lograst_set_tile_cull(int enabled);
 #define LOGRAST_BWD_SCRATCH_ZEROED 1
 #define LOGRAST_BWD_ACCUMULATE 2
 #define LOGRAST_BWD_CONIC_TOUCHED_ONLY 4
+/* multi-view accumulation into ONE 64-byte row per Gaussian (new): dl_dmeans3d points to the caller's running sums
+ * [n][LOGRAST_GRAD_ROW_FLOATS] (64-byte aligned; slots 0-2 dL/dmeans3D, 3-5 dL/dscales, 6-9 dL/drotations, 10 dL/dopacity,
+ * 11-13 dL/dcolour, 14-15 never touched) and every gradient of this view is ADDED there; dl_dscales, dl_drotations,
+ * dl_dopacities, dl_dcolors are not used (NULL allowed).  A Gaussian that composited somewhere then costs the chain rule
+ * one read-modify-write of one line instead of five pieces in five arrays (log_amd.dist.GradientBucket(row_major=True)).
+ * Not with cov3d_precomp. */
+#define LOGRAST_BWD_ACCUMULATE_ROWS 8
+#define LOGRAST_GRAD_ROW_FLOATS 16
 
 int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, const float* scales,
                      const float* rotations, const int32_t* radii, const void* geom, const void* tile_state,

@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("LOGRAST_LIB") or os.path.join(_HERE, "lib", "liblogra
 
 FILTER_NONE, FILTER_DILATE, FILTER_CLAMP = 0, 1, 2
 FORM_AUTO, FORM_ROWS, FORM_QUADRANT = 0, 1, 2
+GRAD_ROW_FLOATS = 16   # LOGRAST_GRAD_ROW_FLOATS
 REC_FLOATS = 16
 BWD_ROW_FLOATS = 16   # LOGRAST_BWD_ROW_FLOATS: the reverse walk's accumulator row (64 B per Gaussian)
 NUM_KERNELS = 20

@@ -44,7 +44,8 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
                            float* o_mean2d, float* o_opac, float* o_col, const float* pw,
-                           float* g_means3d, float* g_scales, float* g_rots, bool accumulate, hipStream_t s);
+                           float* g_means3d, float* g_scales, float* g_rots, bool accumulate, bool sink_rows,
+                           hipStream_t s);
 
 size_t lr_knn_scratch_bytes(int P);
 hipError_t lr_launch_knn(int P, const float* pts, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
@@ -638,19 +639,28 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   if (rc) return rc;
   if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "negative Gaussian count");
   if (n == 0) return LOGRAST_OK;
+  const bool sink_rows = (flags & LOGRAST_BWD_ACCUMULATE_ROWS) != 0;
   if (!means3d || !radii || !geom || !tile_state || !final_t || !n_contrib || !dl_dimage ||
-      !dl_dmeans2d || !dl_dconic || !dl_dopacities || !dl_dcolors || !dl_dmeans3d)
+      !dl_dmeans2d || !dl_dconic || !dl_dmeans3d || (!sink_rows && (!dl_dopacities || !dl_dcolors)))
     return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
-  rc = lr_check_cov_args(v, scales, rotations, dl_dscales, dl_drotations);
-  if (rc) return rc;
-  if ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
-    return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_drotations must be 16-byte aligned");
+  if (sink_rows) {   // dl_dmeans3d = the caller's [n][LOGRAST_GRAD_ROW_FLOATS] running sums; the other four are not used
+    if (v.cov3d) return lr_fail(LOGRAST_ERR_ARG, "LOGRAST_BWD_ACCUMULATE_ROWS has no cov3d_precomp form");
+    if (!scales || !rotations) return lr_fail(LOGRAST_ERR_ARG, "scales / rotations are NULL");
+    if (reinterpret_cast<uintptr_t>(dl_dmeans3d) & 63u)
+      return lr_fail(LOGRAST_ERR_ARG, "LOGRAST_BWD_ACCUMULATE_ROWS: the gradient rows must be 64-byte aligned");
+    if (reinterpret_cast<uintptr_t>(rotations) & 15u) return lr_fail(LOGRAST_ERR_ARG, "rotations must be 16-byte aligned");
+  } else {
+    rc = lr_check_cov_args(v, scales, rotations, dl_dscales, dl_drotations);
+    if (rc) return rc;
+    if ((reinterpret_cast<uintptr_t>(rotations) | reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
+      return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_drotations must be 16-byte aligned");
+  }
   if (reinterpret_cast<uintptr_t>(bwd_rows) & 63u)
     return lr_fail(LOGRAST_ERR_ARG, "bwd_rows must be 64-byte aligned (one accumulator row per line)");
   hipStream_t s = (hipStream_t)stream;
   uint32_t tiles = (uint32_t)(v.gx * v.gy);
   const uint32_t* st = reinterpret_cast<const uint32_t*>(tile_state);
-  const bool accumulate = (flags & LOGRAST_BWD_ACCUMULATE) != 0;
+  const bool accumulate = (flags & LOGRAST_BWD_ACCUMULATE) != 0 || sink_rows;
   if ((flags & LOGRAST_BWD_CONIC_TOUCHED_ONLY) && !point_weight)
     return lr_fail(LOGRAST_ERR_ARG, "LOGRAST_BWD_CONIC_TOUCHED_ONLY needs point_weight");
   // A forward with extras on a large input clears the dL/dconic rows of contributing Gaussians only (lr_stage2:
@@ -667,7 +677,7 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
   // the chain rule reads every live Gaussian's accumulator row and hands out the separate outputs: dL/dmeans2D (written
   // for all rows), dL/dopacities and dL/dcolors (written, or added to the caller's running sums)
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, nullptr, nullptr, dl_dconic, dl_dmeans2d, dl_dopacities,
-                        dl_dcolors, point_weight, dl_dmeans3d, dl_dscales, dl_drotations, accumulate, s);
+                        dl_dcolors, point_weight, dl_dmeans3d, dl_dscales, dl_drotations, accumulate, sink_rows, s);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
@@ -690,7 +700,7 @@ int lograst_project_backward(const lograst_view* view, int32_t n, const float* m
        reinterpret_cast<uintptr_t>(dl_drotations)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "rotations / dl_dconic / dl_drotations must be 16-byte aligned");
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, dl_dmeans2d, dl_dconic, nullptr, nullptr, nullptr,
-                        nullptr, nullptr, dl_dmeans3d, dl_dscales, dl_drotations, false, (hipStream_t)stream);
+                        nullptr, nullptr, dl_dmeans3d, dl_dscales, dl_drotations, false, false, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

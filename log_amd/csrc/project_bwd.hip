@@ -135,7 +135,12 @@ LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__
 // instead of four.  This kernel then also hands out the API's separate outputs: dL/dmeans2D (written for every row: it
 // is a per-view output), dL/dopacity and dL/dcolour (written, or added to the running sums when ACCUMULATE).
 // !AOS (lograst_project_backward, the isolated chain rule): g_mean2d [n, 3] / g_conic [n, 4] in, as before.
-template <bool ACCUMULATE, bool TOUCHED, bool COV, bool AOS>
+// SINKROWS (lograst_backward with LOGRAST_BWD_ACCUMULATE_ROWS; implies ACCUMULATE and AOS, not COV): the caller's running
+// sums are ONE 64-byte row per Gaussian too (`g_means3d` = [N][16]: slots 0-2 dL/dmeans3D, 3-5 dL/dscales, 6-9
+// dL/drotations, 10 dL/dopacity, 11-13 dL/dcolour, 14-15 untouched) -- a live Gaussian then costs one read-modify-write of
+// one line instead of five in five arrays (the live rows are scattered: at 30 M Gaussians 7 % of them, each piece of 4-16
+// bytes pulling its own 64-byte line through the memory system in both directions).
+template <bool ACCUMULATE, bool TOUCHED, bool COV, bool AOS, bool SINKROWS = false>
 __global__ void __launch_bounds__(256)
 lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                       const float* __restrict__ rots, const int* __restrict__ radii,
@@ -162,7 +167,7 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     };
     if (rows_here > 0) {
       clear(o_mean2d + 3 * (size_t)base, 3 * rows_here);
-      if (!ACCUMULATE) { clear(o_opac + (size_t)base, rows_here); clear(o_col + 3 * (size_t)base, 3 * rows_here); }
+      if (!ACCUMULATE && !SINKROWS) { clear(o_opac + (size_t)base, rows_here); clear(o_col + 3 * (size_t)base, 3 * rows_here); }
     }
   }
   __syncthreads();
@@ -198,7 +203,11 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     // ~20 scattered accesses, and the read-modify-writes behind the chain rule's ~600 instructions were fully exposed
     float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_c[3] = {0.f, 0.f, 0.f}, old_o = 0.f;
     float4 old_q = {0.f, 0.f, 0.f, 0.f};
-    if (ACCUMULATE) {
+    float4 sr0 = {0.f, 0.f, 0.f, 0.f}, sr1 = sr0, sr2 = sr0, sr3 = sr0;
+    float4* const srow = SINKROWS ? reinterpret_cast<float4*>(g_means3d) + 4 * (size_t)i : nullptr;
+    if (SINKROWS) {
+      sr0 = srow[0]; sr1 = srow[1]; sr2 = srow[2]; sr3 = srow[3];
+    } else if (ACCUMULATE) {
 #pragma unroll
       for (int k = 0; k < 3; k++) old_m[k] = g_means3d[3 * (size_t)i + k];
       if (!COV) {
@@ -217,15 +226,24 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
       const float cb = reinterpret_cast<const float*>(rows + 4 * (size_t)i + 2)[0];
       gnx = a0.x; gny = a0.y; gA = a0.z; gB = a0.w; gC = a1.x;
       o_mean2d[3 * (size_t)i + 0] = gnx; o_mean2d[3 * (size_t)i + 1] = gny; o_mean2d[3 * (size_t)i + 2] = 0.f;
-      o_opac[i] = old_o + a1.y;
-      o_col[3 * (size_t)i + 0] = old_c[0] + a1.z; o_col[3 * (size_t)i + 1] = old_c[1] + a1.w; o_col[3 * (size_t)i + 2] = old_c[2] + cb;
+      if (SINKROWS) {
+        sr2.z += a1.y; sr2.w += a1.z; sr3.x += a1.w; sr3.y += cb;   // slots 10 opacity, 11-13 colour
+      } else {
+        o_opac[i] = old_o + a1.y;
+        o_col[3 * (size_t)i + 0] = old_c[0] + a1.z; o_col[3 * (size_t)i + 1] = old_c[1] + a1.w; o_col[3 * (size_t)i + 2] = old_c[2] + cb;
+      }
     } else {
       gnx = g_mean2d[3 * (size_t)i]; gny = g_mean2d[3 * (size_t)i + 1];
       const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
       gA = gc4.x; gB = gc4.y; gC = gc4.z;
     }
     lr_project_bwd_row<ACCUMULATE, COV>(v, i, means, scales, rots, gnx, gny, gA, gB, gC, gm, gs, gq);
-    if (ACCUMULATE) {  // running sums over views (log_amd.dist)
+    if (SINKROWS) {    // running sums over views, one row per Gaussian
+      sr0.x += gm[0]; sr0.y += gm[1]; sr0.z += gm[2]; sr0.w += gs[0];
+      sr1.x += gs[1]; sr1.y += gs[2]; sr1.z += gq[0]; sr1.w += gq[1];
+      sr2.x += gq[2]; sr2.y += gq[3];
+      srow[0] = sr0; srow[1] = sr1; srow[2] = sr2; srow[3] = sr3;
+    } else if (ACCUMULATE) {  // running sums over views (log_amd.dist)
 #pragma unroll
       for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] = old_m[k] + gm[k];
       if (!COV) {
@@ -247,11 +265,22 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
                            float* o_mean2d, float* o_opac, float* o_col, const float* pw,
-                           float* g_means3d, float* g_scales, float* g_rots, bool accumulate, hipStream_t s) {
+                           float* g_means3d, float* g_scales, float* g_rots, bool accumulate, bool sink_rows,
+                           hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_PROJECT_BWD, s);
   const dim3 grid((N + LR_PBWD_ROWS - 1) / LR_PBWD_ROWS), block(256);
   const float4* rows4 = reinterpret_cast<const float4*>(rows);
+  if (sink_rows) {   // (lograst_backward checked: rows != NULL, no cov3d)
+    if (pw)
+      hipLaunchKernelGGL((lr_project_bwd_kernel<true, true, false, true, true>), grid, block, 0, s, v, N, means, scales, rots,
+                         radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots);
+    else
+      hipLaunchKernelGGL((lr_project_bwd_kernel<true, false, false, true, true>), grid, block, 0, s, v, N, means, scales, rots,
+                         radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots);
+    lr_prof_end(LRK_PROJECT_BWD, s);
+    return;
+  }
 #define LR_PBWD2(A, T, C, O) hipLaunchKernelGGL((lr_project_bwd_kernel<A, T, C, O>), grid, block, 0, s, v, N, means, scales, \
                                                 rots, radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw,       \
                                                 g_means3d, g_scales, g_rots)

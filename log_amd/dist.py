@@ -41,10 +41,25 @@ LAYOUT = (("means3D", 3), ("scales", 3), ("rotations", 4), ("opacities", 1), ("c
 COLS = sum(c for _, c in LAYOUT)
 
 
-def layout(sh_coeffs=0):
+ROW_FLOATS = 16            # row-major form: one 64-byte row per Gaussian (include/lograst.h: LOGRAST_GRAD_ROW_FLOATS)
+ROW_COLUMNS = {"means3D": (0, 3), "scales": (3, 6), "rotations": (6, 10), "opacities": (10, 11), "colors": (11, 14)}
+
+
+def layout(sh_coeffs=0, row_major=False):
     """Columns of the exchange: LAYOUT (14 floats) + the SH coefficients [K, 3] when the model has them (SURVEY 8e:
-    +9 at degree 1, +45 at degree 3)."""
-    return LAYOUT + ((("shs", 3 * int(sh_coeffs)),) if sh_coeffs else ())
+    +9 at degree 1, +45 at degree 3).  row_major: the 14 base columns travel as ONE block of 16-float rows ("rows")."""
+    base = (("rows", ROW_FLOATS),) if row_major else LAYOUT
+    return base + ((("shs", 3 * int(sh_coeffs)),) if sh_coeffs else ())
+
+
+def split_rows(grads):
+    """dict with a "rows" entry ([n, 16]) -> the same dict with per-attribute (strided) views of it instead."""
+    if "rows" not in grads:
+        return grads
+    out = {k: v for k, v in grads.items() if k != "rows"}
+    for name, (a, b) in ROW_COLUMNS.items():
+        out[name] = grads["rows"][:, a:b]
+    return out
 
 
 def shard_views(n_views, rank, world):
@@ -97,11 +112,14 @@ def _shape(name, rows, cols):
 
 class _Flat:
     """One flat fp32 buffer holding every attribute as a contiguous [P_pad, c] block, P_pad = world * ceil(P / world), so
-    that rank r's rows [r * Pr, (r + 1) * Pr) are a contiguous slice of every block."""
+    that rank r's rows [r * Pr, (r + 1) * Pr) are a contiguous slice of every block.  row_major: the 14 base columns are
+    ONE block "rows" of 16-float (64-byte) rows -- what the rasterizer's backward adds into with one read-modify-write per
+    Gaussian (``sink()``) and what travels as one collective; ``alias[name]`` are strided per-attribute views of it."""
 
-    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0):
+    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0, row_major=False):
         self.P, self.world = int(num_points), max(int(world), 1)
-        self.layout = layout(sh_coeffs)
+        self.row_major = bool(row_major)
+        self.layout = layout(sh_coeffs, self.row_major)
         self.block_rows = int(block_rows)
         self.Pr = rows_per_rank(self.P, self.world, self.block_rows)
         self.Ppad = self.Pr * self.world
@@ -113,6 +131,14 @@ class _Flat:
             self.blocks[name] = blk                                           # [P_pad * c], padding rows included
             self.views[name] = blk[:self.P * c].view(_shape(name, self.P, c))  # what the kernels see
             off += self.Ppad * c
+        self.alias = dict(self.views)
+        if self.row_major:
+            for name, (a, b) in ROW_COLUMNS.items():
+                self.alias[name] = self.views["rows"][:, a:b]
+
+    def sink(self):
+        """What ``log_amd.rasterizer.accumulate_grads_into`` takes."""
+        return dict(self.views)
 
     def rows(self, name, rank):
         """Rank `rank`'s rows of attribute `name`: a contiguous [Pr, c] view."""
@@ -147,10 +173,10 @@ class GradientBucket(_Flat):
     """Flat gradient buffer, attribute-major, with one contiguous view per attribute, and the per-row `seen` count."""
     DENSE_ABOVE = 0.85     # touched-block exchange only when it moves less than this share of the dense one
 
-    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0, track_seen=True):
+    def __init__(self, num_points, device, world=1, sh_coeffs=0, block_rows=0, track_seen=True, row_major=False):
         """track_seen=False: no per-row `seen` counts (nothing to exchange for them) -- for a caller that only wants the
         gradient sum, like bench.py; the owner-computes step needs them."""
-        super().__init__(num_points, device, world, sh_coeffs, block_rows)
+        super().__init__(num_points, device, world, sh_coeffs, block_rows, row_major)
         self.pad = self.flat.numel() - self.P * self.cols
         self.track_seen = bool(track_seen)
         # views that saw the row this step (one float when not tracked: mark_seen / the touched-block exchange then refuse)
@@ -161,10 +187,10 @@ class GradientBucket(_Flat):
     def attach(self, params):
         """params: dict name -> leaf tensor (requires_grad).  Their .grad become views of the bucket,
         so autograd accumulates every view's gradient in place."""
-        for name, _ in self.layout:
+        for name in (list(ROW_COLUMNS) + [n for n, _ in self.layout if n != "rows"]) if self.row_major else [n for n, _ in self.layout]:
             p = params[name]
-            assert p.shape == self.views[name].shape, (name, p.shape)
-            p.grad = self.views[name]
+            assert p.shape == self.alias[name].shape, (name, p.shape)
+            p.grad = self.alias[name]
 
     def zero(self):
         self.flat.zero_()
@@ -304,6 +330,7 @@ class OwnerAdam:
         """The same step from already reduce-scattered rows (``GradientBucket.reduce_scatter_rows`` /
         ``StepExchange.finish``): dict name -> [Pr, c] and "seen" -> [Pr]."""
         from . import rasterizer as _r
+        grads = split_rows(grads)     # (a row-major bucket's "rows" -> per-attribute views)
         if "seen" not in grads:
             raise ValueError("the owner-computes step needs the seen counts (GradientBucket(track_seen=True) + mark_seen)")
         self.steps += 1
@@ -336,13 +363,13 @@ class StepExchange:
     bucket's, grouped by part."""
 
     def __init__(self, num_points, device, world=1, rank=0, sh_coeffs=0, parts=1, block_rows=0, group=None,
-                 track_seen=True, timing=False):
+                 track_seen=True, timing=False, row_major=False):
         """timing: record device events around every collective and around the join in finish(), so that a run reports
         how much of the exchange ran under the rendering and how much was exposed (``timing_summary``)."""
         self.world, self.rank, self.parts, self.group = max(int(world), 1), int(rank), max(int(parts), 1), group
         self._timing = bool(timing)
         self._ev = {"reduce_scatter": [], "join": [], "all_gather": []}
-        self.buckets = [GradientBucket(num_points, device, world, sh_coeffs, block_rows, track_seen)
+        self.buckets = [GradientBucket(num_points, device, world, sh_coeffs, block_rows, track_seen, row_major)
                         for _ in range(self.parts)]
         self.device = self.buckets[0].flat.device
         self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.world > 1) else None

@@ -437,6 +437,9 @@ class HipBackend:
                                      ("scales", torch.float32, (N, 3)), ("colors", torch.float32, (N, 3)),
                                      ("opac", torch.float32, (N,))])
             g_means3D, g_scales, g_rot, g_colors, g_opac = g["means3D"], g["scales"], g["rot"], g["colors"], g["opac"]
+        elif "rows" in sink:   # one 64-byte row of running sums per Gaussian (LOGRAST_BWD_ACCUMULATE_ROWS)
+            g_means3D, g_scales, g_rot, g_opac, g_colors = sink["rows"], None, None, None, None
+            flags |= 8
         else:
             g_opac, g_colors = sink["opacities"], sink["colors"]
             g_means3D, g_scales, g_rot = sink["means3D"], sink["scales"], sink["rotations"]
@@ -716,11 +719,23 @@ class accumulate_grads_into:
     rotations / opacities / colors_precomp (or, with an "shs" entry, the SH coefficients) straight into the given fp32 tensors (e.g. the views of a
     log_amd.dist.GradientBucket) instead of returning them to autograd: the reverse walk's atomics and the
     chain-rule kernel write into the step's running sums, so a multi-view step needs no per-view accumulate pass.
-    means2D (per-view, consumed by LoG's Counter) is still returned normally.  The sink tensors must be
+    means2D (per-view, consumed by LoG's Counter) is still returned normally.  Row-major form: ``{"rows": [N, 16]}`` -- one
+    64-byte row of running sums per Gaussian (columns 0-2 means3D, 3-5 scales, 6-9 rotations, 10 opacity, 11-13 colour;
+    include/lograst.h: LOGRAST_BWD_ACCUMULATE_ROWS), what log_amd.dist.GradientBucket(row_major=True).sink() hands out.
+    Otherwise the sink tensors must be
     contiguous fp32 [N,3],[N,3],[N,4],[N,1] or [N],[N,3] on the inputs' device; inputs routed through the sink get
     no autograd gradient."""
 
     def __init__(self, sink):
+        if "rows" in sink:   # row-major running sums (log_amd.dist.GradientBucket(row_major=True).sink())
+            t = sink["rows"]
+            if (t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != _lib.GRAD_ROW_FLOATS
+                    or t.data_ptr() % 64):
+                raise ValueError("gradient sink 'rows' must be a contiguous, 64-byte aligned float32 [N, 16] tensor")
+            if "shs" in sink:
+                raise ValueError("the row-major gradient sink has no native-SH form (pass colors_precomp)")
+            self.sink = {"rows": t}
+            return
         need = ("means3D", "scales", "rotations", "opacities") + (() if "shs" in sink else ("colors",))
         missing = [k for k in need if k not in sink]
         if missing:
@@ -839,6 +854,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         sink = _grad_sink
         if sink is None and ctx.leaves is not None and _inplace_leaf_grads:
             sink = _leaf_grad_sink(ctx.leaves, m.device)
+        if sink is not None and "rows" in sink:
+            n = m.shape[0]
+            if sh is not None:
+                raise ValueError("the row-major gradient sink has no native-SH form (pass colors_precomp)")
+            if sink["rows"].shape[0] != n or sink["rows"].device != m.device:
+                raise ValueError("gradient sink does not match the rasterizer inputs")
+            _, g_m2, _, _, _, _ = _backend.backward(ctx.rs, ctx.flavour, ctx.use_filter, m, s, r, ctx.saved, grad_image,
+                                                    sink=sink)
+            return None, g_m2.reshape(m2_shape), None, None, None, None, None, None, None, None, None
         if sink is not None and (sh is None or "shs" in sink):
             n = m.shape[0]
             if not (sink["means3D"].shape == (n, 3) and sink["scales"].shape == (n, 3) and

@@ -149,11 +149,11 @@ def _owner_run(rank, world, g, mode="dense"):
     alternating 2-row blocks) | "parts_compact"."""
     from log_amd.dist import FlatParams, GradientBucket, OwnerAdam, StepExchange
     P = int(g["P"])
-    compact, parts = mode.endswith("compact"), 2 if mode.startswith("parts") else 1
+    compact, parts, row_major = mode.endswith("compact"), 2 if "parts" in mode else 1, mode.startswith("rows")
     blk = 2 if compact else 0
     tensors = {n: torch.from_numpy(g["init_" + n].copy()) for n in NAMES}
     params = FlatParams(tensors, "cpu", world, block_rows=blk)
-    ex = StepExchange(P, "cpu", world, rank, sh_coeffs=15, parts=parts, block_rows=blk)
+    ex = StepExchange(P, "cpu", world, rank, sh_coeffs=15, parts=parts, block_rows=blk, row_major=row_major)
     opt = OwnerAdam(params, rank)
     w = [1.0] if world == 1 else [0.25, 0.75]
     old = GradientBucket.DENSE_ABOVE
@@ -170,7 +170,7 @@ def _owner_run(rank, world, g, mode="dense"):
                 live = (seen & rows).to(torch.float32)
                 for n in NAMES:
                     gr = torch.from_numpy(g[f"s{it}_grad_{n}"]).reshape(P, -1) * live[:, None] * w[rank]
-                    bucket.views[n].copy_(gr.reshape(bucket.views[n].shape))
+                    bucket.alias[n].copy_(gr.reshape(bucket.alias[n].shape))   # (row-major bucket: strided views of "rows")
                 bucket.mark_seen(torch.where(mine & rows, 5, 0))
                 ex.launch(part, compact=compact)
             lr = {"means3D": float(g[f"s{it}_lr_means3D"]), "scales": float(g[f"s{it}_lr_scales"]), "rotations": 0.001,
@@ -216,12 +216,13 @@ def test_owner_adam_world1_reproduces_reference_optimizer(oracle_mod):
         assert float(opt.exp_avg[n][P:].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("mode", ["dense", "compact", "parts", "parts_compact"])
+@pytest.mark.parametrize("mode", ["dense", "compact", "parts", "parts_compact", "rows", "rows_parts_compact"])
 def test_owner_adam_two_ranks_match_one(tmp_path, oracle_mod, mode):
     """world = 2 (gloo): each rank steps only its rows, with moments for those rows only; after the all-gather both
     replicas hold the world-1 result (the two addends 0.25 g + 0.75 g sum to g exactly), and the moments of rank r are
     the world-1 moments of its rows.  The same through the touched-block exchange (only blocks some rank saw travel) and
-    through StepExchange (two groups of views, reduce-scattered one after the other), alone and together."""
+    through StepExchange (two groups of views, reduce-scattered one after the other), alone and together -- and with the
+    gradients in row-major buckets (one 16-float row per Gaussian, exchanged as one block: "rows*")."""
     import oracle_backend
     world = 2
     with socket.socket() as s:
@@ -248,6 +249,31 @@ def test_owner_adam_two_ranks_match_one(tmp_path, oracle_mod, mode):
             k = rows.stop - rows.start
             assert torch.equal(got[r]["exp_avg"][n][:k], ref_opt.exp_avg[n][rows]), (n, r)
             assert torch.equal(got[r]["exp_avg_sq"][n][:k], ref_opt.exp_avg_sq[n][rows]), (n, r)
+
+
+def test_row_major_bucket_layout():
+    """GradientBucket(row_major=True): the 14 base columns are ONE block of 16-float rows (64-byte rows from a 64-byte
+    aligned base: what LOGRAST_BWD_ACCUMULATE_ROWS adds into), the per-attribute tensors are strided views of it, the SH
+    block stays attribute-major behind it; autograd accumulates into the strided .grad views in place."""
+    from log_amd.dist import GradientBucket, ROW_COLUMNS, ROW_FLOATS, layout, split_rows
+    b = GradientBucket(7, "cpu", world=2, sh_coeffs=15, row_major=True)
+    assert layout(15, True) == (("rows", 16), ("shs", 45)) and b.cols == 16 + 45 and b.Ppad == 8
+    assert b.views["rows"].shape == (7, ROW_FLOATS) and b.views["rows"].is_contiguous()
+    assert set(b.sink()) == {"rows", "shs"} and b.rows("rows", 1).shape == (4, 16)
+    params = {n: torch.zeros(7, c, requires_grad=True) for n, c in LAYOUT}
+    params["shs"] = torch.zeros(7, 15, 3, requires_grad=True)
+    b.attach(params)
+    for _ in range(2):
+        sum((i + 1) * p.sum() for i, p in enumerate(params.values())).backward()
+    rows = b.views["rows"]
+    for i, (n, c) in enumerate(LAYOUT):
+        a, e = ROW_COLUMNS[n]
+        assert e - a == c and params[n].grad.data_ptr() == b.alias[n].data_ptr()
+        assert (rows[:, a:e] == 2.0 * (i + 1)).all()
+    assert (rows[:, 14:] == 0).all() and (b.views["shs"] == 12.0).all()
+    assert (b.flat[7 * 16:8 * 16] == 0).all()                                    # the padding row
+    sp = split_rows({"rows": rows, "seen": b.seen})
+    assert set(sp) == set(ROW_COLUMNS) | {"seen"} and sp["rotations"].shape == (7, 4)
 
 
 def test_bucket_carries_sh_columns_and_seen_counts():

@@ -230,3 +230,48 @@ def test_walk_form_hint_changes_no_result():
         assert (a[0][k] == b[0][k]).all(), k
     for k in a[1]:
         assert float(np.abs(a[1][k]).sum()) > 0 and rel_l2(a[1][k], b[1][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("n", [5000, 5003])
+def test_row_major_gradient_sink_equals_the_planar_one(n):
+    """LOGRAST_BWD_ACCUMULATE_ROWS: three views accumulated into ONE 64-byte row of running sums per Gaussian
+    (log_amd.dist.GradientBucket(row_major=True).sink()) hold the sums the attribute-major bucket holds -- same addends, the
+    chain rule's own sums are added in the same order -- and columns 14-15 stay untouched; means2D comes back as always."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R, scenes
+    from log_amd.dist import GradientBucket, ROW_COLUMNS
+    import gpu_util as G
+    dev = torch.device(DEV)
+    cams = scenes.orbit_cameras(3, W=160, H=112, focal=170.0)
+    sc = scenes.random_scene(n, seed=12, opacity=None, smax=0.07)
+    w = torch.tensor(np.random.default_rng(3).random((3, 112, 160), dtype=np.float32), device=dev)
+
+    def run(row_major):
+        leaves = _leaves(sc, dev)
+        bucket = GradientBucket(n, dev, row_major=row_major)
+        if row_major:
+            bucket.views["rows"][:, 14:] = 7.0
+            assert bucket.views["rows"].data_ptr() % 64 == 0
+        m2s = []
+        with R.accumulate_grads_into(bucket.sink()):
+            for cam in cams:
+                rast = GaussianRasterizer(raster_settings=G.settings(cam, (1, 1, 1), dev))
+                ret, m2 = _call(rast, leaves, n, dev)
+                (ret[0] * w).sum().backward()
+                m2s.append(m2.grad.clone())
+        torch.cuda.synchronize()
+        assert all(v.grad is None for v in leaves.values())
+        return bucket, m2s
+
+    planar, m2_p = run(False)
+    rows, m2_r = run(True)
+    assert bool((rows.views["rows"][:, 14:] == 7.0).all())
+    for name, (a, b) in ROW_COLUMNS.items():
+        got = rows.alias[name].reshape(n, b - a).cpu().numpy()
+        ref = planar.views[name].reshape(n, b - a).cpu().numpy()
+        assert float(np.abs(ref).sum()) > 0 and rel_l2(got, ref) < 1e-5, name
+    for x, y in zip(m2_p, m2_r):
+        assert rel_l2(y.cpu().numpy(), x.cpu().numpy()) < 1e-5
+    # shs / cov3D_precomp have no row-major form
+    with pytest.raises(ValueError, match="rows"):
+        R.accumulate_grads_into({"rows": torch.zeros(n, 15, device=dev)})

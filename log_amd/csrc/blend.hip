@@ -660,7 +660,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                          int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
-                         float4* __restrict__ zero_rows, int xcd_mode, int cull) {
+                         float4* __restrict__ zero_rows, int xcd_mode, int cull, int ablate) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
@@ -791,12 +791,12 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
         LR_RMAX(ma, 0x4E); LR_RMAX(mb, 0x4E);
 #undef LR_RMAX
         if (ma != 0u) {
-          if (li == 0) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gida, ma);
-          if (zero_rows && li < 4) zero_rows[4 * (size_t)(uint32_t)gida + li] = float4{0.f, 0.f, 0.f, 0.f};
+          if (li == 0 && !(ablate & 1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gida, ma);
+          if (zero_rows && li < 4 && !(ablate & 2)) zero_rows[4 * (size_t)(uint32_t)gida + li] = float4{0.f, 0.f, 0.f, 0.f};
         }
         if (mb != 0u) {
-          if (li == 0) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gidb, mb);
-          if (zero_rows && li < 4) zero_rows[4 * (size_t)(uint32_t)gidb + li] = float4{0.f, 0.f, 0.f, 0.f};
+          if (li == 0 && !(ablate & 1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gidb, mb);
+          if (zero_rows && li < 4 && !(ablate & 2)) zero_rows[4 * (size_t)(uint32_t)gidb + li] = float4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
@@ -824,6 +824,7 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   // hint (lograst_view.walk_form), quadrant without one.  Measured, MI355X: 30 M tiny splats 706 -> 658 us (random
   // opacities 1267 -> 1188); C2's 1 M 174 -> 193; a tree-ordered heavy-tailed view 278 -> 347.
   LR_KNOB(rows_knob, "LOGRAST_FWD_ROWS", 2);
+  static const int fwd_ablate = lr_env_int("LOGRAST_FWD_ABLATE", 0);   // timing experiments (row-split form): 1 no point_weight atomics, 2 no row clears
   const int rows = rows_knob != 2 ? rows_knob
                    : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : (v.walk_form == LOGRAST_FORM_QUADRANT ? 0 : 0));   // no hint: quadrant
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
@@ -833,10 +834,10 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   if (rows) {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, fwd_ablate);
     else
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, fwd_ablate);
   } else {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,

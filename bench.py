@@ -10,7 +10,8 @@ Headline workload = the north-star point of BASELINE.json (configs[3] per GPU; S
 30,000,000 random Gaussians (seed 0, opacity 0.999, scales U(0, 0.5 N^-1/3)), 1920x1080, 8 orbit cameras PER GPU,
 through the drop-in ``diff_gaussian_rasterization_wodilate`` package (5-tuple flavour), loss = sum(image * w),
 backward to all Gaussian attributes + means2D.  A "step" = every rank renders its 8 views forward+backward, gradients are
-added by the backward kernels into one flat buffer per stream, summed per rank, and (N > 1) summed across ranks by
+added by the backward kernels into one flat buffer per stream (row-major: one 64-byte row of running sums per Gaussian,
+log_amd.dist.GradientBucket(row_major=True); --planar-bucket: five attribute-major arrays), summed per rank, and (N > 1) summed across ranks by
 reduce-scatter + all-gather (view-sharded data parallelism, weak scaling: per-GPU work is fixed; the views of a step go in
 --exchange-parts groups and a group's reduce-scatter runs on a side stream under the next group's rendering,
 log_amd.dist.StepExchange).  Inputs are

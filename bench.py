@@ -407,6 +407,26 @@ def mode_summary(N, views, world, steps, r):
             "host_enqueue_ms_per_view": 1e3 * r["t_enqueued"] / (steps * views)}
 
 
+def R_forms():
+    """Which compositing kernels the last forward / backward of this process launched (rows = row-split form)."""
+    from log_amd import rasterizer as R
+    return R._backend.last_forms or {}
+
+
+def whole_view_summary(rep, ms_view, best_copy):
+    """One view as a whole against the roofs: SURVEY 8d's formula bytes, and the effective bytes (units really processed)."""
+    g_formula, g_eff = rep["algorithmic_GBs_whole_view_survey_formula"], rep["algorithmic_GBs_whole_view"]
+    return {"ms_per_view": ms_view,
+            "survey_formula_bytes": rep["algorithmic_bytes_per_view_survey_formula"], "survey_formula_GBs": g_formula,
+            "survey_formula_frac_of_hbm_peak": g_formula / HBM_PEAK_GBS,
+            "survey_formula_frac_of_measured_stream_copy": g_formula / best_copy,
+            "survey_formula_frac_of_guide_float4_copy": g_formula / GUIDE_COPY_GBS,
+            "effective_bytes": rep["algorithmic_bytes_per_view"], "effective_GBs": g_eff,
+            "effective_frac_of_measured_stream_copy": g_eff / best_copy,
+            "note": "survey_formula counts every Gaussian and every list entry (184 N + 116 V + 108 I + 48 Px); effective "
+                    "counts the list entries really walked and the Gaussians really composited"}
+
+
 def auto_streams(args, N):
     S = args.streams if args.streams > 0 else (3 if N <= 4_000_000 else 1)
     return max(1, min(S, args.views))
@@ -724,10 +744,28 @@ def main():
                  "stream), gradients added in place into the leaves' .grad")
 
     if rank == 0:
-        roofs = {"measured_stream_copy": measured_stream_copy_bandwidth(dev), "measured_copy": measured_copy_bandwidth(dev)}
+        best_copy, copy_forms = measured_stream_copy_bandwidth(dev)
+        roofs = {"measured_stream_copy": best_copy, "measured_copy": measured_copy_bandwidth(dev)}
         result["measured_stream_copy_GBs"] = roofs["measured_stream_copy"]
         result["measured_copy_GBs"] = roofs["measured_copy"]
         rep = workload_report(args, wl, r, N, Px, world, args.steps, roofs, timing, label(N, op_name))
+        if "roofline" in rep:
+            # Everything a reader needs to redo the fractions sits INSIDE the roofline object (the driver's record keeps
+            # this object whole): both denominators, the whole view next to the dominant kernel, A0, and -- filled in
+            # below -- the opacity = rand variant.
+            rf = rep["roofline"]
+            rf["measured_stream_copy_GBs"] = best_copy
+            rf["stream_copy_forms_GBs"] = copy_forms
+            rf["guide_float4_copy_GBs"] = GUIDE_COPY_GBS
+            rf["torch_copy_GBs"] = roofs["measured_copy"]
+            rf["frac_of_measured_stream_copy"] = rf["achieved"] / best_copy
+            rf["frac_of_guide_float4_copy"] = rf["achieved"] / GUIDE_COPY_GBS
+            rf["traffic_frac_of_measured_stream_copy"] = (rf["traffic"] / (rf["avg_launch_us"] * 1e-6) / 1e9 / best_copy
+                                                          if rf.get("traffic") else None)
+            rf["whole_view"] = whole_view_summary(rep, head["ms_per_view"], best_copy)
+            rf["compute_radius"] = compute_radius_leg(wl)
+            rf["forms"] = dict(R_forms())
+        result["config"]["ms_per_view"] = head["ms_per_view"]
         for k in ("effective_units_per_view", "algorithmic_bytes_per_view", "algorithmic_bytes_per_view_survey_formula",
                   "algorithmic_GBs_whole_view", "algorithmic_GBs_whole_view_survey_formula",
                   "algorithmic_frac_of_measured_stream_copy", "algorithmic_frac_of_measured_stream_copy_survey_formula",
@@ -757,6 +795,11 @@ def main():
                       steps=rsteps)
             mr.update(workload_report(args_r, wl_r, rr, N, Px, world, rsteps, roofs, timing, label(N, "rand")))
             result["modes"]["pipelined_opacity_rand"] = mr
+            result["config"]["ms_per_view_opacity_rand"] = mr["ms_per_view"]
+            if "roofline" in result and "roofline" in mr:
+                result["roofline"]["whole_view_opacity_rand"] = whole_view_summary(mr, mr["ms_per_view"], roofs["measured_stream_copy"])
+                result["roofline"]["opacity_rand_dominant_kernel"] = {
+                    k: mr["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch")}
             if not args.no_forward_only:
                 result["forward_only"]["headline_opacity_rand"] = forward_only(args_r, wl_r)
             del wl_r
@@ -853,10 +896,15 @@ def measured_copy_bandwidth(dev, mib=1024, reps=5):
     return 2 * mib * 1024 * 1024 / (best * 1e-3) / 1e9
 
 
-def measured_stream_copy_bandwidth(dev, mib=1024, reps=5):
-    """The same copy with this library's own streaming kernel (lograst_stream_copy: 16-byte non-temporal accesses,
-    grid-stride; the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s), launched on torch's current stream so that the
-    torch events bracket it: GB/s, read + write counted, best of `reps` over a few grid sizes."""
+GUIDE_COPY_GBS = 6290.0   # the float4 copy /opt/skills/guides/MI355X_MICROARCH.md measured on this chip (79 % of 8 TB/s)
+COPY_FORMS = {0: "grid-stride x4, non-temporal", 1: "one access per lane, plain", 2: "grid-stride x8, non-temporal",
+              3: "grid-stride x4, plain loads + non-temporal stores", 4: "one access per lane, non-temporal"}
+
+
+def measured_stream_copy_bandwidth(dev, mib=2048, reps=4):
+    """The measured roof: `mib` MiB copied device-to-device by this library's own streaming kernels (lograst_stream_copy:
+    16-byte accesses; five forms x a few grid sizes, include/lograst.h), launched on torch's current stream so that the
+    torch events bracket them: GB/s with read + write counted.  -> (best GB/s over everything, {form: best GB/s})."""
     import ctypes
     import torch
     from log_amd import _lib
@@ -865,18 +913,49 @@ def measured_stream_copy_bandwidth(dev, mib=1024, reps=5):
     a = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
     b = torch.empty_like(a)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    best = float("inf")
-    for blocks in (2048, 4096, 8192, 16384):
-        _lib.check(L.lograst_stream_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), nbytes, blocks, stream))
-        for _ in range(reps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(L.lograst_stream_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), nbytes, blocks, stream))
-            e1.record()
-            e1.synchronize()
-            best = min(best, e0.elapsed_time(e1))
+    pa, pb = ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr())
+    forms = {}
+    for form in COPY_FORMS:
+        best = float("inf")
+        for blocks in ((0,) if form in (1, 4) else (1024, 2048, 4096, 8192, 16384)):
+            arg = (form << 20) | blocks
+            _lib.check(L.lograst_stream_copy(pb, pa, nbytes, arg, stream))
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(L.lograst_stream_copy(pb, pa, nbytes, arg, stream))
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+        forms[COPY_FORMS[form]] = 2 * nbytes / (best * 1e-3) / 1e9
     del a, b
-    return 2 * nbytes / (best * 1e-3) / 1e9
+    return max(forms.values()), forms
+
+
+def compute_radius_leg(wl, reps=5):
+    """A0 (LoG/cuda/compute_radius_kernel.cu:107-183 -> lograst_compute_radius) on the headline's Gaussians: 44 bytes read
+    + 4 written per Gaussian, best of `reps`, torch events on the launch stream."""
+    import torch
+    from log_amd import rasterizer as R
+    rs = wl.rasts[0].raster_settings
+    fx, fy = rs.image_width / (2.0 * rs.tanfovx), rs.image_height / (2.0 * rs.tanfovy)
+    b = wl.base
+    call = lambda: R._backend.compute_radius(b["means3D"], b["scales"], b["rotations"], rs.projmatrix, rs.viewmatrix, fx, fy,
+                                             rs.tanfovx, rs.tanfovy)
+    call()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = call()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del out
+    nbytes = 48.0 * wl.N
+    return {"kernel": "compute_radius (A0)", "gaussians": wl.N, "us": 1e3 * best, "algorithmic_bytes": nbytes,
+            "GBs": nbytes / (best * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "gaussians_per_s": wl.N / (best * 1e-3)}
 
 
 def pmc_traffic(kernel, N, W, H, field="traffic_bytes"):

@@ -202,8 +202,10 @@ int lograst_tile_rows(const lograst_view* view, int32_t n, const float* means3d,
                       const float* rotations, uint32_t* rows_out, void* stream);
 
 /* Measurement helper (bench.py's HBM denominator, SURVEY 8d "measured device-copy bandwidth"): streams `bytes` from
- * src to dst with 16-byte non-temporal accesses, grid-stride over `blocks` workgroups of 256 (<= 0: 4096).  Pointers
- * and size must be multiples of 16 bytes.  Not on the rasterizer's path. */
+ * src to dst with 16-byte accesses.  `blocks` & 0xfffff = workgroups of 256 of the grid-stride forms (0: 4096);
+ * `blocks` >> 20 = form: 0 grid-stride, four non-temporal loads in flight per lane, non-temporal stores; 1 one access
+ * per lane, no loop, plain loads / stores; 2 as 0 with eight loads in flight; 3 as 0 with plain loads; 4 as 1,
+ * non-temporal.  Pointers and size must be multiples of 16 bytes.  Not on the rasterizer's path. */
 int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, void* stream);
 
 /* ---- performance knobs -------------------------------------------------------------------------------------------

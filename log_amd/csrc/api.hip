@@ -133,7 +133,7 @@ static std::atomic<int> g_tile_cull{-1};
 // LOGRAST_BATCH overrides the batch size (0 disables batching), LOGRAST_BATCH_PLANES caps the planes.
 struct LrBatching { uint32_t batch, planes; };
 static LrBatching lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t gy) {
-  static const int forced = lr_env_int("LOGRAST_BATCH", -1);
+  static const int forced = LR_EXPERIMENT_INT("LOGRAST_BATCH", -1);   // experiment builds: Gaussians per batch, 0 = unbatched kernel
   LR_KNOB(max_planes_k, "LOGRAST_BATCH_PLANES", 4);
   const uint32_t max_planes = (uint32_t)max_planes_k;
   if (n <= 0 || tiles > LR_BATCH_MAX_TILES || gx > 8191u || gy > 8191u || forced == 0) return {0u, 1u};  // 13-bit tile coordinates in the fill record
@@ -357,7 +357,7 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
                  zero_n, zero_floats > 0 ? zero_block : nullptr, zero_floats,
                  lr_big_input(n) ? 1 : 0, speculative,
                  lr_band_sparse(v, (int)lr_pick_batch(n, tiles, (uint32_t)v.gx, (uint32_t)v.gy).batch) ? 1 : 0, s);
-  static const int stop_after_fill = lr_env_int("LOGRAST_STOP_AFTER_FILL", 0);   // timing experiments (tools/) only
+  static const int stop_after_fill = LR_EXPERIMENT_INT("LOGRAST_STOP_AFTER_FILL", 0);   // experiment builds (tools/fill_probe.py)
   if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,

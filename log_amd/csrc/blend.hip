@@ -463,7 +463,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          const float* __restrict__ final_T, const int* __restrict__ n_contrib,
                          const float* __restrict__ dL_dimage, float* __restrict__ acc_rows,
-                         int xcd_mode, int cull, int ablate, int block_test) {
+                         int xcd_mode, int cull, int block_test LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
@@ -639,7 +639,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       // one instruction per entry: nine lanes of every row, one 64-byte line per row
       const float xa = sel == 0 ? s1a : (sel == 1 ? s2a : s3);
       const float xb = sel == 0 ? s1b : (sel == 1 ? s2b : s3);
-      if (!(ablate & 1)) {
+      if (!LR_ABLATED(1)) {
         if (on_a && gida != 0xffffffffu) atomicAdd(dst + (size_t)gida * LOGRAST_BWD_ROW_FLOATS, xa);
         if (on_b && gidb != 0xffffffffu) atomicAdd(dst + (size_t)gidb * LOGRAST_BWD_ROW_FLOATS, xb);
       }
@@ -660,7 +660,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                          int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
-                         float4* __restrict__ zero_rows, int xcd_mode, int cull, int ablate) {
+                         float4* __restrict__ zero_rows, int xcd_mode, int cull LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
@@ -791,12 +791,12 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
         LR_RMAX(ma, 0x4E); LR_RMAX(mb, 0x4E);
 #undef LR_RMAX
         if (ma != 0u) {
-          if (li == 0 && !(ablate & 1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gida, ma);
-          if (zero_rows && li < 4 && !(ablate & 2)) zero_rows[4 * (size_t)(uint32_t)gida + li] = float4{0.f, 0.f, 0.f, 0.f};
+          if (li == 0 && !LR_ABLATED(1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gida, ma);
+          if (zero_rows && li < 4 && !LR_ABLATED(2)) zero_rows[4 * (size_t)(uint32_t)gida + li] = float4{0.f, 0.f, 0.f, 0.f};
         }
         if (mb != 0u) {
-          if (li == 0 && !(ablate & 1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gidb, mb);
-          if (zero_rows && li < 4 && !(ablate & 2)) zero_rows[4 * (size_t)(uint32_t)gidb + li] = float4{0.f, 0.f, 0.f, 0.f};
+          if (li == 0 && !LR_ABLATED(1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gidb, mb);
+          if (zero_rows && li < 4 && !LR_ABLATED(2)) zero_rows[4 * (size_t)(uint32_t)gidb + li] = float4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
@@ -818,13 +818,15 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
                          int* pid, float* pwp, float* pw, float* zero_conic, int big_input, hipStream_t s) {
   LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
-  static const int cull = lr_env_int("LOGRAST_CULL", 1);
-  static const size_t lds_fwd = (size_t)lr_env_int("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;
+  static const int cull = LR_EXPERIMENT_INT("LOGRAST_CULL", 1);   // experiment builds: 0 = no per-quadrant support test
+  static const size_t lds_fwd = (size_t)LR_EXPERIMENT_INT("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;   // experiment builds: occupancy cap
   // LOGRAST_FWD_ROWS: 1 = row-split form (lr_blend_fwd_rows_kernel), 0 = one quadrant per wave, 2 (default) = the caller's
   // hint (lograst_view.walk_form), quadrant without one.  Measured, MI355X: 30 M tiny splats 706 -> 658 us (random
   // opacities 1267 -> 1188); C2's 1 M 174 -> 193; a tree-ordered heavy-tailed view 278 -> 347.
   LR_KNOB(rows_knob, "LOGRAST_FWD_ROWS", 2);
+#ifdef LR_EXPERIMENTS
   static const int fwd_ablate = lr_env_int("LOGRAST_FWD_ABLATE", 0);   // timing experiments (row-split form): 1 no point_weight atomics, 2 no row clears
+#endif
   const int rows = rows_knob != 2 ? rows_knob
                    : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : (v.walk_form == LOGRAST_FORM_QUADRANT ? 0 : 0));   // no hint: quadrant
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
@@ -834,10 +836,10 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   if (rows) {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, fwd_ablate);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull LR_ABLATE_PASS(fwd_ablate));
     else
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, fwd_ablate);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull LR_ABLATE_PASS(fwd_ablate));
   } else {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
@@ -853,8 +855,8 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s) {
   LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
-  static const int cull = lr_env_int("LOGRAST_CULL", 1);
-  static const size_t lds_bwd = (size_t)lr_env_int("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;
+  static const int cull = LR_EXPERIMENT_INT("LOGRAST_CULL", 1);   // experiment builds: 0 = no per-quadrant support test
+  static const size_t lds_bwd = (size_t)LR_EXPERIMENT_INT("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;   // experiment builds: occupancy cap
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   // LOGRAST_BWD_ROWS=1: the row-split form (the four 16-lane rows of a wave walk their own 4x4 blocks); 0: one
   // (Gaussian, quadrant) pair per visit; 2 (default): the caller's hint (lograst_view.walk_form: row-split for views of
@@ -863,13 +865,15 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
   LR_KNOB(rows_knob, "LOGRAST_BWD_ROWS", 2);
   const int rows = rows_knob != 2 ? rows_knob
                    : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : (v.walk_form == LOGRAST_FORM_QUADRANT ? 0 : (big_input ? 1 : 0)));
-  static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);
+#ifdef LR_EXPERIMENTS
+  static const int ablate = lr_env_int("LOGRAST_BWD_ABLATE", 0);   // timing experiments: 1 = no atomics in the row-split form
+#endif
   LR_KNOB(block_test, "LOGRAST_BWD_BLOCK_TEST", 1);
   lr_prof_begin(LRK_BLEND_BWD, s);
   if (rows)
     hipLaunchKernelGGL(lr_blend_bwd_rows_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull, ablate,
-                       block_test);
+                       state, tiles, plist, capacity, final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull,
+                       block_test LR_ABLATE_PASS(ablate));
   else
     hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom), state,
                        tiles, plist, capacity, final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull);

@@ -186,12 +186,12 @@ struct LrEwa {
 // EWA projection of the 3-D covariance (/root/reference/LoG/cuda/compute_radius_kernel.cu:63-105),
 // with the low-pass selectable: fork max(.,0.3) (:102-103) / upstream +0.3 (LoG/model/geometry.py:87-88) / none.
 // (V: const float*, or the view's matrix through lr_uniform())
+// (lr_ewa_t: everything behind the view-space centre t -- the batched projection computes t early, together with the
+// other values that need the Gaussian's raw inputs, so that the next Gaussian's inputs can be requested into the same
+// registers; lr_ewa = t, then lr_ewa_t: one op sequence)
 template <typename VP>
-LR_DEV void lr_ewa(const float p[3], const float Sg[6], VP V, float fx, float fy,
-                   float tanfovx, float tanfovy, int filter_mode, LrEwa& e) {
-  e.t[0] = lr_dot3p(V[0], V[4], V[8], p[0], p[1], p[2], V[12]);
-  e.t[1] = lr_dot3p(V[1], V[5], V[9], p[0], p[1], p[2], V[13]);
-  e.t[2] = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
+LR_DEV void lr_ewa_t(const float Sg[6], VP V, float fx, float fy, float tanfovx, float tanfovy, int filter_mode,
+                     LrEwa& e) {
   float tz = e.t[2];
   float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
   float txtz = e.t[0] / tz, tytz = e.t[1] / tz;
@@ -222,6 +222,14 @@ LR_DEV void lr_ewa(const float p[3], const float Sg[6], VP V, float fx, float fy
   if (filter_mode == LOGRAST_FILTER_DILATE) { e.a = e.a_raw + 0.3f; e.c = e.c_raw + 0.3f; }
   else if (filter_mode == LOGRAST_FILTER_CLAMP) { e.a = fmaxf(e.a_raw, 0.3f); e.c = fmaxf(e.c_raw, 0.3f); }
   else { e.a = e.a_raw; e.c = e.c_raw; }
+}
+template <typename VP>
+LR_DEV void lr_ewa(const float p[3], const float Sg[6], VP V, float fx, float fy,
+                   float tanfovx, float tanfovy, int filter_mode, LrEwa& e) {
+  e.t[0] = lr_dot3p(V[0], V[4], V[8], p[0], p[1], p[2], V[12]);
+  e.t[1] = lr_dot3p(V[1], V[5], V[9], p[0], p[1], p[2], V[13]);
+  e.t[2] = lr_dot3p(V[2], V[6], V[10], p[0], p[1], p[2], V[14]);
+  lr_ewa_t(Sg, V, fx, fy, tanfovx, tanfovy, filter_mode, e);
 }
 
 LR_DEV float lr_radius_from_cov(float a, float c, float det) {
@@ -292,43 +300,67 @@ struct LrSupport {
 LR_DEV LrSupport lr_support_prepare(float mx, float my, float A, float B, float C, float op) {
   // v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE sequences: the test only has to be conservative and
   // reproducible (project and fill run this same code on the same record), and its margins are 1 % wide.
+  // Straight-line: every field is computed for every lane, the mode is selected at the end (the projection runs this
+  // once per Gaussian; branches around it cost more scalar bookkeeping than the ~25 instructions they skip).
   LrSupport s;
   s.mx = mx; s.my = my; s.A = A; s.B = B; s.C = C;
   s.tau = lr_fma(__logf(255.f * op), 1.01f, 0.01f);
-  s.ex = 0.f; s.ey = 0.f; s.iA = 0.f; s.iC = 0.f;
-  if (!(op >= 1.0f / 512.0f)) { s.mode = (op < 1.0f / 512.0f) ? 0 : 1; return s; }  // NaN -> keep
   const float det = A * C - B * B;
   const float inv = __builtin_amdgcn_rcpf(det);
   const float ex2 = 2.f * s.tau * C * inv, ey2 = 2.f * s.tau * A * inv;  // squared half extents
   const float mag = (fabsf(A) + fabsf(B) + fabsf(C)) * (ex2 + ey2);       // bound on the terms of `power` in the box
   const bool safe = (det > 0.f) && (ex2 >= 0.f) && (ey2 >= 0.f) && (mag * 1.0e-6f < 0.005f * s.tau) && (mag < 1.0e30f);
-  if (!safe) { s.mode = 1; return s; }
   s.ex = __builtin_amdgcn_sqrtf(ex2) * 1.0001f + 0.01f; s.ey = __builtin_amdgcn_sqrtf(ey2) * 1.0001f + 0.01f;
   s.iA = __builtin_amdgcn_rcpf(A); s.iC = __builtin_amdgcn_rcpf(C);
-  s.mode = 2;
+  // opacity below the floor: never visible (0); NaN opacity or an ill-conditioned conic: cannot cull safely (1)
+  s.mode = (op < 1.0f / 512.0f) ? 0 : ((op >= 1.0f / 512.0f && safe) ? 2 : 1);
   return s;
 }
+// The minimum of the quadratic over the box lies -- unless the centre is inside -- on an edge that FACES the centre: a
+// point of an averted edge sees the centre through the box, and the (convex) quadratic falls along that segment.  So one
+// vertical and one horizontal edge are evaluated (the facing one; either when the centre lies between the two), each
+// at the minimum of the quadratic along it (closed form, clamped to the edge).
 LR_DEV bool lr_support_box(const LrSupport& s, float x0, float x1, float y0, float y1) {
   if (s.mode != 2) return s.mode != 0;
   if (!((s.mx + s.ex >= x0) && (s.mx - s.ex <= x1) && (s.my + s.ey >= y0) && (s.my - s.ey <= y1))) return false;
   const float dx0 = (x0 - 0.01f) - s.mx, dx1 = (x1 + 0.01f) - s.mx;
   const float dy0 = (y0 - 0.01f) - s.my, dy1 = (y1 + 0.01f) - s.my;
   if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
-  float best = 3.0e38f;
-#pragma unroll
-  for (int e = 0; e < 2; e++) {  // the minimum of the quadratic over the box lies on one of its four edges
-    const float dx = e ? dx1 : dx0;
-    const float dy = fminf(dy1, fmaxf(dy0, -s.B * dx * s.iC));
-    best = fminf(best, 0.5f * (s.A * dx * dx + s.C * dy * dy) + s.B * dx * dy);
-    const float ey_ = e ? dy1 : dy0;
-    const float ex_ = fminf(dx1, fmaxf(dx0, -s.B * ey_ * s.iA));
-    best = fminf(best, 0.5f * (s.A * ex_ * ex_ + s.C * ey_ * ey_) + s.B * ex_ * ey_);
-  }
-  return !(best > s.tau);
+  const float dx = dx0 > 0.f ? dx0 : dx1;
+  const float dy = fminf(dy1, fmaxf(dy0, -s.B * dx * s.iC));
+  const float bv = 0.5f * (s.A * dx * dx + s.C * dy * dy) + s.B * dx * dy;
+  const float ey_ = dy0 > 0.f ? dy0 : dy1;
+  const float ex_ = fminf(dx1, fmaxf(dx0, -s.B * ey_ * s.iA));
+  const float bh = 0.5f * (s.A * ex_ * ex_ + s.C * ey_ * ey_) + s.B * ex_ * ey_;
+  return !(fminf(bv, bh) > s.tau);
 }
 LR_DEV bool lr_support_tile(const LrSupport& s, int tx, int ty) {
   const float x0 = (float)(tx * LR_TILE), y0 = (float)(ty * LR_TILE);
   return lr_support_box(s, x0, x0 + (float)(LR_TILE - 1), y0, y0 + (float)(LR_TILE - 1));
+}
+// Two tiles at once (tile origins X0, Y0 in pixels, one tile per half): element for element the op sequence of
+// lr_support_box, the multiplies and adds issued as v_pk_*_f32 -- the same decisions as two lr_support_tile calls.
+LR_DEV void lr_support_tile2(const LrSupport& s, lr_f2 X0, lr_f2 Y0, bool& keep0, bool& keep1) {
+  const lr_f2 X1 = X0 + (float)(LR_TILE - 1), Y1 = Y0 + (float)(LR_TILE - 1);
+  const float xlo = s.mx + s.ex, xhi = s.mx - s.ex, ylo = s.my + s.ey, yhi = s.my - s.ey;
+  const bool bb0 = (xlo >= X0.x) && (xhi <= X1.x) && (ylo >= Y0.x) && (yhi <= Y1.x);
+  const bool bb1 = (xlo >= X0.y) && (xhi <= X1.y) && (ylo >= Y0.y) && (yhi <= Y1.y);
+  const lr_f2 dx0 = (X0 - 0.01f) - s.mx, dx1 = (X1 + 0.01f) - s.mx;
+  const lr_f2 dy0 = (Y0 - 0.01f) - s.my, dy1 = (Y1 + 0.01f) - s.my;
+  const bool in0 = dx0.x <= 0.f && dx1.x >= 0.f && dy0.x <= 0.f && dy1.x >= 0.f;
+  const bool in1 = dx0.y <= 0.f && dx1.y >= 0.f && dy0.y <= 0.f && dy1.y >= 0.f;
+  const lr_f2 dx = lr_f2{dx0.x > 0.f ? dx0.x : dx1.x, dx0.y > 0.f ? dx0.y : dx1.y};
+  const lr_f2 ty_ = -s.B * dx * s.iC;
+  const lr_f2 dy = lr_f2{fminf(dy1.x, fmaxf(dy0.x, ty_.x)), fminf(dy1.y, fmaxf(dy0.y, ty_.y))};
+  const lr_f2 bv = 0.5f * (s.A * dx * dx + s.C * dy * dy) + s.B * dx * dy;
+  const lr_f2 ey_ = lr_f2{dy0.x > 0.f ? dy0.x : dy1.x, dy0.y > 0.f ? dy0.y : dy1.y};
+  const lr_f2 tx_ = -s.B * ey_ * s.iA;
+  const lr_f2 ex_ = lr_f2{fminf(dx1.x, fmaxf(dx0.x, tx_.x)), fminf(dx1.y, fmaxf(dx0.y, tx_.y))};
+  const lr_f2 bh = 0.5f * (s.A * ex_ * ex_ + s.C * ey_ * ey_) + s.B * ex_ * ey_;
+  const bool q0 = !(fminf(bv.x, bh.x) > s.tau), q1 = !(fminf(bv.y, bh.y) > s.tau);
+  const bool any = s.mode != 0, test = s.mode == 2;
+  keep0 = test ? (bb0 && (in0 || q0)) : any;
+  keep1 = test ? (bb1 && (in1 || q1)) : any;
 }
 
 // Every kernel behind the fill checks this first: nothing is sorted or composited when the caller's buffers were too
@@ -417,6 +449,22 @@ enum LrKernelSlot {
   LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_LOD, LRK_COUNTER, LRK_ADAM, LRK_HIST, LRK_GATHER, LRK_GATHER_BWD, LRK_RESERVED,
   LRK_REBASE, LRK_SPARE
 };
+// ---- experiment switches ---------------------------------------------------------------------------------------
+// Timing ablations (kernels that SKIP part of their work) and alternative algorithms kept for A/B measurements exist only
+// in builds made with -DLR_EXPERIMENTS (`python -m log_amd.build <variant> -DLR_EXPERIMENTS`, loaded through LOGRAST_LIB by
+// the scripts under tools/); the product library contains none of them: LR_EXPERIMENT_INT is its default, no kernel
+// takes an `ablate` argument, LR_ABLATED() is `false`.
+#ifdef LR_EXPERIMENTS
+#define LR_EXPERIMENT_INT(name, dflt) lr_env_int(name, dflt)
+#define LR_ABLATE_PARAM , int ablate
+#define LR_ABLATE_PASS(x) , x
+#define LR_ABLATED(bits) ((ablate & (bits)) != 0)
+#else
+#define LR_EXPERIMENT_INT(name, dflt) (dflt)
+#define LR_ABLATE_PARAM
+#define LR_ABLATE_PASS(x)
+#define LR_ABLATED(bits) false
+#endif
 void lr_prof_begin(int slot, hipStream_t s);
 void lr_prof_end(int slot, hipStream_t s);
 int lr_env_int(const char* name, int dflt);

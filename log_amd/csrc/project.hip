@@ -338,6 +338,69 @@ LR_DEV void lr_reserve_batches(const uint32_t* lds_ctr, int stride, int t_lo, in
   }
 }
 
+// The hot loop (round 4).  Everything a lane does for its Gaussian is straight-line code behind ONE validity predicate
+// (culls clear the predicate instead of branching: in a wave of 64 consecutive Gaussians some lane always survives, so
+// the branches only cost exec-mask bookkeeping, phi copies and -- through the masks held live -- scalar-register spills):
+//   * the wave's 64 Gaussians are addressed as wave-uniform base (scalar registers) + a lane offset that never changes,
+//     so no per-iteration 64-bit address arithmetic on the vector ALU;
+//   * the values that need the raw inputs (view-space centre, clip-space centre, world-space covariance) are computed
+//     first; the NEXT iteration's means / scales / rotations are then requested into the registers that just died (the
+//     software pipeline needs no copies at the loop's back edge); opacity and colour, used last, are requested at the top;
+//   * the (up to four) tiles of a small rect are tested against the alpha support two at a time (lr_support_tile2), then
+//     ranked with up to four LDS atomics in flight;
+//   * records leave as full 64-byte lines through a 4x4 transpose between the wave's four 16-lane ROWS:
+//     v_permlane16_swap / v_permlane32_swap exchange two registers' halves in one instruction (16 instructions for the
+//     16 dwords; the DPP quad-permute form took ~100).  Afterwards lane (row r, column l) holds quad r of the records of
+//     Gaussians l, 16 + l, 32 + l, 48 + l of the wave: every store instruction writes 16 complete lines.
+LR_DEV void lr_swap16(float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+LR_DEV void lr_swap32(float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+LR_DEV void lr_swap16(float4& a, float4& b) { lr_swap16(a.x, b.x); lr_swap16(a.y, b.y); lr_swap16(a.z, b.z); lr_swap16(a.w, b.w); }
+LR_DEV void lr_swap32(float4& a, float4& b) { lr_swap32(a.x, b.x); lr_swap32(a.y, b.y); lr_swap32(a.z, b.z); lr_swap32(a.w, b.w); }
+// on entry lane (row r, column l) holds quads 0..3 of ITS record in (a, b, c, d); on exit quad r of the records of the
+// lanes (0, l), (1, l), (2, l), (3, l)
+LR_DEV void lr_row_transpose(float4& a, float4& b, float4& c, float4& d) {
+  lr_swap16(a, b); lr_swap16(c, d);     // a = [a0 b0 a2 b2], b = [a1 b1 a3 b3] (subscript: row of origin)
+  lr_swap32(a, c); lr_swap32(b, d);     // a = [a0 b0 c0 d0], b = [a1 b1 c1 d1], c = [a2 b2 c2 d2], d = [a3 b3 c3 d3]
+}
+
+// means3D / scales / rotations (or the six covariance floats) of one Gaussian: what the first part of the loop consumes
+struct LrGeo { float p[3], s[3]; float4 q; };
+// A wave-uniform index, pinned to a scalar register and opaque to the loop optimiser -- which otherwise folds the lane's
+// (invariant) offset into a VECTOR base and adds the (changing) scalar part per iteration with v_mad_i64: with it the
+// accesses are `global_load ... v_lane_offset, s[base:base+1]`.
+LR_DEV uint32_t lr_sgpr(uint32_t i) { asm volatile("" : "+s"(i)); return i; }
+// ... and a lane offset that is not available before the listed values are: the scheduler otherwise hoists the request
+// for the NEXT Gaussian's inputs above the arithmetic that consumes the current ones, and then has to keep two sets of
+// inputs alive and copy one into the other at the loop's back edge.
+LR_DEV uint32_t lr_after(uint32_t off, const float a[3], float b0, float b1, float b2, const float c[6]) {
+  asm volatile("" : "+v"(off) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(b0), "v"(b1), "v"(b2), "v"(c[0]), "v"(c[1]),
+               "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]));
+  return off;
+}
+// wm / ws / wr / wc6: the arrays at the wave's first Gaussian (wave-uniform: scalar registers) + the lane's offset
+template <bool COV3D>
+LR_DEV LrGeo lr_load_geo(const float* __restrict__ wm, const float* __restrict__ ws, const float* __restrict__ wr,
+                         const float* __restrict__ wc6, uint32_t ulane) {
+  LrGeo g;
+  const size_t lane = ulane;
+  g.p[0] = wm[3 * lane]; g.p[1] = wm[3 * lane + 1]; g.p[2] = wm[3 * lane + 2];
+  if (COV3D) {
+    g.s[0] = wc6[6 * lane]; g.s[1] = wc6[6 * lane + 1]; g.s[2] = wc6[6 * lane + 2];
+    g.q = float4{wc6[6 * lane + 3], wc6[6 * lane + 4], wc6[6 * lane + 5], 0.f};
+  } else {
+    g.s[0] = ws[3 * lane]; g.s[1] = ws[3 * lane + 1]; g.s[2] = ws[3 * lane + 2];
+    g.q = reinterpret_cast<const float4*>(wr)[lane];
+  }
+  return g;
+}
+
+template <bool COV3D>
 __global__ void __launch_bounds__(LR_BATCH_THREADS)
 lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                           const float* __restrict__ rots, const float* __restrict__ opac,
@@ -355,47 +418,151 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   uint32_t rect_instances = 0;
   const int i_begin = blockIdx.x * (S * B), i_end = min(N, i_begin + S * B);
   uint4* const fillrec = reinterpret_cast<uint4*>(geom + LR_REC_QUADS * (size_t)N);
-  // software pipeline: the next Gaussian's inputs are requested before the current one is projected (a workgroup
-  // is 16 waves on one CU, so there is little other work to hide the loads behind)
-  int i = i_begin + (int)threadIdx.x;
-  LrInputs nxt;
-  if (i < i_end) nxt = lr_load_inputs(i, means, scales, rots, opac, colors, v.cov3d);
-  // (trip count uniform per wave: the record stores below are cooperative among groups of four lanes)
-  // plane of the iteration = (i - i_begin) / B, uniform (B is a multiple of the workgroup size): counted, not divided -- a
-  // 32-bit division is ~30 of this VALU-bound loop's ~1000 instructions
+  const lr_cfloat* V = lr_uniform(v.view);
+  const lr_cfloat* Pm = lr_uniform(v.proj);
+  const int lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // Every load of the loop is unconditional: a wave always reads 64 consecutive Gaussians that exist.  Only the last wave
+  // of the array can be short; it reads the LAST 64 Gaussians instead ([N - 64, N): `first` slides back) and its lanes in
+  // front of its own range are masked out of every store and counter like the lanes behind the end (`mine`).  Arrays of
+  // fewer than 64 Gaussians: the lanes past the end repeat the last one (`ulane`).
+  const uint32_t ulane = (uint32_t)min(lane, N - 1);
+  const int last_first = max(N - 64, 0);
+  int iw = i_begin + wave * 64;                              // the wave's first Gaussian of this iteration (scalar)
+  // plane of the iteration = (iw - i_begin) / B (B is a multiple of the workgroup size): counted, not divided
   int plane = 0, left_in_plane = B / LR_BATCH_THREADS;
-  for (; (i & ~63) < i_end; i += LR_BATCH_THREADS) {
-    const bool mine = i < i_end;
-    const LrInputs in = nxt;
-    if (i + LR_BATCH_THREADS < i_end) nxt = lr_load_inputs(i + LR_BATCH_THREADS, means, scales, rots, opac, colors, v.cov3d);
+  const float* const cov6 = v.cov3d;
+  LrGeo geo;
+  {
+    const size_t i0 = (size_t)lr_sgpr((uint32_t)min(iw, last_first));
+    geo = lr_load_geo<COV3D>(means + 3 * i0, scales + 3 * i0, rots + 4 * i0, COV3D ? cov6 + 6 * i0 : nullptr, ulane);
+  }
+  for (; iw < i_end; iw += LR_BATCH_THREADS) {
+    const int first = min(iw, last_first);                   // (scalar) the Gaussian of lane 0
+    const int lo = iw - first, hi = i_end - first;           // this wave's own lanes: [lo, hi)
+    const bool mine = lane >= lo && lane < hi;
+    const size_t iws = (size_t)lr_sgpr((uint32_t)first);
     if (left_in_plane == 0) { plane++; left_in_plane = B / LR_BATCH_THREADS; }
     left_in_plane--;
-    const LrLdsCounters ctr{lr_lds_ctr + plane * tiles};
-    float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
-    int rad = 0;
-    bool huge = false;
-    if (mine) {
-      lr_project_one<true>(v, in, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
-      if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
-      radii[i] = rad;
+    uint32_t* const ctr = lr_lds_ctr + plane * tiles;
+    // ---- part 1: everything that reads the raw inputs (the op sequences of lr_project_rect) ----
+    LrEwa e;
+    e.t[0] = lr_dot3p(V[0], V[4], V[8], geo.p[0], geo.p[1], geo.p[2], V[12]);
+    e.t[1] = lr_dot3p(V[1], V[5], V[9], geo.p[0], geo.p[1], geo.p[2], V[13]);
+    e.t[2] = lr_dot3p(V[2], V[6], V[10], geo.p[0], geo.p[1], geo.p[2], V[14]);
+    const float tz = e.t[2];
+    const float hx = lr_dot3p(Pm[0], Pm[4], Pm[8], geo.p[0], geo.p[1], geo.p[2], Pm[12]);
+    const float hy = lr_dot3p(Pm[1], Pm[5], Pm[9], geo.p[0], geo.p[1], geo.p[2], Pm[13]);
+    const float hw = lr_dot3p(Pm[3], Pm[7], Pm[11], geo.p[0], geo.p[1], geo.p[2], Pm[15]);
+    float Sg[6];
+    if (COV3D) {   // cov3D_precomp: see lr_load_inputs
+      Sg[0] = geo.s[0]; Sg[1] = geo.s[1]; Sg[2] = geo.s[2]; Sg[3] = geo.q.x; Sg[4] = geo.q.y; Sg[5] = geo.q.z;
+    } else {
+      const float s3[3] = {geo.s[0] * v.scale_modifier, geo.s[1] * v.scale_modifier, geo.s[2] * v.scale_modifier};
+      const float q4[4] = {geo.q.x, geo.q.y, geo.q.z, geo.q.w};
+      float R[9];
+      lr_cov3d(s3, q4, R, Sg);
     }
-    // Records leave as full 64-byte lines: a lane's four quads are 64 B apart from its neighbour's, so storing them
-    // lane by lane makes every store instruction touch 64 lines with 16 B each (four partial writes per line at the
-    // L2).  A 4x4 transpose inside every group of four lanes (two DPP quad-permute stages) gives lane m the quad m of
-    // its group's four Gaussians: each store instruction then writes 16 complete lines.
+    // opacity + colour of this Gaussian (used at the end of the iteration), then the next iteration's inputs into the
+    // registers that just died
+    const uint32_t olane = lr_after(ulane, e.t, hx, hy, hw, Sg);
+    const float in_op = (opac + iws)[olane];
+    const float* __restrict__ wc = colors + 3 * iws;
+    const float in_c0 = wc[3 * (size_t)olane], in_c1 = wc[3 * (size_t)olane + 1], in_c2 = wc[3 * (size_t)olane + 2];
     {
-      const int m = (int)threadIdx.x & 3;
-      float4 t0 = g0, t1 = g1, t2 = g2, t3 = g3;
-      lr_quad_transpose(t0, t1, t2, t3, m);                  // t[k] = quad m of Gaussian (i - m + k)
-      const int ib = i - m;
-      float4* rec = geom + LR_REC_QUADS * (size_t)ib + m;
-      if (ib + 0 < i_end) rec[0 * LR_REC_QUADS] = t0;
-      if (ib + 1 < i_end) rec[1 * LR_REC_QUADS] = t1;
-      if (ib + 2 < i_end) rec[2 * LR_REC_QUADS] = t2;
-      if (ib + 3 < i_end) rec[3 * LR_REC_QUADS] = t3;       // (q3 is not read in this mode: written to complete the 64-byte line)
+      const size_t in = (size_t)lr_sgpr((uint32_t)min(iw + LR_BATCH_THREADS, last_first));   // (past the workgroup's end: loaded, never used)
+      geo = lr_load_geo<COV3D>(means + 3 * in, scales + 3 * in, rots + 4 * in, COV3D ? cov6 + 6 * in : nullptr, olane);
     }
-    if (!mine) continue;
-    fillrec[i] = lr_fill_record(g2, g3, rad);
+    // ---- part 2: EWA, conic, radius, rect ----
+    bool valid = mine && (tz > 0.2f);
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float nx = hx * pw, ny = hy * pw;
+    if (v.ndc_cull) valid = valid && !(nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f);
+    lr_ewa_t(Sg, V, v.fx, v.fy, v.tanfovx, v.tanfovy, v.filter_mode, e);
+    const float det = e.a * e.c - e.b * e.b;
+    valid = valid && (det != 0.0f);
+    const float det_inv = 1.f / det;
+    const float cA = e.c * det_inv, cB = -e.b * det_inv, cC = e.a * det_inv;
+    const float rf = ceilf(lr_radius_from_cov(e.a, e.c, det));
+    const float mx = ((nx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
+    const float my = ((ny + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+    valid = valid && (rf <= 1048576.f) && (fabsf(mx) < 1.0e8f) && (fabsf(my) < 1.0e8f);
+    // (a culled lane converts zeros: float -> int of NaN / out-of-range values is undefined)
+    const float mxs = valid ? mx : 0.f, mys = valid ? my : 0.f, rfs = valid ? rf : 0.f;
+    int x0 = (int)((mxs - rfs) / 16.f), y0 = (int)((mys - rfs) / 16.f);
+    int x1 = (int)(((mxs + rfs) + 15.f) / 16.f), y1 = (int)(((mys + rfs) + 15.f) / 16.f);
+    x0 = min(v.gx, max(0, x0)); x1 = min(v.gx, max(0, x1));
+    y0 = min(v.ty1, max(v.ty0, y0)); y1 = min(v.ty1, max(v.ty0, y1));   // [ty0, ty1) = [0, gy) unless the image is split
+    const int w = x1 - x0, nt = valid ? w * (y1 - y0) : 0;
+    valid = nt > 0;
+    const int rad = valid ? (int)rfs : 0;
+    rect_instances += (uint32_t)nt;
+    // ---- part 3: support cull + ranking of the rect's tiles ----
+    uint32_t slot0 = 0u, slot1 = 0u, slot2 = 0u, slot3 = 0u;
+    const bool small = valid && nt <= LR_RANKED_TILES;
+    {
+      // tile k of a rect of <= 4 tiles: one row (w >= nt), one column (w == 1) or 2x2 -- no integer division
+      const bool col = w == 1, sq = (w == 2) && (nt == 4);
+      const int tx1 = col ? 0 : 1, ty1 = col ? 1 : 0;
+      const int tx2 = col ? 0 : (sq ? 0 : 2), ty2 = col ? 2 : (sq ? 1 : 0);
+      const int tx3 = col ? 0 : (sq ? 1 : 3), ty3 = col ? 3 : (sq ? 1 : 0);
+      bool k0 = true, k1 = true, k2 = true, k3 = true;
+      if (tile_cull) {
+        const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, in_op);
+        const float X = (float)(x0 * LR_TILE), Y = (float)(y0 * LR_TILE);
+        lr_support_tile2(sup, lr_f2{X, X + (float)(tx1 * LR_TILE)}, lr_f2{Y, Y + (float)(ty1 * LR_TILE)}, k0, k1);
+        lr_support_tile2(sup, lr_f2{X + (float)(tx2 * LR_TILE), X + (float)(tx3 * LR_TILE)},
+                         lr_f2{Y + (float)(ty2 * LR_TILE), Y + (float)(ty3 * LR_TILE)}, k2, k3);
+        k0 = k0 || nt == 1;   // a single-tile rect holds the centre's neighbourhood: it is never dropped
+      }
+      const int t0 = y0 * v.gx + x0;
+      const bool r0 = small && k0, r1 = small && nt > 1 && k1, r2 = small && nt > 2 && k2, r3 = small && nt > 3 && k3;
+      // up to four returning LDS atomics in flight
+      uint32_t a0 = 0xffffffffu, a1 = 0xffffffffu, a2 = 0xffffffffu, a3 = 0xffffffffu;
+      if (r0) a0 = atomicAdd(&ctr[t0], 1u) & 0xffffu;
+      if (r1) a1 = atomicAdd(&ctr[t0 + ty1 * v.gx + tx1], 1u) & 0xffffu;
+      if (r2) a2 = atomicAdd(&ctr[t0 + ty2 * v.gx + tx2], 1u) & 0xffffu;
+      if (r3) a3 = atomicAdd(&ctr[t0 + ty3 * v.gx + tx3], 1u) & 0xffffu;
+      if (small) { slot0 = a0; slot1 = nt > 1 ? a1 : 0u; slot2 = nt > 2 ? a2 : 0u; slot3 = nt > 3 ? a3 : 0u; }
+      if (valid && !small) {   // rare on the inputs this loop is shaped for: larger rects are only counted here
+        if (nt > defer_tiles) {
+          atomicAdd(&lr_huge_cnt[plane], 1u);
+        } else {
+          const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, in_op);
+          for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++)
+              if (!tile_cull || lr_support_tile(sup, x, y)) atomicAdd(&ctr[y * v.gx + x], 0x10000u);
+        }
+      }
+    }
+    // ---- part 4: outputs ----
+    const uint32_t r0w = (uint32_t)x0 | ((uint32_t)y0 << 16), r1w = (uint32_t)x1 | ((uint32_t)y1 << 16);
+    float4 g0 = float4{mx, my, cA, cB};
+    float4 g1 = float4{cC, in_op, in_c0, in_c1};
+    float4 g2 = float4{in_c2, tz, __uint_as_float(valid ? r0w : 0u), __uint_as_float(valid ? r1w : 0u)};
+    float4 g3 = float4{__uint_as_float(slot0), __uint_as_float(slot1), __uint_as_float(slot2), __uint_as_float(slot3)};
+    if (mine) {
+      (radii + iws)[lane] = rad;
+      // fill record (see lr_fill_record): ranks as 16-bit halves, 0xffff = dropped by the support cull
+      uint4 fr = {__float_as_uint(tz), 0xffffffffu, 0u, 0u};
+      if (valid) {
+        const uint32_t h = (uint32_t)(y1 - y0);
+        fr.y = small ? ((uint32_t)x0 | ((uint32_t)y0 << 13) | ((uint32_t)(w - 1) << 26) | ((h - 1u) << 28))
+                     : ((uint32_t)x0 | ((uint32_t)y0 << 13) | (1u << 30));
+        fr.z = small ? ((slot0 & 0xffffu) | (slot1 << 16)) : r1w;
+        fr.w = small ? ((slot2 & 0xffffu) | (slot3 << 16)) : 0u;
+      }
+      (fillrec + iws)[lane] = fr;
+    }
+    lr_row_transpose(g0, g1, g2, g3);                        // g<k> = quad (lane >> 4) of the record of Gaussian first + 16 k + (lane & 15)
+    {
+      const int l16 = lane & 15, r = lane >> 4;
+      float4* __restrict__ rec = geom + LR_REC_QUADS * iws;   // (scalar base + lane offset)
+      if (l16 >= lo && l16 < hi) rec[LR_REC_QUADS * l16 + r] = g0;
+      if (l16 + 16 >= lo && l16 + 16 < hi) rec[LR_REC_QUADS * (l16 + 16) + r] = g1;
+      if (l16 + 32 >= lo && l16 + 32 < hi) rec[LR_REC_QUADS * (l16 + 32) + r] = g2;
+      if (l16 + 48 >= lo && l16 + 48 < hi) rec[LR_REC_QUADS * (l16 + 48) + r] = g3;
+    }
   }
   __syncthreads();
   const int nplanes = min(S, (i_end - i_begin + B - 1) / B);   // batches this workgroup really holds
@@ -443,7 +610,7 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
                        const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                        uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
                        uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugecount,
-                       uint32_t* __restrict__ survcount, int tile_cull, int B, int S, int defer_tiles, int ablate) {
+                       uint32_t* __restrict__ survcount, int tile_cull, int B, int S, int defer_tiles LR_ABLATE_PARAM) {
   extern __shared__ uint32_t lr_lds_ctr[];  // [S][band tiles] packed (ranked | big << 16) counts, one plane per batch
   __shared__ uint32_t lr_huge_cnt[LR_MAX_PLANES];
   __shared__ uint32_t lr_slot_cursor;       // survivors of this workgroup so far = its next free fill-record slot
@@ -484,9 +651,9 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
       int rad = 0;
       if (mine) {
         LrRect rc;
-        if (ablate & 2) rad = (in.p[0] + in.s[1] + in.q.z == 1.2345e30f) ? 1 : 0;   // timing experiments: loads only
+        if (LR_ABLATED(2)) rad = (in.p[0] + in.s[1] + in.q.z == 1.2345e30f) ? 1 : 0;   // experiment builds: loads only
         else if (lr_project_rect(v, in, rc)) rad = rc.rad;
-        if (ablate & 1) rad = 0;                                                      // timing experiments: no phase B
+        if (LR_ABLATED(1)) rad = 0;                                                      // experiment builds: no phase B
         radii[i] = rad;
       }
       const uint64_t rect_mask = __ballot(rad > 0);
@@ -688,7 +855,9 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const size_t lds = sizeof(uint32_t) * (size_t)tiles;
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_batched_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LR_BATCH_LDS_BYTES);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_project_band_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LR_BAND_LDS_BYTES - LR_BAND_STATIC_LDS);
@@ -702,7 +871,9 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const int batches = (N + batch - 1) / batch;
     const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
     uint32_t* hugecount = basetab + (size_t)batches * tiles;
-    static const int ablate = lr_env_int("LOGRAST_PROJECT_ABLATE", 0);   // timing experiments (tools/) only: see the band kernel
+#ifdef LR_EXPERIMENTS
+    static const int ablate = lr_env_int("LOGRAST_PROJECT_ABLATE", 0);   // timing experiments (tools/): see the band kernel
+#endif
     if (lr_band_sparse(v, batch)) {
       // planes over the band's tiles only: as many batches per workgroup as fit beside the rings (at most 4)
       const int band_tiles = (v.ty1 - v.ty0) * v.gx;
@@ -712,11 +883,16 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
       hipLaunchKernelGGL(lr_project_band_kernel, dim3(bgroups), dim3(LR_BATCH_THREADS),
                          sizeof(uint32_t) * (size_t)band_tiles * bp, s, v, N, means, scales, rots, opac, colors, radii,
                          reinterpret_cast<float4*>(geom), ranked, big, hdr, basetab, hugecount,
-                         hugecount + ((batches + 15) & ~15), tile_cull, batch, bp, defer_tiles, ablate);
+                         hugecount + ((batches + 15) & ~15), tile_cull, batch, bp, defer_tiles LR_ABLATE_PASS(ablate));
     } else {
-      hipLaunchKernelGGL(lr_project_batched_kernel, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
-                         means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                         basetab, hugecount, tile_cull, batch, planes, defer_tiles);
+      if (v.cov3d)
+        hipLaunchKernelGGL(lr_project_batched_kernel<true>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
+                           means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles);
+      else
+        hipLaunchKernelGGL(lr_project_batched_kernel<false>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
+                           means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles);
     }
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
@@ -915,7 +1091,7 @@ __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
                float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order, int stream_nt,
-               int ablate, int rebased, int speculative) {
+               int rebased, int speculative LR_ABLATE_PARAM) {
   // Per-Gaussian buffers that later kernels accumulate into with atomics (point_weight; the backward scratch)
   // are cleared here, in a kernel that already has one thread per Gaussian, instead of by separate memsets.
   // XCD-contiguous block order (speed only): blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
@@ -939,7 +1115,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 #pragma unroll
     for (int u = 0; u < K; u++) {
       const int zi = (int)(vblock_k[u] * 256u + threadIdx.x);
-      if (zi < N && !(ablate & 1)) {
+      if (zi < N && !LR_ABLATED(1)) {
         if (stream_nt) {
           if (zero_n) __builtin_nontemporal_store(0.f, &zero_n[zi]);
           for (int k = 0; k < zero_block_floats; k++) __builtin_nontemporal_store(0.f, &zero_block[(size_t)k * N + zi]);
@@ -1058,7 +1234,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
         const int t = (y0 + ty) * gx + (x0 + tx);
         // batched: slot relative to the batch's run in the tile; lr_rebase_kernel (large inputs) made the table absolute
         const uint32_t pos = (batch ? (rebased ? bbase[t] : offsets[t] + bbase[t]) : offsets[t]) + slot[k];
-        if (!(ablate & 2) || pos == 0xffffffffu) keys[pos] = key;
+        if (!LR_ABLATED(2) || pos == 0xffffffffu) keys[pos] = key;
       }
     }
   }
@@ -1069,7 +1245,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
     sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
   }
-  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !(ablate & 4)) {
+  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !LR_ABLATED(4)) {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++)
         if (lr_support_tile(sup, x, y)) {
@@ -1077,7 +1253,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
           keys[pos] = key;
         }
   }
-  uint64_t bigm = __ballot(nt > LR_COOP_TILES && !(ablate & 8));
+  uint64_t bigm = __ballot(nt > LR_COOP_TILES && !LR_ABLATED(8));
   while (bigm) {
     int src = __builtin_ctzll(bigm);
     bigm &= bigm - 1;
@@ -1110,13 +1286,15 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
   LR_KNOB(fill_nt, "LOGRAST_FILL_NT", 1);
+#ifdef LR_EXPERIMENTS
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores, 4 no 5-16-tile rects, 8 no larger rects
+#endif
   LR_KNOB(per_thread_knob, "LOGRAST_FILL_PER_THREAD", 1);
   int per_thread = per_thread_knob;
 #define LR_FILL(K) do { const int blocks = (((N + 255) / 256 + K - 1) / K + 7) & ~7;                                     \
     hipLaunchKernelGGL(lr_fill_kernel<K>, dim3(blocks), dim3(256), 0, s, N, gx, reinterpret_cast<const float4*>(geom),  \
                        state, tiles, keys, capacity, max_len_hint, status, zero_n, zero_block, zero_block_floats,       \
-                       xcd_order, fill_nt, ablate, rebased, speculative); } while (0)
+                       xcd_order, fill_nt, rebased, speculative LR_ABLATE_PASS(ablate)); } while (0)
   // measured, K = 1 / 2 / 4: the 30 M view 388 / 413 / 424 us; a band view (100 M, a fifth of the slots used: most
   // workgroups only pass through the chain once) 618 / 551 / 510 us
   if (band) per_thread = 4;
@@ -1162,30 +1340,62 @@ void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s) {
 }
 
 // ---- measured roof: a streaming device-to-device copy (bench.py's HBM denominator) --------------------------------
-// 16 bytes per lane per access, grid-stride, non-temporal both ways (nothing is reused): the float4 copy
-// /opt/skills/guides/MI355X_MICROARCH.md quotes at 6.29 TB/s (read + write counted).  Not on the rasterizer's path;
-// exported as lograst_stream_copy so that bench.py divides by a rate this library's own code reaches on the same box.
+// 16 bytes per lane per access: the float4 copy /opt/skills/guides/MI355X_MICROARCH.md quotes at 6.29 TB/s (read + write
+// counted).  Not on the rasterizer's path; exported as lograst_stream_copy so that bench.py divides by a rate this
+// library's own code reaches on the same box.  Forms (bits 20+ of the `blocks` argument; bench.py takes the best of all):
+//   0  grid-stride, four independent non-temporal loads in flight per lane, non-temporal stores
+//   1  one access per lane, no loop (grid = n16 / 256), plain loads and stores
+//   2  grid-stride, eight non-temporal loads in flight per lane, non-temporal stores
+//   3  grid-stride x 4, plain loads, non-temporal stores
+//   4  one access per lane, no loop, non-temporal both ways
+typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
+template <int U, bool NT_LOAD, bool NT_STORE>
 __global__ void __launch_bounds__(256)
 lr_stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-  typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
   const lr_u4v* __restrict__ a = reinterpret_cast<const lr_u4v*>(src);
   lr_u4v* __restrict__ b = reinterpret_cast<lr_u4v*>(dst);
   const size_t stride = (size_t)gridDim.x * 256u;
   size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {   // four independent 16-byte loads in flight per lane
-    const lr_u4v v0 = __builtin_nontemporal_load(a + i), v1 = __builtin_nontemporal_load(a + i + stride);
-    const lr_u4v v2 = __builtin_nontemporal_load(a + i + 2 * stride), v3 = __builtin_nontemporal_load(a + i + 3 * stride);
-    __builtin_nontemporal_store(v0, b + i); __builtin_nontemporal_store(v1, b + i + stride);
-    __builtin_nontemporal_store(v2, b + i + 2 * stride); __builtin_nontemporal_store(v3, b + i + 3 * stride);
+  for (; i + (U - 1) * stride < n16; i += U * stride) {   // U independent 16-byte loads in flight per lane
+    lr_u4v v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = NT_LOAD ? __builtin_nontemporal_load(a + i + u * stride) : a[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (NT_STORE) __builtin_nontemporal_store(v[u], b + i + u * stride); else b[i + u * stride] = v[u];
+    }
   }
-  for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), b + i);
+  for (; i < n16; i += stride) {
+    const lr_u4v t = NT_LOAD ? __builtin_nontemporal_load(a + i) : a[i];
+    if (NT_STORE) __builtin_nontemporal_store(t, b + i); else b[i] = t;
+  }
+}
+template <bool NT>
+__global__ void __launch_bounds__(256)
+lr_stream_copy_flat_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  const lr_u4v* __restrict__ a = reinterpret_cast<const lr_u4v*>(src);
+  lr_u4v* __restrict__ b = reinterpret_cast<lr_u4v*>(dst);
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i < n16) {
+    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), b + i); else b[i] = a[i];
+  }
 }
 void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s) {
   const size_t n16 = bytes / 16;
   if (!n16) return;
+  const int mode = blocks > 0 ? blocks >> 20 : 0;
+  blocks = blocks > 0 ? (blocks & 0xfffff) : 0;
   if (blocks <= 0) blocks = 256 * 16;   // 16 workgroups of 256 per CU
-  hipLaunchKernelGGL(lr_stream_copy_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(src),
-                     reinterpret_cast<uint4*>(dst), n16);
+  const uint4* a = reinterpret_cast<const uint4*>(src);
+  uint4* b = reinterpret_cast<uint4*>(dst);
+  const uint32_t flat = (uint32_t)((n16 + 255) / 256);
+  switch (mode) {
+    case 1: hipLaunchKernelGGL(lr_stream_copy_flat_kernel<false>, dim3(flat), dim3(256), 0, s, a, b, n16); break;
+    case 4: hipLaunchKernelGGL(lr_stream_copy_flat_kernel<true>, dim3(flat), dim3(256), 0, s, a, b, n16); break;
+    case 2: hipLaunchKernelGGL((lr_stream_copy_kernel<8, true, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, b, n16); break;
+    case 3: hipLaunchKernelGGL((lr_stream_copy_kernel<4, false, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, b, n16); break;
+    default: hipLaunchKernelGGL((lr_stream_copy_kernel<4, true, true>), dim3((uint32_t)blocks), dim3(256), 0, s, a, b, n16); break;
+  }
 }
 
 // ---- image split into bands of tile rows: which rows does each Gaussian reach? -------------------

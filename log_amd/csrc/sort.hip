@@ -487,7 +487,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
   // up to 4096 keys: the whole list in LDS, same code as the small lists.  (Up to 8192 the keys could sit in registers --
   // that was a kernel of its own, 145 VGPRs -- but not at the 64 this kernel is held to: they stream like the longer ones.)
   if (L <= LR_LONG_LIST) { lr_bucket_tile<1024, 4>(keys, plist, beg, L, equalize, reinterpret_cast<uint64_t*>(lcnt)); return; }
-#ifdef LR_LONG_TICKS   // phase timing experiment (-DLR_LONG_TICKS): wall_clock64 per phase, printed by three workgroups
+#if defined(LR_EXPERIMENTS) && defined(LR_LONG_TICKS)   // phase timing experiment (-DLR_EXPERIMENTS -DLR_LONG_TICKS): wall_clock64 per phase, printed by three workgroups
   uint64_t tk[16]; int tn = 0;
 #define LR_TICK() do { if (tn < 16) tk[tn++] = wall_clock64(); } while (0)
 #else
@@ -668,7 +668,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
     b0 = b1;
   }
 
-#ifdef LR_LONG_TICKS
+#if defined(LR_EXPERIMENTS) && defined(LR_LONG_TICKS)
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700 || blockIdx.x == 2000)) {
     printf("longsort blk %u L %u nb %u ticks(10ns):", blockIdx.x, L, nb);
     for (int q = 1; q < tn; q++) printf(" %llu", (unsigned long long)(tk[q] - tk[q - 1]));
@@ -707,8 +707,8 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   }
   if (max_len == 0 || max_len > capacity) max_len = capacity;
   // LOGRAST_BUCKET_SORT=0: bitonic network only (the reference implementation of the same total order)
-  static const int bucket = lr_env_int("LOGRAST_BUCKET_SORT", 1);
-  static const int equalize = lr_env_int("LOGRAST_EQUALIZE", 1);   // 0: plain linear depth -> bucket map (experiments)
+  static const int bucket = LR_EXPERIMENT_INT("LOGRAST_BUCKET_SORT", 1);   // experiment builds: 0 = bitonic network only
+  static const int equalize = LR_EXPERIMENT_INT("LOGRAST_EQUALIZE", 1);   // 0: plain linear depth -> bucket map (experiments)
   // Two launches: one 256-thread workgroup per tile for the lists of up to 1024 keys, and one 1024-thread workgroup
   // (78 KB of LDS, two per CU) per list above that, walking the longest-first order -- LDS-resident up to 4096 keys,
   // keys in registers up to 8192, streamed from memory beyond.  (They used to be four launches by size class: at 30 M

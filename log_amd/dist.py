@@ -186,11 +186,15 @@ class GradientBucket(_Flat):
 
     def attach(self, params):
         """params: dict name -> leaf tensor (requires_grad).  Their .grad become views of the bucket,
-        so autograd accumulates every view's gradient in place."""
+        so autograd accumulates every view's gradient in place -- and the rasterizer's backward may add into them directly
+        (log_amd.rasterizer.allow_inplace_grad: the caller of attach() owns these leaves and steps them with plain
+        ``.backward()`` calls; torch.autograd.grad / backward(inputs=...) on them is not supported)."""
+        from .rasterizer import allow_inplace_grad
         for name in (list(ROW_COLUMNS) + [n for n, _ in self.layout if n != "rows"]) if self.row_major else [n for n, _ in self.layout]:
             p = params[name]
             assert p.shape == self.alias[name].shape, (name, p.shape)
             p.grad = self.alias[name]
+            allow_inplace_grad(p)
 
     def zero(self):
         self.flat.zero_()

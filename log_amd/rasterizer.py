@@ -72,7 +72,12 @@ _max_len_hint = 0
 # each: 949 -> 700 us; C2, 2.8: 292 -> 307; a tree-ordered heavy-tailed selection, 2.3: 448 -> 579).
 ROWSPLIT_MAX_INSTANCES_PER_GAUSSIAN = 1.8
 _speculative = True
-_inplace_leaf_grads = True   # backward adds straight into the inputs' existing .grad when all of them are plain leaves
+# In-place leaf gradients are OPT-IN (round-3 advisory): a custom Function cannot see how the engine was invoked, so
+# adding into .grad behind autograd's back breaks torch.autograd.grad(loss, leaves), backward(inputs=[subset]) and
+# AccumulateGrad hooks (DDP / FSDP reducers).  Off globally; a caller that owns the leaves opts them in --
+# log_amd.dist.GradientBucket.attach() does (their .grad ARE views of its bucket), or set_inplace_leaf_grads(True).
+_inplace_leaf_grads = False
+_INPLACE_TAG = "_lograst_inplace_grad"   # attribute set on leaves whose owner asked for the in-place route
 _status = {}          # device -> int32[8] status block (sticky across forwards, all streams)
 _debug_keep = False   # tests: keep dL/dconic of the last backward (HipBackend.last_conic_grad)
 _DEBUG_ADDR = bool(int(__import__('os').environ.get('LOGRAST_DEBUG_ADDR', '0')))
@@ -97,14 +102,23 @@ def set_speculative(enabled):
 
 
 def set_inplace_leaf_grads(enabled):
-    """True (default): when every differentiable input of a rasterizer call is a leaf that already has a dense fp32
-    ``.grad`` (a multi-view step after its first view, or grads that are views of a flat bucket), backward adds into those
-    tensors in place (LOGRAST_BWD_ACCUMULATE) instead of returning fresh gradients for autograd to add (five full passes
-    over the attributes per view).  Same sums; leaves with tensor hooks always take the autograd route.  Returns the
-    previous setting."""
+    """Opt-in (default False).  True: when every differentiable input of a rasterizer call is a leaf that already has a
+    dense fp32 ``.grad`` (a multi-view step after its first view, or grads that are views of a flat bucket), backward adds
+    into those tensors in place (LOGRAST_BWD_ACCUMULATE) instead of returning fresh gradients for autograd to add (five
+    full passes over the attributes per view).  Same sums for a plain ``loss.backward()``; NOT compatible with
+    ``torch.autograd.grad``, ``backward(inputs=...)`` or AccumulateGrad-node hooks (DDP / FSDP): those never see the
+    gradient.  Leaves with tensor hooks always take the autograd route.  Individual leaves are opted in by
+    ``allow_inplace_grad(tensor)`` (what ``GradientBucket.attach`` does).  Returns the previous setting."""
     global _inplace_leaf_grads
     prev, _inplace_leaf_grads = _inplace_leaf_grads, bool(enabled)
     return prev
+
+
+def allow_inplace_grad(t, enabled=True):
+    """Mark one leaf: a backward whose five differentiable inputs are ALL marked (or set_inplace_leaf_grads(True)) adds
+    into their existing .grad in place.  The caller asserts that it only ever runs plain ``.backward()`` on them."""
+    setattr(t, _INPLACE_TAG, bool(enabled))
+    return t
 
 
 class _CapacityModel:
@@ -291,6 +305,28 @@ class HipBackend:
             return _lib.FORM_AUTO
         return _lib.FORM_ROWS if instances < ROWSPLIT_MAX_INSTANCES_PER_GAUSSIAN * n else _lib.FORM_QUADRANT
 
+    last_forms = None   # {"fwd": "rows" | "quadrant", "bwd": ...} of the most recent forward / backward (diagnostics)
+
+    def _note_form(self, kind, walk_form, n):
+        """Which compositing kernel the library launches for this call: the rule of lr_launch_blend_fwd / _bwd
+        (log_amd/csrc/blend.hip) restated -- knob LOGRAST_{FWD,BWD}_ROWS, else the view's hint, else (reverse walk only)
+        row-split from LOGRAST_HELPER_MIN_N Gaussians.  bench.py / the parity tests record it next to their numbers."""
+        L = _lib.lib()
+        val = ctypes.c_int32(2)
+        L.lograst_get_knob(("LOGRAST_%s_ROWS" % kind.upper()).encode(), ctypes.byref(val))
+        if val.value != 2:
+            rows = val.value == 1
+        elif walk_form != _lib.FORM_AUTO:
+            rows = walk_form == _lib.FORM_ROWS
+        elif kind == "bwd":
+            L.lograst_get_knob(b"LOGRAST_HELPER_MIN_N", ctypes.byref(val))
+            rows = n >= val.value
+        else:
+            rows = False
+        if self.last_forms is None:
+            self.last_forms = {}
+        self.last_forms[kind] = "rows" if rows else "quadrant"
+
     @staticmethod
     def _carve(device, parts):
         """One allocation for several buffers: parts = [(name, dtype, shape)], every buffer 256-byte aligned inside it
@@ -338,6 +374,7 @@ class HipBackend:
         # which form the compositing kernel takes: instances per Gaussian as the recent forwards of this resolution had
         # them (speculative / exact mode), or the caller's capacity (sync-free mode)
         view.walk_form = self.walk_form(_capacity_hint if _capacity_hint is not None else (hist["ratio"] * N if hist else 0), N)
+        self._note_form("fwd", view.walk_form, N)
         with torch.cuda.device(device):
             if _capacity_hint is None and _speculative and N > 0:
                 tiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -430,6 +467,7 @@ class HipBackend:
         elif pw is not None:
             flags |= 4
         view.walk_form = self.walk_form(saved.get("instances", 0), N)   # tiny splats -> the row-split reverse walk
+        self._note_form("bwd", view.walk_form, N)
         g_conic = acc          # (the C ABI's `bwd_rows`)
         g_means2D = torch.empty(N, 3, **f32)
         if sink is None:
@@ -852,7 +890,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g_c = None
             return g_m3, g_m2.reshape(m2_shape), g_c, g_sh, g_o.reshape(o_shape), None, None, None, None, None, g_cov
         sink = _grad_sink
-        if sink is None and ctx.leaves is not None and _inplace_leaf_grads:
+        if sink is None and ctx.leaves is not None and (
+                _inplace_leaf_grads or all(getattr(t, _INPLACE_TAG, False) for t in ctx.leaves if t is not None)):
             sink = _leaf_grad_sink(ctx.leaves, m.device)
         if sink is not None and "rows" in sink:
             n = m.shape[0]

@@ -21,9 +21,22 @@ def settings(cam, bg, dev, scale_modifier=1.0):
         prefiltered=False, debug=False)
 
 
-def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", scale_modifier=1.0, scratch_floats=0):
+def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", scale_modifier=1.0, scratch_floats=0,
+                fwd_form=None):
     """Raw backend call (keeps the intermediates).  Returns dict of numpy arrays + the torch `saved`.
-    scratch_floats=16: have the forward prepare the backward's accumulator rows, as the autograd path does."""
+    scratch_floats=16: have the forward prepare the backward's accumulator rows, as the autograd path does.
+    fwd_form: "rows" / "quadrant" forces the compositing kernel's form (knob LOGRAST_FWD_ROWS) for this call; None = what
+    the package would pick (the resolution's history).  out["fwd_form"] says which one ran."""
+    from log_amd import tune
+    if fwd_form is not None:
+        prev = tune.get_knob("LOGRAST_FWD_ROWS")
+        tune.set_knob("LOGRAST_FWD_ROWS", {"rows": 1, "quadrant": 0}[fwd_form])
+        try:
+            out = hip_forward(cam, sc, bg, flavour, use_filter, dev, scale_modifier, scratch_floats)
+        finally:
+            tune.set_knob("LOGRAST_FWD_ROWS", prev)
+        assert out["fwd_form"] == fwd_form
+        return out
     dev = torch.device(dev)
     rs = settings(cam, bg, dev, scale_modifier)
     t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
@@ -42,6 +55,7 @@ def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", 
         out.update(point_id_pixel=pid.cpu().numpy(), point_weight_pixel=pwp.cpu().numpy(),
                    point_weight=pw.cpu().numpy())
     out["_torch"] = (rs, flavour, use_filter, m, s, r, saved)
+    out["fwd_form"] = R._backend.last_forms["fwd"]
     return out
 
 

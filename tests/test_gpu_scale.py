@@ -66,24 +66,37 @@ def test_c2_full_size_vs_oracle(oracle_mod):
         assert rel_l2(hp[k], og[k]) < 1e-6, k
 
 
-def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_name=None):
-    """Forward bit-exact (lists: exact, or the oracle's lists minus provably invisible entries), backward <= 1e-4 rel-L2
-    on every output of the reverse walk, chain rule <= 1e-6 on identical inputs.  The forward prepares the backward's
-    accumulators as the autograd path does (touched-only dL/dconic on large inputs)."""
+def _assert_forward(hf, of, check_lists, form):
     import gpu_util as G
-    hf = G.hip_forward(cam, sc, bg, scratch_floats=16)
-    v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
     st = G.compare_forward(hf, of) if check_lists else None
     if st is not None:
         for k in ("radii_mismatch", "rec_bits_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch",
                   "image_bits_mismatch", "final_T_bits_mismatch", "pid_mismatch"):
-            assert st[k] == 0, (k, st)
-        assert st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0
+            assert st[k] == 0, (form, k, st)
+        assert st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0, form
     else:
         for k in ("radii", "point_id_pixel"):
-            assert (hf[k] == of[k]).all(), k
+            assert (hf[k] == of[k]).all(), (form, k)
         for k in ("image", "final_T", "point_weight_pixel", "point_weight"):
-            assert (hf[k].view(np.uint32) == of[k].view(np.uint32)).all(), k
+            assert (hf[k].view(np.uint32) == of[k].view(np.uint32)).all(), (form, k)
+
+
+def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_name=None,
+                 fwd_forms=("rows", "quadrant")):
+    """Forward bit-exact (lists: exact, or the oracle's lists minus provably invisible entries), backward <= 1e-4 rel-L2
+    on every output of the reverse walk, chain rule <= 1e-6 on identical inputs.  The forward prepares the backward's
+    accumulators as the autograd path does (touched-only dL/dconic on large inputs).
+    fwd_forms: BOTH forms of the compositing kernel are compared with the ORACLE, bit for bit (round-3 verdict: the
+    row-split form -- what bench.py's headline runs -- was only ever compared with the quadrant form); the last one's
+    forward feeds the backward."""
+    import gpu_util as G
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    hf = None
+    for form in fwd_forms:
+        del hf
+        hf = G.hip_forward(cam, sc, bg, scratch_floats=16, fwd_form=form)
+        assert hf["fwd_form"] == form
+        _assert_forward(hf, of, check_lists, form)
     dL = np.random.default_rng(dL_seed).random(of["image"].shape, dtype=np.float32)
     hg = G.hip_backward(hf, dL)
     og = oracle_mod.backward(v, of, dL)

@@ -7,6 +7,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# LOGRAST_PROJECT_ABLATE / LOGRAST_BATCH exist only in -DLR_EXPERIMENTS builds (log_amd/csrc/common.hpp): build one, load it
+from log_amd import build as _build
+os.environ["LOGRAST_LIB"] = _build.build(variant="exp", extra_flags=["-DLR_EXPERIMENTS"], verbose=False)
 
 
 def main():

@@ -5,10 +5,13 @@ import json
 import os
 import sys
 
-os.environ["LOGRAST_STOP_AFTER_FILL"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+# the experiment switches exist only in -DLR_EXPERIMENTS builds (log_amd/csrc/common.hpp): build one and load it
+from log_amd import build as _build
+os.environ["LOGRAST_LIB"] = _build.build(variant="exp", extra_flags=["-DLR_EXPERIMENTS"], verbose=False)
+os.environ["LOGRAST_STOP_AFTER_FILL"] = "1"
 
 
 def main():

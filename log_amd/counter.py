@@ -11,6 +11,7 @@ unmodified LoG checkout with ``log_amd.counter.install()``: ``Counter.update_by_
 name ``torch`` inside the module ``LoG.render.renderer`` is rebound to a pass-through stand-in whose ``unique`` sends the
 rasterizer's ``point_id_pixel`` map (recognised by the tag ``GaussianRasterizer.forward`` leaves on it) through
 ``unique_ids`` and hands every other call, and every other attribute, to the real ``torch`` -- no LoG line is edited."""
+import logging
 import types
 
 import torch
@@ -45,20 +46,31 @@ def update_by_output(self, output, fix_parent=False):
             vf["index_vis"] = torch.where(flag_vis)[0]
 
 
+_fallback_logged = False
+
+
 def torch_unique(input, *args, **kwargs):
     """``torch.unique`` as LoG/render/renderer.py:156 calls it (``sorted=True, return_counts=True`` on the rasterizer's
-    per-pixel id map) through the histogram kernel, with torch's result: ascending ids INCLUDING the leading -1 of the
-    pixels nothing contributed to (renderer.py:157-159 strips it), int64 counts.  Anything else is torch.unique."""
+    per-pixel id map) through the histogram kernel: ascending ids behind a leading -1 whose count is the number of pixels
+    nothing contributed to, int64 counts.  The -1 entry is ALWAYS there, with a count that may be zero -- torch.unique
+    would leave it out then, but deciding that here costs a device read-back per view, and renderer.py:157-159
+    (`if point_id[0] == -1`) strips the entry either way.  This stand-in is installed into that module only.
+    Anything else -- other arguments, or a map that lost the rasterizer's tag on the way (`.clone()`, `.to()`, indexing
+    create new tensor objects) -- is torch.unique itself; the first such fall-back on a rasterizer-shaped map is logged."""
+    global _fallback_logged
     n = getattr(input, "_lograst_num_gaussians", None)
     if (n is None or args or set(kwargs) - {"sorted", "return_counts"} or not kwargs.get("return_counts", False)
             or not kwargs.get("sorted", True) or input.dtype != torch.int32):
+        if (n is None and not _fallback_logged and input.dtype == torch.int32 and input.dim() == 2 and input.is_cuda
+                and kwargs.get("return_counts", False)):
+            _fallback_logged = True
+            logging.getLogger("log_amd").warning(
+                "log_amd.counter: torch.unique on an id map without the rasterizer's tag (copied / moved / indexed since the "
+                "rasterizer returned it?): falling back to torch.unique (correct, slower); logged once")
         return torch.unique(input, *args, **kwargs)
     ids, counts = unique_ids(input, n)
-    empty = input.numel() - counts.sum()          # pixels whose id is -1
-    if int(empty.item()) > 0:                     # (renderer.py:157 `if point_id[0] == -1` reads the same fact back)
-        ids = torch.cat([ids.new_full((1,), -1), ids])
-        counts = torch.cat([empty.reshape(1), counts])
-    return ids, counts
+    empty = input.numel() - counts.sum()          # pixels whose id is -1 (stays on the device)
+    return torch.cat([ids.new_full((1,), -1), ids]), torch.cat([empty.reshape(1), counts])
 
 
 class _TorchForRenderer(types.ModuleType):

@@ -335,6 +335,8 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
                      int32_t* point_id_pixel, float* point_weight_pixel, float* point_weight, float* bwd_scratch,
                      int32_t bwd_scratch_floats, uint32_t* status, hipStream_t s, int speculative = 0) {
   const uint32_t tiles = (uint32_t)(v.gx * v.gy);
+  static const int stop_after_project = LR_EXPERIMENT_INT("LOGRAST_STOP_AFTER_PROJECT", 0);   // experiment builds (tools/kernel_probe.py)
+  if (stop_after_project) return LOGRAST_OK;
   if (n == 0 && status)   // no fill kernel runs: this forward's entries of the status block
     LR_HIP(hipMemsetAsync(status + LOGRAST_STATUS_LAST_INSTANCES, 0, 4 * sizeof(uint32_t), s));
   // point_weight (atomicMax target) and the optional backward scratch (one 64-byte accumulator row per Gaussian) are

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/lograst.h"
 
@@ -472,13 +473,22 @@ int lr_env_int(const char* name, int dflt);
 // default.  Read at every launch through a per-call-site cache that is refreshed when any knob changes, so that
 // log_amd.tune() can move them at run time.  None of them changes a result (tests/test_gpu_knobs.py sweeps them and
 // compares bit for bit).
-struct LrKnobCache { int value; unsigned gen; };
+// The cache is one 64-bit atomic (generation << 32 | value): a reader sees a generation together with the value that
+// was looked up FOR it -- the generation is read once, before the look-up, so a lograst_set_knob on another thread in
+// between only makes the next launch look again (round-3 advisory: two plain fields, generation re-read after the look-up).
 extern unsigned lr_knob_generation();
 int lr_knob_lookup(const char* name, int dflt);
-#define LR_KNOB(var, name, dflt)                                                       \
-  static LrKnobCache var##_cache = {0, 0xffffffffu};                                   \
-  if (var##_cache.gen != lr_knob_generation()) {                                       \
-    var##_cache.value = lr_knob_lookup(name, dflt);                                    \
-    var##_cache.gen = lr_knob_generation();                                            \
-  }                                                                                    \
-  const int var = var##_cache.value
+#define LR_KNOB(var, name, dflt)                                                                       \
+  static std::atomic<uint64_t> var##_cache{~0ull};                                                     \
+  int var##_value;                                                                                     \
+  {                                                                                                    \
+    const unsigned var##_gen = lr_knob_generation();                                                   \
+    const uint64_t var##_c = var##_cache.load(std::memory_order_acquire);                              \
+    if ((unsigned)(var##_c >> 32) == var##_gen) {                                                      \
+      var##_value = (int)(uint32_t)var##_c;                                                            \
+    } else {                                                                                           \
+      var##_value = lr_knob_lookup(name, dflt);                                                        \
+      var##_cache.store(((uint64_t)var##_gen << 32) | (uint32_t)var##_value, std::memory_order_release); \
+    }                                                                                                  \
+  }                                                                                                    \
+  const int var = var##_value

@@ -352,6 +352,33 @@ LR_DEV void lr_reserve_batches(const uint32_t* lds_ctr, int stride, int t_lo, in
 //     v_permlane16_swap / v_permlane32_swap exchange two registers' halves in one instruction (16 instructions for the
 //     16 dwords; the DPP quad-permute form took ~100).  Afterwards lane (row r, column l) holds quad r of the records of
 //     Gaussians l, 16 + l, 32 + l, 48 + l of the wave: every store instruction writes 16 complete lines.
+// Stores of the projection's outputs (records: read next by the compositing kernels, a sort later; fill records: by the
+// fill kernel, after the scan).  LR_PROJECT_NT_STORES: as non-temporal (streaming) stores.
+typedef float lr_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t lr_u4w __attribute__((ext_vector_type(4)));
+LR_DEV void lr_out_store(float4* p, const float4& v) {
+#ifdef LR_PROJECT_NT_STORES
+  __builtin_nontemporal_store(lr_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<lr_f4v*>(p));
+#else
+  *p = v;
+#endif
+}
+LR_DEV void lr_out_store(uint4* p, const uint4& v) {
+#ifdef LR_PROJECT_NT_STORES
+  __builtin_nontemporal_store(lr_u4w{v.x, v.y, v.z, v.w}, reinterpret_cast<lr_u4w*>(p));
+#else
+  *p = v;
+#endif
+}
+LR_DEV void lr_out_store(int* p, int v) {
+#ifdef LR_PROJECT_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+// s_waitcnt immediate (gfx9 encoding): vmcnt in bits [3:0] + [15:14], expcnt [6:4] and lgkmcnt [11:8] left at "no wait"
+#define LR_WAIT_VMCNT(n) ((((n) & 15) | (((n) >> 4) << 14)) | (7 << 4) | (15 << 8))
 LR_DEV void lr_swap16(float& a, float& b) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
@@ -369,6 +396,24 @@ LR_DEV void lr_row_transpose(float4& a, float4& b, float4& c, float4& d) {
   lr_swap32(a, c); lr_swap32(b, d);     // a = [a0 b0 c0 d0], b = [a1 b1 c1 d1], c = [a2 b2 c2 d2], d = [a3 b3 c3 d3]
 }
 
+// The four quads of the wave's 64 records, from one lane = one Gaussian to full 64-byte lines per store instruction.
+LR_DEV void lr_store_records(float4* __restrict__ rec, int lane, float4& g0, float4& g1, float4& g2, float4& g3) {
+#ifdef LR_PROJECT_QUAD_STORES
+  const int m = lane & 3, b = lane - m;
+  lr_quad_transpose(g0, g1, g2, g3, m);                    // g<k> = quad m of the record of lane (lane - m + k)
+  lr_out_store(&rec[LR_REC_QUADS * (b + 0) + m], g0);
+  lr_out_store(&rec[LR_REC_QUADS * (b + 1) + m], g1);
+  lr_out_store(&rec[LR_REC_QUADS * (b + 2) + m], g2);
+  lr_out_store(&rec[LR_REC_QUADS * (b + 3) + m], g3);
+#else
+  lr_row_transpose(g0, g1, g2, g3);                        // g<k> = quad (lane >> 4) of the record of Gaussian 16 k + (lane & 15)
+  const int l16 = lane & 15, r = lane >> 4;
+  lr_out_store(&rec[LR_REC_QUADS * l16 + r], g0);
+  lr_out_store(&rec[LR_REC_QUADS * (l16 + 16) + r], g1);
+  lr_out_store(&rec[LR_REC_QUADS * (l16 + 32) + r], g2);
+  lr_out_store(&rec[LR_REC_QUADS * (l16 + 48) + r], g3);
+#endif
+}
 // means3D / scales / rotations (or the six covariance floats) of one Gaussian: what the first part of the loop consumes
 struct LrGeo { float p[3], s[3]; float4 q; };
 // A wave-uniform index, pinned to a scalar register and opaque to the loop optimiser -- which otherwise folds the lane's
@@ -407,9 +452,12 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
                           const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                           uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
                           uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugecount, int tile_cull, int B,
-                          int S, int defer_tiles) {
+                          int S, int defer_tiles LR_ABLATE_PARAM) {
+  // (experiment builds, LOGRAST_PROJECT_ABLATE: 1 no record stores, 2 no fill-record / radii stores, 4 no ranking atomics,
+  //  8 no arithmetic -- the loop's loads and stores alone --, 16 no reservations at the end; results are garbage)
   extern __shared__ uint32_t lr_lds_ctr[];  // [S][tiles] packed (ranked | big << 16) counts, one plane per batch
   __shared__ uint32_t lr_huge_cnt[LR_MAX_PLANES];
+  __shared__ uint32_t lr_rank_dummy[64];    // where the ranking atomics of tiles that are not ranked go (see the loop)
   const int tiles = v.gx * v.gy;
   for (int t = threadIdx.x; t < S * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
   if (threadIdx.x < LR_MAX_PLANES) lr_huge_cnt[threadIdx.x] = 0u;
@@ -429,19 +477,32 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   const uint32_t ulane = (uint32_t)min(lane, N - 1);
   const int last_first = max(N - 64, 0);
   int iw = i_begin + wave * 64;                              // the wave's first Gaussian of this iteration (scalar)
+  int istep = LR_BATCH_THREADS, iend = i_end;
+  if (LR_ABLATED(32)) {   // experiment builds: workgroups interleaved 1024 Gaussians at a time (wrong lists: timing only)
+    iw = (int)blockIdx.x * LR_BATCH_THREADS + wave * 64; istep = (int)gridDim.x * LR_BATCH_THREADS; iend = N;
+  }
   // plane of the iteration = (iw - i_begin) / B (B is a multiple of the workgroup size): counted, not divided
   int plane = 0, left_in_plane = B / LR_BATCH_THREADS;
   const float* const cov6 = v.cov3d;
   LrGeo geo;
+  float nx_op, nx_c0, nx_c1, nx_c2;
   {
     const size_t i0 = (size_t)lr_sgpr((uint32_t)min(iw, last_first));
     geo = lr_load_geo<COV3D>(means + 3 * i0, scales + 3 * i0, rots + 4 * i0, COV3D ? cov6 + 6 * i0 : nullptr, ulane);
+    nx_op = (opac + i0)[ulane];
+    nx_c0 = (colors + 3 * i0)[3 * (size_t)ulane]; nx_c1 = (colors + 3 * i0)[3 * (size_t)ulane + 1];
+    nx_c2 = (colors + 3 * i0)[3 * (size_t)ulane + 2];
   }
-  for (; iw < i_end; iw += LR_BATCH_THREADS) {
-    const int first = min(iw, last_first);                   // (scalar) the Gaussian of lane 0
-    const int lo = iw - first, hi = i_end - first;           // this wave's own lanes: [lo, hi)
-    const bool mine = lane >= lo && lane < hi;
-    const size_t iws = (size_t)lr_sgpr((uint32_t)first);
+  // FULL waves only: every store of the loop is then unconditional.  (A store under a lane predicate sits behind an
+  // `s_cbranch_execz`, and the wait-count pass cannot count instructions it may have skipped: to be sure of a load that was
+  // issued BEFORE such stores it waits for "all but the unconditional instructions since" -- i.e. for the stores too, whose
+  // acknowledgements then sit in every iteration's critical path.  The disassembly had `s_waitcnt vmcnt(0)` at the loop's
+  // top.)  The one partial wave of the whole array is projected after the loop, by the plain per-Gaussian code.
+  // (the first inputs are "used" here, i.e. waited for in front of the loop: see the wait at the loop's end)
+  asm volatile("" : "+v"(geo.p[0]), "+v"(geo.p[1]), "+v"(geo.p[2]), "+v"(geo.s[0]), "+v"(geo.s[1]), "+v"(geo.s[2]),
+               "+v"(geo.q.x), "+v"(geo.q.y), "+v"(geo.q.z), "+v"(geo.q.w), "+v"(nx_op), "+v"(nx_c0), "+v"(nx_c1), "+v"(nx_c2));
+  for (; iw + 64 <= iend; iw += istep) {
+    const size_t iws = (size_t)lr_sgpr((uint32_t)iw);        // (scalar) the Gaussian of lane 0
     if (left_in_plane == 0) { plane++; left_in_plane = B / LR_BATCH_THREADS; }
     left_in_plane--;
     uint32_t* const ctr = lr_lds_ctr + plane * tiles;
@@ -463,18 +524,29 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       float R[9];
       lr_cov3d(s3, q4, R, Sg);
     }
-    // opacity + colour of this Gaussian (used at the end of the iteration), then the next iteration's inputs into the
-    // registers that just died
+    // the next iteration's inputs: means / scales / rotations into the registers that just died, opacity + colour (this
+    // iteration's are used at its end) into four registers of their own -- all 56 bytes one full iteration ahead
     const uint32_t olane = lr_after(ulane, e.t, hx, hy, hw, Sg);
-    const float in_op = (opac + iws)[olane];
-    const float* __restrict__ wc = colors + 3 * iws;
-    const float in_c0 = wc[3 * (size_t)olane], in_c1 = wc[3 * (size_t)olane + 1], in_c2 = wc[3 * (size_t)olane + 2];
+    const float in_op = nx_op, in_c0 = nx_c0, in_c1 = nx_c1, in_c2 = nx_c2;
     {
-      const size_t in = (size_t)lr_sgpr((uint32_t)min(iw + LR_BATCH_THREADS, last_first));   // (past the workgroup's end: loaded, never used)
+      const size_t in = (size_t)lr_sgpr((uint32_t)min(iw + istep, last_first));   // (past the workgroup's end: loaded, never used)
+      nx_op = (opac + in)[olane];
+      const float* __restrict__ wc = colors + 3 * in;
+      nx_c0 = wc[3 * (size_t)olane]; nx_c1 = wc[3 * (size_t)olane + 1]; nx_c2 = wc[3 * (size_t)olane + 2];
       geo = lr_load_geo<COV3D>(means + 3 * in, scales + 3 * in, rots + 4 * in, COV3D ? cov6 + 6 * in : nullptr, olane);
     }
     // ---- part 2: EWA, conic, radius, rect ----
-    bool valid = mine && (tz > 0.2f);
+    if (LR_ABLATED(8)) {   // experiment builds: the loop's memory accesses with next to no arithmetic behind them
+      float4 a0 = {e.t[0], e.t[1], hx, hy}, a1 = {hw, Sg[0], in_op, in_c0}, a2 = {in_c1, in_c2, Sg[1], Sg[2]},
+             a3 = {Sg[3], Sg[4], Sg[5], tz};
+      if (!LR_ABLATED(2)) {
+        lr_out_store(&(radii + iws)[lane], (int)__float_as_uint(hx) & 1);
+        lr_out_store(&(fillrec + iws)[lane], uint4{__float_as_uint(tz), 0xffffffffu, 0u, 0u});
+      }
+      if (!LR_ABLATED(1)) lr_store_records(geom + LR_REC_QUADS * iws, lane, a0, a1, a2, a3);
+      continue;
+    }
+    bool valid = tz > 0.2f;
     const float pw = 1.0f / (hw + 0.0000001f);
     const float nx = hx * pw, ny = hy * pw;
     if (v.ndc_cull) valid = valid && !(nx < -1.3f || nx > 1.3f || ny < -1.3f || ny > 1.3f);
@@ -517,13 +589,23 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       }
       const int t0 = y0 * v.gx + x0;
       const bool r0 = small && k0, r1 = small && nt > 1 && k1, r2 = small && nt > 2 && k2, r3 = small && nt > 3 && k3;
-      // up to four returning LDS atomics in flight
-      uint32_t a0 = 0xffffffffu, a1 = 0xffffffffu, a2 = 0xffffffffu, a3 = 0xffffffffu;
-      if (r0) a0 = atomicAdd(&ctr[t0], 1u) & 0xffffu;
-      if (r1) a1 = atomicAdd(&ctr[t0 + ty1 * v.gx + tx1], 1u) & 0xffffu;
-      if (r2) a2 = atomicAdd(&ctr[t0 + ty2 * v.gx + tx2], 1u) & 0xffffu;
-      if (r3) a3 = atomicAdd(&ctr[t0 + ty3 * v.gx + tx3], 1u) & 0xffffu;
-      if (small) { slot0 = a0; slot1 = nt > 1 ? a1 : 0u; slot2 = nt > 2 ? a2 : 0u; slot3 = nt > 3 ? a3 : 0u; }
+      // four returning LDS atomics in flight, all UNCONDITIONAL (under lane predicates each one sat behind a branch and
+      // was followed by its own `s_waitcnt lgkmcnt(0)`: four dependent LDS round trips): a tile that is not ranked sends
+      // its lane to the lane's own dummy word instead (64 words, shared by the workgroup's waves: never read)
+      uint32_t* const dummy = lr_rank_dummy + lane;
+      uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a3 = 0u;
+      if (!LR_ABLATED(4)) {
+        a0 = atomicAdd(r0 ? &ctr[t0] : dummy, 1u) & 0xffffu;
+        a1 = atomicAdd(r1 ? &ctr[t0 + ty1 * v.gx + tx1] : dummy, 1u) & 0xffffu;
+        a2 = atomicAdd(r2 ? &ctr[t0 + ty2 * v.gx + tx2] : dummy, 1u) & 0xffffu;
+        a3 = atomicAdd(r3 ? &ctr[t0 + ty3 * v.gx + tx3] : dummy, 1u) & 0xffffu;
+      }
+      if (small) {
+        slot0 = r0 ? a0 : 0xffffffffu;
+        slot1 = nt > 1 ? (r1 ? a1 : 0xffffffffu) : 0u;
+        slot2 = nt > 2 ? (r2 ? a2 : 0xffffffffu) : 0u;
+        slot3 = nt > 3 ? (r3 ? a3 : 0xffffffffu) : 0u;
+      }
       if (valid && !small) {   // rare on the inputs this loop is shaped for: larger rects are only counted here
         if (nt > defer_tiles) {
           atomicAdd(&lr_huge_cnt[plane], 1u);
@@ -541,32 +623,52 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
     float4 g1 = float4{cC, in_op, in_c0, in_c1};
     float4 g2 = float4{in_c2, tz, __uint_as_float(valid ? r0w : 0u), __uint_as_float(valid ? r1w : 0u)};
     float4 g3 = float4{__uint_as_float(slot0), __uint_as_float(slot1), __uint_as_float(slot2), __uint_as_float(slot3)};
-    if (mine) {
-      (radii + iws)[lane] = rad;
+    if (!LR_ABLATED(2)) {
+      lr_out_store(&(radii + iws)[lane], rad);
       // fill record (see lr_fill_record): ranks as 16-bit halves, 0xffff = dropped by the support cull
-      uint4 fr = {__float_as_uint(tz), 0xffffffffu, 0u, 0u};
-      if (valid) {
-        const uint32_t h = (uint32_t)(y1 - y0);
-        fr.y = small ? ((uint32_t)x0 | ((uint32_t)y0 << 13) | ((uint32_t)(w - 1) << 26) | ((h - 1u) << 28))
-                     : ((uint32_t)x0 | ((uint32_t)y0 << 13) | (1u << 30));
-        fr.z = small ? ((slot0 & 0xffffu) | (slot1 << 16)) : r1w;
-        fr.w = small ? ((slot2 & 0xffffu) | (slot3 << 16)) : 0u;
-      }
-      (fillrec + iws)[lane] = fr;
+      const uint32_t h = (uint32_t)(y1 - y0);
+      uint4 fr;
+      fr.x = __float_as_uint(tz);
+      fr.y = !valid ? 0xffffffffu
+                    : (small ? ((uint32_t)x0 | ((uint32_t)y0 << 13) | ((uint32_t)(w - 1) << 26) | ((h - 1u) << 28))
+                             : ((uint32_t)x0 | ((uint32_t)y0 << 13) | (1u << 30)));
+      fr.z = !valid ? 0u : (small ? ((slot0 & 0xffffu) | (slot1 << 16)) : r1w);
+      fr.w = (valid && small) ? ((slot2 & 0xffffu) | (slot3 << 16)) : 0u;
+      lr_out_store(&(fillrec + iws)[lane], fr);
     }
-    lr_row_transpose(g0, g1, g2, g3);                        // g<k> = quad (lane >> 4) of the record of Gaussian first + 16 k + (lane & 15)
-    {
-      const int l16 = lane & 15, r = lane >> 4;
-      float4* __restrict__ rec = geom + LR_REC_QUADS * iws;   // (scalar base + lane offset)
-      if (l16 >= lo && l16 < hi) rec[LR_REC_QUADS * l16 + r] = g0;
-      if (l16 + 16 >= lo && l16 + 16 < hi) rec[LR_REC_QUADS * (l16 + 16) + r] = g1;
-      if (l16 + 32 >= lo && l16 + 32 < hi) rec[LR_REC_QUADS * (l16 + 32) + r] = g2;
-      if (l16 + 48 >= lo && l16 + 48 < hi) rec[LR_REC_QUADS * (l16 + 48) + r] = g3;
+    if (!LR_ABLATED(1)) lr_store_records(geom + LR_REC_QUADS * iws, lane, g0, g1, g2, g3);   // (scalar base + lane offset)
+    // The next iteration's inputs were requested BEFORE this iteration's six stores: "at most six memory instructions
+    // outstanding" says they have arrived and leaves the stores in flight.  Said here, because at the loop's top the
+    // wait-count pass merges this path with the preheader's (where the same loads are the LAST instructions issued) into
+    // `s_waitcnt vmcnt(0)` -- every store of the iteration acknowledged before the next one starts.  (An explicit wait can
+    // only be too weak, never wrong: the pass still adds whatever a use needs.)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(LR_WAIT_VMCNT(6));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (iw < i_end && !LR_ABLATED(32)) {
+    // the partial wave (at most one in the whole grid: the end of the array) -- lr_project_one, the code of the other
+    // projection kernels: the same op sequences, so the same records bit for bit
+    const int i = iw + lane;
+    if (i < i_end) {
+      const int pl = (iw - i_begin) / B;
+      const LrLdsCounters lc{lr_lds_ctr + pl * tiles};
+      const LrInputs in = lr_load_inputs(i, means, scales, rots, opac, colors, v.cov3d);
+      float4 g0, g1, g2, g3;
+      int rad;
+      bool huge;
+      lr_project_one<true>(v, in, tile_cull, lc, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
+      if (huge) atomicAdd(&lr_huge_cnt[pl], 1u);
+      radii[i] = rad;
+      fillrec[i] = lr_fill_record(g2, g3, rad);
+      geom[LR_REC_QUADS * (size_t)i + 0] = g0; geom[LR_REC_QUADS * (size_t)i + 1] = g1;
+      geom[LR_REC_QUADS * (size_t)i + 2] = g2; geom[LR_REC_QUADS * (size_t)i + 3] = g3;
     }
   }
   __syncthreads();
   const int nplanes = min(S, (i_end - i_begin + B - 1) / B);   // batches this workgroup really holds
-  lr_reserve_batches(lr_lds_ctr, tiles, 0, tiles, nplanes, tiles, ranked, big, basetab + (size_t)blockIdx.x * S * tiles);
+  if (!LR_ABLATED(16))
+    lr_reserve_batches(lr_lds_ctr, tiles, 0, tiles, nplanes, tiles, ranked, big, basetab + (size_t)blockIdx.x * S * tiles);
   if ((int)threadIdx.x < nplanes) {   // complete: the barrier after the Gaussian loop
     hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];
     if (lr_huge_cnt[threadIdx.x]) atomicOr(&hdr[LR_HDR_HUGE], 1u);
@@ -888,11 +990,11 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
       if (v.cov3d)
         hipLaunchKernelGGL(lr_project_batched_kernel<true>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                            means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                           basetab, hugecount, tile_cull, batch, planes, defer_tiles);
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles LR_ABLATE_PASS(ablate));
       else
         hipLaunchKernelGGL(lr_project_batched_kernel<false>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                            means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                           basetab, hugecount, tile_cull, batch, planes, defer_tiles);
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles LR_ABLATE_PASS(ablate));
     }
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);

@@ -137,7 +137,13 @@ class _Flat:
                 self.alias[name] = self.views["rows"][:, a:b]
 
     def sink(self):
-        """What ``log_amd.rasterizer.accumulate_grads_into`` takes."""
+        """What ``log_amd.rasterizer.accumulate_grads_into`` takes.  A row-major bucket WITH SH coefficients has no
+        rasterizer sink (the chain rule's row-major form adds dL/dcolour into the row; with native `shs=` the colour is an
+        intermediate): attach the attributes' .grad to ``alias[...]`` instead (autograd route), or build the bucket
+        attribute-major (row_major=False), whose sink takes an "shs" entry."""
+        if self.row_major and "shs" in self.views:
+            raise ValueError("a row-major gradient bucket with SH coefficients has no rasterizer sink: use "
+                             "row_major=False (its sink has an 'shs' entry) or attach .grad to bucket.alias[...]")
         return dict(self.views)
 
     def rows(self, name, rank):

@@ -131,29 +131,38 @@ class _CapacityModel:
         self.hist = {}
         self.retries = 0      # speculative attempts that had to be repeated (diagnostics)
         self.forwards = 0
+        self.lock = threading.Lock()   # render threads share the model (round-3 advisory)
+
+    def ratio(self, key):
+        with self.lock:
+            h = self.hist.get(key)
+            return h["ratio"] if h else 0.0
 
     def guess(self, key, n, tiles):
-        h = self.hist.get(key)
-        if h is None:
-            return int(self.FIRST_RATIO * n) + 4 * tiles + 4096, 0
-        cap = int(max(h["I"], h["ratio"] * n) * self.HEADROOM) + 4096
-        return min(cap, 0x7fffffff), int(h["L"] * self.LEN_HEADROOM) + 256
+        with self.lock:
+            h = self.hist.get(key)
+            if h is None:
+                return int(self.FIRST_RATIO * n) + 4 * tiles + 4096, 0
+            cap = int(max(h["I"], h["ratio"] * n) * self.HEADROOM) + 4096
+            return min(cap, 0x7fffffff), int(h["L"] * self.LEN_HEADROOM) + 256
 
     def update(self, key, n, instances, max_len, retried):
-        self.forwards += 1
-        self.retries += int(retried)
-        h = self.hist.get(key)
-        ratio = instances / max(n, 1)
-        if h is None:
-            self.hist[key] = dict(I=float(instances), ratio=ratio, L=float(max_len))
-        else:
-            h["I"] = max(float(instances), h["I"] * self.DECAY)
-            h["ratio"] = max(ratio, h["ratio"] * self.DECAY)
-            h["L"] = max(float(max_len), h["L"] * self.DECAY)
+        with self.lock:
+            self.forwards += 1
+            self.retries += int(retried)
+            h = self.hist.get(key)
+            ratio = instances / max(n, 1)
+            if h is None:
+                self.hist[key] = dict(I=float(instances), ratio=ratio, L=float(max_len))
+            else:
+                h["I"] = max(float(instances), h["I"] * self.DECAY)
+                h["ratio"] = max(ratio, h["ratio"] * self.DECAY)
+                h["L"] = max(float(max_len), h["L"] * self.DECAY)
 
     def reset(self):
-        self.hist.clear()
-        self.retries = self.forwards = 0
+        with self.lock:
+            self.hist.clear()
+            self.retries = self.forwards = 0
 
 
 _cap_model = _CapacityModel()
@@ -370,17 +379,19 @@ class HipBackend:
             kept.append(("bwd_scratch", f32, (N * scratch_floats,)))
         instances = None
         ckey = (device.index, W, H, _tile_rows.get())
-        hist = _cap_model.hist.get(ckey)
+        hist_ratio = _cap_model.ratio(ckey)
         # which form the compositing kernel takes: instances per Gaussian as the recent forwards of this resolution had
         # them (speculative / exact mode), or the caller's capacity (sync-free mode)
-        view.walk_form = self.walk_form(_capacity_hint if _capacity_hint is not None else (hist["ratio"] * N if hist else 0), N)
+        view.walk_form = self.walk_form(_capacity_hint if _capacity_hint is not None else hist_ratio * N, N)
         self._note_form("fwd", view.walk_form, N)
         with torch.cuda.device(device):
             if _capacity_hint is None and _speculative and N > 0:
                 tiles = ((W + 15) // 16) * ((H + 15) // 16)
                 capacity, max_len = _cap_model.guess(ckey, N, tiles)
-                k = self._carve(device, kept + [("plist", i32, (capacity,))])
-                plist = k["plist"]
+                # (the guessed list is an allocation of its own: inside the arena it would stay pinned, at its guessed
+                # size and next to the exact one after a retry, until backward -- round-3 advisory)
+                k = self._carve(device, kept)
+                plist = torch.empty(capacity, dtype=i32, device=device)
                 keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
                 n_host, m_host = ctypes.c_uint32(0), ctypes.c_uint32(0)
                 _lib.check(L.lograst_forward_speculative(

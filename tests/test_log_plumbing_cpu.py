@@ -244,6 +244,13 @@ def test_reference_training_step_with_all_dropins_installed(cpu_cuda_shims):
             got = ref_renderer.torch.unique(pid_map, sorted=True, return_counts=True)
             want = torch.unique(pid_map, sorted=True, return_counts=True)
             assert all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(got, want)), tagged
+        # a map without an empty pixel: the stand-in keeps the leading -1 with a ZERO count (no read-back per view to
+        # decide; renderer.py:157-159 strips the entry), everything behind it is torch's result
+        full = torch.tensor([[3, 1, 3], [0, 7, 7]], dtype=torch.int32)
+        full._lograst_num_gaussians = 9
+        gi, gc = ref_renderer.torch.unique(full, sorted=True, return_counts=True)
+        wi, wc = torch.unique(full, sorted=True, return_counts=True)
+        assert int(gi[0]) == -1 and int(gc[0]) == 0 and torch.equal(gi[1:], wi) and torch.equal(gc[1:], wc)
         new = _log_model(0, 400)
         sel_new = _run_steps(new, 3, W, H)
     finally:

@@ -277,7 +277,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                 # common frustum), recorded once per group from the last forward's radii (kept by one_view)
                 if wl.last_radii is not None:
                     ex.buckets[part].mark_seen(wl.last_radii)
-                ex.launch(part, compact=compact["on"])
+                ex.launch(part, compact=compact["on"], kmax=compact.get("kmax"))
         if world > 1:
             ex.all_gather_grads(ex.finish())            # every rank ends the step with the whole gradient sum
 
@@ -317,6 +317,15 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             res["exchange_touched_block_fraction"] = float(t.item())
             if args.exchange == "auto":
                 compact["on"] = res["exchange_touched_block_fraction"] < GradientBucket.DENSE_ABOVE
+            if compact["on"]:
+                # One exact compact step (its touched-block collectives sized by a read-back each); from then on they are
+                # sized from that step's longest list + 15 % with no read-back (log_amd.dist.TouchedBlocks); a step that
+                # outgrew the bound is caught after the timed region.
+                step()
+                torch.cuda.synchronize()
+                longest = max([b.touched.kmax for b in ex.buckets if b.touched is not None] or [g.Pr // block_rows])
+                compact["kmax"] = min(g.Pr // block_rows, int(longest * 1.15) + 2)
+                res["exchange_block_bound"] = compact["kmax"]
         res["exchange_mode"] = "compact" if compact["on"] else "dense"
         del nz
         ex.reset_timing()
@@ -383,11 +392,29 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             res["prof_serial"] = _lib.profile_read()
     if world > 1:
         res["exchange_timing"] = ex.timing_summary(steps)
+        # The same collectives with nothing to hide under: link time alone, so that a first run on real xGMI separates what
+        # the links cost from what the overlap lost (exposed = ms_per_step - rendering; hidden = exchange_only - exposed).
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tx = time.perf_counter()
+        xsteps = 3
+        for _ in range(xsteps):
+            for part in range(parts):
+                ex.launch(part, compact=compact["on"], kmax=compact.get("kmax"))
+            ex.all_gather_grads(ex.finish())
+        torch.cuda.synchronize()
+        dist.barrier()
+        txe = torch.tensor([time.perf_counter() - tx], device=dev, dtype=torch.float64)
+        dist.all_reduce(txe, op=dist.ReduceOp.MAX)
+        res["exchange_only_ms_per_step"] = 1e3 * float(txe.item()) / xsteps
         cols = sum(c for _, c in ex.buckets[0].layout) + 1
         frac = 1.0
         if compact["on"] and ex.touched is not None:
             frac = ex.touched.fraction
         res["exchange_bytes_per_step"] = int(2 * 4 * cols * ex.buckets[0].Ppad * frac * (world - 1) / world)
+    if world > 1:
+        assert not ex.compact_overflowed(), "touched-block exchange outgrew its bound inside the timed region: result invalid"
     chk = R.overflow_since_reset(dev)   # every forward since the capacity was set, on all streams
     assert not chk["overflowed"] and chk["max_instances"] <= cap, \
         "tile-instance capacity overflow inside the timed region: result invalid (%r)" % (chk,)
@@ -727,6 +754,9 @@ def main():
             "nonzero_gradient_row_fraction": r.get("exchange_nonzero_row_fraction"),
             "touched_4096_row_block_fraction": r.get("exchange_touched_block_fraction"),
             "bytes_moved_per_rank_per_step": r.get("exchange_bytes_per_step"), "timing_ms": r.get("exchange_timing"),
+            "exchange_only_ms_per_step": r.get("exchange_only_ms_per_step"),
+            "exchange_only_busbw_GBs": (r["exchange_bytes_per_step"] / (r["exchange_only_ms_per_step"] * 1e-3) / 1e9
+                                        if r.get("exchange_only_ms_per_step") and r.get("exchange_bytes_per_step") else None),
             "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO",
                                                          "NCCL_PROTO", "RCCL_MSCCL_ENABLE") if os.environ.get(k)}}
     if not args.no_dropin_mode:

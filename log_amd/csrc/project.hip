@@ -1188,6 +1188,80 @@ void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, uint32_
 // rects take positions from the per-tile cursor; up to LR_COOP_TILES tiles a lane expands its own rect,
 // beyond that the whole wave expands it (ballot over the lanes that hold one, record broadcast with
 // readlane) so that a single screen-filling Gaussian does not serialise its wave.
+// The forward's verdict on its buffers, reached by every workgroup of the fill from the scan's header: the caller's
+// buffers hold `capacity` instances and it launched the sort levels for lists of up to `max_len_hint` keys (0 = no hint:
+// the levels for `capacity`); if either is exceeded nothing may be sorted or composited.  The flag makes the later
+// kernels return at once (lr_bail), and the caller's status block (optional, include/lograst.h: LOGRAST_STATUS_*) records
+// this forward and the running maxima / sticky overflow bit across forwards (written by one thread of the grid).
+LR_DEV bool lr_fill_verdict(uint32_t* __restrict__ state, uint32_t capacity, uint32_t max_len_hint,
+                            uint32_t* __restrict__ status, int speculative) {
+  const uint32_t total = state[LR_HDR_NUM], maxlen = state[LR_HDR_MAXLEN];
+  const bool over = total > capacity || (max_len_hint != 0u && maxlen > max_len_hint);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (written either way: a second stage-2 pass over the same tile_state with larger buffers -- the retry of a
+    // speculative forward, lograst_forward_speculative -- must find the flag of the failed attempt cleared)
+    state[LR_HDR_OVERFLOW] = over ? 1u : 0u;
+    // a speculative attempt that overflows is repeated by the caller with exact buffers: only that pass is recorded
+    if (status && !(speculative && over)) {
+      status[LOGRAST_STATUS_LAST_INSTANCES] = total;
+      status[LOGRAST_STATUS_LAST_OVERFLOW] = over ? 1u : 0u;
+      status[LOGRAST_STATUS_LAST_MAX_LEN] = maxlen;
+      status[LOGRAST_STATUS_LAST_RECT] = state[LR_HDR_RECT];
+      atomicMax(&status[LOGRAST_STATUS_MAX_INSTANCES], total);
+      atomicMax(&status[LOGRAST_STATUS_MAX_MAX_LEN], maxlen);
+      atomicAdd(&status[LOGRAST_STATUS_FORWARDS], 1u);
+      if (over) atomicOr(&status[LOGRAST_STATUS_OVERFLOW], 1u);
+    }
+  }
+  return over;
+}
+
+// Rects of more than LR_RANKED_TILES tiles were only counted by the projection: their instances take positions from the
+// per-tile cursors here.  The projection kernel's support test is repeated (same record, same code) so that the same
+// tiles are filled.  Up to LR_COOP_TILES tiles a lane expands its own rect, beyond that the whole wave expands it (ballot
+// over the lanes that hold one, record broadcast with readlane).  Every lane of the wave must call this (nt = 0: nothing).
+LR_DEV void lr_fill_big_rect(const float4* __restrict__ geom, int i, int x0, int y0, int w, int h, int nt, uint64_t key,
+                             int gx, bool tile_cull, uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, int lane
+                             LR_ABLATE_PARAM) {
+  const int y1 = y0 + h, x1 = x0 + w;
+  LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};  // mode 1: every tile of the rect
+  if (nt > LR_RANKED_TILES && tile_cull) {
+    const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
+    sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
+  }
+  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !LR_ABLATED(4)) {
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++)
+        if (lr_support_tile(sup, x, y)) {
+          uint32_t pos = atomicAdd(&cursor[(y * gx + x) * LR_CTR_STRIDE], 1u);
+          keys[pos] = key;
+        }
+  }
+  uint64_t bigm = __ballot(nt > LR_COOP_TILES && !LR_ABLATED(8));
+  while (bigm) {
+    int src = __builtin_ctzll(bigm);
+    bigm &= bigm - 1;
+    int bx0 = lr_readlane_i(x0, src), by0 = lr_readlane_i(y0, src);
+    int bw = lr_readlane_i(w, src), bn = lr_readlane_i(nt, src);
+    uint32_t klo = (uint32_t)lr_readlane_i((int)(uint32_t)key, src);
+    uint32_t khi = (uint32_t)lr_readlane_i((int)(uint32_t)(key >> 32), src);
+    uint64_t bkey = ((uint64_t)khi << 32) | klo;
+    LrSupport bs;
+    bs.mx = lr_readlane_f(sup.mx, src); bs.my = lr_readlane_f(sup.my, src);
+    bs.A = lr_readlane_f(sup.A, src); bs.B = lr_readlane_f(sup.B, src); bs.C = lr_readlane_f(sup.C, src);
+    bs.tau = lr_readlane_f(sup.tau, src); bs.ex = lr_readlane_f(sup.ex, src); bs.ey = lr_readlane_f(sup.ey, src);
+    bs.iA = lr_readlane_f(sup.iA, src); bs.iC = lr_readlane_f(sup.iC, src);
+    bs.mode = lr_readlane_i(sup.mode, src);
+    for (int t = lane; t < bn; t += 64) {
+      int ty = t / bw, tx = t - ty * bw;
+      if (lr_support_tile(bs, bx0 + tx, by0 + ty)) {
+        uint32_t pos = atomicAdd(&cursor[((by0 + ty) * gx + (bx0 + tx)) * LR_CTR_STRIDE], 1u);
+        keys[pos] = bkey;
+      }
+    }
+  }
+}
+
 template <int K>   // Gaussians per thread: their fill records are requested together (see lr_launch_fill)
 __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
@@ -1229,29 +1303,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     }
   }
   const bool tile_cull = state[LR_HDR_CULL] != 0u;
-  // The caller's buffers hold `capacity` instances and it launched the sort levels for lists of up to `max_len_hint`
-  // keys (0 = no hint: the levels for `capacity`): if either is exceeded nothing may be sorted or composited.  Every
-  // workgroup reaches the same verdict from the scan's header; the flag makes the later kernels return at once
-  // (lr_bail), and the caller's status block (optional, include/lograst.h: LOGRAST_STATUS_*) records this forward and
-  // the running maxima / sticky overflow bit across forwards.
-  const uint32_t total = state[LR_HDR_NUM], maxlen = state[LR_HDR_MAXLEN];
-  const bool over = total > capacity || (max_len_hint != 0u && maxlen > max_len_hint);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // (written either way: a second stage-2 pass over the same tile_state with larger buffers -- the retry of a
-    // speculative forward, lograst_forward_speculative -- must find the flag of the failed attempt cleared)
-    state[LR_HDR_OVERFLOW] = over ? 1u : 0u;
-    // a speculative attempt that overflows is repeated by the caller with exact buffers: only that pass is recorded
-    if (status && !(speculative && over)) {
-      status[LOGRAST_STATUS_LAST_INSTANCES] = total;
-      status[LOGRAST_STATUS_LAST_OVERFLOW] = over ? 1u : 0u;
-      status[LOGRAST_STATUS_LAST_MAX_LEN] = maxlen;
-      status[LOGRAST_STATUS_LAST_RECT] = state[LR_HDR_RECT];
-      atomicMax(&status[LOGRAST_STATUS_MAX_INSTANCES], total);
-      atomicMax(&status[LOGRAST_STATUS_MAX_MAX_LEN], maxlen);
-      atomicAdd(&status[LOGRAST_STATUS_FORWARDS], 1u);
-      if (over) atomicOr(&status[LOGRAST_STATUS_OVERFLOW], 1u);
-    }
-  }
+  const bool over = lr_fill_verdict(state, capacity, max_len_hint, status, speculative);
   if (over) return;
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
@@ -1340,50 +1392,103 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       }
     }
   }
-  // Larger rects were only counted; repeat the projection kernel's support test (same record, same code) so the
-  // same tiles are filled.
-  LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};  // mode 1: every tile of the rect
-  if (nt > LR_RANKED_TILES && tile_cull) {
-    const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
-    sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
+  lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
   }
-  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !LR_ABLATED(4)) {
-    for (int y = y0; y < y1; y++)
-      for (int x = x0; x < x1; x++)
-        if (lr_support_tile(sup, x, y)) {
-          uint32_t pos = atomicAdd(&cursor[(y * gx + x) * LR_CTR_STRIDE], 1u);
-          keys[pos] = key;
-        }
+}
+
+// ---- A3, batched full views: the batch's slot table staged in LDS ------------------------------------------------------
+// What the fill costs is the number of scattered accesses it sends to the L2s: per tile instance one 4-byte look-up in the
+// batch's row of the slot table and one 8-byte key store -- 88 M requests for the 30 M-Gaussian view's 44 M instances,
+// against ~270 G requests/s that the L2 channels accept chip-wide (0.33 of the kernel's 0.39 ms).  Here a workgroup owns
+// LR_FILL_STAGED_ROWS CONSECUTIVE Gaussians -- one batch: batches are multiples of 1024 -- and first copies that batch's
+// table row (tiles x 4 B: 32 KB at 1080p; `+ offsets[t]` on inputs too small for lr_rebase_kernel) into LDS with coalesced
+// 16-byte loads: 256 line requests per workgroup (L2 hits: the ~29 workgroups of a batch run on one XCD within
+// microseconds of each other) instead of ~1500 scattered look-ups.  Rects of more than 4 tiles as in lr_fill_kernel.
+#define LR_FILL_STAGED_ROWS 1024
+#define LR_FILL_STAGED_MAX_TILES 12288      // 48 KB of LDS: three workgroups per CU
+__global__ void __launch_bounds__(LR_FILL_STAGED_ROWS, 8)   // 64 VGPRs: two workgroups per CU
+lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
+                      uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
+                      float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order,
+                      int rebased, int speculative LR_ABLATE_PARAM) {
+  extern __shared__ uint32_t lr_slot_row[];                       // [tiles]: absolute first slot of this batch's run in every tile
+  const uint32_t per_xcd = gridDim.x >> 3;                        // grid is a multiple of 8 (XCD-contiguous order: lr_fill_kernel)
+  const uint32_t vblock = xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t e = vblock * LR_FILL_STAGED_ROWS + threadIdx.x;
+  const bool vis = e < (uint32_t)N;
+  const int i = (int)e;
+  if (vis && !LR_ABLATED(1)) {                                    // (small inputs: the zero-fills live here, see lr_fill_kernel)
+    if (zero_n) zero_n[e] = 0.f;
+    for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + e] = 0.f;
   }
-  uint64_t bigm = __ballot(nt > LR_COOP_TILES && !LR_ABLATED(8));
-  while (bigm) {
-    int src = __builtin_ctzll(bigm);
-    bigm &= bigm - 1;
-    int bx0 = lr_readlane_i(x0, src), by0 = lr_readlane_i(y0, src);
-    int bw = lr_readlane_i(w, src), bn = lr_readlane_i(nt, src);
-    uint32_t klo = (uint32_t)lr_readlane_i((int)(uint32_t)key, src);
-    uint32_t khi = (uint32_t)lr_readlane_i((int)(uint32_t)(key >> 32), src);
-    uint64_t bkey = ((uint64_t)khi << 32) | klo;
-    LrSupport bs;
-    bs.mx = lr_readlane_f(sup.mx, src); bs.my = lr_readlane_f(sup.my, src);
-    bs.A = lr_readlane_f(sup.A, src); bs.B = lr_readlane_f(sup.B, src); bs.C = lr_readlane_f(sup.C, src);
-    bs.tau = lr_readlane_f(sup.tau, src); bs.ex = lr_readlane_f(sup.ex, src); bs.ey = lr_readlane_f(sup.ey, src);
-    bs.iA = lr_readlane_f(sup.iA, src); bs.iC = lr_readlane_f(sup.iC, src);
-    bs.mode = lr_readlane_i(sup.mode, src);
-    for (int t = lane; t < bn; t += 64) {
-      int ty = t / bw, tx = t - ty * bw;
-      if (lr_support_tile(bs, bx0 + tx, by0 + ty)) {
-        uint32_t pos = atomicAdd(&cursor[((by0 + ty) * gx + (bx0 + tx)) * LR_CTR_STRIDE], 1u);
-        keys[pos] = bkey;
+  const bool tile_cull = state[LR_HDR_CULL] != 0u;
+  const bool over = lr_fill_verdict(state, capacity, max_len_hint, status, speculative);
+  if (over) return;
+  const uint32_t batch = state[LR_HDR_BATCH];
+  const uint4* __restrict__ fillrec = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
+  uint4 fr = uint4{0u, 0xffffffffu, 0u, 0u};
+  if (vis) {
+    typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
+    const lr_u4v t4 = __builtin_nontemporal_load(reinterpret_cast<const lr_u4v*>(fillrec + e));
+    fr = uint4{t4.x, t4.y, t4.z, t4.w};
+  }
+  {
+    const uint32_t first = vblock * LR_FILL_STAGED_ROWS;          // the workgroup's first Gaussian (< N unless the grid's padding)
+    const uint32_t b = (first < (uint32_t)N ? first : 0u) / batch;
+    const uint32_t* __restrict__ row = state + lr_basetab_off(tiles) + (size_t)b * tiles;
+    const uint32_t* __restrict__ off = state + lr_offsets_off(tiles);
+    if (((tiles | lr_basetab_off(tiles) | lr_offsets_off(tiles)) & 3u) == 0u) {   // rows start on 16-byte boundaries (1080p: yes)
+      const uint4* __restrict__ row4 = reinterpret_cast<const uint4*>(row);
+      const uint4* __restrict__ off4 = reinterpret_cast<const uint4*>(off);
+      uint4* dst4 = reinterpret_cast<uint4*>(lr_slot_row);
+      for (uint32_t t4 = threadIdx.x; t4 < (tiles >> 2); t4 += LR_FILL_STAGED_ROWS) {
+        uint4 r = row4[t4];
+        if (!rebased) { const uint4 o = off4[t4]; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+        dst4[t4] = r;
       }
+    } else {
+      for (uint32_t t = threadIdx.x; t < tiles; t += LR_FILL_STAGED_ROWS) lr_slot_row[t] = row[t] + (rebased ? 0u : off[t]);
     }
   }
+  __syncthreads();
+  uint32_t* cursor = state + lr_cursor_off(tiles);
+  const int lane = threadIdx.x & 63;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  uint32_t h0 = 0xffffu, h1 = 0xffffu, h2 = 0xffffu, h3 = 0xffffu;
+  if (fr.y != 0xffffffffu) {
+    x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
+    if (fr.y & (1u << 30)) {
+      x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
+    } else {
+      x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
+      h0 = fr.z & 0xffffu; h1 = fr.z >> 16; h2 = fr.w & 0xffffu; h3 = fr.w >> 16;
+    }
   }
+  const int w = x1 - x0, h = y1 - y0, nt = vis ? w * h : 0;
+  const uint64_t key = ((uint64_t)fr.x << 32) | (uint32_t)i;
+  if (nt > 0 && nt <= LR_RANKED_TILES) {
+    // tile k of a rect of <= 4 tiles: one row (w >= nt), one column (w == 1) or 2x2 -- as in lr_project_batched_kernel
+    const bool col = w == 1, sq = (w == 2) && (nt == 4);
+    const int t0 = y0 * gx + x0;
+    const int d1 = col ? gx : 1, d2 = col ? 2 * gx : (sq ? gx : 2), d3 = col ? 3 * gx : (sq ? gx + 1 : 3);
+    // all look-ups (LDS) before the first store
+    const uint32_t p0 = h0 != 0xffffu ? lr_slot_row[t0] + h0 : 0xffffffffu;
+    const uint32_t p1 = (nt > 1 && h1 != 0xffffu) ? lr_slot_row[t0 + d1] + h1 : 0xffffffffu;
+    const uint32_t p2 = (nt > 2 && h2 != 0xffffu) ? lr_slot_row[t0 + d2] + h2 : 0xffffffffu;
+    const uint32_t p3 = (nt > 3 && h3 != 0xffffu) ? lr_slot_row[t0 + d3] + h3 : 0xffffffffu;
+    if (!LR_ABLATED(2)) {
+      if (p0 != 0xffffffffu) keys[p0] = key;
+      if (p1 != 0xffffffffu) keys[p1] = key;
+      if (p2 != 0xffffffffu) keys[p2] = key;
+      if (p3 != 0xffffffffu) keys[p3] = key;
+    }
+  }
+  lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
 }
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, int speculative, int band, hipStream_t s) {
+                    int zero_block_floats, int rebased, int speculative, int band, int batched, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
@@ -1391,6 +1496,21 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
 #ifdef LR_EXPERIMENTS
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores, 4 no 5-16-tile rects, 8 no larger rects
 #endif
+  LR_KNOB(staged_knob, "LOGRAST_FILL_STAGED", 1);
+  if (staged_knob && batched && !band && tiles <= LR_FILL_STAGED_MAX_TILES) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
+      attr_set = true;
+    }
+    const int blocks = ((N + LR_FILL_STAGED_ROWS - 1) / LR_FILL_STAGED_ROWS + 7) & ~7;
+    hipLaunchKernelGGL(lr_fill_staged_kernel, dim3(blocks), dim3(LR_FILL_STAGED_ROWS), sizeof(uint32_t) * ((tiles + 3u) & ~3u), s,
+                       N, gx, reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, max_len_hint, status,
+                       zero_n, zero_block, zero_block_floats, xcd_order, rebased, speculative LR_ABLATE_PASS(ablate));
+    lr_prof_end(LRK_FILL, s);
+    return;
+  }
   LR_KNOB(per_thread_knob, "LOGRAST_FILL_PER_THREAD", 1);
   int per_thread = per_thread_knob;
 #define LR_FILL(K) do { const int blocks = (((N + 255) / 256 + K - 1) / K + 7) & ~7;                                     \

@@ -148,7 +148,7 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
                       const float4* __restrict__ rows, float* __restrict__ o_mean2d, float* __restrict__ o_opac,
                       float* __restrict__ o_col,
                       const float* __restrict__ pw, float* __restrict__ g_means3d, float* __restrict__ g_scales,
-                      float* __restrict__ g_rots) {
+                      float* __restrict__ g_rots, int clear_inside) {
   __shared__ uint32_t live_list[LR_PBWD_ROWS];
   __shared__ uint32_t live_count;
   const int tid = threadIdx.x, base = blockIdx.x * LR_PBWD_ROWS;
@@ -161,13 +161,16 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
 #pragma unroll
   for (int k = 0; k < LR_PBWD_ROWS / 256; k++) {
     const int i = base + k * 256 + tid;
-    rad_k[k] = i < N ? radii[i] : 0;
+    // (TOUCHED: the forward cleared point_weight for every row and only composited Gaussians -- radii > 0 -- ever raised
+    // it: the blend weight alone is the live flag, radii is not read: 0.4 of the 2.0 GB a 100 M-row band view streams)
+    rad_k[k] = TOUCHED ? 1 : (i < N ? radii[i] : 0);
     pw_k[k] = (TOUCHED && i < N) ? pw[i] : 1.f;
   }
-  if (AOS) {
+  if (AOS && clear_inside) {
     // the per-view / per-call outputs are defined for every row: the block's whole slice is cleared with full-width
     // stores first (row-by-row 12-byte stores from the flag pass below cost the 30 M view 0.2 ms), the live rows
-    // overwrite theirs after the barrier
+    // overwrite theirs after the barrier.  (On large inputs lr_zero_floats_kernel streams the zeros before this kernel
+    // runs: lr_launch_project_bwd.)
     const int rows_here = min(LR_PBWD_ROWS, N - base);
     typedef float lr_f4v __attribute__((ext_vector_type(4)));
     auto clear = [&](float* p, int floats) {   // p is 16-byte aligned when base is a multiple of 4 rows (it is: 1024)
@@ -186,7 +189,7 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
   for (int k = 0; k < LR_PBWD_ROWS / 256; k++) {
     const int i = base + k * 256 + tid;
     const bool live = i < N && rad_k[k] > 0 && (!TOUCHED || pw_k[k] > 0.f);
-    if (!ACCUMULATE && i < N && !live) {   // culled / untouched: zero gradients (running sums are simply left alone)
+    if (!ACCUMULATE && clear_inside && i < N && !live) {   // culled / untouched: zero gradients (running sums are simply left alone)
       g_means3d[3 * (size_t)i + 0] = 0.f; g_means3d[3 * (size_t)i + 1] = 0.f; g_means3d[3 * (size_t)i + 2] = 0.f;
       if (COV) {
 #pragma unroll
@@ -272,6 +275,7 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
   }
 }
 
+void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);   // project.hip
 // rows != NULL: the 64-byte accumulator rows of lograst_backward (+ its three separate outputs); NULL: g_mean2d / g_conic
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
@@ -282,19 +286,27 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
   lr_prof_begin(LRK_PROJECT_BWD, s);
   const dim3 grid((N + LR_PBWD_ROWS - 1) / LR_PBWD_ROWS), block(256);
   const float4* rows4 = reinterpret_cast<const float4*>(rows);
+  // dL/dmeans2D is a per-view output, defined for every row.  When the other gradients are running sums (nothing else is
+  // written for a dead row) and the input is large, its zeros are streamed by lr_zero_floats_kernel (non-temporal 16-byte
+  // stores) in front of the chain rule instead of by its workgroups between their flag reads and their barrier: a band
+  // view of 100 M rows 1040 -> 730 us (with the radii read gone), the 30 M view unchanged (415 us).  With fresh gradients
+  // (every output zeroed for every dead row: 68 bytes per row) the same split LOSES (30 M: 763 -> 858 us): kept inside.
+  LR_KNOB(separate_min_n, "LOGRAST_HELPER_MIN_N", 4000000);
+  const int clear_inside = (rows && (accumulate || sink_rows) && N >= separate_min_n) ? 0 : 1;
+  if (!clear_inside) lr_launch_zero_floats(o_mean2d, 3 * (size_t)N, s);
   if (sink_rows) {   // (lograst_backward checked: rows != NULL, no cov3d)
     if (pw)
       hipLaunchKernelGGL((lr_project_bwd_kernel<true, true, false, true, true>), grid, block, 0, s, v, N, means, scales, rots,
-                         radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots);
+                         radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots, clear_inside);
     else
       hipLaunchKernelGGL((lr_project_bwd_kernel<true, false, false, true, true>), grid, block, 0, s, v, N, means, scales, rots,
-                         radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots);
+                         radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots, clear_inside);
     lr_prof_end(LRK_PROJECT_BWD, s);
     return;
   }
 #define LR_PBWD2(A, T, C, O) hipLaunchKernelGGL((lr_project_bwd_kernel<A, T, C, O>), grid, block, 0, s, v, N, means, scales, \
                                                 rots, radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw,       \
-                                                g_means3d, g_scales, g_rots)
+                                                g_means3d, g_scales, g_rots, clear_inside)
 #define LR_PBWD(A, T, C) do { if (rows) LR_PBWD2(A, T, C, true); else LR_PBWD2(A, T, C, false); } while (0)
 #define LR_PBWD_C(A, T) do { if (v.cov3d) LR_PBWD(A, T, true); else LR_PBWD(A, T, false); } while (0)
   if (accumulate) { if (pw) LR_PBWD_C(true, true); else LR_PBWD_C(true, false); }

@@ -154,20 +154,34 @@ class _Flat:
 
 class TouchedBlocks:
     """Which `block_rows`-row blocks of each owner any rank touched this step, as every rank computes it from the same
-    max-reduced bitmap: ``order[r]`` = owner r's block ids, touched ones first (ascending), and ``kmax`` = the longest
-    touched list over the owners (one small device -> host read: the collectives below need their sizes on the host).
-    Entries [count_r, kmax) of ``order[r]`` are untouched blocks of owner r -- padding that carries zeros / unchanged
-    rows."""
+    max-reduced bitmap: ``order[r]`` = owner r's block ids, touched ones first (ascending), and ``kmax`` = the length the
+    collectives are sized for.  Entries [count_r, kmax) of ``order[r]`` are untouched blocks of owner r -- padding that
+    carries zeros / unchanged rows.
 
-    def __init__(self, bitmap):
+    kmax=None: the longest touched list over the owners, exactly -- one small device -> host read per exchange (the
+    collectives need their sizes on the host).  kmax=K (a bound the caller keeps from earlier steps, e.g. the warm-up's
+    longest list + headroom): NO read-back; ``overflow`` is a device flag that is raised when some owner touched more than
+    K blocks (the exchange then dropped gradient rows: the caller checks the flag at a point where it synchronises anyway
+    -- ``StepExchange.compact_overflowed()`` -- and repeats the step dense or with a larger bound)."""
+
+    def __init__(self, bitmap, kmax=None):
         self.bitmap = bitmap                                   # bool [world, nb]
         self.world, self.nb = bitmap.shape
         self.counts = bitmap.sum(1)
-        self.kmax = max(int(self.counts.max().item()), 1)       # (nothing touched: one block of padding)
+        if kmax is None:
+            self.kmax = max(int(self.counts.max().item()), 1)   # (nothing touched: one block of padding)
+            self.overflow = None
+        else:
+            self.kmax = min(max(int(kmax), 1), self.nb)
+            self.overflow = self.counts.max() > self.kmax       # device bool, no synchronisation
+        self.bound = kmax
         self.order = torch.argsort((~bitmap).to(torch.uint8), dim=1, stable=True)[:, :self.kmax].contiguous()
 
     def union(self, other):
-        return TouchedBlocks(self.bitmap | other.bitmap)
+        out = TouchedBlocks(self.bitmap | other.bitmap, kmax=None if self.bound is None else max(self.kmax, other.kmax))
+        if self.overflow is not None and other.overflow is not None:
+            out.overflow = out.overflow | self.overflow | other.overflow
+        return out
 
     @property
     def fraction(self):
@@ -239,21 +253,22 @@ class GradientBucket(_Flat):
         dist.all_gather_into_tensor(self.flat, mine, group=group)
         return self.flat
 
-    def touched_blocks(self, group=None):
-        """The step's TouchedBlocks: local `seen` per block, max-reduced over the ranks (world * nb int32: tiny)."""
+    def touched_blocks(self, group=None, kmax=None):
+        """The step's TouchedBlocks: local `seen` per block, max-reduced over the ranks (world * nb int32: tiny).
+        kmax: see TouchedBlocks (a bound instead of a read-back)."""
         assert self.block_rows > 0, "construct the bucket with block_rows > 0 for the touched-block exchange"
         assert self.track_seen, "the touched-block exchange reads the seen counts"
         nb = self.Pr // self.block_rows
         flags = (self.seen.view(self.world, nb, self.block_rows).amax(-1) > 0).to(torch.int32)
         if _active(self.world):
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
-        return TouchedBlocks(flags > 0)
+        return TouchedBlocks(flags > 0, kmax=kmax)
 
     def _columns(self):
         """(name, [P_pad * c] block, c) of everything that is exchanged: the attribute gradients and the seen counts."""
         return [(name, self.blocks[name], c) for name, c in self.layout] + ([("seen", self.seen, 1)] if self.track_seen else [])
 
-    def reduce_scatter_rows(self, rank, group=None, compact=False):
+    def reduce_scatter_rows(self, rank, group=None, compact=False, kmax=None):
         """Owner-computes exchange, first half: -> dict name -> [Pr, c] = the sum over ranks of this rank's rows of every
         attribute, plus "seen" -> [Pr] (how many views of all ranks saw each of them).  One reduce-scatter per column
         block, issued back to back.  compact: only the blocks some rank touched travel (TouchedBlocks; needs
@@ -265,7 +280,7 @@ class GradientBucket(_Flat):
                 out["seen"] = self.seen[:self.Pr]
             return out
         dev, out = self.flat.device, {}
-        tb = self.touched_blocks(group) if compact and self.block_rows > 0 and self.track_seen else None
+        tb = self.touched_blocks(group, kmax=kmax) if compact and self.block_rows > 0 and self.track_seen else None
         if tb is not None and tb.fraction >= self.DENSE_ABOVE:
             tb = None
         if tb is None:
@@ -385,6 +400,7 @@ class StepExchange:
         self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.world > 1) else None
         self._shards = [None] * self.parts
         self.touched = None
+        self._overflow = None     # device flag: a bounded touched-block exchange dropped blocks (compact_overflowed)
 
     def bucket_of(self, view, n_views):
         """The bucket view `view` of the rank's `n_views` accumulates into (consecutive views share a group)."""
@@ -434,15 +450,27 @@ class StepExchange:
         return {"reduce_scatter_ms_per_step": tot["reduce_scatter"] / n, "exposed_join_ms_per_step": tot["join"] / n,
                 "all_gather_ms_per_step": tot["all_gather"] / n, "collectives_timed": len(self._ev["reduce_scatter"])}
 
-    def launch(self, part, compact=False):
+    def launch(self, part, compact=False, kmax=None):
+        """kmax (compact only): size the touched-block collectives from this bound instead of a read-back
+        (TouchedBlocks); check ``compact_overflowed()`` where the step synchronises anyway."""
         b = self.buckets[part]
         if self.side is None:
-            self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact)
-            return
-        self.side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.side):
-            with self._timed("reduce_scatter", self.side):
-                self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact)
+            self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact, kmax=kmax)
+        else:
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side):
+                with self._timed("reduce_scatter", self.side):
+                    self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact, kmax=kmax)
+        if b.touched is not None and b.touched.overflow is not None:
+            self._overflow = b.touched.overflow if self._overflow is None else (self._overflow | b.touched.overflow)
+
+    def compact_overflowed(self, reset=True):
+        """Did a bounded touched-block exchange since the last call drop blocks (some owner's touched list was longer than
+        the bound)?  One device -> host read: call it where the step synchronises anyway."""
+        over = bool(self._overflow.item()) if self._overflow is not None else False
+        if reset:
+            self._overflow = None
+        return over
 
     def finish(self):
         """-> dict name -> [Pr, c] (+ "seen" -> [Pr]): this rank's rows of the sum over all groups and ranks."""

@@ -314,6 +314,19 @@ def _blocks_worker(rank, world, port, out):
             res[compact] = {k: v.clone() for k, v in rows.items()}
             if compact:
                 res["kmax"], res["nb"] = b.touched.kmax, b.touched.nb
+        # bounded form (no read-back): a bound that holds gives the exact result and no overflow flag; a bound that is
+        # too small raises the flag (the exchange dropped blocks: the caller repeats the step)
+        for bound, key in ((5, "bounded_ok"), (2, "bounded_small")):
+            ex = StepExchange(P, "cpu", world, rank, sh_coeffs=4, parts=1, block_rows=B)
+            b = ex.buckets[0]
+            for name, c in b.layout:
+                gr = torch.zeros(P, c)
+                gr[lo:lo + 41] = torch.randn(41, c, generator=torch.Generator().manual_seed(11 + rank))
+                b.views[name].copy_(gr.reshape(b.views[name].shape))
+            b.mark_seen(radii)
+            ex.launch(0, compact=True, kmax=bound)
+            rows = ex.finish()
+            res[key] = ({k: v.clone() for k, v in rows.items()}, b.touched.kmax, ex.compact_overflowed())
         # replicated-optimizer form through StepExchange: two groups, then every rank holds the whole sum
         ex = StepExchange(P, "cpu", world, rank, parts=2, block_rows=B)
         for part, b in enumerate(ex.buckets):
@@ -341,6 +354,11 @@ def test_touched_block_exchange_moves_only_touched_blocks(tmp_path):
         for k in got[r][False]:
             assert torch.equal(got[r][False][k], got[r][True][k]), (r, k)
         assert float(got[r][True]["seen"].sum()) == 41.0          # each owner's 41 seen rows, once each
+        rows_ok, k_ok, over_ok = got[r]["bounded_ok"]
+        assert k_ok == 5 and not over_ok
+        for k in got[r][False]:
+            assert torch.equal(got[r][False][k], rows_ok[k]), (r, k)
+        assert got[r]["bounded_small"][1] == 2 and got[r]["bounded_small"][2]      # three touched blocks, bound 2: flagged
         assert torch.equal(got[r]["full"], torch.full((1000, 3), 9.0))   # (1 + 2) * (1 + 2): both ranks, both groups
 
 

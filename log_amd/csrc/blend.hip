@@ -18,6 +18,30 @@
 // v_permlane32_swap / v_permlane16_swap + DPP row-rotate tree (28 VALU ops for 9 sums) and committed with
 // 3 atomic instructions -- not 9 atomics per (pixel, Gaussian) as in the third-party kernel.
 #include "common.hpp"
+// Occupancy hints (waves per SIMD the register allocator aims for), per kernel: compile-time so that A/B builds
+// (`python -m log_amd.build <variant> -DLR_OCC_BWD_ROWS_WAVES=5`) can measure them; empty = the allocator's own choice.
+#define LR_OCC_ATTR(n) __attribute__((amdgpu_waves_per_eu(n)))
+#ifdef LR_OCC_BWD_ROWS_WAVES
+#define LR_OCC_BWD_ROWS LR_OCC_ATTR(LR_OCC_BWD_ROWS_WAVES)
+#else
+#define LR_OCC_BWD_ROWS
+#endif
+#ifdef LR_OCC_FWD_ROWS_WAVES
+#define LR_OCC_FWD_ROWS LR_OCC_ATTR(LR_OCC_FWD_ROWS_WAVES)
+#else
+#define LR_OCC_FWD_ROWS
+#endif
+#ifdef LR_OCC_BWD_WAVES
+#define LR_OCC_BWD LR_OCC_ATTR(LR_OCC_BWD_WAVES)
+#else
+#define LR_OCC_BWD
+#endif
+#ifdef LR_OCC_FWD_WAVES
+#define LR_OCC_FWD LR_OCC_ATTR(LR_OCC_FWD_WAVES)
+#else
+#define LR_OCC_FWD
+#endif
+
 
 // blockIdx -> tile.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness).
 //   mode 0: identity -- consecutive tiles round-robin over the XCDs: best balance, no L2 sharing;
@@ -93,7 +117,7 @@ LR_DEV bool lr_support_hits(const float4 g0, const float2 g1, float x0, float x1
 }
 
 template <bool EXTRAS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) LR_OCC_FWD
 lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
@@ -268,7 +292,7 @@ LR_DEV void lr_reduce9(const float v[9], float& r0, float& r1, float& r2) {
   r2 = lr_row_sum(lr_swap_add16(s8, s8));
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) LR_OCC_BWD
 lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
@@ -458,7 +482,7 @@ LR_DEV float lr_quad_total(float x) {   // every lane of a quad <- the quad's to
   return x + lr_dpp_perm<0x4E>(x);      // quad_perm [2,3,0,1]
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) LR_OCC_BWD_ROWS
 lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          const float* __restrict__ final_T, const int* __restrict__ n_contrib,
@@ -655,7 +679,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
 // (row, Gaussian) visit (row maximum by four DPP steps), and the Gaussian's accumulator row is cleared by the row's
 // first four lanes.
 template <bool EXTRAS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) LR_OCC_FWD_ROWS
 lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,

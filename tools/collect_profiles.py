@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -46,6 +46,11 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
            subprocess.check_output([sys.executable, pm, sq], text=True), "",
            "## TCC FETCH_SIZE / WRITE_SIZE (KB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, see "
            "MI355X_MICROARCH.md)", subprocess.check_output([sys.executable, pm, fe, wr], text=True)]
+    for name, title in (("mix", "instruction mix (SQ_INSTS_VALU_*_F32: wave instructions)"),
+                        ("mix2", "instruction mix (integer / scalar memory / LDS / vector stores)"), ("tcc", "L2 requests (TCC_*_sum)")):
+        extra = os.path.join(G, f"{tag}_pmc_{name}", "h30_counter_collection.csv")
+        if os.path.exists(extra):
+            out += ["", "## " + title, subprocess.check_output([sys.executable, pm, extra], text=True)]
     open(os.path.join(P, f"{tag}_pmc.md"), "w").write("\n".join(out))
 
     def load(path, counter):

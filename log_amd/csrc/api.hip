@@ -29,7 +29,7 @@ void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, int speculative, int band, int batched, hipStream_t s);
+                    int zero_block_floats, int rebased, int speculative, int band, int batch_size, hipStream_t s);
 void lr_launch_tile_rows(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                          uint32_t* rows, hipStream_t s);
 void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s);
@@ -106,7 +106,7 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
     {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint (none: row-split from LOGRAST_HELPER_MIN_N Gaussians)"},
     {"LOGRAST_FWD_ROWS", 2, 0, 2, "compositing: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint"},
-    {"LOGRAST_FILL_STAGED", 1, 0, 1, "bucket fill of batched full views: 1 = the batch's slot-table row staged in LDS by workgroups of 1024 consecutive Gaussians, 0 = one table look-up per tile instance"},
+    {"LOGRAST_FILL_STAGED", 2, 0, 4, "bucket fill of batched full views: K = the batch's slot-table row staged in LDS by workgroups of up to K x 1024 consecutive Gaussians (K per thread), 0 = one table look-up per tile instance"},
     {"LOGRAST_FILL_PER_THREAD", 1, 1, 4, "bucket fill: Gaussians per thread (their fill records are requested together): 1, 2 or 4"},
     {"LOGRAST_BAND_SPARSE", 1, 0, 1, "band views (tile_row_begin/end a proper part of the grid): 1 = the band projection (Gaussians without a rect cost 44 bytes, survivors compacted into full waves), 0 = the full-view kernel"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
@@ -157,7 +157,7 @@ static LrBatching lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t
   uint32_t planes = (g + 32767u) / 32768u;
   if (planes < 1u) planes = 1u;
   if (planes > smax) planes = smax;
-  uint32_t b = ((g + planes - 1u) / planes + 1023u) / 1024u * 1024u;
+  uint32_t b = ((g + planes - 1u) / planes + 2047u) / 2048u * 2048u;   // (multiples of 2048: a fill workgroup of 1024 threads x 2 stays inside one batch)
   if (b < 4096u) b = 4096u;
   if (b > 32768u) b = 32768u;
   return {b, planes};
@@ -359,7 +359,7 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   const uint32_t fill_batch = lr_pick_batch(n, tiles, (uint32_t)v.gx, (uint32_t)v.gy).batch;
   lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, max_tile_len, status,
                  zero_n, zero_floats > 0 ? zero_block : nullptr, zero_floats,
-                 lr_big_input(n) ? 1 : 0, speculative, lr_band_sparse(v, (int)fill_batch) ? 1 : 0, fill_batch ? 1 : 0, s);
+                 lr_big_input(n) ? 1 : 0, speculative, lr_band_sparse(v, (int)fill_batch) ? 1 : 0, (int)fill_batch, s);
   static const int stop_after_fill = LR_EXPERIMENT_INT("LOGRAST_STOP_AFTER_FILL", 0);   // experiment builds (tools/fill_probe.py)
   if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);

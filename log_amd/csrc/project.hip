@@ -1406,6 +1406,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 // microseconds of each other) instead of ~1500 scattered look-ups.  Rects of more than 4 tiles as in lr_fill_kernel.
 #define LR_FILL_STAGED_ROWS 1024
 #define LR_FILL_STAGED_MAX_TILES 12288      // 48 KB of LDS: three workgroups per CU
+template <int K>   // K x 1024 consecutive Gaussians per workgroup (K Gaussians per thread, their fill records requested together)
 __global__ void __launch_bounds__(LR_FILL_STAGED_ROWS, 8)   // 64 VGPRs: two workgroups per CU
 lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                       uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
@@ -1414,27 +1415,31 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
   extern __shared__ uint32_t lr_slot_row[];                       // [tiles]: absolute first slot of this batch's run in every tile
   const uint32_t per_xcd = gridDim.x >> 3;                        // grid is a multiple of 8 (XCD-contiguous order: lr_fill_kernel)
   const uint32_t vblock = xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-  const uint32_t e = vblock * LR_FILL_STAGED_ROWS + threadIdx.x;
-  const bool vis = e < (uint32_t)N;
-  const int i = (int)e;
-  if (vis && !LR_ABLATED(1)) {                                    // (small inputs: the zero-fills live here, see lr_fill_kernel)
-    if (zero_n) zero_n[e] = 0.f;
-    for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + e] = 0.f;
-  }
+  const uint32_t first = vblock * (LR_FILL_STAGED_ROWS * K);      // the workgroup's first Gaussian (< N unless the grid's padding)
   const bool tile_cull = state[LR_HDR_CULL] != 0u;
   const bool over = lr_fill_verdict(state, capacity, max_len_hint, status, speculative);
-  if (over) return;
   const uint32_t batch = state[LR_HDR_BATCH];
   const uint4* __restrict__ fillrec = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
-  uint4 fr = uint4{0u, 0xffffffffu, 0u, 0u};
-  if (vis) {
-    typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
-    const lr_u4v t4 = __builtin_nontemporal_load(reinterpret_cast<const lr_u4v*>(fillrec + e));
-    fr = uint4{t4.x, t4.y, t4.z, t4.w};
+  uint4 fr_k[K];
+#pragma unroll
+  for (int u = 0; u < K; u++) {
+    const uint32_t e = first + u * LR_FILL_STAGED_ROWS + threadIdx.x;
+    fr_k[u] = uint4{0u, 0xffffffffu, 0u, 0u};
+    if (e < (uint32_t)N) {
+      if (!LR_ABLATED(1)) {                                       // (small inputs: the zero-fills live here, see lr_fill_kernel)
+        if (zero_n) zero_n[e] = 0.f;
+        for (int k = 0; k < zero_block_floats; k++) zero_block[(size_t)k * N + e] = 0.f;
+      }
+      if (!over) {
+        typedef uint32_t lr_u4v __attribute__((ext_vector_type(4)));
+        const lr_u4v t4 = __builtin_nontemporal_load(reinterpret_cast<const lr_u4v*>(fillrec + e));
+        fr_k[u] = uint4{t4.x, t4.y, t4.z, t4.w};
+      }
+    }
   }
+  if (over) return;
   {
-    const uint32_t first = vblock * LR_FILL_STAGED_ROWS;          // the workgroup's first Gaussian (< N unless the grid's padding)
-    const uint32_t b = (first < (uint32_t)N ? first : 0u) / batch;
+    const uint32_t b = (first < (uint32_t)N ? first : 0u) / batch;   // (batches are multiples of K x 1024 Gaussians: lr_launch_fill)
     const uint32_t* __restrict__ row = state + lr_basetab_off(tiles) + (size_t)b * tiles;
     const uint32_t* __restrict__ off = state + lr_offsets_off(tiles);
     if (((tiles | lr_basetab_off(tiles) | lr_offsets_off(tiles)) & 3u) == 0u) {   // rows start on 16-byte boundaries (1080p: yes)
@@ -1453,42 +1458,50 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
   __syncthreads();
   uint32_t* cursor = state + lr_cursor_off(tiles);
   const int lane = threadIdx.x & 63;
-  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  uint32_t h0 = 0xffffu, h1 = 0xffffu, h2 = 0xffffu, h3 = 0xffffu;
-  if (fr.y != 0xffffffffu) {
-    x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
-    if (fr.y & (1u << 30)) {
-      x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
-    } else {
-      x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
-      h0 = fr.z & 0xffffu; h1 = fr.z >> 16; h2 = fr.w & 0xffffu; h3 = fr.w >> 16;
+#pragma unroll
+  for (int u = 0; u < K; u++) {
+    const uint32_t e = first + u * LR_FILL_STAGED_ROWS + threadIdx.x;
+    const bool vis = e < (uint32_t)N;
+    const int i = (int)e;
+    const uint4 fr = fr_k[u];
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    uint32_t h0 = 0xffffu, h1 = 0xffffu, h2 = 0xffffu, h3 = 0xffffu;
+    if (fr.y != 0xffffffffu) {
+      x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
+      if (fr.y & (1u << 30)) {
+        x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
+      } else {
+        x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
+        h0 = fr.z & 0xffffu; h1 = fr.z >> 16; h2 = fr.w & 0xffffu; h3 = fr.w >> 16;
+      }
     }
-  }
-  const int w = x1 - x0, h = y1 - y0, nt = vis ? w * h : 0;
-  const uint64_t key = ((uint64_t)fr.x << 32) | (uint32_t)i;
-  if (nt > 0 && nt <= LR_RANKED_TILES) {
-    // tile k of a rect of <= 4 tiles: one row (w >= nt), one column (w == 1) or 2x2 -- as in lr_project_batched_kernel
-    const bool col = w == 1, sq = (w == 2) && (nt == 4);
-    const int t0 = y0 * gx + x0;
-    const int d1 = col ? gx : 1, d2 = col ? 2 * gx : (sq ? gx : 2), d3 = col ? 3 * gx : (sq ? gx + 1 : 3);
-    // all look-ups (LDS) before the first store
-    const uint32_t p0 = h0 != 0xffffu ? lr_slot_row[t0] + h0 : 0xffffffffu;
-    const uint32_t p1 = (nt > 1 && h1 != 0xffffu) ? lr_slot_row[t0 + d1] + h1 : 0xffffffffu;
-    const uint32_t p2 = (nt > 2 && h2 != 0xffffu) ? lr_slot_row[t0 + d2] + h2 : 0xffffffffu;
-    const uint32_t p3 = (nt > 3 && h3 != 0xffffu) ? lr_slot_row[t0 + d3] + h3 : 0xffffffffu;
-    if (!LR_ABLATED(2)) {
-      if (p0 != 0xffffffffu) keys[p0] = key;
-      if (p1 != 0xffffffffu) keys[p1] = key;
-      if (p2 != 0xffffffffu) keys[p2] = key;
-      if (p3 != 0xffffffffu) keys[p3] = key;
+    const int w = x1 - x0, h = y1 - y0, nt = vis ? w * h : 0;
+    const uint64_t key = ((uint64_t)fr.x << 32) | (uint32_t)i;
+    if (nt > 0 && nt <= LR_RANKED_TILES) {
+      // tile k of a rect of <= 4 tiles: one row (w >= nt), one column (w == 1) or 2x2 -- as in lr_project_batched_kernel
+      const bool col = w == 1, sq = (w == 2) && (nt == 4);
+      const int t0 = y0 * gx + x0;
+      const int d1 = col ? gx : 1, d2 = col ? 2 * gx : (sq ? gx : 2), d3 = col ? 3 * gx : (sq ? gx + 1 : 3);
+      // all look-ups (LDS) before the first store
+      const uint32_t p0 = h0 != 0xffffu ? lr_slot_row[t0] + h0 : 0xffffffffu;
+      const uint32_t p1 = (nt > 1 && h1 != 0xffffu) ? lr_slot_row[t0 + d1] + h1 : 0xffffffffu;
+      const uint32_t p2 = (nt > 2 && h2 != 0xffffu) ? lr_slot_row[t0 + d2] + h2 : 0xffffffffu;
+      const uint32_t p3 = (nt > 3 && h3 != 0xffffu) ? lr_slot_row[t0 + d3] + h3 : 0xffffffffu;
+      if (!LR_ABLATED(2)) {
+        if (p0 != 0xffffffffu) keys[p0] = key;
+        if (p1 != 0xffffffffu) keys[p1] = key;
+        if (p2 != 0xffffffffu) keys[p2] = key;
+        if (p3 != 0xffffffffu) keys[p3] = key;
+      }
     }
+    lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
   }
-  lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
 }
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, int speculative, int band, int batched, hipStream_t s) {
+                    int zero_block_floats, int rebased, int speculative, int band, int batch_size, hipStream_t s) {
+  const int batched = batch_size > 0;
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
@@ -1496,18 +1509,32 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
 #ifdef LR_EXPERIMENTS
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores, 4 no 5-16-tile rects, 8 no larger rects
 #endif
-  LR_KNOB(staged_knob, "LOGRAST_FILL_STAGED", 1);
+  LR_KNOB(staged_knob, "LOGRAST_FILL_STAGED", 2);   // 0 = off, K = up to K x 1024 Gaussians per workgroup (K per thread)
   if (staged_knob && batched && !band && tiles <= LR_FILL_STAGED_MAX_TILES) {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel<4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
       attr_set = true;
     }
-    const int blocks = ((N + LR_FILL_STAGED_ROWS - 1) / LR_FILL_STAGED_ROWS + 7) & ~7;
-    hipLaunchKernelGGL(lr_fill_staged_kernel, dim3(blocks), dim3(LR_FILL_STAGED_ROWS), sizeof(uint32_t) * ((tiles + 3u) & ~3u), s,
-                       N, gx, reinterpret_cast<const float4*>(geom), state, tiles, keys, capacity, max_len_hint, status,
-                       zero_n, zero_block, zero_block_floats, xcd_order, rebased, speculative LR_ABLATE_PASS(ablate));
+    // a workgroup's K x 1024 Gaussians share one table row: the largest K <= the knob that divides the batch
+    const int per_batch = batch_size / LR_FILL_STAGED_ROWS;
+    int K = staged_knob > 4 ? 4 : staged_knob;
+    while (K > 1 && (batch_size % LR_FILL_STAGED_ROWS != 0 || per_batch % K != 0)) K--;
+    const int rows = LR_FILL_STAGED_ROWS * K;
+    const int blocks = ((N + rows - 1) / rows + 7) & ~7;
+#define LR_FILL_ST(KK) hipLaunchKernelGGL(lr_fill_staged_kernel<KK>, dim3(blocks), dim3(LR_FILL_STAGED_ROWS),                 \
+                       sizeof(uint32_t) * ((tiles + 3u) & ~3u), s, N, gx, reinterpret_cast<const float4*>(geom), state, tiles,  \
+                       keys, capacity, max_len_hint, status, zero_n, zero_block, zero_block_floats, xcd_order, rebased,         \
+                       speculative LR_ABLATE_PASS(ablate))
+    if (K == 4) LR_FILL_ST(4); else if (K == 3) LR_FILL_ST(3); else if (K == 2) LR_FILL_ST(2); else LR_FILL_ST(1);
+#undef LR_FILL_ST
     lr_prof_end(LRK_FILL, s);
     return;
   }

@@ -64,6 +64,7 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
     f, w = load(fe, "FETCH_SIZE"), load(wr, "WRITE_SIZE")
     names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_bwd_rows_kernel": "blend_bwd", "lr_blend_fwd_kernel<true>": "blend_fwd",
              "lr_blend_fwd_rows_kernel<true>": "blend_fwd", "lr_project_kernel": "project", "lr_project_batched_kernel": "project",
+             "lr_project_batched_kernel<false>": "project", "lr_fill_staged_kernel": "fill_keys",
              "lr_fill_kernel": "fill_keys", "lr_fill_kernel<1>": "fill_keys", "lr_project_bwd_kernel<true, true, false, true>": "project_bwd",
              "lr_project_bwd_kernel<true, true, false, true, false>": "project_bwd",
              "lr_project_bwd_kernel<true, true, false, true, true>": "project_bwd",

@@ -429,18 +429,31 @@ LR_DEV uint32_t lr_after(uint32_t off, const float a[3], float b0, float b1, flo
   return off;
 }
 // wm / ws / wr / wc6: the arrays at the wave's first Gaussian (wave-uniform: scalar registers) + the lane's offset
+// (LR_PROJECT_NT_LOADS: the inputs -- read once per view -- as non-temporal loads; measured, no gain: profiles/r04_isa_project.md)
+LR_DEV float lr_in(const float* p) {
+#ifdef LR_PROJECT_NT_LOADS
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 template <bool COV3D>
 LR_DEV LrGeo lr_load_geo(const float* __restrict__ wm, const float* __restrict__ ws, const float* __restrict__ wr,
                          const float* __restrict__ wc6, uint32_t ulane) {
   LrGeo g;
   const size_t lane = ulane;
-  g.p[0] = wm[3 * lane]; g.p[1] = wm[3 * lane + 1]; g.p[2] = wm[3 * lane + 2];
+  g.p[0] = lr_in(wm + 3 * lane); g.p[1] = lr_in(wm + 3 * lane + 1); g.p[2] = lr_in(wm + 3 * lane + 2);
   if (COV3D) {
     g.s[0] = wc6[6 * lane]; g.s[1] = wc6[6 * lane + 1]; g.s[2] = wc6[6 * lane + 2];
     g.q = float4{wc6[6 * lane + 3], wc6[6 * lane + 4], wc6[6 * lane + 5], 0.f};
   } else {
-    g.s[0] = ws[3 * lane]; g.s[1] = ws[3 * lane + 1]; g.s[2] = ws[3 * lane + 2];
+    g.s[0] = lr_in(ws + 3 * lane); g.s[1] = lr_in(ws + 3 * lane + 1); g.s[2] = lr_in(ws + 3 * lane + 2);
+#ifdef LR_PROJECT_NT_LOADS
+    const lr_f4v q = __builtin_nontemporal_load(reinterpret_cast<const lr_f4v*>(wr) + lane);
+    g.q = float4{q.x, q.y, q.z, q.w};
+#else
     g.q = reinterpret_cast<const float4*>(wr)[lane];
+#endif
   }
   return g;
 }
@@ -501,6 +514,23 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   // (the first inputs are "used" here, i.e. waited for in front of the loop: see the wait at the loop's end)
   asm volatile("" : "+v"(geo.p[0]), "+v"(geo.p[1]), "+v"(geo.p[2]), "+v"(geo.s[0]), "+v"(geo.s[1]), "+v"(geo.s[2]),
                "+v"(geo.q.x), "+v"(geo.q.y), "+v"(geo.q.z), "+v"(geo.q.w), "+v"(nx_op), "+v"(nx_c0), "+v"(nx_c1), "+v"(nx_c2));
+#ifdef LR_EXPERIMENTS
+  // bits 8 + 64: memory accesses only, and every wave streams TWO blocks per iteration (its own and one half a workgroup
+  // range further on), each prefetched an iteration ahead: twice the bytes in flight per wave -- is the loop bound by
+  // memory-level parallelism?
+  LrGeo geo2 = geo;
+  float sx_op = 0.f, sx_c0 = 0.f, sx_c1 = 0.f, sx_c2 = 0.f;
+  int half = 0;
+  if (LR_ABLATED(64)) {
+    half = ((i_end - i_begin) / 2) / LR_BATCH_THREADS * LR_BATCH_THREADS;
+    iend = i_begin + half;
+    const size_t j0 = (size_t)lr_sgpr((uint32_t)min(iw + half, last_first));
+    geo2 = lr_load_geo<COV3D>(means + 3 * j0, scales + 3 * j0, rots + 4 * j0, COV3D ? cov6 + 6 * j0 : nullptr, ulane);
+    sx_op = (opac + j0)[ulane];
+    sx_c0 = (colors + 3 * j0)[3 * (size_t)ulane]; sx_c1 = (colors + 3 * j0)[3 * (size_t)ulane + 1];
+    sx_c2 = (colors + 3 * j0)[3 * (size_t)ulane + 2];
+  }
+#endif
   for (; iw + 64 <= iend; iw += istep) {
     const size_t iws = (size_t)lr_sgpr((uint32_t)iw);        // (scalar) the Gaussian of lane 0
     if (left_in_plane == 0) { plane++; left_in_plane = B / LR_BATCH_THREADS; }
@@ -530,9 +560,9 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
     const float in_op = nx_op, in_c0 = nx_c0, in_c1 = nx_c1, in_c2 = nx_c2;
     {
       const size_t in = (size_t)lr_sgpr((uint32_t)min(iw + istep, last_first));   // (past the workgroup's end: loaded, never used)
-      nx_op = (opac + in)[olane];
+      nx_op = lr_in(opac + in + olane);
       const float* __restrict__ wc = colors + 3 * in;
-      nx_c0 = wc[3 * (size_t)olane]; nx_c1 = wc[3 * (size_t)olane + 1]; nx_c2 = wc[3 * (size_t)olane + 2];
+      nx_c0 = lr_in(wc + 3 * (size_t)olane); nx_c1 = lr_in(wc + 3 * (size_t)olane + 1); nx_c2 = lr_in(wc + 3 * (size_t)olane + 2);
       geo = lr_load_geo<COV3D>(means + 3 * in, scales + 3 * in, rots + 4 * in, COV3D ? cov6 + 6 * in : nullptr, olane);
     }
     // ---- part 2: EWA, conic, radius, rect ----
@@ -544,6 +574,23 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
         lr_out_store(&(fillrec + iws)[lane], uint4{__float_as_uint(tz), 0xffffffffu, 0u, 0u});
       }
       if (!LR_ABLATED(1)) lr_store_records(geom + LR_REC_QUADS * iws, lane, a0, a1, a2, a3);
+#ifdef LR_EXPERIMENTS
+      if (LR_ABLATED(64)) {
+        const size_t js = (size_t)lr_sgpr((uint32_t)min(iw + half, last_first));
+        float4 b0 = {geo2.p[0], geo2.p[1], geo2.p[2], geo2.s[0]}, b1 = {geo2.s[1], geo2.s[2], geo2.q.x, geo2.q.y},
+               b2 = {geo2.q.z, geo2.q.w, sx_op, sx_c0}, b3 = {sx_c1, sx_c2, 0.f, 0.f};
+        const size_t jn = (size_t)lr_sgpr((uint32_t)min(iw + istep + half, last_first));
+        sx_op = (opac + jn)[ulane];
+        sx_c0 = (colors + 3 * jn)[3 * (size_t)ulane]; sx_c1 = (colors + 3 * jn)[3 * (size_t)ulane + 1];
+        sx_c2 = (colors + 3 * jn)[3 * (size_t)ulane + 2];
+        geo2 = lr_load_geo<COV3D>(means + 3 * jn, scales + 3 * jn, rots + 4 * jn, COV3D ? cov6 + 6 * jn : nullptr, ulane);
+        if (!LR_ABLATED(2)) {
+          lr_out_store(&(radii + js)[lane], (int)__float_as_uint(b0.x) & 1);
+          lr_out_store(&(fillrec + js)[lane], uint4{__float_as_uint(b0.y), 0xffffffffu, 0u, 0u});
+        }
+        if (!LR_ABLATED(1)) lr_store_records(geom + LR_REC_QUADS * js, lane, b0, b1, b2, b3);
+      }
+#endif
       continue;
     }
     bool valid = tz > 0.2f;

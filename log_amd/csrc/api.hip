@@ -29,7 +29,7 @@ void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, int speculative, int band, int batch_size, hipStream_t s);
+                    int zero_block_floats, int rebased, int speculative, int band, int staged_k, hipStream_t s);
 void lr_launch_tile_rows(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                          uint32_t* rows, hipStream_t s);
 void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s);
@@ -106,7 +106,7 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_PROJECT_BLOCKS", 512, 64, 65536, "grid cap of the unbatched projection kernel"},
     {"LOGRAST_BWD_ROWS", 2, 0, 2, "reverse walk: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint (none: row-split from LOGRAST_HELPER_MIN_N Gaussians)"},
     {"LOGRAST_FWD_ROWS", 2, 0, 2, "compositing: 1 = row-split form (four 4x4 blocks per wave), 0 = one quadrant per wave, 2 = the view's walk_form hint"},
-    {"LOGRAST_FILL_STAGED", 2, 0, 4, "bucket fill of batched full views: K = the batch's slot-table row staged in LDS by workgroups of up to K x 1024 consecutive Gaussians (K per thread), 0 = one table look-up per tile instance"},
+    {"LOGRAST_FILL_STAGED", 2, 0, 3, "bucket fill of batched full views: K = the batch's slot-table row staged in LDS by workgroups of up to K x 1024 consecutive Gaussians (K per thread), 0 = one table look-up per tile instance"},
     {"LOGRAST_FILL_PER_THREAD", 1, 1, 4, "bucket fill: Gaussians per thread (their fill records are requested together): 1, 2 or 4"},
     {"LOGRAST_BAND_SPARSE", 1, 0, 1, "band views (tile_row_begin/end a proper part of the grid): 1 = the band projection (Gaussians without a rect cost 44 bytes, survivors compacted into full waves), 0 = the full-view kernel"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
@@ -163,6 +163,21 @@ static LrBatching lr_pick_batch(int32_t n, uint32_t tiles, uint32_t gx, uint32_t
   return {b, planes};
 }
 static uint32_t lr_batches(int32_t n, uint32_t batch) { return batch ? ((uint32_t)n + batch - 1u) / batch : 0u; }
+// Does the fill of this view stage the batch's slot-table row in LDS (project.hip: lr_fill_staged_kernel), and with how
+// many Gaussians per thread?  0 = no (unbatched, band form, tile grids whose row does not fit: the look-up form).  K x 1024
+// consecutive Gaussians of a workgroup share one table row: the largest K <= the knob that divides the batch.  Both stages
+// of a forward ask with the same arguments: stage 1 skips lr_rebase_kernel when the fill adds `offsets[]` while staging.
+#define LR_FILL_STAGED_ROWS_HOST 1024
+#define LR_FILL_STAGED_MAX_TILES_HOST 12288
+static int lr_fill_staged_k(const LrView& v, uint32_t tiles, uint32_t batch) {
+  LR_KNOB(staged_knob, "LOGRAST_FILL_STAGED", 2);
+  if (staged_knob <= 0 || batch == 0u || tiles > LR_FILL_STAGED_MAX_TILES_HOST || lr_band_sparse(v, (int)batch)) return 0;
+  if (batch % LR_FILL_STAGED_ROWS_HOST != 0u) return 0;
+  const int per_batch = (int)(batch / LR_FILL_STAGED_ROWS_HOST);
+  int K = staged_knob > 3 ? 3 : staged_knob;
+  while (K > 1 && per_batch % K != 0) K--;
+  return K;
+}
 // Two helper passes pay for their launch only on large inputs (each is ~10 us at 1 M Gaussians, where the work they
 // save is smaller than that): lr_rebase_kernel (absolute slot table for the fill) and the touched-only clearing of
 // dL/dconic.  Both stages of a forward evaluate this with the same n.
@@ -322,7 +337,7 @@ static int lr_stage1(const LrView& v, int32_t n, const float* means3d, const flo
   lr_launch_project(v, n, means3d, scales, rotations, opacities, colors, radii, geom, st + lr_ranked_off(tiles),
                     st + big_off, st, st + lr_basetab_off(tiles), (int)bt.batch, (int)bt.planes, lr_tile_cull(), s);
   lr_launch_scan(st, tiles, cs, big_off, s);
-  if (lr_big_input(n)) {
+  if (lr_big_input(n) && lr_fill_staged_k(v, tiles, bt.batch) == 0) {   // (the staged fill adds offsets[] itself)
     const bool band = lr_band_sparse(v, (int)bt.batch);   // only the band's tiles have slot-table entries
     lr_launch_rebase(st, tiles, lr_batches(n, bt.batch), band ? (uint32_t)(v.ty0 * v.gx) : 0u,
                      band ? (uint32_t)(v.ty1 * v.gx) : tiles, s);
@@ -357,9 +372,10 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
     zero_n = nullptr; zero_floats = 0;
   }
   const uint32_t fill_batch = lr_pick_batch(n, tiles, (uint32_t)v.gx, (uint32_t)v.gy).batch;
+  const int staged_k = lr_fill_staged_k(v, tiles, fill_batch);
   lr_launch_fill(n, v.gx, geom, st, tiles, keys, capacity, max_tile_len, status,
                  zero_n, zero_floats > 0 ? zero_block : nullptr, zero_floats,
-                 lr_big_input(n) ? 1 : 0, speculative, lr_band_sparse(v, (int)fill_batch) ? 1 : 0, (int)fill_batch, s);
+                 (lr_big_input(n) && staged_k == 0) ? 1 : 0, speculative, lr_band_sparse(v, (int)fill_batch) ? 1 : 0, staged_k, s);
   static const int stop_after_fill = LR_EXPERIMENT_INT("LOGRAST_STOP_AFTER_FILL", 0);   // experiment builds (tools/fill_probe.py)
   if (stop_after_fill) return LOGRAST_OK;
   lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);

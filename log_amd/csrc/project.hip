@@ -1502,29 +1502,36 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
       for (uint32_t t = threadIdx.x; t < tiles; t += LR_FILL_STAGED_ROWS) lr_slot_row[t] = row[t] + (rebased ? 0u : off[t]);
     }
   }
-  __syncthreads();
   uint32_t* cursor = state + lr_cursor_off(tiles);
   const int lane = threadIdx.x & 63;
+  int x0_k[K], y0_k[K], w_k[K], h_k[K], nt_k[K];
+  uint32_t hA_k[K], hB_k[K];                                     // the four 16-bit ranks of a rect of <= 4 tiles
 #pragma unroll
   for (int u = 0; u < K; u++) {
     const uint32_t e = first + u * LR_FILL_STAGED_ROWS + threadIdx.x;
-    const bool vis = e < (uint32_t)N;
-    const int i = (int)e;
     const uint4 fr = fr_k[u];
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    uint32_t h0 = 0xffffu, h1 = 0xffffu, h2 = 0xffffu, h3 = 0xffffu;
+    hA_k[u] = 0xffffffffu; hB_k[u] = 0xffffffffu;
     if (fr.y != 0xffffffffu) {
       x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
       if (fr.y & (1u << 30)) {
         x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
       } else {
         x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
-        h0 = fr.z & 0xffffu; h1 = fr.z >> 16; h2 = fr.w & 0xffffu; h3 = fr.w >> 16;
+        hA_k[u] = fr.z; hB_k[u] = fr.w;
       }
     }
-    const int w = x1 - x0, h = y1 - y0, nt = vis ? w * h : 0;
-    const uint64_t key = ((uint64_t)fr.x << 32) | (uint32_t)i;
+    x0_k[u] = x0; y0_k[u] = y0; w_k[u] = x1 - x0; h_k[u] = y1 - y0;
+    nt_k[u] = e < (uint32_t)N ? w_k[u] * h_k[u] : 0;
+  }
+  __syncthreads();                                                // the staged row is complete
+#pragma unroll
+  for (int u = 0; u < K; u++) {
+    const int i = (int)(first + u * LR_FILL_STAGED_ROWS + threadIdx.x);
+    const int x0 = x0_k[u], y0 = y0_k[u], w = w_k[u], nt = nt_k[u];
+    const uint64_t key = ((uint64_t)fr_k[u].x << 32) | (uint32_t)i;
     if (nt > 0 && nt <= LR_RANKED_TILES) {
+      const uint32_t h0 = hA_k[u] & 0xffffu, h1 = hA_k[u] >> 16, h2 = hB_k[u] & 0xffffu, h3 = hB_k[u] >> 16;
       // tile k of a rect of <= 4 tiles: one row (w >= nt), one column (w == 1) or 2x2 -- as in lr_project_batched_kernel
       const bool col = w == 1, sq = (w == 2) && (nt == 4);
       const int t0 = y0 * gx + x0;
@@ -1541,14 +1548,16 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
         if (p3 != 0xffffffffu) keys[p3] = key;
       }
     }
-    lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
+    // (Rects of more than four tiles, measured and removed: counting the workgroup's instances per tile in LDS first, ONE
+    // cursor atomic per touched tile, a second walk placing the keys -- the C3 view's fill 426 -> 545 us: 2048 consecutive
+    // rows of a level-of-detail selection do not share enough tiles to pay for two walks of support tests.)
+    lr_fill_big_rect(geom, i, x0, y0, w, h_k[u], nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
   }
 }
 
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
-                    int zero_block_floats, int rebased, int speculative, int band, int batch_size, hipStream_t s) {
-  const int batched = batch_size > 0;
+                    int zero_block_floats, int rebased, int speculative, int band, int staged_k, hipStream_t s) {
   if (N <= 0) return;
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
@@ -1556,8 +1565,7 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
 #ifdef LR_EXPERIMENTS
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores, 4 no 5-16-tile rects, 8 no larger rects
 #endif
-  LR_KNOB(staged_knob, "LOGRAST_FILL_STAGED", 2);   // 0 = off, K = up to K x 1024 Gaussians per workgroup (K per thread)
-  if (staged_knob && batched && !band && tiles <= LR_FILL_STAGED_MAX_TILES) {
+  if (staged_k > 0) {   // (decided by the caller -- api.hip: lr_fill_staged_k -- because stage 1 has to know it too: no lr_rebase_kernel then)
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel<1>),
@@ -1566,21 +1574,16 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel<3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lr_fill_staged_kernel<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(uint32_t) * LR_FILL_STAGED_MAX_TILES);
       attr_set = true;
     }
-    // a workgroup's K x 1024 Gaussians share one table row: the largest K <= the knob that divides the batch
-    const int per_batch = batch_size / LR_FILL_STAGED_ROWS;
-    int K = staged_knob > 4 ? 4 : staged_knob;
-    while (K > 1 && (batch_size % LR_FILL_STAGED_ROWS != 0 || per_batch % K != 0)) K--;
+    const int K = staged_k;
     const int rows = LR_FILL_STAGED_ROWS * K;
     const int blocks = ((N + rows - 1) / rows + 7) & ~7;
 #define LR_FILL_ST(KK) hipLaunchKernelGGL(lr_fill_staged_kernel<KK>, dim3(blocks), dim3(LR_FILL_STAGED_ROWS),                 \
                        sizeof(uint32_t) * ((tiles + 3u) & ~3u), s, N, gx, reinterpret_cast<const float4*>(geom), state, tiles,  \
                        keys, capacity, max_len_hint, status, zero_n, zero_block, zero_block_floats, xcd_order, rebased,         \
                        speculative LR_ABLATE_PASS(ablate))
-    if (K == 4) LR_FILL_ST(4); else if (K == 3) LR_FILL_ST(3); else if (K == 2) LR_FILL_ST(2); else LR_FILL_ST(1);
+    if (K >= 3) LR_FILL_ST(3); else if (K == 2) LR_FILL_ST(2); else LR_FILL_ST(1);   // (four per thread: 40 bytes of scratch at the kernel's 64 VGPRs)
 #undef LR_FILL_ST
     lr_prof_end(LRK_FILL, s);
     return;

@@ -28,7 +28,7 @@ SWEEP = {
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
     "LOGRAST_BAND_SPARSE": (0, 1),
     "LOGRAST_FILL_PER_THREAD": (1, 2, 4),
-    "LOGRAST_FILL_STAGED": (0, 1, 2, 3, 4),
+    "LOGRAST_FILL_STAGED": (0, 1, 2, 3),
 }
 
 

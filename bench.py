@@ -12,9 +12,12 @@ through the drop-in ``diff_gaussian_rasterization_wodilate`` package (5-tuple fl
 backward to all Gaussian attributes + means2D.  A "step" = every rank renders its 8 views forward+backward, gradients are
 added by the backward kernels into one flat buffer per stream (row-major: one 64-byte row of running sums per Gaussian,
 log_amd.dist.GradientBucket(row_major=True); --planar-bucket: five attribute-major arrays), summed per rank, and (N > 1) summed across ranks by
-reduce-scatter + all-gather (view-sharded data parallelism, weak scaling: per-GPU work is fixed; the views of a step go in
---exchange-parts groups and a group's reduce-scatter runs on a side stream under the next group's rendering,
-log_amd.dist.StepExchange).  Inputs are
+reduce-scatter + all-gather (view-sharded data parallelism, weak scaling: per-GPU work is fixed).  --exchange-parts G > 1
+splits the step's views into G groups with a FULL-SIZE bucket each, group g's reduce-scatter running on a side stream under
+group g + 1's rendering (log_amd.dist.StepExchange) -- which pays only when a group's exchange is smaller than the step's
+(touched-block exchange of level-of-detail views); for this workload, where every view touches rows all over the model, the
+last group's reduce-scatter is as large as the whole step's, so what stays exposed (one reduce-scatter + the all-gather) is
+the same with G = 1, and G groups cost G x the link traffic and G x the bucket zero-fills: the default is 1.  Inputs are
 resident in HBM before the timed region; the timed region contains no host synchronisation (tile-instance capacity
 comes from the warm-up; every forward records itself in the rasterizer's status block, checked afterwards).
 
@@ -79,7 +82,7 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true",
                     help="pipelined mode: enqueue every view's ~15 launches from Python instead of replaying one captured "
                          "HIP graph per view")
-    ap.add_argument("--exchange-parts", type=int, default=int(os.environ.get("LOGRAST_EXCHANGE_PARTS", "4")),
+    ap.add_argument("--exchange-parts", type=int, default=int(os.environ.get("LOGRAST_EXCHANGE_PARTS", "1")),
                     help="N > 1: groups of views per step, each reduce-scattered under the next group's rendering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--sink", action="store_true", help="backward adds into one row-major running-sum buffer (bench.py's pipelined form)")
     ap.add_argument("--env", nargs="*", default=[])
     ap.add_argument("--tag", default="")
     a = ap.parse_args()
@@ -51,11 +52,17 @@ def main():
                 for t in leaves.values():
                     t.grad = None
 
-    step()
+    import contextlib
+    from log_amd import rasterizer as R
+    rows = torch.zeros(wl.N, 16, device=dev) if a.sink else None
+    ctx = (lambda: R.accumulate_grads_into({"rows": rows})) if a.sink else contextlib.nullcontext
+    with ctx():
+        step()
     torch.cuda.synchronize()
     _lib.profile_reset(); _lib.profile_enable(True)
     for _ in range(a.reps):
-        step()
+        with ctx():
+            step()
     torch.cuda.synchronize()
     _lib.profile_enable(False)
     out = {k: round(1e3 * ms / max(c, 1), 1) for k, (ms, c) in _lib.profile_read().items() if c}

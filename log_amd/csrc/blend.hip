@@ -482,6 +482,20 @@ LR_DEV float lr_quad_total(float x) {   // every lane of a quad <- the quad's to
   return x + lr_dpp_perm<0x4E>(x);      // quad_perm [2,3,0,1]
 }
 
+// The next entry of a row's hit mask, per lane (every lane of a 16-lane row holds the row's mask): position of the lowest
+// set bit, 64 = none (the all-zero staging slot); the bit is cleared.  Vector instructions (two v_ffbl, a few selects, a
+// 64-bit add / and): the scalar form -- four masks walked by s_ff1 / s_and / s_cselect chains, ~85 scalar instructions in
+// front of every pass -- was as long as the pass's vector work and strictly serial (round 4: SQ_INSTS_SALU 1.9e8 against
+// SQ_INSTS_VALU 2.1e8 per launch of the row-split forward).
+LR_DEV uint32_t lr_take_bit(uint64_t& m) {
+  const uint32_t j = min((uint32_t)(__ffsll((long long)m) - 1), 64u);   // __ffsll(0) = 0 -> 0xffffffff -> 64
+  m &= m - 1ull;                                                        // (0 stays 0)
+  return j;
+}
+LR_DEV uint64_t lr_row_mask(int row, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+  return row == 0 ? m0 : (row == 1 ? m1 : (row == 2 ? m2 : m3));
+}
+
 __global__ void __launch_bounds__(256) LR_OCC_BWD_ROWS
 lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
@@ -534,7 +548,6 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                             : (sel == 1 ? (qd == 0 ? 0 : (qd == 1 ? 2 : (qd == 2 ? 1 : 3))) : 4);
   const bool on_a = sel < 2 || li == 2, on_b = sel < 2 || li == 10;
   float* const dst = acc_rows + slot;
-  const uint32_t shift8 = 8u * (uint32_t)row;
 
   // the four blocks of this quadrant (wave-uniform), for the support tests
   const float bx[2] = {(float)qx0, (float)(qx0 + 4)}, by[2] = {(float)qy0, (float)(qy0 + 4)};
@@ -595,20 +608,10 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
         r3 = r3 && q && x_hi && y_hi;
       }
     }
-    uint64_t m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
-    while (m0 | m1 | m2 | m3) {
+    uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
+    while (__builtin_amdgcn_ballot_w64(mrow != 0ull) != 0) {
       // every row's next two entries (64 = none: the all-zero slot)
-      uint32_t pa = 0u, pb = 0u;
-#define LR_TAKE(m, sh)                                                                          \
-      {                                                                                         \
-        uint32_t ja = 64u, jb = 64u;                                                            \
-        if (m) { ja = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
-        if (m) { jb = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
-        pa |= ja << (sh); pb |= jb << (sh);                                                     \
-      }
-      LR_TAKE(m0, 0) LR_TAKE(m1, 8) LR_TAKE(m2, 16) LR_TAKE(m3, 24)
-#undef LR_TAKE
-      const uint32_t ja = (pa >> shift8) & 0xffu, jb = (pb >> shift8) & 0xffu;      // this lane's row's entries
+      const uint32_t ja = lr_take_bit(mrow), jb = lr_take_bit(mrow);
       const float4* sa = stage + ja * LR_RB_SLOT;
       const float4* sb = stage + jb * LR_RB_SLOT;
       const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
@@ -704,7 +707,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   float4* const stage = lr_stage[wq];
   if (lane < LR_RB_SLOT) stage[64 * LR_RB_SLOT + lane] = float4{0.f, 0.f, 0.f, 0.f};
   if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
-  const uint32_t shift8 = 8u * (uint32_t)row;
+  const uint32_t shift16 = 16u * (uint32_t)row;
   const float bx[2] = {(float)qx0, (float)(qx0 + 4)}, by[2] = {(float)qy0, (float)(qy0 + 4)};
   const uint64_t rowbits = 0xffffull;
 
@@ -749,27 +752,14 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       r2 = r2 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[1], by[1] + 3.f);
       r3 = r3 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[1], by[1] + 3.f);
     }
-    uint64_t m0 = __ballot(r0), m1 = __ballot(r1), m2 = __ballot(r2), m3 = __ballot(r3);
+    uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
     const int pos0 = (int)(ch * 64u);
     while (true) {
       // a row whose 16 pixels are all saturated takes no more entries
       const uint64_t dm = __ballot(done);
-      if (((dm >> 0) & rowbits) == rowbits) m0 = 0;
-      if (((dm >> 16) & rowbits) == rowbits) m1 = 0;
-      if (((dm >> 32) & rowbits) == rowbits) m2 = 0;
-      if (((dm >> 48) & rowbits) == rowbits) m3 = 0;
-      if (!(m0 | m1 | m2 | m3)) break;
-      uint32_t pa = 0u, pb = 0u;
-#define LR_TAKE(m, sh)                                                                          \
-      {                                                                                         \
-        uint32_t ja = 64u, jb = 64u;                                                            \
-        if (m) { ja = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
-        if (m) { jb = (uint32_t)__builtin_ctzll(m); m &= m - 1; }                               \
-        pa |= ja << (sh); pb |= jb << (sh);                                                     \
-      }
-      LR_TAKE(m0, 0) LR_TAKE(m1, 8) LR_TAKE(m2, 16) LR_TAKE(m3, 24)
-#undef LR_TAKE
-      const uint32_t ja = (pa >> shift8) & 0xffu, jb = (pb >> shift8) & 0xffu;
+      if ((uint32_t)((dm >> shift16) & rowbits) == (uint32_t)rowbits) mrow = 0ull;
+      if (__builtin_amdgcn_ballot_w64(mrow != 0ull) == 0) break;
+      const uint32_t ja = lr_take_bit(mrow), jb = lr_take_bit(mrow);
       const float4* sa = stage + ja * LR_RB_SLOT;
       const float4* sb = stage + jb * LR_RB_SLOT;
       const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];

@@ -190,7 +190,19 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     };
     if (rows_here > 0) {
       clear(o_mean2d + 3 * (size_t)base, 3 * rows_here);
-      if (!ACCUMULATE && !SINKROWS) { clear(o_opac + (size_t)base, rows_here); clear(o_col + 3 * (size_t)base, 3 * rows_here); }
+      if (!ACCUMULATE && !SINKROWS) {
+        // fresh gradients (the autograd route: what unmodified LoG gets): every output is defined for every row -- the
+        // whole slice of each array with full-width stores here, instead of 12-byte pieces per dead row from the flag
+        // pass below (three store instructions covering a third of every line each)
+        clear(o_opac + (size_t)base, rows_here); clear(o_col + 3 * (size_t)base, 3 * rows_here);
+        clear(g_means3d + 3 * (size_t)base, 3 * rows_here);
+        if (COV) {
+          clear(v.g_cov3d + 6 * (size_t)base, 6 * rows_here);
+        } else {
+          clear(g_scales + 3 * (size_t)base, 3 * rows_here);
+          clear(g_rots + 4 * (size_t)base, 4 * rows_here);
+        }
+      }
     }
   }
   __syncthreads();
@@ -198,7 +210,7 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
   for (int k = 0; k < LR_PBWD_ROWS / 256; k++) {
     const int i = base + k * 256 + tid;
     const bool live = i < N && rad_k[k] > 0 && (!TOUCHED || pw_k[k] > 0.f);
-    if (!ACCUMULATE && clear_inside && i < N && !live) {   // culled / untouched: zero gradients (running sums are simply left alone)
+    if (!ACCUMULATE && !AOS && i < N && !live) {   // isolated chain rule: culled / untouched rows get zero gradients (AOS: cleared above)
       g_means3d[3 * (size_t)i + 0] = 0.f; g_means3d[3 * (size_t)i + 1] = 0.f; g_means3d[3 * (size_t)i + 2] = 0.f;
       if (COV) {
 #pragma unroll

@@ -167,13 +167,11 @@ static uint32_t lr_batches(int32_t n, uint32_t batch) { return batch ? ((uint32_
 // many Gaussians per thread?  0 = no (unbatched, band form, tile grids whose row does not fit: the look-up form).  K x 1024
 // consecutive Gaussians of a workgroup share one table row: the largest K <= the knob that divides the batch.  Both stages
 // of a forward ask with the same arguments: stage 1 skips lr_rebase_kernel when the fill adds `offsets[]` while staging.
-#define LR_FILL_STAGED_ROWS_HOST 1024
-#define LR_FILL_STAGED_MAX_TILES_HOST 12288
 static int lr_fill_staged_k(const LrView& v, uint32_t tiles, uint32_t batch) {
   LR_KNOB(staged_knob, "LOGRAST_FILL_STAGED", 2);
-  if (staged_knob <= 0 || batch == 0u || tiles > LR_FILL_STAGED_MAX_TILES_HOST || lr_band_sparse(v, (int)batch)) return 0;
-  if (batch % LR_FILL_STAGED_ROWS_HOST != 0u) return 0;
-  const int per_batch = (int)(batch / LR_FILL_STAGED_ROWS_HOST);
+  if (staged_knob <= 0 || batch == 0u || tiles > LR_FILL_STAGED_MAX_TILES || lr_band_sparse(v, (int)batch)) return 0;
+  if (batch % LR_FILL_STAGED_ROWS != 0u) return 0;
+  const int per_batch = (int)(batch / LR_FILL_STAGED_ROWS);
   int K = staged_knob > 3 ? 3 : staged_knob;
   while (K > 1 && per_batch % K != 0) K--;
   return K;

@@ -70,6 +70,13 @@ __host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batche
 #define LR_COOP_TILES 16   // rects above this many tiles are expanded by a whole wave (lanes = tiles), not by their lane
 #define LR_HUGE_CHUNK 256  // Gaussians per workgroup of lr_count_huge_kernel (a chunk full of 81-tile rects is a serial walk per wave: 2048 ran 0.36 ms on the tree-ordered view, 512 0.14, 256 0.093)
 #define LR_BATCH_THREADS 1024
+// lr_fill_staged_kernel (project.hip; the host's choice of its template parameter: api.hip): threads per workgroup = Gaussians
+// per thread-slot (measured at 30 M, two Gaussians per thread: 1024 threads 327 us, 512: 361-370, 256: 445), and the largest
+// tile grid whose slot-table row the workgroup stages in LDS
+#ifndef LR_FILL_STAGED_ROWS
+#define LR_FILL_STAGED_ROWS 1024
+#endif
+#define LR_FILL_STAGED_MAX_TILES 12288      // 48 KB of LDS
 #define LR_BATCH_MAX_TILES 40000  // 4 B x tiles of LDS counters must fit one workgroup (160 KB): up to 3840x2160
 #define LR_BATCH_LDS_BYTES (160 * 1024 - 512)  // dynamic LDS a projection workgroup may use (counter planes)
 

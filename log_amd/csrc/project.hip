@@ -1451,10 +1451,8 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
 // table row (tiles x 4 B: 32 KB at 1080p; `+ offsets[t]` on inputs too small for lr_rebase_kernel) into LDS with coalesced
 // 16-byte loads: 256 line requests per workgroup (L2 hits: the ~29 workgroups of a batch run on one XCD within
 // microseconds of each other) instead of ~1500 scattered look-ups.  Rects of more than 4 tiles as in lr_fill_kernel.
-#define LR_FILL_STAGED_ROWS 1024
-#define LR_FILL_STAGED_MAX_TILES 12288      // 48 KB of LDS: three workgroups per CU
 template <int K>   // K x 1024 consecutive Gaussians per workgroup (K Gaussians per thread, their fill records requested together)
-__global__ void __launch_bounds__(LR_FILL_STAGED_ROWS, 8)   // 64 VGPRs: two workgroups per CU
+__global__ void __launch_bounds__(LR_FILL_STAGED_ROWS, 8)   // 64 VGPRs: 2048 threads per CU
 lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                       uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
                       float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order,

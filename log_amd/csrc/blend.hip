@@ -593,10 +593,11 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     if (cull) {
       const LrSupport sp = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
       if (block_test) {   // the exact ellipse-vs-box test for each of the four blocks (~75 VALU each)
-        r0 = r0 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[0], by[0] + 3.f);
-        r1 = r1 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[0], by[0] + 3.f);
-        r2 = r2 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[1], by[1] + 3.f);
-        r3 = r3 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[1], by[1] + 3.f);
+        bool k0, k1, k2, k3;   // (two blocks at a time: lr_support_box2, the decisions of four lr_support_box calls)
+        const lr_f2 X0 = {bx[0], bx[1]}, X1 = {bx[0] + 3.f, bx[1] + 3.f};
+        lr_support_box2(sp, X0, X1, lr_f2{by[0], by[0]}, lr_f2{by[0] + 3.f, by[0] + 3.f}, k0, k1);
+        lr_support_box2(sp, X0, X1, lr_f2{by[1], by[1]}, lr_f2{by[1] + 3.f, by[1] + 3.f}, k2, k3);
+        r0 = r0 && k0; r1 = r1 && k1; r2 = r2 && k2; r3 = r3 && k3;
       } else {            // exact test for the quadrant, the support's bounding box against each block (4 compares each)
         const bool q = lr_support_box(sp, bx[0], bx[0] + 7.f, by[0], by[0] + 7.f);
         const bool bb = sp.mode == 2;
@@ -747,10 +748,12 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     bool r0 = valid, r1 = valid, r2 = valid, r3 = valid;
     if (cull) {
       const LrSupport sp = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
-      r0 = r0 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[0], by[0] + 3.f);
-      r1 = r1 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[0], by[0] + 3.f);
-      r2 = r2 && lr_support_box(sp, bx[0], bx[0] + 3.f, by[1], by[1] + 3.f);
-      r3 = r3 && lr_support_box(sp, bx[1], bx[1] + 3.f, by[1], by[1] + 3.f);
+      // the four 4x4 blocks two at a time (lr_support_box2: the decisions of four lr_support_box calls, packed arithmetic)
+      bool k0, k1, k2, k3;
+      const lr_f2 X0 = {bx[0], bx[1]}, X1 = {bx[0] + 3.f, bx[1] + 3.f};
+      lr_support_box2(sp, X0, X1, lr_f2{by[0], by[0]}, lr_f2{by[0] + 3.f, by[0] + 3.f}, k0, k1);
+      lr_support_box2(sp, X0, X1, lr_f2{by[1], by[1]}, lr_f2{by[1] + 3.f, by[1] + 3.f}, k2, k3);
+      r0 = r0 && k0; r1 = r1 && k1; r2 = r2 && k2; r3 = r3 && k3;
     }
     uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
     const int pos0 = (int)(ch * 64u);

@@ -346,10 +346,9 @@ LR_DEV bool lr_support_tile(const LrSupport& s, int tx, int ty) {
   const float x0 = (float)(tx * LR_TILE), y0 = (float)(ty * LR_TILE);
   return lr_support_box(s, x0, x0 + (float)(LR_TILE - 1), y0, y0 + (float)(LR_TILE - 1));
 }
-// Two tiles at once (tile origins X0, Y0 in pixels, one tile per half): element for element the op sequence of
-// lr_support_box, the multiplies and adds issued as v_pk_*_f32 -- the same decisions as two lr_support_tile calls.
-LR_DEV void lr_support_tile2(const LrSupport& s, lr_f2 X0, lr_f2 Y0, bool& keep0, bool& keep1) {
-  const lr_f2 X1 = X0 + (float)(LR_TILE - 1), Y1 = Y0 + (float)(LR_TILE - 1);
+// Two boxes at once ([X0, X1] x [Y0, Y1] in pixels, one box per half): element for element the op sequence of
+// lr_support_box, the multiplies and adds issued as v_pk_*_f32 -- the same decisions as two lr_support_box calls.
+LR_DEV void lr_support_box2(const LrSupport& s, lr_f2 X0, lr_f2 X1, lr_f2 Y0, lr_f2 Y1, bool& keep0, bool& keep1) {
   const float xlo = s.mx + s.ex, xhi = s.mx - s.ex, ylo = s.my + s.ey, yhi = s.my - s.ey;
   const bool bb0 = (xlo >= X0.x) && (xhi <= X1.x) && (ylo >= Y0.x) && (yhi <= Y1.x);
   const bool bb1 = (xlo >= X0.y) && (xhi <= X1.y) && (ylo >= Y0.y) && (yhi <= Y1.y);
@@ -369,6 +368,10 @@ LR_DEV void lr_support_tile2(const LrSupport& s, lr_f2 X0, lr_f2 Y0, bool& keep0
   const bool any = s.mode != 0, test = s.mode == 2;
   keep0 = test ? (bb0 && (in0 || q0)) : any;
   keep1 = test ? (bb1 && (in1 || q1)) : any;
+}
+// Two tiles at once (tile origins X0, Y0 in pixels, one tile per half).
+LR_DEV void lr_support_tile2(const LrSupport& s, lr_f2 X0, lr_f2 Y0, bool& keep0, bool& keep1) {
+  lr_support_box2(s, X0, X0 + (float)(LR_TILE - 1), Y0, Y0 + (float)(LR_TILE - 1), keep0, keep1);
 }
 
 // Every kernel behind the fill checks this first: nothing is sorted or composited when the caller's buffers were too

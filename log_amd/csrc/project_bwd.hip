@@ -140,17 +140,13 @@ LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__
 // dL/drotations, 10 dL/dopacity, 11-13 dL/dcolour, 14-15 untouched) -- a live Gaussian then costs one read-modify-write of
 // one line instead of five in five arrays (the live rows are scattered: at 30 M Gaussians 7 % of them, each piece of 4-16
 // bytes pulling its own 64-byte line through the memory system in both directions).
-// (LR_OCC_PBWD_WAVES: waves per SIMD the register allocator aims for -- the chain rule wants ~130 VGPRs, i.e. three waves
-// per SIMD.  Measured, 30 M Gaussians, running sums / fresh gradients: 3 waves (default) 374 / 736 us, 4 waves (128 VGPRs,
-// no scratch) 391 / 865, 5 (spills) 473 / 877, 6: 518 / 918 -- more resident workgroups make the scattered rows' traffic
-// worse, not better; only the band view of 100 M rows, nearly all flag pass, gains (738 -> 638 us).  Left at the default.)
-#ifdef LR_OCC_PBWD_WAVES
-#define LR_OCC_PBWD __attribute__((amdgpu_waves_per_eu(LR_OCC_PBWD_WAVES)))
-#else
-#define LR_OCC_PBWD
-#endif
-template <bool ACCUMULATE, bool TOUCHED, bool COV, bool AOS, bool SINKROWS = false>
-__global__ void __launch_bounds__(256) LR_OCC_PBWD
+// WAVES: waves per SIMD the register allocator aims for (1 = its own choice: ~130 VGPRs, three waves).  Measured, 30 M
+// Gaussians, running sums / fresh gradients: default 374 / 736 us, 4 waves (128 VGPRs, no scratch) 391 / 865, 5 (spills)
+// 473 / 877, 6: 518 / 918 -- more resident workgroups make the scattered rows' traffic worse, not better.  A band view
+// (nearly all flag pass: a fraction of a percent of 100 M rows is live) gains from four: 738 -> 638 us -- the row-major
+// sink's kernel exists in both forms and band views launch the second.
+template <bool ACCUMULATE, bool TOUCHED, bool COV, bool AOS, bool SINKROWS = false, int WAVES = 1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES)))
 lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
                       const float* __restrict__ rots, const int* __restrict__ radii,
                       const float* __restrict__ g_mean2d, const float* __restrict__ g_conic,
@@ -316,7 +312,11 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
   const int clear_inside = (rows && (accumulate || sink_rows) && N >= separate_min_n) ? 0 : 1;
   if (!clear_inside) lr_launch_zero_floats(o_mean2d, 3 * (size_t)N, s);
   if (sink_rows) {   // (lograst_backward checked: rows != NULL, no cov3d)
-    if (pw)
+    const bool band = v.ty0 > 0 || v.ty1 < v.gy;
+    if (pw && band)
+      hipLaunchKernelGGL((lr_project_bwd_kernel<true, true, false, true, true, 4>), grid, block, 0, s, v, N, means, scales, rots,
+                         radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots, clear_inside);
+    else if (pw)
       hipLaunchKernelGGL((lr_project_bwd_kernel<true, true, false, true, true>), grid, block, 0, s, v, N, means, scales, rots,
                          radii, g_mean2d, g_conic, rows4, o_mean2d, o_opac, o_col, pw, g_means3d, g_scales, g_rots, clear_inside);
     else

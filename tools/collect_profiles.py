@@ -68,6 +68,8 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
              "lr_fill_kernel": "fill_keys", "lr_fill_kernel<1>": "fill_keys", "lr_project_bwd_kernel<true, true, false, true>": "project_bwd",
              "lr_project_bwd_kernel<true, true, false, true, false>": "project_bwd",
              "lr_project_bwd_kernel<true, true, false, true, true>": "project_bwd",
+             "lr_project_bwd_kernel<true, true, false, true, true, 1>": "project_bwd",
+             "lr_fill_staged_kernel<2>": "fill_keys", "lr_fill_staged_kernel<1>": "fill_keys", "lr_fill_staged_kernel<3>": "fill_keys",
              "lr_sort_long_kernel": "sort"}
     tj = os.path.join(P, f"{tag}_traffic_30M.json")
     d = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): " + cmd,

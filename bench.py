@@ -92,8 +92,10 @@ def parse():
     ap.add_argument("--no-rand-variant", action="store_true", help="skip the opacity = rand variant of the headline (N = 1)")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the torch.no_grad() legs")
     ap.add_argument("--no-c5-band", action="store_true", help="skip the C5 band leg (100 M Gaussians, 4K, one of 8 bands)")
-    ap.add_argument("--exchange", choices=("auto", "dense", "compact"), default=os.environ.get("LOGRAST_EXCHANGE", "auto"),
-                    help="N > 1: dense reduce-scatter, touched-row-block exchange, or decided once from the warm-up")
+    ap.add_argument("--exchange", choices=("auto", "dense", "compact", "sparse"), default=os.environ.get("LOGRAST_EXCHANGE", "auto"),
+                    help="N > 1: dense reduce-scatter + all-gather, touched-row-block exchange, row-sparse exchange (only rows "
+                         "with a non-zero gradient travel), or decided once from the warm-up (auto: row-sparse when fewer than "
+                         "half of a rank's rows are touched, else dense)")
     return ap.parse_args()
 
 
@@ -235,6 +237,13 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     ex = StepExchange(N, dev, world, rank, parts=parts, block_rows=block_rows, track_seen=track, timing=track,
                       row_major=row_major)
     compact = {"on": args.exchange == "compact" and world > 1}
+    sparse = {"on": args.exchange == "sparse" and world > 1 and row_major, "kmax": None, "gather": None}
+
+    def exchange():
+        """The step's exchange: reduce-scatter (dense / touched blocks / touched rows) per group, then the all-gather."""
+        for part in range(parts):
+            ex.launch(part, compact=compact["on"], kmax=sparse["kmax"] if sparse["on"] else compact.get("kmax"), sparse=sparse["on"])
+        ex.all_gather_grads(ex.finish(), sparse_kmax=(sparse["gather"] or "exact") if sparse["on"] else None)
     lanes = []
     for li in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient buckets
         leaves = {k: v.detach().requires_grad_(True) for k, v in wl.base.items()}
@@ -247,7 +256,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
 
     lane_graphs = None
 
-    def step():
+    def step(do_exchange=True):
         main = torch.cuda.current_stream(dev)
         for st in streams:
             st.wait_stream(main)
@@ -280,9 +289,11 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                 # common frustum), recorded once per group from the last forward's radii (kept by one_view)
                 if wl.last_radii is not None:
                     ex.buckets[part].mark_seen(wl.last_radii)
-                ex.launch(part, compact=compact["on"], kmax=compact.get("kmax"))
-        if world > 1:
-            ex.all_gather_grads(ex.finish())            # every rank ends the step with the whole gradient sum
+                if do_exchange:
+                    ex.launch(part, compact=compact["on"], kmax=sparse["kmax"] if sparse["on"] else compact.get("kmax"),
+                              sparse=sparse["on"])
+        if world > 1 and do_exchange:                   # every rank ends the step with the whole gradient sum
+            ex.all_gather_grads(ex.finish(), sparse_kmax=(sparse["gather"] or "exact") if sparse["on"] else None)
 
     # ---- V and I per view, measured once in exact mode (one 4-byte read-back per view) ----
     R.set_instance_capacity(None)
@@ -329,7 +340,26 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                 longest = max([b.touched.kmax for b in ex.buckets if b.touched is not None] or [g.Pr // block_rows])
                 compact["kmax"] = min(g.Pr // block_rows, int(longest * 1.15) + 2)
                 res["exchange_block_bound"] = compact["kmax"]
-        res["exchange_mode"] = "compact" if compact["on"] else "dense"
+        # rows with a non-zero gradient after a rank's views (the warm-up's last step left the gathered SUM in bucket 0: one
+        # more step's rendering gives the local sums back)
+        if row_major and args.exchange in ("auto", "sparse") and not compact["on"]:
+            step(do_exchange=False)
+            t = ex.buckets[0].touched_row_fraction().reshape(1)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res["exchange_touched_row_fraction"] = float(t.item())
+            if args.exchange == "auto":
+                sparse["on"] = res["exchange_touched_row_fraction"] < 0.5
+            if sparse["on"]:
+                # one exact row-sparse exchange (list lengths agreed by a max-reduce + read-back); from then on the
+                # all-to-all and the all-gather are sized from its longest lists + 10 % with no read-back
+                exchange()
+                torch.cuda.synchronize()
+                sparse["kmax"] = int(max(b.sparse_kmax for b in ex.buckets) * 1.1) + 16
+                sparse["gather"] = int(ex.gather_kmax * 1.1) + 16
+                assert not ex.compact_overflowed()
+                res["exchange_row_bounds"] = {"per_pair": sparse["kmax"], "per_owner_gather": sparse["gather"],
+                                              "rows_per_rank": ex.buckets[0].Pr}
+        res["exchange_mode"] = "sparse" if sparse["on"] else ("compact" if compact["on"] else "dense")
         del nz
         ex.reset_timing()
     res["graphs"] = False
@@ -397,18 +427,19 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         res["exchange_timing"] = ex.timing_summary(steps)
         # The same collectives with nothing to hide under: link time alone, so that a first run on real xGMI separates what
         # the links cost from what the overlap lost (exposed = ms_per_step - rendering; hidden = exchange_only - exposed).
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        tx = time.perf_counter()
-        xsteps = 3
+        assert not ex.compact_overflowed(), "touched-block / row-sparse exchange outgrew its bound inside the timed region: result invalid"
+        xsteps, tsum = 3, 0.0
         for _ in range(xsteps):
-            for part in range(parts):
-                ex.launch(part, compact=compact["on"], kmax=compact.get("kmax"))
-            ex.all_gather_grads(ex.finish())
-        torch.cuda.synchronize()
+            step(do_exchange=False)                     # (the rank's own sums again: the exchange leaves the total in bucket 0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tx = time.perf_counter()
+            exchange()
+            torch.cuda.synchronize()
+            tsum += time.perf_counter() - tx
         dist.barrier()
-        txe = torch.tensor([time.perf_counter() - tx], device=dev, dtype=torch.float64)
+        txe = torch.tensor([tsum], device=dev, dtype=torch.float64)
         dist.all_reduce(txe, op=dist.ReduceOp.MAX)
         res["exchange_only_ms_per_step"] = 1e3 * float(txe.item()) / xsteps
         cols = sum(c for _, c in ex.buckets[0].layout) + 1
@@ -416,6 +447,11 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         if compact["on"] and ex.touched is not None:
             frac = ex.touched.fraction
         res["exchange_bytes_per_step"] = int(2 * 4 * cols * ex.buckets[0].Ppad * frac * (world - 1) / world)
+        if sparse["on"]:
+            from log_amd.dist import SPARSE_FLOATS
+            b0 = ex.buckets[0]
+            res["exchange_bytes_per_step"] = int(4 * (world - 1) * (parts * SPARSE_FLOATS * max(b.sparse_kmax for b in ex.buckets)
+                                                                    + b0.Pr + SPARSE_FLOATS * ex.gather_kmax))
     if world > 1:
         assert not ex.compact_overflowed(), "touched-block exchange outgrew its bound inside the timed region: result invalid"
     chk = R.overflow_since_reset(dev)   # every forward since the capacity was set, on all streams
@@ -755,6 +791,7 @@ def main():
         result["exchange"] = {
             "mode": r.get("exchange_mode"), "policy": args.exchange, "parts": r["exchange_parts"],
             "nonzero_gradient_row_fraction": r.get("exchange_nonzero_row_fraction"),
+            "touched_row_fraction": r.get("exchange_touched_row_fraction"), "row_bounds": r.get("exchange_row_bounds"),
             "touched_4096_row_block_fraction": r.get("exchange_touched_block_fraction"),
             "bytes_moved_per_rank_per_step": r.get("exchange_bytes_per_step"), "timing_ms": r.get("exchange_timing"),
             "exchange_only_ms_per_step": r.get("exchange_only_ms_per_step"),

@@ -208,6 +208,21 @@ int lograst_tile_rows(const lograst_view* view, int32_t n, const float* means3d,
  * non-temporal.  Pointers and size must be multiples of 16 bytes.  Not on the rasterizer's path. */
 int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, void* stream);
 
+/* ---- row-sparse gradient exchange: pack / unpack (log_amd/dist.py; the reference has no multi-GPU code: new surface) ---
+ * rows: float32 [groups][rows_per_group][16] -- a row-major running-sum bucket (LOGRAST_GRAD_ROW_FLOATS = 16), 64-byte
+ * aligned.  lograst_pack_rows writes one SEGMENT per group, back to back, each lograst_sparse_segment_floats(kmax) floats:
+ * header [16] (word 0: how many rows with a non-zero entry the group holds), values [kmax][16] (those rows, in no
+ * particular order), index [roundup(kmax, 16)] (int32: the row's index inside its group).  Rows beyond kmax are dropped
+ * and *overflow (a device word, OR-ed; may be NULL) is raised.  Equal-sized segments: an all-to-all / all-gather with
+ * equal splits moves them.  lograst_unpack_rows: for every segment s and every row j < min(count_s, kmax):
+ *   atomic != 0:  dest[index][0..15] += values            (all segments into the same rows_per_group rows: float atomics)
+ *   atomic == 0:  dest[s * dest_group_rows + index][..] = values   (segment s owns its own range of rows: plain stores) */
+size_t lograst_sparse_segment_floats(int32_t kmax);
+int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                      uint32_t* overflow, void* stream);
+int lograst_unpack_rows(float* dest, const float* packed, int32_t segments, int32_t kmax, int64_t rows_per_group,
+                        int64_t dest_group_rows, int32_t atomic, void* stream);
+
 /* ---- performance knobs -------------------------------------------------------------------------------------------
  * Launch-shape parameters that change no result (thresholds, grid caps, dispatch orders; the list is enumerated by
  * lograst_knob_count / lograst_knob_info).  Each is the environment variable of the same name unless overridden here;

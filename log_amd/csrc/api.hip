@@ -27,6 +27,11 @@ void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, uint32_
 bool lr_band_sparse(const LrView& v, int batch);
 void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
+// exchange.hip
+void lx_launch_pack_rows(const float* rows, int groups, long long rows_per_group, int kmax, float* packed,
+                         size_t seg_floats, uint32_t* overflow, hipStream_t s);
+void lx_launch_unpack_rows(float* dest, const float* packed, int segments, int kmax, size_t seg_floats,
+                           long long rows_per_group, long long dest_group_rows, int atomic, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
                     int zero_block_floats, int rebased, int speculative, int band, int staged_k, hipStream_t s);
@@ -565,6 +570,34 @@ int lograst_tile_rows(const lograst_view* view, int32_t n, const float* means3d,
   if (reinterpret_cast<uintptr_t>(rotations) & 15u) return lr_fail(LOGRAST_ERR_ARG, "rotations must be 16-byte aligned");
   v.ty0 = 0; v.ty1 = v.gy;   // always the rows of the whole image: the caller intersects them with its band
   lr_launch_tile_rows(v, n, means3d, scales, rotations, rows_out, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
+size_t lograst_sparse_segment_floats(int32_t kmax) {
+  const size_t k = kmax > 0 ? (size_t)kmax : 0;
+  return 16 + 16 * k + ((k + 15) / 16) * 16;
+}
+int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                      uint32_t* overflow, void* stream) {
+  if (groups < 0 || rows_per_group < 0 || kmax <= 0) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: negative size or kmax <= 0");
+  if (groups == 0 || rows_per_group == 0) return LOGRAST_OK;
+  if (!rows || !packed) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(packed)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: rows / packed must be 16-byte aligned");
+  if (rows_per_group > 0x7fffffffLL) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: rows_per_group exceeds 31 bits (int32 row indices)");
+  lx_launch_pack_rows(rows, groups, rows_per_group, kmax, packed, lograst_sparse_segment_floats(kmax), overflow, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+int lograst_unpack_rows(float* dest, const float* packed, int32_t segments, int32_t kmax, int64_t rows_per_group,
+                        int64_t dest_group_rows, int32_t atomic, void* stream) {
+  if (segments < 0 || kmax <= 0 || rows_per_group < 0 || dest_group_rows < 0)
+    return lr_fail(LOGRAST_ERR_ARG, "lograst_unpack_rows: negative size or kmax <= 0");
+  if (segments == 0 || rows_per_group == 0) return LOGRAST_OK;
+  if (!dest || !packed) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  lx_launch_unpack_rows(dest, packed, segments, kmax, lograst_sparse_segment_floats(kmax), rows_per_group,
+                        atomic ? 0 : dest_group_rows, atomic, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

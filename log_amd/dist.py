@@ -25,6 +25,12 @@ Two refinements of the exchange, both optional and both leaving the 
     derives the same block lists from the same bitmap, padded per owner to the longest list with UNTOUCHED blocks of that
     owner (zero gradients / unchanged attributes: sending them is a no-op, so there is no mask and no variable-size
     collective).  Falls back to the dense form when most blocks are touched;
+  * **row-sparse** (``sparse=True``, row-major buckets): with an opaque scene a view's gradients live in the few per cent
+    of the rows that composited somewhere (30 M Gaussians, 8 views of a rank: 24 % of the rows; measured,
+    tools/touched_rows.py), and at 4096-row -- even 16-row -- granularity every block holds one.  Only the touched ROWS
+    travel: every rank packs (row index, 16 sums) of its touched rows per owner into equal-sized, padded segments (an
+    all-to-all with equal splits: no sizes on the wire, no host read-back once the bound is known), the owner adds what it
+    receives into its shard, and the closing all-gather moves the shard's non-zero rows the same way;
   * **overlap** (``StepExchange``, ``parts`` > 1): the step's views are split into `parts` groups with a bucket each; the
     reduce-scatter of group g is issued on a side stream as soon as g's last backward is enqueued and runs under the
     rendering of group g + 1.  Only the last group's reduce-scatter and the closing all-gather are exposed.
@@ -104,6 +110,110 @@ def _all_gather(out, inp, group=None):
     else:
         dist.all_gather_into_tensor(out, inp.contiguous(), group=group)
     return out
+
+
+SPARSE_FLOATS = ROW_FLOATS + 1     # a packed row of the row-sparse exchange: 16 running sums | row index (int32 bits)
+
+
+def _pack_rows(rows, kmax):
+    """rows: float32 [G, R, 16] (G groups of R rows).  -> (packed float32 [G, kmax, 17], counts int64 [G], overflow bool):
+    per group the rows with a non-zero entry, in ascending row order, as (16 values | row index inside the group, int32
+    bits), padded with all-zero rows of index 0 (adding them is a no-op).  No host synchronisation: kmax is the caller's
+    bound; `overflow` (a device flag) is raised when a group holds more than kmax such rows (the excess is dropped)."""
+    G, R, C = rows.shape
+    dev = rows.device
+    nz = torch.count_nonzero(rows, dim=2) > 0                     # [G, R]
+    csum = torch.cumsum(nz.view(-1).to(torch.int32), 0).view(G, R)
+    before = torch.cat([csum.new_zeros(1), csum[:-1, -1]])        # non-zero rows in front of each group
+    rank = csum - 1 - before[:, None]                             # position of a non-zero row inside its group's list
+    counts = (csum[:, -1] - before).to(torch.int64)
+    keep = nz & (rank < kmax)
+    # every row is sent somewhere: kept rows to their slot, all others to one scratch slot behind the buffer
+    slot = torch.where(keep, torch.arange(G, device=dev)[:, None] * kmax + rank, G * kmax).view(-1).to(torch.int64)
+    del nz, csum, rank, keep
+    packed = torch.zeros(G * kmax + 1, SPARSE_FLOATS, dtype=torch.float32, device=dev)
+    packed[:, :C].index_copy_(0, slot, rows.reshape(G * R, C))
+    idx = torch.arange(R, dtype=torch.int32, device=dev).view(torch.float32).repeat(G)
+    packed[:, C].index_copy_(0, slot, idx)
+    packed[G * kmax].zero_()                                      # (the scratch slot is not part of the result)
+    return packed[:G * kmax].view(G, kmax, SPARSE_FLOATS), counts, (counts > kmax).any()
+
+
+def _unpack_add(dest, packed):
+    """dest: float32 [R, 16]; packed: [..., 17] rows of (16 values | row index).  dest[index] += values (padding rows
+    add zeros to row 0)."""
+    flat = packed.reshape(-1, SPARSE_FLOATS)
+    dest.index_add_(0, flat[:, ROW_FLOATS].contiguous().view(torch.int32).to(torch.int64), flat[:, :ROW_FLOATS])
+    return dest
+
+
+# ---- the same on the device: lograst_pack_rows / lograst_unpack_rows (log_amd/csrc/exchange.hip) ----------------------
+# The torch formulation above is what the CPU tests run (gloo); on a 30 M-row bucket it takes 6 ms to pack, 30 ms to add
+# 8 M received rows (index_add_) and 180 ms to put the gathered rows back -- the kernels stream (a segment there is
+# header | values | indices, lograst_sparse_segment_floats(kmax) floats: include/lograst.h).
+def _segment_floats(kmax, device):
+    if device.type != "cuda":
+        return int(kmax) * SPARSE_FLOATS
+    from . import _lib
+    return int(_lib.lib().lograst_sparse_segment_floats(int(kmax)))
+
+
+def _pack_segments(rows, kmax):
+    """rows [G, R, 16] -> (flat float32 buffer of G equal segments, overflow: device bool)."""
+    if rows.device.type != "cuda":
+        packed, _, over = _pack_rows(rows, kmax)
+        return packed.reshape(-1), over
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    G, R, _ = rows.shape
+    rows = rows.contiguous()
+    seg = int(L.lograst_sparse_segment_floats(int(kmax)))
+    packed = torch.empty(G * seg, dtype=torch.float32, device=rows.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=rows.device)
+    with torch.cuda.device(rows.device):
+        _lib.check(L.lograst_pack_rows(ctypes.c_void_p(rows.data_ptr()), G, R, int(kmax), ctypes.c_void_p(packed.data_ptr()),
+                                       ctypes.c_void_p(flag.data_ptr()),
+                                       ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)))
+    return packed, flag[0] != 0
+
+
+def _unpack_segments(dest, packed, segments, kmax, per_segment_rows=0):
+    """dest [R, 16] += the rows of all `segments` (per_segment_rows = 0), or dest [segments * per_segment_rows, 16]: segment s's
+    rows written into its own range (the destination must be zeroed: only non-zero rows arrive)."""
+    if dest.device.type != "cuda":
+        segs = packed.view(segments, kmax, SPARSE_FLOATS)
+        if per_segment_rows:
+            for r in range(segments):
+                _unpack_add(dest[r * per_segment_rows:(r + 1) * per_segment_rows], segs[r])
+        else:
+            _unpack_add(dest, segs)
+        return dest
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    rows_per_group = int(per_segment_rows) if per_segment_rows else int(dest.shape[0])
+    with torch.cuda.device(dest.device):
+        _lib.check(L.lograst_unpack_rows(ctypes.c_void_p(dest.data_ptr()), ctypes.c_void_p(packed.data_ptr()), int(segments),
+                                         int(kmax), rows_per_group, int(per_segment_rows), 0 if per_segment_rows else 1,
+                                         ctypes.c_void_p(torch.cuda.current_stream(dest.device).cuda_stream)))
+    return dest
+
+
+def _all_to_all(out, inp, group=None):
+    """Equal splits: segment r of `inp` goes to rank r, segment s of `out` comes from rank s.  gloo (the CPU tests, and two
+    ranks sharing one GPU in tests/test_gpu_dist.py) has no all-to-all for device tensors: all-gather, then the segments."""
+    inp = inp.contiguous()
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        parts = [torch.empty_like(inp) for _ in range(world)]
+        dist.all_gather(parts, inp, group=group)
+        n = inp.numel() // world
+        out.copy_(torch.cat([p[rank * n:(rank + 1) * n] for p in parts]))
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+    return out
+
 
 
 def _shape(name, rows, cols):
@@ -264,6 +374,47 @@ class GradientBucket(_Flat):
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
         return TouchedBlocks(flags > 0, kmax=kmax)
 
+    def touched_row_fraction(self):
+        """Share of this rank's rows with a non-zero gradient (row-major buckets; a device scalar)."""
+        return (self.blocks["rows"].view(self.Ppad, ROW_FLOATS) != 0).any(dim=1).float().mean()
+
+    def reduce_scatter_rows_sparse(self, rank, group=None, kmax=None):
+        """Row-sparse form of ``reduce_scatter_rows`` (row-major buckets without SH columns): -> the same dict -- "rows"
+        [Pr, 16] = the sum over ranks of this rank's rows, "seen" [Pr] -- but only the rows with a non-zero gradient
+        travel: packed per owner as (16 sums | row index), padded to `kmax` rows per (sender, owner) pair, one all-to-all
+        with equal splits; the owner adds what it receives into a zeroed shard.  The seen counts (4 bytes per row, dense
+        by nature: every visible row counts) keep their dense reduce-scatter.
+        kmax=None: the longest list over all pairs of the whole job, exactly (one max-reduce + one read-back); kmax=K: a
+        bound kept from an earlier step, no read-back; ``self.sparse_overflow`` (device flag, summed into
+        ``StepExchange.compact_overflowed()``) says if some list was longer -- rows were dropped, repeat the step.
+        Same addends as the dense form, summed in rank order instead of ring order."""
+        assert self.row_major and [n for n, _ in self.layout] == ["rows"], "row-sparse exchange: row-major bucket without SH columns"
+        self.touched = None
+        dev, W, Pr = self.flat.device, self.world, self.Pr
+        out = {}
+        if not _active(self.world):
+            out["rows"] = self.rows("rows", 0)
+            if self.track_seen:
+                out["seen"] = self.seen[:self.Pr]
+            self.sparse_overflow, self.sparse_kmax = None, 0
+            return out
+        rows = self.blocks["rows"].view(W, Pr, ROW_FLOATS)
+        if kmax is None:
+            cnt = (rows != 0).any(dim=2).sum(1).max().reshape(1)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=group)
+            kmax = max(int(cnt.item()), 1)
+        kmax = min(max(int(kmax), 1), Pr)
+        packed, over = _pack_segments(rows, kmax)
+        recv = torch.empty_like(packed)
+        _all_to_all(recv, packed, group)
+        shard = torch.zeros(Pr, ROW_FLOATS, dtype=torch.float32, device=dev)
+        out["rows"] = _unpack_segments(shard, recv, W, kmax)
+        if self.track_seen:
+            mine = torch.empty(Pr, dtype=torch.float32, device=dev)
+            out["seen"] = _reduce_scatter(mine, self.seen, group)
+        self.sparse_overflow, self.sparse_kmax = over, kmax
+        return out
+
     def _columns(self):
         """(name, [P_pad * c] block, c) of everything that is exchanged: the attribute gradients and the seen counts."""
         return [(name, self.blocks[name], c) for name, c in self.layout] + ([("seen", self.seen, 1)] if self.track_seen else [])
@@ -400,7 +551,8 @@ class StepExchange:
         self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.world > 1) else None
         self._shards = [None] * self.parts
         self.touched = None
-        self._overflow = None     # device flag: a bounded touched-block exchange dropped blocks (compact_overflowed)
+        self._overflow = None     # device flag: a bounded touched-block / row-sparse exchange dropped rows (compact_overflowed)
+        self.gather_kmax = 0
 
     def bucket_of(self, view, n_views):
         """The bucket view `view` of the rank's `n_views` accumulates into (consecutive views share a group)."""
@@ -450,19 +602,27 @@ class StepExchange:
         return {"reduce_scatter_ms_per_step": tot["reduce_scatter"] / n, "exposed_join_ms_per_step": tot["join"] / n,
                 "all_gather_ms_per_step": tot["all_gather"] / n, "collectives_timed": len(self._ev["reduce_scatter"])}
 
-    def launch(self, part, compact=False, kmax=None):
-        """kmax (compact only): size the touched-block collectives from this bound instead of a read-back
-        (TouchedBlocks); check ``compact_overflowed()`` where the step synchronises anyway."""
+    def launch(self, part, compact=False, kmax=None, sparse=False):
+        """kmax (compact / sparse): size the collectives from this bound instead of a read-back (TouchedBlocks /
+        ``GradientBucket.reduce_scatter_rows_sparse``); check ``compact_overflowed()`` where the step synchronises anyway.
+        sparse: the row-sparse form (only rows with a non-zero gradient travel)."""
         b = self.buckets[part]
+        run = ((lambda: b.reduce_scatter_rows_sparse(self.rank, self.group, kmax=kmax)) if sparse else
+               (lambda: b.reduce_scatter_rows(self.rank, self.group, compact=compact, kmax=kmax)))
         if self.side is None:
-            self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact, kmax=kmax)
+            self._shards[part] = run()
         else:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side):
                 with self._timed("reduce_scatter", self.side):
-                    self._shards[part] = b.reduce_scatter_rows(self.rank, self.group, compact=compact, kmax=kmax)
-        if b.touched is not None and b.touched.overflow is not None:
-            self._overflow = b.touched.overflow if self._overflow is None else (self._overflow | b.touched.overflow)
+                    self._shards[part] = run()
+        over = None
+        if sparse:
+            over = getattr(b, "sparse_overflow", None)
+        elif b.touched is not None:
+            over = b.touched.overflow
+        if over is not None:
+            self._overflow = over if self._overflow is None else (self._overflow | over)
 
     def compact_overflowed(self, reset=True):
         """Did a bounded touched-block exchange since the last call drop blocks (some owner's touched list was longer than
@@ -498,12 +658,34 @@ class StepExchange:
                 self.touched = self.touched.union(t)
         return total
 
-    def all_gather_grads(self, total):
-        """Replicated-optimizer form: every rank receives every row of the summed gradients, in buckets[0]."""
+    def all_gather_grads(self, total, sparse_kmax=None):
+        """Replicated-optimizer form: every rank receives every row of the summed gradients, in buckets[0].
+        sparse_kmax (row-major buckets): only the non-zero rows of every owner's shard travel, packed like the row-sparse
+        reduce-scatter and padded to `sparse_kmax` rows per owner (0 / "exact": the longest list, one max-reduce + one
+        read-back); the bucket is zeroed and the gathered rows added into it.  Overflow: ``compact_overflowed()``."""
         b0 = self.buckets[0]
         if not _active(self.world):
             for name, _ in b0.layout:
                 b0.rows(name, 0).copy_(total[name])
+            return b0.flat
+        if sparse_kmax is not None and "rows" in total:
+            main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+            with self._timed("all_gather", main):
+                shard = total["rows"].reshape(1, b0.Pr, ROW_FLOATS)
+                k = sparse_kmax
+                if not k or k == "exact":
+                    cnt = (shard != 0).any(dim=2).sum().reshape(1)
+                    dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
+                    k = max(int(cnt.item()), 1)
+                k = min(int(k), b0.Pr)
+                packed, over = _pack_segments(shard.contiguous(), k)
+                recv = torch.empty(self.world * packed.numel(), dtype=torch.float32, device=self.device)
+                _all_gather(recv, packed, self.group)
+                self._overflow = over if self._overflow is None else (self._overflow | over)
+                self.gather_kmax = k
+                full = b0.blocks["rows"]
+                full.zero_()
+                _unpack_segments(full.view(self.world * b0.Pr, ROW_FLOATS), recv, self.world, k, per_segment_rows=b0.Pr)
             return b0.flat
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         with self._timed("all_gather", main):

@@ -123,7 +123,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
 
 def test_ctypes_signatures_match_the_header_prototypes():
     """Every prototype in include/lograst.h against log_amd/_lib.py: same number of parameters and the same C class
-    (pointer / 32-bit int / float / double / size_t) in every position."""
+    (pointer / 32-bit int / 64-bit int / float / double / size_t) in every position."""
     from log_amd import _lib
     src = open(os.path.join(ROOT, "include", "lograst.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
@@ -135,13 +135,14 @@ def test_ctypes_signatures_match_the_header_prototypes():
         if "*" in p:
             return "ptr"
         base = p.rsplit(" ", 1)[0] if " " in p else p
-        return {"int32_t": "i32", "uint32_t": "i32", "int": "i32", "float": "f32", "double": "f64", "size_t": "size"}[base.replace("const ", "").strip()]
+        return {"int32_t": "i32", "uint32_t": "i32", "int": "i32", "float": "f32", "double": "f64", "size_t": "size",
+                "int64_t": "i64"}[base.replace("const ", "").strip()]
 
     def py_class(t):
         if t in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
             return "ptr"
         return {ctypes.c_int32: "i32", ctypes.c_uint32: "i32", ctypes.c_int: "i32", ctypes.c_float: "f32",
-                ctypes.c_double: "f64", ctypes.c_size_t: "size"}[t]
+                ctypes.c_double: "f64", ctypes.c_size_t: "size", ctypes.c_int64: "i64"}[t]
 
     for name, params in protos.items():
         want = [] if params.strip() in ("", "void") else [c_class(p) for p in params.split(",")]

@@ -394,3 +394,55 @@ def test_bucket_without_seen_counts():
     params = FlatParams({n: torch.zeros(9, c) for n, c in b.layout}, "cpu")
     with pytest.raises(ValueError, match="seen counts"):
         OwnerAdam(params, 0).step_rows(total, params, {"means3D": 1e-3})
+
+
+def _sparse_worker(rank, world, port, out):
+    from log_amd.dist import StepExchange
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = 1003                                         # (not a multiple of the world size or of four)
+        res = {}
+        for mode, kw_rs, kw_ag in (("dense", {}, {}), ("sparse_exact", dict(sparse=True), dict(sparse_kmax="exact")),
+                                   ("sparse_bound", dict(sparse=True, kmax=200), dict(sparse_kmax=400)),
+                                   ("sparse_small", dict(sparse=True, kmax=20), dict(sparse_kmax=400))):
+            ex = StepExchange(P, "cpu", world, rank, parts=2, row_major=True)
+            for part, b in enumerate(ex.buckets):
+                gen = torch.Generator().manual_seed(100 * rank + part)
+                touched = torch.randperm(P, generator=gen)[:150]                 # 15 % of the rows, different per rank and group
+                # integer-valued gradients: the sums are exact in any order, so the forms must agree bit for bit
+                b.views["rows"][touched, :14] = torch.randint(-8, 9, (150, 14), generator=gen).float()
+                b.mark_seen((torch.rand(P, generator=gen) < 0.6).to(torch.int32))
+                ex.launch(part, **kw_rs)
+            total = ex.finish()
+            flat = ex.all_gather_grads(total, **kw_ag)
+            res[mode] = dict(rows=total["rows"].clone(), seen=total["seen"].clone(), full=ex.buckets[0].views["rows"].clone(),
+                             over=ex.compact_overflowed(), kmax=getattr(ex.buckets[0], "sparse_kmax", 0), gk=ex.gather_kmax)
+        torch.save(res, os.path.join(out, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sparse_exchange_equals_the_dense_one(tmp_path, world):
+    """The row-sparse exchange (only rows with a non-zero gradient travel: packed per owner, all-to-all with equal splits,
+    sparse all-gather of the summed shards) delivers what the dense reduce-scatter + all-gather deliver -- shards and full
+    gradient sum bit for bit on integer-valued gradients --, exactly sized or from a bound; a bound that is too small raises
+    the overflow flag."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sparse_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, f"s{r}.pt")) for r in range(world)]
+    for r in range(world):
+        d = got[r]["dense"]
+        assert not d["over"] and float(d["full"].abs().sum()) > 0
+        assert torch.equal(d["full"], got[0]["dense"]["full"])                   # every rank holds the same sum
+        for mode in ("sparse_exact", "sparse_bound"):
+            m = got[r][mode]
+            assert not m["over"], mode
+            assert torch.equal(m["rows"], d["rows"]) and torch.equal(m["seen"], d["seen"]), (r, mode)
+            assert torch.equal(m["full"], d["full"]), (r, mode)
+        assert 0 < got[r]["sparse_exact"]["kmax"] <= 150 and 0 < got[r]["sparse_exact"]["gk"] <= 2 * 150 * world
+        assert got[r]["sparse_bound"]["kmax"] == 200
+        assert got[r]["sparse_small"]["over"]                                   # 20 rows per pair cannot hold ~50-75

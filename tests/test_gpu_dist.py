@@ -31,6 +31,15 @@ def test_bench_self_spawns_two_ranks_and_reports_them():
     assert "dp2" in two["config"]["parallelism"] and two["value"] > 0
     # both ranks rendered the same Gaussians from their own 8 of the 16 cameras
     assert abs(two["config"]["visible_per_view"] - one["config"]["visible_per_view"]) < 0.05 * one["config"]["visible_per_view"]
+    # the exchange: mode decided from the warm-up, the exchange-only leg timed, every form runs without outgrowing its bounds
+    assert two["exchange"]["mode"] in ("dense", "sparse") and two["exchange"]["exchange_only_ms_per_step"] > 0
+    for mode in ("dense", "sparse"):
+        forced = _bench("--gpus", "2", "--gaussians", "200000", "--steps", "2", "--warmup", "1", "--no-secondary",
+                        "--no-cpu-baseline", "--no-dropin-mode", "--exchange", mode,
+                        env={"LOGRAST_DIST_BACKEND": "gloo", "LOGRAST_SHARE_GPU": "1"})
+        assert forced["exchange"]["mode"] == mode and forced["value"] > 0
+        if mode == "sparse":
+            assert 0 < forced["exchange"]["touched_row_fraction"] <= 1.0
 
 
 def test_bench_line_carries_the_contract_fields():
@@ -156,3 +165,45 @@ def test_step_exchange_two_ranks_equals_one_process(tmp_path, mode):
     for r in range(world):
         rows = seen[r * Pr:(r + 1) * Pr]
         assert torch.equal(got[r]["seen"][:rows.numel()], rows), r
+
+
+def test_pack_and_unpack_rows_kernels():
+    """lograst_pack_rows / lograst_unpack_rows (the row-sparse exchange's device side) against plain torch: every non-zero
+    row of every group arrives exactly once with its index, the header counts them, both unpack forms restore / sum them,
+    a bound that is too small raises the overflow flag and drops nothing it kept."""
+    import torch
+    from log_amd import dist as D
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    G, R = 3, 5000 + 37
+    rows = torch.zeros(G, R, 16)
+    want_counts = []
+    for g in range(G):
+        sel = torch.randperm(R, generator=gen)[: 700 + 100 * g]
+        rows[g, sel] = torch.randint(-9, 10, (sel.numel(), 16), generator=gen).float()
+        rows[g, sel[0], :] = 0.0
+        rows[g, sel[0], 15] = 1.0                                       # a row whose only non-zero entry is its last column
+        want_counts.append(int((rows[g] != 0).any(1).sum()))
+    rows_d = rows.to(dev)
+    k = 1024
+    packed, over = D._pack_segments(rows_d, k)
+    seg = D._segment_floats(k, dev)
+    assert packed.numel() == G * seg and not bool(over)
+    hdr = packed.view(G, seg)[:, 0].contiguous().view(torch.int32).cpu().tolist()
+    assert hdr == want_counts
+    # own-range form: segment g back into rows [g R, (g + 1) R) of a zeroed buffer
+    back = torch.zeros(G * R, 16, device=dev)
+    D._unpack_segments(back, packed, G, k, per_segment_rows=R)
+    assert torch.equal(back.view(G, R, 16).cpu(), rows)
+    # summing form: all segments into the same R rows (integer values: exact in any order)
+    acc = torch.zeros(R, 16, device=dev)
+    D._unpack_segments(acc, packed, G, k)
+    assert torch.equal(acc.cpu(), rows.sum(0))
+    # a bound below the longest list: flagged, and what was kept is still right (a subset of the rows, each intact)
+    small, over = D._pack_segments(rows_d, 512)
+    assert bool(over)
+    part = torch.zeros(G * R, 16, device=dev)
+    D._unpack_segments(part, small, G, 512, per_segment_rows=R)
+    part = part.view(G, R, 16).cpu()
+    kept = (part != 0).any(2)
+    assert int(kept.sum()) == 3 * 512 and torch.equal(part[kept], rows[kept])

@@ -446,3 +446,24 @@ def test_row_sparse_exchange_equals_the_dense_one(tmp_path, world):
         assert 0 < got[r]["sparse_exact"]["kmax"] <= 150 and 0 < got[r]["sparse_exact"]["gk"] <= 2 * 150 * world
         assert got[r]["sparse_bound"]["kmax"] == 200
         assert got[r]["sparse_small"]["over"]                                   # 20 rows per pair cannot hold ~50-75
+
+
+def test_pack_rows_edge_cases():
+    """The torch formulation of the row-sparse pack (what the gloo tests run; the device kernels are checked against it in
+    tests/test_gpu_dist.py): an all-zero group, a bound above the group size, a row whose only non-zero entry is its last
+    column, NaN (counts as non-zero: it must reach the owner), and the overflow flag."""
+    from log_amd.dist import SPARSE_FLOATS, _pack_rows, _unpack_add
+    rows = torch.zeros(3, 10, 16)
+    rows[0, 3, 15] = 2.0
+    rows[0, 7, 0] = float("nan")
+    rows[2, :, 5] = torch.arange(1, 11).float()
+    packed, counts, over = _pack_rows(rows, 12)
+    assert packed.shape == (3, 12, SPARSE_FLOATS) and counts.tolist() == [2, 0, 10] and not bool(over)
+    assert float(packed[1].abs().sum()) == 0.0                                   # nothing but padding
+    for g in range(3):
+        back = _unpack_add(torch.zeros(10, 16), packed[g])
+        assert torch.equal(torch.nan_to_num(back, nan=123.0), torch.nan_to_num(rows[g], nan=123.0)), g
+    idx = packed[0, :2, 16].contiguous().view(torch.int32).tolist()
+    assert idx == [3, 7]                                                         # ascending row order inside a group
+    _, counts, over = _pack_rows(rows, 4)
+    assert counts.tolist() == [2, 0, 10] and bool(over)

@@ -94,6 +94,10 @@ def parse():
     ap.add_argument("--no-rand-variant", action="store_true", help="skip the opacity = rand variant of the headline (N = 1)")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the torch.no_grad() legs")
     ap.add_argument("--no-c5-band", action="store_true", help="skip the C5 band leg (100 M Gaussians, 4K, one of 8 bands)")
+    ap.add_argument("--no-trained-like", action="store_true",
+                    help="skip the trained-like variant of the headline (log-normal scales, bounded anisotropy, sigmoid-normal opacity)")
+    ap.add_argument("--scene", choices=("random", "trained"), default="random",
+                    help="headline scene generator: check_gui's uniform draws (SURVEY 8d) or log_amd.scenes.trained_like_scene")
     ap.add_argument("--exchange", choices=("auto", "dense", "compact", "sparse"), default=os.environ.get("LOGRAST_EXCHANGE", "auto"),
                     help="N > 1: dense reduce-scatter + all-gather, touched-row-block exchange, row-sparse exchange (only rows "
                          "with a non-zero gradient travel), or decided once from the warm-up (auto: row-sparse when fewer than "
@@ -174,7 +178,11 @@ class RasterWorkload:
         from log_amd import scenes
         self.N, self.W, self.H, self.dev, self.views = N, args.width, args.height, dev, args.views
         W, H = self.W, self.H
-        self.sc = scenes.random_scene(N, seed=0, opacity=(None if args.opacity < 0 else args.opacity))
+        if getattr(args, "scene", "random") == "trained":
+            # the statistics of a trained model instead of check_gui's uniform draws (log_amd.scenes.trained_like_scene)
+            self.sc = scenes.trained_like_scene(N, seed=0)
+        else:
+            self.sc = scenes.random_scene(N, seed=0, opacity=(None if args.opacity < 0 else args.opacity))
         all_cams = scenes.orbit_cameras(args.views * world, W=W, H=H, focal=2139.0 * W / 1920.0,
                                         end_deg=360.0 * (1 - 1.0 / (args.views * world)))
         self.cams = [all_cams[i] for i in range(rank, len(all_cams), world)]   # round-robin view ownership
@@ -800,7 +808,7 @@ def main():
     }
     if world > 1:
         result["exchange"] = {
-            "mode": r.get("exchange_mode"), "policy": args.exchange, "parts": r["exchange_parts"],
+            "mode": r.get("exchange_mode"), "policy": args.exchange, "parts": r["exchange_parts"], "backend": backend,
             "nonzero_gradient_row_fraction": r.get("exchange_nonzero_row_fraction"),
             "touched_row_fraction": r.get("exchange_touched_row_fraction"), "row_bounds": r.get("exchange_row_bounds"),
             "sparse_error": r.get("exchange_sparse_error"),
@@ -889,6 +897,31 @@ def main():
             result["modes"]["pipelined_opacity_rand"] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
 
+    if world == 1 and not args.no_trained_like and args.scene == "random":
+        # Round-4 verdict, missing #4: the same 30 M / 1080p / 8-view step on a scene with the statistics of a TRAINED model
+        # (log-normal scales sigma 0.5, anisotropy <= 10, sigmoid-normal opacity; tests/test_gpu_scale.py checks the very
+        # same scene against the oracle) -- neither an opaque cube where 93 % of the Gaussians never composite nor uniform
+        # needles and pancakes.
+        try:
+            args_t = argparse.Namespace(**dict(vars(args), scene="trained"))
+            wl_t = RasterWorkload(args_t, N, dev, rank, world, torch, np)
+            tsteps = max(2, min(args.steps, 5))
+            rt = measure(args_t, wl_t, S, fused, tsteps, max(1, min(args.warmup, 2)), world, timing, graphs=not args.no_graphs)
+            mt = dict(mode_summary(N, args.views, world, tsteps, rt), streams=S, sync_free=True, hip_graphs=rt["graphs"],
+                      steps=tsteps)
+            mt.update(workload_report(args_t, wl_t, rt, N, Px, world, tsteps, roofs, timing,
+                                      "trained-like scene: %d Gaussians (log_amd.scenes.trained_like_scene, seed 0), %dx%d, "
+                                      "%d orbit views, same harness as the headline" % (N, W, H, args.views)))
+            mt["forms"] = dict(R_forms())
+            result["modes"]["pipelined_trained_like"] = mt
+            result["config"]["ms_per_view_trained_like"] = mt["ms_per_view"]
+            if "roofline" in result:
+                result["roofline"]["whole_view_trained_like"] = whole_view_summary(mt, mt["ms_per_view"], roofs["measured_stream_copy"])
+            del wl_t
+        except Exception as e:
+            result["modes"]["pipelined_trained_like"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
     if world == 1 and not args.no_secondary:
         sec = {}
         try:
@@ -921,10 +954,59 @@ def main():
         result["secondary"] = sec
 
     if rank == 0:
+        flatten_for_the_driver(result)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def flatten_for_the_driver(result):
+    """The driver's record keeps the SCALAR keys of `roofline` and `config` (nested objects are dropped from its `parsed`
+    copy): everything the nested objects say that a reader of BENCH_rNN.json needs is repeated as scalars -- the A0 leg,
+    the whole view against the measured copy (opaque / opacity = rand / trained-like), which compositing form ran, the
+    drop-in default mode, and the secondary legs' per-view times (round-4 verdict, missing #5 / next #8)."""
+    rf = result.get("roofline")
+    if not isinstance(rf, dict):
+        return
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    put = lambda k, v: rf.__setitem__(k, v) if v is not None else None
+    put("compute_radius_us", g(rf, "compute_radius", "us"))
+    put("compute_radius_frac", g(rf, "compute_radius", "frac_of_hbm_peak"))
+    put("compute_radius_GBs", g(rf, "compute_radius", "GBs"))
+    put("whole_view_ms", g(rf, "whole_view", "ms_per_view"))
+    put("whole_view_frac_of_measured_stream_copy", g(rf, "whole_view", "survey_formula_frac_of_measured_stream_copy"))
+    put("whole_view_frac_of_hbm_peak", g(rf, "whole_view", "survey_formula_frac_of_hbm_peak"))
+    put("whole_view_effective_frac_of_measured_stream_copy", g(rf, "whole_view", "effective_frac_of_measured_stream_copy"))
+    put("whole_view_rand_ms", g(rf, "whole_view_opacity_rand", "ms_per_view"))
+    put("whole_view_rand_frac_of_measured_stream_copy",
+        g(rf, "whole_view_opacity_rand", "survey_formula_frac_of_measured_stream_copy"))
+    put("whole_view_rand_effective_frac_of_measured_stream_copy",
+        g(rf, "whole_view_opacity_rand", "effective_frac_of_measured_stream_copy"))
+    put("whole_view_trained_like_ms", g(rf, "whole_view_trained_like", "ms_per_view"))
+    put("whole_view_trained_like_frac_of_measured_stream_copy",
+        g(rf, "whole_view_trained_like", "survey_formula_frac_of_measured_stream_copy"))
+    put("whole_view_trained_like_effective_frac_of_measured_stream_copy",
+        g(rf, "whole_view_trained_like", "effective_frac_of_measured_stream_copy"))
+    put("fwd_form", g(rf, "forms", "fwd"))
+    put("bwd_form", g(rf, "forms", "bwd"))
+    put("trained_like_fwd_form", g(result, "modes", "pipelined_trained_like", "forms", "fwd"))
+    put("trained_like_bwd_form", g(result, "modes", "pipelined_trained_like", "forms", "bwd"))
+    put("dropin_default_ms_per_view", g(result, "modes", "dropin_default", "ms_per_view"))
+    put("forward_only_ms_per_view", g(result, "forward_only", "headline", "capacity_hint", "ms_per_view"))
+    for name, k in (result.get("kernels") or {}).items():          # the per-kernel table of the headline, in microseconds
+        put("kernel_us_" + name, k.get("avg_us"))
+    cfg = result.get("config", {})
+    sec = result.get("secondary") or {}
+    for key, path in (("c2_ms_per_view", ("c2", "modes", "pipelined", "ms_per_view")),
+                      ("c2_dropin_default_ms_per_view", ("c2", "modes", "dropin_default", "ms_per_view")),
+                      ("c3_ms_per_view", ("c3", "ms_per_view")),
+                      ("c5_band_ms_per_view_gradient_sink", ("c5_band", "ms_per_view_band_clipped_gradient_sink"))):
+        v = g(sec, *path)
+        if v is not None:
+            cfg[key] = v
+    for name, k in (g(sec, "c2", "kernels") or {}).items():
+        put("c2_kernel_us_" + name, k.get("avg_us"))
 
 
 def roof(prof, alg, alg_eff, N, W, H):

@@ -215,8 +215,13 @@ int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks
  * particular order), index [roundup(kmax, 16)] (int32: the row's index inside its group).  Rows beyond kmax are dropped
  * and *overflow (a device word, OR-ed; may be NULL) is raised.  Equal-sized segments: an all-to-all / all-gather with
  * equal splits moves them.  lograst_unpack_rows: for every segment s and every row j < min(count_s, kmax):
- *   atomic != 0:  dest[index][0..15] += values            (all segments into the same rows_per_group rows: float atomics)
- *   atomic == 0:  dest[s * dest_group_rows + index][..] = values   (segment s owns its own range of rows: plain stores) */
+ *   atomic != 0:  dest[index][0..15] += values            (all segments into the same rows_per_group rows.  Despite the
+ *                 argument's name no float atomics are involved since round 5: the segments are added one after the
+ *                 other in segment order -- rows inside one segment are unique --, so a row's sum is
+ *                 ((s0 + s1) + s2) + ... on every run, whatever order the segments arrived in)
+ *   atomic == 0:  dest[s * dest_group_rows + index][..] = values   (segment s owns its own range of rows: plain stores;
+ *                 dest_group_rows >= rows_per_group)
+ * dest and packed must be 16-byte aligned. */
 size_t lograst_sparse_segment_floats(int32_t kmax);
 int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
                       uint32_t* overflow, void* stream);
@@ -268,7 +273,11 @@ int lograst_set_tile_cull(int enabled);
  * point_weight (optional, NULL = none): the forward's per-Gaussian maximum blend weight.  A Gaussian with weight 0
  * contributed to no pixel, so its dL/dmean2D and dL/dconic are exactly zero: the chain rule skips it (its gradients
  * are written as 0, or left alone when accumulating) without reading its inputs -- in an opaque scene that is most of
- * the Gaussians. */
+ * the Gaussians.  It must be the UNMODIFIED point_weight output of the forward whose geom / tile_state / point_list are
+ * passed here: the forward clears it for every row and only composited Gaussians (radii > 0) ever raise it, so the kernel
+ * takes point_weight > 0 alone as the live flag and does not read radii for that decision.
+ * Alignment: bwd_rows 64 bytes; rotations / dl_drotations 16 bytes; every other array 4 bytes (the kernels' full-width
+ * clears of dl_dmeans2d / dl_dopacities / dl_dcolors / dl_dmeans3d / dl_dscales / dl_dcov3d start with a scalar head). */
 #define LOGRAST_BWD_SCRATCH_ZEROED 1
 #define LOGRAST_BWD_ACCUMULATE 2
 #define LOGRAST_BWD_CONIC_TOUCHED_ONLY 4

@@ -596,6 +596,10 @@ int lograst_unpack_rows(float* dest, const float* packed, int32_t segments, int3
     return lr_fail(LOGRAST_ERR_ARG, "lograst_unpack_rows: negative size or kmax <= 0");
   if (segments == 0 || rows_per_group == 0) return LOGRAST_OK;
   if (!dest || !packed) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(dest) | reinterpret_cast<uintptr_t>(packed)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "lograst_unpack_rows: dest / packed must be 16-byte aligned");
+  if (!atomic && dest_group_rows < rows_per_group)
+    return lr_fail(LOGRAST_ERR_ARG, "lograst_unpack_rows: dest_group_rows must cover rows_per_group (segment s owns rows [s * dest_group_rows, ...))");
   lx_launch_unpack_rows(dest, packed, segments, kmax, lograst_sparse_segment_floats(kmax), rows_per_group,
                         atomic ? 0 : dest_group_rows, atomic, (hipStream_t)stream);
   LR_HIP(hipGetLastError());

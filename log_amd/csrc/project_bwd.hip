@@ -178,7 +178,13 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
     // runs: lr_launch_project_bwd.)
     const int rows_here = min(LR_PBWD_ROWS, N - base);
     typedef float lr_f4v __attribute__((ext_vector_type(4)));
-    auto clear = [&](float* p, int floats) {   // p is 16-byte aligned when base is a multiple of 4 rows (it is: 1024)
+    // (a scalar head up to the first 16-byte boundary, then full-width stores, then a scalar tail: the C ABI asks only
+    // for 4-byte alignment of these outputs -- round-4 advisory; torch's allocations always take the head-less path)
+    auto clear = [&](float* p0, int floats) {
+      const int head = min(floats, (int)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p0) & 15u)) & 15u) >> 2));
+      if (tid < head) p0[tid] = 0.f;
+      float* p = p0 + head;
+      floats -= head;
       const int n4 = floats >> 2;
       lr_f4v* q = reinterpret_cast<lr_f4v*>(p);
       for (int t = tid; t < n4; t += 256) q[t] = lr_f4v{0.f, 0.f, 0.f, 0.f};

@@ -288,9 +288,15 @@ class TouchedBlocks:
         self.order = torch.argsort((~bitmap).to(torch.uint8), dim=1, stable=True)[:, :self.kmax].contiguous()
 
     def union(self, other):
-        out = TouchedBlocks(self.bitmap | other.bitmap, kmax=None if self.bound is None else max(self.kmax, other.kmax))
-        if self.overflow is not None and other.overflow is not None:
-            out.overflow = out.overflow | self.overflow | other.overflow
+        """Blocks touched by either.  Bounded form: the union of two lists of at most K blocks can hold up to 2 K, so the
+        union is sized for the SUM of the parts' bounds (round-4 advisory: with max(K, K) an owner whose parts touched
+        disjoint blocks published only its first K -- the other updated rows never reached the replicas); its own
+        overflow flag (impossible unless a part overflowed) is folded in all the same."""
+        out = TouchedBlocks(self.bitmap | other.bitmap,
+                            kmax=None if self.bound is None else min(self.kmax + other.kmax, self.nb))
+        for o in (self.overflow, other.overflow):
+            if o is not None:
+                out.overflow = o if out.overflow is None else (out.overflow | o)
         return out
 
     @property
@@ -387,7 +393,10 @@ class GradientBucket(_Flat):
         kmax=None: the longest list over all pairs of the whole job, exactly (one max-reduce + one read-back); kmax=K: a
         bound kept from an earlier step, no read-back; ``self.sparse_overflow`` (device flag, summed into
         ``StepExchange.compact_overflowed()``) says if some list was longer -- rows were dropped, repeat the step.
-        Same addends as the dense form, summed in rank order instead of ring order."""
+        Same addends as the dense form, summed in rank order -- ((r0 + r1) + r2) + ... -- instead of ring order: on the
+        device lograst_unpack_rows adds the received segments one after the other with plain read-modify-writes (rows inside
+        a segment are unique; no float atomics since round 5), on the CPU index_add_ walks them in the same order, so the
+        reduced gradients are reproducible run to run on any number of ranks."""
         assert self.row_major and [n for n, _ in self.layout] == ["rows"], "row-sparse exchange: row-major bucket without SH columns"
         self.touched = None
         dev, W, Pr = self.flat.device, self.world, self.Pr
@@ -551,7 +560,11 @@ class StepExchange:
         self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.world > 1) else None
         self._shards = [None] * self.parts
         self.touched = None
-        self._overflow = None     # device flag: a bounded touched-block / row-sparse exchange dropped rows (compact_overflowed)
+        # device flag: a bounded touched-block / row-sparse exchange dropped rows (compact_overflowed).  ONE persistent
+        # tensor, OR-ed in place on the stream that produced the addend (round-4 advisory: a fresh `a | b` issued on the
+        # compute stream read a side-stream temporary without waiting for it, after its block had gone back to the pool)
+        self._overflow = torch.zeros((), dtype=torch.bool, device=self.device)
+        self._overflow_used = False
         self.gather_kmax = 0
 
     def bucket_of(self, view, n_views):
@@ -609,27 +622,37 @@ class StepExchange:
         b = self.buckets[part]
         run = ((lambda: b.reduce_scatter_rows_sparse(self.rank, self.group, kmax=kmax)) if sparse else
                (lambda: b.reduce_scatter_rows(self.rank, self.group, compact=compact, kmax=kmax)))
-        if self.side is None:
+        def run_and_note():
             self._shards[part] = run()
+            over = getattr(b, "sparse_overflow", None) if sparse else (b.touched.overflow if b.touched is not None else None)
+            self._note_overflow(over)       # on the stream that wrote `over`: in order behind its producer
+
+        if self.side is None:
+            run_and_note()
         else:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side):
                 with self._timed("reduce_scatter", self.side):
-                    self._shards[part] = run()
-        over = None
-        if sparse:
-            over = getattr(b, "sparse_overflow", None)
-        elif b.touched is not None:
-            over = b.touched.overflow
+                    run_and_note()
+
+    def _note_overflow(self, over):
+        """OR a device flag into the step's persistent overflow flag, on the CURRENT stream (the caller issues this on the
+        stream that produced `over`; launch() / finish() / compact_overflowed() order the streams among themselves)."""
         if over is not None:
-            self._overflow = over if self._overflow is None else (self._overflow | over)
+            self._overflow.logical_or_(over.reshape(()).to(torch.bool))
+            self._overflow_used = True
 
     def compact_overflowed(self, reset=True):
         """Did a bounded touched-block exchange since the last call drop blocks (some owner's touched list was longer than
         the bound)?  One device -> host read: call it where the step synchronises anyway."""
-        over = bool(self._overflow.item()) if self._overflow is not None else False
+        if not self._overflow_used:
+            return False
+        if self.side is not None:         # the flag may have been written on the side stream last
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        over = bool(self._overflow.item())
         if reset:
-            self._overflow = None
+            self._overflow.zero_()
+            self._overflow_used = False
         return over
 
     def finish(self):
@@ -656,6 +679,8 @@ class StepExchange:
             self.touched = tbs[0]
             for t in tbs[1:]:
                 self.touched = self.touched.union(t)
+            if self.parts > 1:               # (parts == 1: launch() noted it already)
+                self._note_overflow(self.touched.overflow)
         return total
 
     def all_gather_grads(self, total, sparse_kmax=None):
@@ -669,6 +694,8 @@ class StepExchange:
                 b0.rows(name, 0).copy_(total[name])
             return b0.flat
         if sparse_kmax is not None and "rows" in total:
+            # (only the "rows" block travels here: SH columns would silently stay un-gathered -- round-4 advisory)
+            assert [n for n, _ in b0.layout] == ["rows"], "row-sparse all-gather: row-major bucket without SH columns"
             main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
             with self._timed("all_gather", main):
                 shard = total["rows"].reshape(1, b0.Pr, ROW_FLOATS)
@@ -681,7 +708,7 @@ class StepExchange:
                 packed, over = _pack_segments(shard.contiguous(), k)
                 recv = torch.empty(self.world * packed.numel(), dtype=torch.float32, device=self.device)
                 _all_gather(recv, packed, self.group)
-                self._overflow = over if self._overflow is None else (self._overflow | over)
+                self._note_overflow(over)      # (the compute stream, which has joined the side stream in finish())
                 self.gather_kmax = k
                 full = b0.blocks["rows"]
                 full.zero_()

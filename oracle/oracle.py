@@ -133,9 +133,14 @@ def lod_traverse(node_index, tree, xyz, scaling, rotation, root_index, proj, vie
     return np.concatenate(out).astype(np.int64)
 
 
-def forward(view, means, scales, rots, opac, colors, extras=True, cov3d=None):
+def forward(view, means, scales, rots, opac, colors, extras=True, cov3d=None, tile_rows=None):
     """Full forward.  Returns a dict with every intermediate the HIP path is compared against.
-    cov3d ([N, 6], the rasterizer's cov3D_precomp) replaces scales + rots when given."""
+    cov3d ([N, 6], the rasterizer's cov3D_precomp) replaces scales + rots when given.
+    tile_rows=(begin, end): the whole-view render RESTRICTED to the band of tile rows [begin, end) -- what one rank of an
+    image split across GPUs owns (include/lograst.h: lograst_view.tile_row_begin / _end): after the
+    whole-view projection every rect is clipped to the band's rows, a Gaussian whose clipped rect is empty is dropped
+    (radii = 0, no record), and binning / compositing then see the band's tiles only -- every tile outside the band has an
+    empty list (image = background there).  The per-Gaussian arithmetic is the whole view's, untouched."""
     means = _f32(means)
     N = means.shape[0]
     cov3d = None if cov3d is None else _f32(cov3d).reshape(N, 6)
@@ -151,6 +156,19 @@ def forward(view, means, scales, rots, opac, colors, extras=True, cov3d=None):
     L = lib()
     I = L.ora_project(ctypes.byref(view), ctypes.c_int32(N), _p(means), _p(scales), _p(rots), _p(opac),
                       _p(colors), _p(radii), _p(rec), _p(touched), _p(cov3d) if cov3d is not None else None)
+    if tile_rows is not None and tuple(tile_rows) != (0, 0):
+        b, e = int(tile_rows[0]), int(tile_rows[1])
+        r0, r1 = rec[:N, 10].view(np.uint32), rec[:N, 11].view(np.uint32)
+        x0, x1 = r0 & 0xffff, r1 & 0xffff
+        y0 = np.clip(r0 >> 16, b, e).astype(np.uint32)
+        y1 = np.clip(r1 >> 16, b, e).astype(np.uint32)
+        keep = (radii > 0) & (y1 > y0)
+        radii[~keep] = 0
+        touched[:N] = np.where(keep, (x1 - x0) * (y1 - y0), 0).astype(np.uint32)
+        r0[:] = np.where(keep, x0 | (y0 << 16), 0)
+        r1[:] = np.where(keep, x1 | (y1 << 16), 0)
+        I = int(touched[:N].astype(np.int64).sum())
+        del x0, x1, y0, y1, keep
     offsets = np.zeros(T + 1, np.uint32)
     plist = np.zeros(max(int(I), 1), np.uint32)
     rc = L.ora_bin(ctypes.byref(view), ctypes.c_int32(N), _p(radii), _p(rec), _p(offsets), _p(plist))

@@ -81,14 +81,14 @@ def hip_project_backward(hf, g_mean2d, g_conic):
     return dict(means3D=g3.cpu().numpy(), scales=gs.cpu().numpy(), rotations=gr.cpu().numpy())
 
 
-def oracle_forward(oracle, cam, sc, bg, flavour=R.WODILATE, use_filter=True, scale_modifier=1.0):
+def oracle_forward(oracle, cam, sc, bg, flavour=R.WODILATE, use_filter=True, scale_modifier=1.0, tile_rows=None):
     tfx, tfy = cam_tan(cam)
     fm = flavour.filter_mode if use_filter else _lib.FILTER_NONE
     v = oracle.make_view(cam["image_width"], cam["image_height"], tfx, tfy, cam["world_view_transform"],
                          cam["full_proj_transform"], bg, scale_modifier=scale_modifier, filter_mode=fm,
                          ndc_cull=flavour.ndc_cull)
     f = oracle.forward(v, sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["colors"],
-                       extras=bool(flavour.extras))
+                       extras=bool(flavour.extras), tile_rows=tile_rows)
     f["_view"] = v
     return v, f
 
@@ -207,8 +207,11 @@ def gradient_anchor_stats(hg, og, g64):
     for k in ("means2D", "conic", "opacities", "colors"):
         ref = g64[k].reshape(len(g64[k]), -1)
         nr = max(float(np.linalg.norm(ref)), 1e-300)
+        no = max(float(np.linalg.norm(og[k].astype(f64))), 1e-300)
         st[k] = dict(rel_l2_hip=float(np.linalg.norm(hg[k].reshape(ref.shape).astype(f64) - ref) / nr),
-                     rel_l2_oracle=float(np.linalg.norm(og[k].reshape(ref.shape).astype(f64) - ref) / nr))
+                     rel_l2_oracle=float(np.linalg.norm(og[k].reshape(ref.shape).astype(f64) - ref) / nr),
+                     rel_l2_hip_vs_oracle=float(np.linalg.norm(hg[k].reshape(ref.shape).astype(f64)
+                                                               - og[k].reshape(ref.shape).astype(f64)) / no))
     cond = g64["cond"]
     for j, k in enumerate(("means3D", "scales", "rotations")):
         ref = g64[k]
@@ -226,6 +229,8 @@ def gradient_anchor_stats(hg, og, g64):
         st[k] = dict(rows=int(live.sum()), excluded_fraction=float((live & ~well).sum() / max(int(live.sum()), 1)),
                      rel_l2_well_hip=float(np.linalg.norm(dh[well]) / nw), rel_l2_well_oracle=float(np.linalg.norm(do[well]) / nw),
                      rel_l2_all_hip=float(np.linalg.norm(dh) / na), rel_l2_all_oracle=float(np.linalg.norm(do) / na),
+                     # end to end, EVERY row, HIP against the fp32 oracle itself (round-4 verdict weak #1b: never printed)
+                     rel_l2_all_hip_vs_oracle=float(np.linalg.norm(dh - do) / max(float(np.linalg.norm(og[k].astype(f64))), 1e-300)),
                      max_row_rel_well_hip=float((eh[well] / y[well]).max()) if well.any() else 0.0,
                      row_bound_violations=int((excess > ROW_FLOOR).sum()), worst_row_excess_units=float(excess.max()) if live.any() else 0.0,
                      err_l2_ratio=float(np.linalg.norm(eh) / max(float(np.linalg.norm(eo)), 1e-300)),
@@ -236,8 +241,13 @@ def gradient_anchor_stats(hg, og, g64):
     return st
 
 
-def assert_gradients_anchored(st, tol=1e-4, max_excluded=0.06, name=None):
-    """The four claims above; `name`: also dump the statistics to gpurun_out/parity_stats/<name>.json (best effort)."""
+def assert_gradients_anchored(st, tol=1e-4, max_excluded=0.06, name=None, all_rows_tol=None):
+    """The four claims above; `name`: also dump the statistics to gpurun_out/parity_stats/<name>.json (best effort).
+    all_rows_tol: additionally the PLAIN criterion of BASELINE.json's north_star -- relative L2 over ALL rows, no row
+    excluded, no conditioning -- for dL/dmeans3D, dL/dscales, dL/drotations end to end: HIP against the float64 twin AND
+    against the fp32 oracle.  Asserted on the realistic inputs (the level-of-detail selection of a tree, the trained-like
+    scene); on check_gui's uniform draws (needles and pancakes by construction) the float64 distance of ANY fp32
+    evaluation is dominated by a few degenerate rows -- those cases print the all-rows numbers and assert claims 1-4."""
     if name:
         import json
         import os
@@ -261,3 +271,6 @@ def assert_gradients_anchored(st, tol=1e-4, max_excluded=0.06, name=None):
         assert s["row_bound_violations"] == 0, (k, s)
         assert s["err_l2_excess_units"] <= L2_FLOOR, (k, s)
         assert s["zero_rows_nonzero"] == 0, (k, s)
+        if all_rows_tol is not None:
+            assert s["rel_l2_all_hip"] <= all_rows_tol, (k, s)
+            assert s["rel_l2_all_hip_vs_oracle"] <= all_rows_tol, (k, s)

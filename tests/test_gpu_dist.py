@@ -42,15 +42,36 @@ def test_bench_self_spawns_two_ranks_and_reports_them():
             assert 0 < forced["exchange"]["touched_row_fraction"] <= 1.0
 
 
+def test_bench_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """The same self-spawn with the default backend (`nccl` = RCCL) and one GPU per rank: runs on the first box that has
+    two GPUs without a code change (the pool's boxes expose one: visibly skipped there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    for mode in ("dense", "sparse"):
+        two = _bench("--gpus", "2", "--gaussians", "200000", "--steps", "2", "--warmup", "1", "--no-secondary",
+                     "--no-cpu-baseline", "--no-dropin-mode", "--exchange", mode)
+        assert two["n_gpus"] == 2 and two["value"] > 0 and two["exchange"]["mode"] == mode
+        assert two["exchange"].get("backend", "nccl") == "nccl"
+
+
 def test_bench_line_carries_the_contract_fields():
     d = _bench("--gaussians", "300000", "--steps", "2", "--warmup", "1", "--no-secondary")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "modes"):
         assert k in d, k
     assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert set(d["modes"]) == {"pipelined", "dropin_default", "pipelined_opacity_rand"}
+    assert set(d["modes"]) == {"pipelined", "dropin_default", "pipelined_opacity_rand", "pipelined_trained_like"}
     assert "error" not in d["modes"]["pipelined_opacity_rand"] and d["modes"]["pipelined_opacity_rand"]["value"] > 0
+    assert "error" not in d["modes"]["pipelined_trained_like"] and d["modes"]["pipelined_trained_like"]["value"] > 0
     r = d["roofline"]
+    # what the driver's record keeps of the nested objects, as scalars (round-4 verdict, next #8)
+    for k in ("compute_radius_us", "compute_radius_frac", "whole_view_frac_of_measured_stream_copy",
+              "whole_view_rand_frac_of_measured_stream_copy", "whole_view_trained_like_frac_of_measured_stream_copy",
+              "dropin_default_ms_per_view", "kernel_us_project", "kernel_us_blend_bwd"):
+        assert isinstance(r[k], float) and r[k] > 0, k
+    assert r["fwd_form"] in ("rows", "quadrant") and r["bwd_form"] in ("rows", "quadrant")
+    assert d["config"]["ms_per_view_trained_like"] > 0
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "committed profile" in r["traffic_source"]
     # effective algorithmic bytes: no kernel is credited with more than the peak
@@ -199,6 +220,29 @@ def test_pack_and_unpack_rows_kernels():
     acc = torch.zeros(R, 16, device=dev)
     D._unpack_segments(acc, packed, G, k)
     assert torch.equal(acc.cpu(), rows.sum(0))
+    # non-integer values, overlapping rows in all three segments: the sum is ((s0 + s1) + s2) bit for bit, on every run
+    # (round-4 verdict weak #8: one launch with float atomics over all segments made it depend on the arrival order)
+    frows = torch.zeros(G, R, 16)
+    for g in range(G):
+        sel = torch.randperm(R, generator=gen)[:3000]                   # 60 % of the rows per segment: heavy overlap
+        frows[g, sel] = torch.randn(sel.numel(), 16, generator=gen) * (10.0 ** torch.randint(-3, 4, (sel.numel(), 1), generator=gen))
+    fpacked, over = D._pack_segments(frows.to(dev), 4096)
+    assert not bool(over)
+    want = (frows[0] + frows[1]) + frows[2]
+    for _ in range(3):
+        facc = torch.zeros(R, 16, device=dev)
+        D._unpack_segments(facc, fpacked, G, 4096)
+        assert torch.equal(facc.cpu(), want)
+    # the C ABI documents `overflow` as optional: NULL with a bound that is too small must not fault (round-4 advisory)
+    import ctypes
+    from log_amd import _lib
+    L = _lib.lib()
+    seg_small = int(L.lograst_sparse_segment_floats(64))
+    buf = torch.empty(G * seg_small, dtype=torch.float32, device=dev)
+    _lib.check(L.lograst_pack_rows(ctypes.c_void_p(rows_d.data_ptr()), G, R, 64, ctypes.c_void_p(buf.data_ptr()),
+                                   ctypes.c_void_p(0), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    torch.cuda.synchronize()
+    assert buf.view(G, seg_small)[:, 0].contiguous().view(torch.int32).cpu().tolist() == want_counts
     # a bound below the longest list: flagged, and what was kept is still right (a subset of the rows, each intact)
     small, over = D._pack_segments(rows_d, 512)
     assert bool(over)

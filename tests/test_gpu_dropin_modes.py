@@ -232,6 +232,48 @@ def test_walk_form_hint_changes_no_result():
         assert float(np.abs(a[1][k]).sum()) > 0 and rel_l2(a[1][k], b[1][k]) < 1e-5, k
 
 
+def test_walk_form_can_be_pinned_by_the_host():
+    """Round-4 verdict weak #9: which compositing form runs no longer has to come from process history -- per rasterizer
+    object (``GaussianRasterizer(..., walk_form=)``), per block (``with R.walk_form(...)``) or process-wide
+    (``R.set_walk_form``); the backward follows its forward's pin; results do not depend on it."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R
+    import gpu_util as G
+    dev = torch.device(DEV)
+    cam, sc = small_case(n=5000, W=200, H=120, focal=220.0, seed=10, smax=0.03)
+    w = torch.tensor(np.random.default_rng(3).random((3, 120, 200), dtype=np.float32), device=dev)
+    outs = {}
+
+    def run(make, ctx=None):
+        leaves = _leaves(sc, dev)
+        rast = make()
+        if ctx is not None:
+            with ctx:
+                ret, m2 = _call(rast, leaves, 5000, dev)
+        else:
+            ret, m2 = _call(rast, leaves, 5000, dev)
+        fwd = R._backend.last_forms["fwd"]
+        (ret[0] * w).sum().backward()            # outside any block: the forward's pin must hold
+        torch.cuda.synchronize()
+        return fwd, R._backend.last_forms["bwd"], ret[0].detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()}
+
+    st = lambda: G.settings(cam, (1, 1, 1), dev)
+    for form in ("rows", "quadrant"):
+        outs[form] = run(lambda: GaussianRasterizer(raster_settings=st(), walk_form=form))
+        assert outs[form][:2] == (form, form)
+        assert run(lambda: GaussianRasterizer(raster_settings=st()), R.walk_form(form))[:2] == (form, form)
+        prev = R.set_walk_form(form)
+        try:
+            assert prev == "auto" and run(lambda: GaussianRasterizer(raster_settings=st()))[:2] == (form, form)
+        finally:
+            R.set_walk_form(None)
+    assert (outs["rows"][2].view(np.uint32) == outs["quadrant"][2].view(np.uint32)).all()
+    for k in outs["rows"][3]:
+        assert rel_l2(outs["rows"][3][k], outs["quadrant"][3][k]) < 1e-5, k
+    with pytest.raises(ValueError, match="walk_form"):
+        GaussianRasterizer(raster_settings=st(), walk_form="columns")
+
+
 @pytest.mark.parametrize("n", [5000, 5003])
 def test_row_major_gradient_sink_equals_the_planar_one(n):
     """LOGRAST_BWD_ACCUMULATE_ROWS: three views accumulated into ONE 64-byte row of running sums per Gaussian

@@ -82,7 +82,7 @@ def _assert_forward(hf, of, check_lists, form):
 
 
 def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_name=None,
-                 fwd_forms=("rows", "quadrant")):
+                 fwd_forms=("rows", "quadrant"), all_rows_tol=None):
     """Forward bit-exact (lists: exact, or the oracle's lists minus provably invisible entries), backward <= 1e-4 rel-L2
     on every output of the reverse walk, chain rule <= 1e-6 on identical inputs.  The forward prepares the backward's
     accumulators as the autograd path does (touched-only dL/dconic on large inputs).
@@ -109,7 +109,10 @@ def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_nam
     # 1e-4 rel-L2 over all rows the chain rule conditions to better than 500x, HIP no further from float64 than twice the
     # fp32 oracle on EVERY row, exact zeros where the gradient is zero); no masked or quantile criterion
     g64 = oracle_mod.backward_f64(v, of, dL)
-    G.assert_gradients_anchored(G.gradient_anchor_stats(hg, og, g64), name=stats_name)
+    # all_rows_tol: north_star's plain criterion on top -- rel-L2 <= tol over ALL rows of dL/dmeans3D / dL/dscales /
+    # dL/drotations end to end, HIP vs float64 and HIP vs the fp32 oracle (the realistic inputs assert it; every case dumps
+    # the numbers: gpurun_out/parity_stats -> profiles/r05_gradient_anchor_stats.md)
+    G.assert_gradients_anchored(G.gradient_anchor_stats(hg, og, g64), name=stats_name, all_rows_tol=all_rows_tol)
     return of
 
 
@@ -164,9 +167,95 @@ def test_tree_ordered_heavy_tailed_vs_oracle(oracle_mod):
               rotation=(q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)).astype(np.float32),
               opacity=(1.0 / (1.0 + np.exp(-(rng.standard_normal((sel.shape[0], 1)) + 1.0)))).astype(np.float32),
               colors=rng.random((sel.shape[0], 3), dtype=np.float32))
-    of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), stats_name="tree_ordered_heavy_tailed")
+    of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), stats_name="tree_ordered_heavy_tailed", all_rows_tol=1e-4)
     radii = of["radii"]
     assert (radii > 16).mean() > 0.01 and of["I"] > 2 * sel.shape[0]
+
+
+@pytest.mark.parametrize("n,view", [(1_000_000, 3), (30_000_000, 1)], ids=["trained_like_1M", "trained_like_30M"])
+def test_trained_like_scene_vs_oracle(oracle_mod, n, view):
+    """Round-4 verdict, missing #4 / next #1c: a scene with the statistics of a TRAINED model (log_amd.scenes.
+    trained_like_scene: log-normal scales sigma 0.5, anisotropy <= 10, sigmoid-normal opacity) at C2 size and at the 30 M
+    north-star size, 1080p: forward bit for bit in both compositing forms, lists, reverse walk, chain rule -- and the
+    PLAIN gradient criterion of north_star: rel-L2 <= 1e-4 over ALL rows, end to end, against float64 and against the
+    fp32 oracle (no row excluded)."""
+    from log_amd import scenes
+    cam = scenes.orbit_cameras(8, W=1920, H=1080, focal=2139.0)[view]
+    sc = scenes.trained_like_scene(n, seed=0)
+    of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), stats_name="trained_like_%dM" % (n // 1_000_000),
+                      all_rows_tol=1e-4)
+    assert of["I"] > 2 * n and 0.1 < float((of["point_weight"] > 0).mean()) < 0.9
+
+
+def test_c5_band_full_size_vs_oracle(oracle_mod):
+    """BASELINE configs[4] on one of its 8 GPUs AT ITS SIZE against the oracle (round-4 verdict, missing #3 / next #1a):
+    100 M Gaussians, 3840x2160, band 3 of 8 (tile rows [50, 67)), through lr_project_band_kernel (the default for band
+    views) and the gradient path the multi-GPU step uses (row-major sink) as well as fresh gradients -- against the
+    oracle's whole-view render restricted to the band (oracle.forward(tile_rows=...)): radii of all 100 M, records of the
+    band's Gaussians, the band's tile lists, image / final_T / fork maps bit for bit, reverse-walk gradients <= 1e-4, the
+    chain rule end to end anchored on the float64 twin.  The record array (6.4 GB) and the accumulator rows (6.4 GB) put
+    every byte offset past 4 GiB under a check for the first time."""
+    import gpu_util as G
+    from log_amd import dist as D, rasterizer as R
+    try:   # ~90 GB of host arrays (inputs, oracle records, fp32 + float64 gradients of 100 M rows): never drive a box out of memory
+        avail_gb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")) / 1e6
+    except (OSError, StopIteration):
+        avail_gb = 1e9
+    if avail_gb < 200:
+        pytest.skip("needs ~90 GB of host memory for the oracle side (MemAvailable %.0f GB)" % avail_gb)
+    N, W, H, bands, band = 100_000_000, 3840, 2160, 8, 3
+    cam, sc = _scene(N, W, H, seed=0, opacity=0.999, view=1)
+    rows = D.band_rows(band, bands, H)
+    b, e = D.band_pixels(band, bands, H)
+    bg = (1.0, 1.0, 1.0)
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg, tile_rows=rows)
+    vis = of["radii"] > 0
+    assert 10_000_000 < int(vis.sum()) < 40_000_000 and of["I"] > 20_000_000
+    with R.tile_rows(*rows):
+        hf = G.hip_forward(cam, sc, bg, scratch_floats=16)
+    assert hf["rec"].nbytes > (1 << 32)                       # records past the 4 GiB mark are among those compared
+    last = np.nonzero(vis)[0][-1]
+    assert 64 * int(last) > (1 << 32)
+    st = G.compare_forward(hf, of)
+    for k in ("radii_mismatch", "rec_bits_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch",
+              "image_bits_mismatch", "final_T_bits_mismatch", "pid_mismatch"):
+        assert st[k] == 0, (k, st)
+    assert st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0
+    assert (hf["image"][:, :b] == 1.0).all() and (hf["image"][:, e:] == 1.0).all()     # outside the band: background
+    dL = np.zeros((3, H, W), np.float32)
+    dL[:, b:e] = np.random.default_rng(2).random((3, e - b, W), dtype=np.float32)
+    hg = G.hip_backward(hf, dL)                               # fresh gradients: five 100 M-row tensors
+    og = oracle_mod.backward(v, of, dL)
+    for k in ("means2D", "conic", "opacities", "colors"):     # the reverse walk: every row
+        assert rel_l2(hg[k], og[k]) < 1e-4, (k, rel_l2(hg[k], og[k]))
+    # end to end against the float64 twin, on the band's rows (the statistics of 100 M mostly-zero rows would need ~40 GB
+    # of float64 temporaries); every row outside the band must be exactly zero
+    g64 = oracle_mod.backward_f64(v, of, dL)
+    for k in ("means3D", "scales", "rotations", "means2D", "opacities", "colors"):
+        assert not hg[k][~vis].any(), k
+    take = lambda d: {k: (a[vis] if isinstance(a, np.ndarray) and a.shape[:1] == (N,) else a) for k, a in d.items()}
+    g64v = take({k: a for k, a in g64.items() if k != "chain32"})
+    g64v["chain32"] = take(g64["chain32"])
+    G.assert_gradients_anchored(G.gradient_anchor_stats(take(hg), take(og), g64v), name="c5_band_100M_3840x2160")
+    # the multi-GPU step's form: the same view's gradients ADDED into one 64-byte row per Gaussian (6.4 GB of running
+    # sums: LOGRAST_BWD_ACCUMULATE_ROWS) -- twice, so that the second pass really adds
+    rs, flavour, use_filter, m, s_, r_, saved = hf["_torch"]
+    del hf["rec"], st
+    dev = m.device
+    sink = {"rows": torch.zeros(N, 16, device=dev)}
+    g = torch.tensor(dL, device=dev)
+    for rep in range(2):
+        with R.tile_rows(*rows):
+            hf2 = G.hip_forward(cam, sc, bg, scratch_floats=16)
+        R._backend.backward(rs, flavour, use_filter, m, s_, r_, hf2["_torch"][6], g, sink=sink)
+        del hf2
+    torch.cuda.synchronize()
+    got = sink["rows"].cpu().numpy()
+    assert not got[~vis].any() and not got[:, 14:].any()
+    for k, (c0, c1) in D.ROW_COLUMNS.items():
+        want = 2.0 * og[k].reshape(N, -1)[vis]
+        tol = 1e-4 if k in ("opacities", "colors") else 2e-3      # (chain-rule outputs: summation-order noise on a few ill-conditioned rows, as in test_band_projection_at_scale)
+        assert rel_l2(got[vis][:, c0:c1], want) < tol, (k, rel_l2(got[vis][:, c0:c1], want))
 
 
 @pytest.mark.parametrize("n,W,H", [(2_000_000, 3840, 2160), (10_000_000, 1920, 1080)],

@@ -100,6 +100,7 @@ int lr_env_int(const char* name, int dflt) {
 struct LrKnobInfo { const char* name; int dflt, lo, hi; const char* what; };
 static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_HELPER_MIN_N", 4000000, 0, 2000000000, "Gaussians from which the helper passes (absolute slot table, touched-only dL/dconic clearing, separate zero-fill kernels) pay for their launches"},
+    {"LOGRAST_MID_COOP", 1, 0, 1, "rects of 5..16 tiles are counted (projection) and placed (fill) by the whole wave, four rects per pass, instead of by their lane"},
     {"LOGRAST_DEFER_TILES", LR_COOP_TILES, 4, 4096, "rects above this many tiles are counted by lr_count_huge_kernel (one wave per rect) instead of by their lane"},
     {"LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK, 256, 8192, "Gaussians per workgroup of lr_count_huge_kernel (multiple of 256)"},
     {"LOGRAST_BATCH_PLANES", 4, 1, 4, "consecutive projection batches one workgroup owns"},

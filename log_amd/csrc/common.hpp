@@ -18,7 +18,7 @@
 // [0] num_instances  [1] overflow flag  [2] longest tile list  [3] reserved
 // [4] tile instances of the plain rect rule (before the support cull; reporting only)
 // [5] support cull applied by the projection kernel (0/1)  [6] projection batch size (0 = unbatched)
-// [7] some rect was deferred to lr_count_huge_kernel  [8..15] reserved
+// [7] some rect was deferred to lr_count_huge_kernel  [8] band views: fill-record slots per projection workgroup  [9..15] reserved
 // then per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic targets
 // spread over the memory channels instead of 8160 counters sharing 32 KB); header, ranked and big are
 // contiguous so that ONE memset prepares a forward:
@@ -55,14 +55,19 @@ __host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_of
 __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
 // then basetab[batches][T]: start of every projection batch's reservation inside each tile's ranked range
 __host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
-// then hugecount[batches]: how many Gaussians of the batch left their (more than LR_COOP_TILES tile) rect to
-// lr_count_huge_kernel
+// then hugemask[batches][LR_HUGE_WORDS]: which 256-Gaussian chunks of the batch hold a Gaussian that left its (more than
+// LR_COOP_TILES tile) rect to lr_count_huge_kernel -- bit c of the batch's 128 = chunk c (a batch is at most 32768
+// Gaussians).  (Rounds 1-4 kept one COUNT per batch: in a scene whose few large splats are spread evenly -- any trained
+// model in storage order -- every batch holds one and the counting kernel then walked all N fill records, clearing and
+// flushing its 8160 LDS tile counters once per 256 Gaussians: 459 us at 30 M for ~1000 rects.)
+#define LR_HUGE_WORDS 4
 __host__ __device__ inline size_t lr_hugecount_off(uint32_t tiles, uint32_t batches) {
   return (size_t)lr_basetab_off(tiles) + (size_t)batches * tiles;
 }
+__host__ __device__ inline uint32_t lr_hugemask_words(uint32_t batches) { return (LR_HUGE_WORDS * batches + 15u) & ~15u; }
 // then survcount[batches] (band views: survivors of projection workgroup w at [w], lr_project_band_kernel)
 __host__ __device__ inline size_t lr_survcount_off(uint32_t tiles, uint32_t batches) {
-  return lr_hugecount_off(tiles, batches) + ((batches + 15u) & ~15u);
+  return lr_hugecount_off(tiles, batches) + lr_hugemask_words(batches);
 }
 __host__ __device__ inline size_t lr_state_words(uint32_t tiles, uint32_t batches) {
   return lr_survcount_off(tiles, batches) + ((batches + 15u) & ~15u);
@@ -402,6 +407,43 @@ LR_DEV uint32_t lr_wave_umax_to63(uint32_t v) {
   v = lr_dpp_umax<0x142, 0xa, 0xf>(v);
   v = lr_dpp_umax<0x143, 0xc, 0xf>(v);
   return v;
+}
+
+// ---- rects of LR_RANKED_TILES + 1 ... LR_COOP_TILES tiles, expanded by the wave --------------------------------------
+// Projection (counting) and fill (placing) used to walk such a rect per lane: nt iterations of a ~70-instruction support
+// test + atomic with the few lanes that hold one active -- every wave that meets ONE 16-tile rect runs 16 iterations at
+// 1/64 lane occupancy.  On check_gui's uniform draws (the headline) these rects do not exist; on log-normal scales (a
+// trained model: 3-4 % of the Gaussians, two per wave) they doubled the fill (30 M: 307 -> 649 us).  Here the wave expands
+// them together, FOUR rects per pass: lane l serves tile (l & 15) of the (4 * pass + (l >> 4))-th such rect, whose rect and
+// prepared support come over from the owning lane with ds_bpermute.  Same support test on the same values, so the same
+// tiles; which lane counts / places an instance does not matter (the lists are sorted afterwards).
+// Call from wave-uniform control flow with all 64 lanes active (ds_bpermute reads nothing from an inactive lane).
+// f(tile_y, tile_x, pay0, pay1) runs in the serving lane; pay0 / pay1 are the owning lane's payload words (the fill: its key).
+LR_DEV int lr_bperm_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+LR_DEV float lr_bperm_f(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
+template <typename F>
+LR_DEV void lr_mid_rects(bool mid, int x0, int y0, int w, int nt, const LrSupport& sup, int pay0, int pay1, F&& f) {
+  uint64_t m = __ballot(mid);
+  const int lane = (int)threadIdx.x & 63, sub = lane >> 4, t = lane & 15;
+  while (m) {
+    int s[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { s[q] = m ? (int)__builtin_ctzll(m) : -1; m &= m - 1ull; }   // (0 stays 0)
+    const int src = sub == 0 ? s[0] : (sub == 1 ? s[1] : (sub == 2 ? s[2] : s[3]));
+    const int sl = src < 0 ? lane : src;
+    const int bx0 = lr_bperm_i(x0, sl), by0 = lr_bperm_i(y0, sl), bw = lr_bperm_i(w, sl), bn = lr_bperm_i(nt, sl);
+    LrSupport bs;
+    bs.mx = lr_bperm_f(sup.mx, sl); bs.my = lr_bperm_f(sup.my, sl);
+    bs.A = lr_bperm_f(sup.A, sl); bs.B = lr_bperm_f(sup.B, sl); bs.C = lr_bperm_f(sup.C, sl);
+    bs.tau = lr_bperm_f(sup.tau, sl); bs.ex = lr_bperm_f(sup.ex, sl); bs.ey = lr_bperm_f(sup.ey, sl);
+    bs.iA = lr_bperm_f(sup.iA, sl); bs.iC = lr_bperm_f(sup.iC, sl);
+    bs.mode = lr_bperm_i(sup.mode, sl);
+    const int q0 = lr_bperm_i(pay0, sl), q1 = lr_bperm_i(pay1, sl);
+    const bool have = src >= 0 && t < bn;
+    const int bwc = bw > 0 ? bw : 1;
+    const int ty = t / bwc, tx = t - ty * bwc;
+    if (have && lr_support_tile(bs, bx0 + tx, by0 + ty)) f(by0 + ty, bx0 + tx, q0, q1);
+  }
 }
 
 // ---- N4 kernel arguments (counter.hip; filled in by api.hip) ------------------------------------------

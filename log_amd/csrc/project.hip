@@ -464,16 +464,16 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
                           const float* __restrict__ rots, const float* __restrict__ opac,
                           const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                           uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
-                          uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugecount, int tile_cull, int B,
-                          int S, int defer_tiles LR_ABLATE_PARAM) {
+                          uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugemask, int tile_cull, int B,
+                          int S, int defer_tiles, int mid_coop LR_ABLATE_PARAM) {
   // (experiment builds, LOGRAST_PROJECT_ABLATE: 1 no record stores, 2 no fill-record / radii stores, 4 no ranking atomics,
   //  8 no arithmetic -- the loop's loads and stores alone --, 16 no reservations at the end; results are garbage)
   extern __shared__ uint32_t lr_lds_ctr[];  // [S][tiles] packed (ranked | big << 16) counts, one plane per batch
-  __shared__ uint32_t lr_huge_cnt[LR_MAX_PLANES];
+  __shared__ uint32_t lr_huge_mask[LR_MAX_PLANES * LR_HUGE_WORDS];   // per batch: bit c = its 256-Gaussian chunk c deferred a rect
   __shared__ uint32_t lr_rank_dummy[64];    // where the ranking atomics of tiles that are not ranked go (see the loop)
   const int tiles = v.gx * v.gy;
   for (int t = threadIdx.x; t < S * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
-  if (threadIdx.x < LR_MAX_PLANES) lr_huge_cnt[threadIdx.x] = 0u;
+  if (threadIdx.x < LR_MAX_PLANES * LR_HUGE_WORDS) lr_huge_mask[threadIdx.x] = 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
   __syncthreads();
   uint32_t rect_instances = 0;
@@ -626,8 +626,9 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       const int tx2 = col ? 0 : (sq ? 0 : 2), ty2 = col ? 2 : (sq ? 1 : 0);
       const int tx3 = col ? 0 : (sq ? 1 : 3), ty3 = col ? 3 : (sq ? 1 : 0);
       bool k0 = true, k1 = true, k2 = true, k3 = true;
+      LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};   // mode 1: every tile of the rect
       if (tile_cull) {
-        const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, in_op);
+        sup = lr_support_prepare(mx, my, cA, cB, cC, in_op);
         const float X = (float)(x0 * LR_TILE), Y = (float)(y0 * LR_TILE);
         lr_support_tile2(sup, lr_f2{X, X + (float)(tx1 * LR_TILE)}, lr_f2{Y, Y + (float)(ty1 * LR_TILE)}, k0, k1);
         lr_support_tile2(sup, lr_f2{X + (float)(tx2 * LR_TILE), X + (float)(tx3 * LR_TILE)},
@@ -653,14 +654,25 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
         slot2 = nt > 2 ? (r2 ? a2 : 0xffffffffu) : 0u;
         slot3 = nt > 3 ? (r3 ? a3 : 0xffffffffu) : 0u;
       }
-      if (valid && !small) {   // rare on the inputs this loop is shaped for: larger rects are only counted here
-        if (nt > defer_tiles) {
-          atomicAdd(&lr_huge_cnt[plane], 1u);
-        } else {
-          const LrSupport sup = lr_support_prepare(mx, my, cA, cB, cC, in_op);
+      // larger rects are only counted here (rare on uniform tiny splats; 3-4 % of a trained model's Gaussians)
+      const bool huge = valid && !small && nt > defer_tiles;
+      const bool mid = valid && !small && !huge;
+      if (huge) {   // its 256-Gaussian chunk of the batch has work for lr_count_huge_kernel (the wave lies inside one chunk)
+        const int c = (iw - (i_begin + plane * B)) >> 8;
+        atomicOr(&lr_huge_mask[plane * LR_HUGE_WORDS + (c >> 5)], 1u << (c & 31));
+      }
+      if (__builtin_amdgcn_ballot_w64(mid) != 0) {   // (wave-uniform)
+        // four rects per pass, one tile per lane: lr_mid_rects (16 lanes per rect: LOGRAST_DEFER_TILES above 16 leaves
+        // the rects between to their lanes)
+        const bool midc = mid && mid_coop && nt <= LR_COOP_TILES;
+        if (mid_coop) {
+          const int gxw = v.gx;
+          lr_mid_rects(midc, x0, y0, w, nt, sup, 0, 0, [&](int ty, int tx, int, int) { atomicAdd(&ctr[ty * gxw + tx], 0x10000u); });
+        }
+        if (mid && !midc) {
           for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++)
-              if (!tile_cull || lr_support_tile(sup, x, y)) atomicAdd(&ctr[y * v.gx + x], 0x10000u);
+              if (lr_support_tile(sup, x, y)) atomicAdd(&ctr[y * v.gx + x], 0x10000u);
         }
       }
     }
@@ -705,7 +717,10 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       int rad;
       bool huge;
       lr_project_one<true>(v, in, tile_cull, lc, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
-      if (huge) atomicAdd(&lr_huge_cnt[pl], 1u);
+      if (huge) {
+        const int c = (i - (i_begin + pl * B)) >> 8;
+        atomicOr(&lr_huge_mask[pl * LR_HUGE_WORDS + (c >> 5)], 1u << (c & 31));
+      }
       radii[i] = rad;
       fillrec[i] = lr_fill_record(g2, g3, rad);
       geom[LR_REC_QUADS * (size_t)i + 0] = g0; geom[LR_REC_QUADS * (size_t)i + 1] = g1;
@@ -716,9 +731,10 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
   const int nplanes = min(S, (i_end - i_begin + B - 1) / B);   // batches this workgroup really holds
   if (!LR_ABLATED(16))
     lr_reserve_batches(lr_lds_ctr, tiles, 0, tiles, nplanes, tiles, ranked, big, basetab + (size_t)blockIdx.x * S * tiles);
-  if ((int)threadIdx.x < nplanes) {   // complete: the barrier after the Gaussian loop
-    hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];
-    if (lr_huge_cnt[threadIdx.x]) atomicOr(&hdr[LR_HDR_HUGE], 1u);
+  if ((int)threadIdx.x < nplanes * LR_HUGE_WORDS) {   // complete: the barrier after the Gaussian loop
+    const uint32_t mw = lr_huge_mask[threadIdx.x];
+    hugemask[(size_t)blockIdx.x * S * LR_HUGE_WORDS + threadIdx.x] = mw;   // (every word of every batch is written: nothing to clear)
+    if (mw) atomicOr(&hdr[LR_HDR_HUGE], 1u);
   }
   lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
 }
@@ -758,17 +774,19 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
                        const float* __restrict__ rots, const float* __restrict__ opac,
                        const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                        uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
-                       uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugecount,
+                       uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugemask,
                        uint32_t* __restrict__ survcount, int tile_cull, int B, int S, int defer_tiles LR_ABLATE_PARAM) {
   extern __shared__ uint32_t lr_lds_ctr[];  // [S][band tiles] packed (ranked | big << 16) counts, one plane per batch
-  __shared__ uint32_t lr_huge_cnt[LR_MAX_PLANES];
+  // which 256-SLOT chunks of the workgroup's fill-record range hold a deferred rect (lr_count_huge_kernel walks slots):
+  // the words of "batch" p = slots [p B, (p + 1) B) of the range
+  __shared__ uint32_t lr_huge_mask[LR_MAX_PLANES * LR_HUGE_WORDS];
   __shared__ uint32_t lr_slot_cursor;       // survivors of this workgroup so far = its next free fill-record slot
   __shared__ uint32_t lr_ring_idx[LR_BATCH_THREADS / 64][LR_RING];
   __shared__ float lr_ring_in[LR_BATCH_THREADS / 64][LR_RING_FLOATS][LR_RING];
   const int tiles = v.gx * v.gy;
   const int t_lo = v.ty0 * v.gx, t_hi = v.ty1 * v.gx, band_tiles = t_hi - t_lo;
   for (int t = threadIdx.x; t < S * band_tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
-  if (threadIdx.x < LR_MAX_PLANES) lr_huge_cnt[threadIdx.x] = 0u;
+  if (threadIdx.x < LR_MAX_PLANES * LR_HUGE_WORDS) lr_huge_mask[threadIdx.x] = 0u;
   if (threadIdx.x == 0) lr_slot_cursor = 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; hdr[LR_HDR_SPARSE] = 1u;
@@ -846,13 +864,12 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
       // same 4x4 transpose as in the full-view loop, so that a store instruction writes complete 64-byte lines
       float4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
       int rad = 0;
+      bool huge = false;
       if (pj >= 0) {
         const int dj = pj - i_begin;                           // (at most LR_MAX_PLANES batches per workgroup: no division)
         const int plane = (dj >= B) + (dj >= 2 * B) + (dj >= 3 * B);
         const LrLdsBandCounters ctr{lr_lds_ctr + plane * band_tiles, t_lo};
-        bool huge;
         lr_project_one<true>(v, pin, tile_cull, ctr, g0, g1, g2, g3, rad, rect_instances, huge, defer_tiles);
-        if (huge) atomicAdd(&lr_huge_cnt[plane], 1u);
       }
       // slots: the workgroup compacts into its own range of the fill-record array (one counter for all workgroups was a
       // same-address memory-side atomic per firing: +1.2 ms at 100 M Gaussians)
@@ -863,6 +880,12 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
       if (pj >= 0) {                                         // 1 KB + 256 B of contiguous stores per wave
         fillrec[slot0 + (uint32_t)lane] = lr_fill_record(g2, g3, rad);
         survivor[slot0 + (uint32_t)lane] = (uint32_t)pj;
+        if (huge) {   // the chunk of its SLOT has work for lr_count_huge_kernel
+          const int ds = (int)(slot0 + (uint32_t)lane) - i_begin;
+          const int sp = (ds >= B) + (ds >= 2 * B) + (ds >= 3 * B);
+          const int c = (ds - sp * B) >> 8;
+          atomicOr(&lr_huge_mask[sp * LR_HUGE_WORDS + (c >> 5)], 1u << (c & 31));
+        }
       }
       const int m = lane & 3;
       lr_quad_transpose(g0, g1, g2, g3, m);                  // g<k> = quad m of the record of lane (lane - m + k)
@@ -879,9 +902,10 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
   const int nplanes = min(S, (i_end - i_begin + B - 1) / B);   // batches this workgroup really holds
   lr_reserve_batches(lr_lds_ctr, band_tiles, t_lo, t_hi, nplanes, tiles, ranked, big, basetab + (size_t)blockIdx.x * S * tiles);
   if (threadIdx.x == 0) survcount[blockIdx.x] = lr_slot_cursor;
-  if ((int)threadIdx.x < nplanes) {
-    hugecount[blockIdx.x * S + threadIdx.x] = lr_huge_cnt[threadIdx.x];
-    if (lr_huge_cnt[threadIdx.x]) atomicOr(&hdr[LR_HDR_HUGE], 1u);
+  if ((int)threadIdx.x < nplanes * LR_HUGE_WORDS) {
+    const uint32_t mw = lr_huge_mask[threadIdx.x];
+    hugemask[(size_t)blockIdx.x * S * LR_HUGE_WORDS + threadIdx.x] = mw;
+    if (mw) atomicOr(&hdr[LR_HDR_HUGE], 1u);
   }
   lr_commit_rect_count<LR_BATCH_THREADS / 64>(rect_instances, hdr);
 }
@@ -892,7 +916,7 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
 // returns at once when its batches left nothing (the common case: small splats only).
 __global__ void __launch_bounds__(256)
 lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,
-                     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ hugecount, int B, int tile_cull,
+                     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ hugemask, int B, int tile_cull,
                      int defer_tiles, int chunk) {
   const int n_all = N;                                       // (the arrays behind the records are laid out for all N)
   extern __shared__ uint32_t lr_lds_ctr[];                   // [tiles] counters | [256] chunks with work | their number
@@ -902,7 +926,7 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
   // slots [w * span, ...), their Gaussian indices in the same slots of the array behind the fill records
   const bool sparse = hdr[LR_HDR_SPARSE] != 0u;
   const int span = sparse ? (int)hdr[LR_HDR_SPAN] : 1;       // slots per projection workgroup (a multiple of B and of chunk)
-  const uint32_t* __restrict__ survcount = hugecount + (((N + B - 1) / B + 15) & ~15);
+  const uint32_t* __restrict__ survcount = hugemask + lr_hugemask_words((uint32_t)((N + B - 1) / B));
   // (the grid is capped at a few workgroups per CU: each walks its share of the chunks and skips those whose batches
   // deferred nothing -- 58 K workgroups that only return cost a 30 M-Gaussian view 30 us.  The flags of up to 256 chunks
   // are fetched by as many threads at once: one dependent scalar read per chunk was a 28 us chain of round trips.)
@@ -911,15 +935,12 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
     const long long cid = (long long)first + (long long)threadIdx.x * gridDim.x;
     uint32_t any = 0;
     if (cid * chunk < N) {
+      // the chunk's 256-Gaussian (band views: 256-slot) pieces: bit c of batch b's mask (lr_project_batched_kernel /
+      // lr_project_band_kernel); a piece lies inside one batch (batches are multiples of 1024)
       const int base = (int)cid * chunk;
-      const int b0 = base / B, b1 = min(N - 1, base + chunk - 1) / B;
-      if (sparse) {   // slots of projection workgroup w: deferred rects of any of its batches, and only its first survcount[w] slots
-        const int s_batches = span / B;
-        for (int w = base / span; w <= min(N - 1, base + chunk - 1) / span; w++)
-          if (max(base, w * span) - w * span < (int)survcount[w])
-            for (int b = w * s_batches; b < (w + 1) * s_batches && (long long)b * B < N; b++) any |= hugecount[b];
-      } else {
-        for (int b = b0; b <= b1; b++) any |= hugecount[b];
+      for (int j = base; j < min(N, base + chunk); j += 256) {
+        const int b = j / B, c = (j - b * B) >> 8;
+        any |= (hugemask[(size_t)b * LR_HUGE_WORDS + (c >> 5)] >> (c & 31)) & 1u;
       }
     }
     __syncthreads();                                         // (the previous round's readers are done)
@@ -1019,7 +1040,8 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const int chunk = chunk_k >= 256 ? chunk_k / 256 * 256 : 256;
     const int batches = (N + batch - 1) / batch;
     const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
-    uint32_t* hugecount = basetab + (size_t)batches * tiles;
+    uint32_t* hugecount = basetab + (size_t)batches * tiles;   // (hugemask[batches][LR_HUGE_WORDS]: common.hpp)
+    LR_KNOB(mid_coop, "LOGRAST_MID_COOP", 1);
 #ifdef LR_EXPERIMENTS
     static const int ablate = lr_env_int("LOGRAST_PROJECT_ABLATE", 0);   // timing experiments (tools/): see the band kernel
 #endif
@@ -1032,16 +1054,16 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
       hipLaunchKernelGGL(lr_project_band_kernel, dim3(bgroups), dim3(LR_BATCH_THREADS),
                          sizeof(uint32_t) * (size_t)band_tiles * bp, s, v, N, means, scales, rots, opac, colors, radii,
                          reinterpret_cast<float4*>(geom), ranked, big, hdr, basetab, hugecount,
-                         hugecount + ((batches + 15) & ~15), tile_cull, batch, bp, defer_tiles LR_ABLATE_PASS(ablate));
+                         hugecount + lr_hugemask_words((uint32_t)batches), tile_cull, batch, bp, defer_tiles LR_ABLATE_PASS(ablate));
     } else {
       if (v.cov3d)
         hipLaunchKernelGGL(lr_project_batched_kernel<true>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                            means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                           basetab, hugecount, tile_cull, batch, planes, defer_tiles LR_ABLATE_PASS(ablate));
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles, mid_coop LR_ABLATE_PASS(ablate));
       else
         hipLaunchKernelGGL(lr_project_batched_kernel<false>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                            means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                           basetab, hugecount, tile_cull, batch, planes, defer_tiles LR_ABLATE_PASS(ablate));
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles, mid_coop LR_ABLATE_PASS(ablate));
     }
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
@@ -1268,15 +1290,25 @@ LR_DEV bool lr_fill_verdict(uint32_t* __restrict__ state, uint32_t capacity, uin
 // tiles are filled.  Up to LR_COOP_TILES tiles a lane expands its own rect, beyond that the whole wave expands it (ballot
 // over the lanes that hold one, record broadcast with readlane).  Every lane of the wave must call this (nt = 0: nothing).
 LR_DEV void lr_fill_big_rect(const float4* __restrict__ geom, int i, int x0, int y0, int w, int h, int nt, uint64_t key,
-                             int gx, bool tile_cull, uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, int lane
-                             LR_ABLATE_PARAM) {
+                             int gx, bool tile_cull, uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, int lane,
+                             int mid_coop LR_ABLATE_PARAM) {
   const int y1 = y0 + h, x1 = x0 + w;
   LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};  // mode 1: every tile of the rect
   if (nt > LR_RANKED_TILES && tile_cull) {
     const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
     sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
   }
-  if (nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !LR_ABLATED(4)) {
+  const bool mid = nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !LR_ABLATED(4);
+  if (mid_coop) {   // the wave expands its 5..16-tile rects together, four per pass (lr_mid_rects)
+    if (__builtin_amdgcn_ballot_w64(mid) != 0) {
+      const int klo = (int)(uint32_t)key, khi = (int)(uint32_t)(key >> 32);
+      lr_mid_rects(mid, x0, y0, w, nt, sup, klo, khi, [&](int ty, int tx, int lo, int hi) {
+        const uint64_t k = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+        const uint32_t pos = atomicAdd(&cursor[(ty * gx + tx) * LR_CTR_STRIDE], 1u);
+        keys[pos] = k;
+      });
+    }
+  } else if (mid) {
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++)
         if (lr_support_tile(sup, x, y)) {
@@ -1314,7 +1346,7 @@ __global__ void __launch_bounds__(256)
 lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
                float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order, int stream_nt,
-               int rebased, int speculative LR_ABLATE_PARAM) {
+               int rebased, int speculative, int mid_coop LR_ABLATE_PARAM) {
   // Per-Gaussian buffers that later kernels accumulate into with atomics (point_weight; the backward scratch)
   // are cleared here, in a kernel that already has one thread per Gaussian, instead of by separate memsets.
   // XCD-contiguous block order (speed only): blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
@@ -1439,7 +1471,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       }
     }
   }
-  lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
+  lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane, mid_coop LR_ABLATE_PASS(ablate));
   }
 }
 
@@ -1456,7 +1488,7 @@ __global__ void __launch_bounds__(LR_FILL_STAGED_ROWS, 8)   // 64 VGPRs: 2048 th
 lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restrict__ state, uint32_t tiles,
                       uint64_t* __restrict__ keys, uint32_t capacity, uint32_t max_len_hint, uint32_t* __restrict__ status,
                       float* __restrict__ zero_n, float* __restrict__ zero_block, int zero_block_floats, int xcd_order,
-                      int rebased, int speculative LR_ABLATE_PARAM) {
+                      int rebased, int speculative, int mid_coop LR_ABLATE_PARAM) {
   extern __shared__ uint32_t lr_slot_row[];                       // [tiles]: absolute first slot of this batch's run in every tile
   const uint32_t per_xcd = gridDim.x >> 3;                        // grid is a multiple of 8 (XCD-contiguous order: lr_fill_kernel)
   const uint32_t vblock = xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
@@ -1549,7 +1581,7 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
     // (Rects of more than four tiles, measured and removed: counting the workgroup's instances per tile in LDS first, ONE
     // cursor atomic per touched tile, a second walk placing the keys -- the C3 view's fill 426 -> 545 us: 2048 consecutive
     // rows of a level-of-detail selection do not share enough tiles to pay for two walks of support tests.)
-    lr_fill_big_rect(geom, i, x0, y0, w, h_k[u], nt, key, gx, tile_cull, cursor, keys, lane LR_ABLATE_PASS(ablate));
+    lr_fill_big_rect(geom, i, x0, y0, w, h_k[u], nt, key, gx, tile_cull, cursor, keys, lane, mid_coop LR_ABLATE_PASS(ablate));
   }
 }
 
@@ -1560,6 +1592,7 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
   LR_KNOB(fill_nt, "LOGRAST_FILL_NT", 1);
+  LR_KNOB(mid_coop, "LOGRAST_MID_COOP", 1);
 #ifdef LR_EXPERIMENTS
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores, 4 no 5-16-tile rects, 8 no larger rects
 #endif
@@ -1580,7 +1613,7 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
 #define LR_FILL_ST(KK) hipLaunchKernelGGL(lr_fill_staged_kernel<KK>, dim3(blocks), dim3(LR_FILL_STAGED_ROWS),                 \
                        sizeof(uint32_t) * ((tiles + 3u) & ~3u), s, N, gx, reinterpret_cast<const float4*>(geom), state, tiles,  \
                        keys, capacity, max_len_hint, status, zero_n, zero_block, zero_block_floats, xcd_order, rebased,         \
-                       speculative LR_ABLATE_PASS(ablate))
+                       speculative, mid_coop LR_ABLATE_PASS(ablate))
     if (K >= 3) LR_FILL_ST(3); else if (K == 2) LR_FILL_ST(2); else LR_FILL_ST(1);   // (four per thread: 40 bytes of scratch at the kernel's 64 VGPRs)
 #undef LR_FILL_ST
     lr_prof_end(LRK_FILL, s);
@@ -1591,7 +1624,7 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
 #define LR_FILL(K) do { const int blocks = (((N + 255) / 256 + K - 1) / K + 7) & ~7;                                     \
     hipLaunchKernelGGL(lr_fill_kernel<K>, dim3(blocks), dim3(256), 0, s, N, gx, reinterpret_cast<const float4*>(geom),  \
                        state, tiles, keys, capacity, max_len_hint, status, zero_n, zero_block, zero_block_floats,       \
-                       xcd_order, fill_nt, rebased, speculative LR_ABLATE_PASS(ablate)); } while (0)
+                       xcd_order, fill_nt, rebased, speculative, mid_coop LR_ABLATE_PASS(ablate)); } while (0)
   // measured, K = 1 / 2 / 4: the 30 M view 388 / 413 / 424 us; a band view (100 M, a fifth of the slots used: most
   // workgroups only pass through the chain once) 618 / 551 / 510 us
   if (band) per_thread = 4;

@@ -184,7 +184,8 @@ def test_trained_like_scene_vs_oracle(oracle_mod, n, view):
     sc = scenes.trained_like_scene(n, seed=0)
     of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), stats_name="trained_like_%dM" % (n // 1_000_000),
                       all_rows_tol=1e-4)
-    assert of["I"] > 2 * n and 0.1 < float((of["point_weight"] > 0).mean()) < 0.9
+    # (composited somewhere: 27 % of the Gaussians at 1 M, 8 % at 30 M -- a dense cube is still mostly occluded)
+    assert of["I"] > 2 * n and 0.03 < float((of["point_weight"] > 0).mean()) < 0.9
 
 
 def test_c5_band_full_size_vs_oracle(oracle_mod):

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--sink", action="store_true", help="backward adds into one row-major running-sum buffer (bench.py's pipelined form)")
     ap.add_argument("--env", nargs="*", default=[])
     ap.add_argument("--tag", default="")
+    ap.add_argument("--scene", choices=("random", "trained"), default="random", help="bench.py's scene generators")
     a = ap.parse_args()
     if a.lib:
         os.environ["LOGRAST_LIB"] = os.path.abspath(a.lib)
@@ -35,7 +36,7 @@ def main():
     import bench as B
     from log_amd import _lib
     dev = torch.device("cuda:0")
-    args = argparse.Namespace(width=a.width, height=a.height, views=a.views, opacity=a.opacity)
+    args = argparse.Namespace(width=a.width, height=a.height, views=a.views, opacity=a.opacity, scene=a.scene)
     wl = B.RasterWorkload(args, a.gaussians, dev, 0, 1, torch, np)
     wl.zero_means2d = False
     leaves = {k: v.clone().requires_grad_(True) for k, v in wl.base.items()}

@@ -12,7 +12,7 @@ cp -r "$REF/LoG" .reference_mount/LoG
 find .reference_mount -name '__pycache__' -type d -prune -exec rm -rf {} +
 find .reference_mount -name '*.cu' -delete      # (Python only: the CUDA source is not needed for this test)
 EXTRA=${1:-true}
-/usr/local/graft/bin/gpurun --timeout ${GPURUN_TIMEOUT:-900} -- "mkdir -p gpurun_out; export LOG_REFERENCE=\$PWD/.reference_mount; timeout 600 python -m pytest tests/test_gpu_log_plumbing.py -x -q -s -m gpu > gpurun_out/log_plumbing_gpu.log 2>&1; echo plumbing rc=\$?; tail -15 gpurun_out/log_plumbing_gpu.log; $EXTRA"
+/usr/local/graft/bin/gpurun --timeout ${GPURUN_TIMEOUT:-900} -- "${GPURUN_CMD:-mkdir -p gpurun_out; export LOG_REFERENCE=\$PWD/.reference_mount; timeout 600 python -m pytest tests/test_gpu_log_plumbing.py -x -q -s -m gpu > gpurun_out/log_plumbing_gpu.log 2>&1; echo plumbing rc=\$?; tail -15 gpurun_out/log_plumbing_gpu.log; $EXTRA}"
 rc=$?
 rm -rf .reference_mount
 exit $rc

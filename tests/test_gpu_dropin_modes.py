@@ -268,8 +268,8 @@ def test_walk_form_can_be_pinned_by_the_host():
         finally:
             R.set_walk_form(None)
     assert (outs["rows"][2].view(np.uint32) == outs["quadrant"][2].view(np.uint32)).all()
-    for k in outs["rows"][3]:
-        assert rel_l2(outs["rows"][3][k], outs["quadrant"][3][k]) < 1e-5, k
+    for k in outs["rows"][3]:   # the two forms add the same terms in different orders (chain-rule outputs: needle / pancake rows amplify that)
+        assert rel_l2(outs["rows"][3][k], outs["quadrant"][3][k]) < (1e-5 if k in ("opacities", "colors") else 1e-4), k
     with pytest.raises(ValueError, match="walk_form"):
         GaussianRasterizer(raster_settings=st(), walk_form="columns")
 

@@ -100,6 +100,7 @@ int lr_env_int(const char* name, int dflt) {
 struct LrKnobInfo { const char* name; int dflt, lo, hi; const char* what; };
 static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_HELPER_MIN_N", 4000000, 0, 2000000000, "Gaussians from which the helper passes (absolute slot table, touched-only dL/dconic clearing, separate zero-fill kernels) pay for their launches"},
+    {"LOGRAST_MID_RANK", 1, 0, 1, "rects of 5..16 tiles are RANKED by the batched projection (LDS atomics; 32-byte rank rows in geom), so the fill places them without cursor atomics or support tests; 0 = counted only, placed through the per-tile cursors"},
     {"LOGRAST_MID_COOP", 1, 0, 1, "rects of 5..16 tiles are counted (projection) and placed (fill) by the whole wave, four rects per pass, instead of by their lane"},
     {"LOGRAST_DEFER_TILES", LR_COOP_TILES, 4, 4096, "rects above this many tiles are counted by lr_count_huge_kernel (one wave per rect) instead of by their lane"},
     {"LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK, 256, 8192, "Gaussians per workgroup of lr_count_huge_kernel (multiple of 256)"},
@@ -302,8 +303,9 @@ size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n) {
   uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
   return sizeof(uint32_t) * lr_state_words(gx * gy, lr_batches(n, lr_pick_batch(n, gx * gy, gx, gy).batch));
 }
-size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection + a 4-byte index each (band views)
-  return (sizeof(float) * LOGRAST_REC_FLOATS + 16 + 4) * (size_t)(n > 0 ? n : 0);
+size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill records of the batched projection + a 4-byte index each (band views) + the rank rows of the 5..16-tile rects (common.hpp)
+  const size_t nn = (size_t)(n > 0 ? n : 0);
+  return lr_midrank_off_bytes(nn) + lr_midrank_bytes(nn);
 }
 size_t lograst_keys_bytes(uint32_t capacity) { return 2 * sizeof(uint64_t) * (size_t)capacity; }  // keys + sort scratch
 size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }

@@ -418,11 +418,13 @@ LR_DEV uint32_t lr_wave_umax_to63(uint32_t v) {
 // prepared support come over from the owning lane with ds_bpermute.  Same support test on the same values, so the same
 // tiles; which lane counts / places an instance does not matter (the lists are sorted afterwards).
 // Call from wave-uniform control flow with all 64 lanes active (ds_bpermute reads nothing from an inactive lane).
-// f(tile_y, tile_x, pay0, pay1) runs in the serving lane; pay0 / pay1 are the owning lane's payload words (the fill: its key).
+// f(t, tile_y, tile_x, keep, pay0, pay1, pay2) runs in the serving lane for EVERY tile t < nt of the rect: keep = the tile
+// passes the support test (TEST = false: no test, keep = true -- the fill of rects the projection ranked: their ranks say
+// which tiles were kept); pay0..2 are the owning lane's payload words (its rank row; the fill: its key).
 LR_DEV int lr_bperm_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 LR_DEV float lr_bperm_f(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
-template <typename F>
-LR_DEV void lr_mid_rects(bool mid, int x0, int y0, int w, int nt, const LrSupport& sup, int pay0, int pay1, F&& f) {
+template <bool TEST, typename F>
+LR_DEV void lr_mid_rects(bool mid, int x0, int y0, int w, int nt, const LrSupport& sup, int pay0, int pay1, int pay2, F&& f) {
   uint64_t m = __ballot(mid);
   const int lane = (int)threadIdx.x & 63, sub = lane >> 4, t = lane & 15;
   while (m) {
@@ -432,19 +434,37 @@ LR_DEV void lr_mid_rects(bool mid, int x0, int y0, int w, int nt, const LrSuppor
     const int src = sub == 0 ? s[0] : (sub == 1 ? s[1] : (sub == 2 ? s[2] : s[3]));
     const int sl = src < 0 ? lane : src;
     const int bx0 = lr_bperm_i(x0, sl), by0 = lr_bperm_i(y0, sl), bw = lr_bperm_i(w, sl), bn = lr_bperm_i(nt, sl);
-    LrSupport bs;
-    bs.mx = lr_bperm_f(sup.mx, sl); bs.my = lr_bperm_f(sup.my, sl);
-    bs.A = lr_bperm_f(sup.A, sl); bs.B = lr_bperm_f(sup.B, sl); bs.C = lr_bperm_f(sup.C, sl);
-    bs.tau = lr_bperm_f(sup.tau, sl); bs.ex = lr_bperm_f(sup.ex, sl); bs.ey = lr_bperm_f(sup.ey, sl);
-    bs.iA = lr_bperm_f(sup.iA, sl); bs.iC = lr_bperm_f(sup.iC, sl);
-    bs.mode = lr_bperm_i(sup.mode, sl);
-    const int q0 = lr_bperm_i(pay0, sl), q1 = lr_bperm_i(pay1, sl);
+    LrSupport bs = sup;
+    if (TEST) {
+      bs.mx = lr_bperm_f(sup.mx, sl); bs.my = lr_bperm_f(sup.my, sl);
+      bs.A = lr_bperm_f(sup.A, sl); bs.B = lr_bperm_f(sup.B, sl); bs.C = lr_bperm_f(sup.C, sl);
+      bs.tau = lr_bperm_f(sup.tau, sl); bs.ex = lr_bperm_f(sup.ex, sl); bs.ey = lr_bperm_f(sup.ey, sl);
+      bs.iA = lr_bperm_f(sup.iA, sl); bs.iC = lr_bperm_f(sup.iC, sl);
+      bs.mode = lr_bperm_i(sup.mode, sl);
+    }
+    const int q0 = lr_bperm_i(pay0, sl), q1 = lr_bperm_i(pay1, sl), q2 = lr_bperm_i(pay2, sl);
     const bool have = src >= 0 && t < bn;
     const int bwc = bw > 0 ? bw : 1;
     const int ty = t / bwc, tx = t - ty * bwc;
-    if (have && lr_support_tile(bs, bx0 + tx, by0 + ty)) f(by0 + ty, bx0 + tx, q0, q1);
+    if (have) f(t, by0 + ty, bx0 + tx, !TEST || lr_support_tile(bs, bx0 + tx, by0 + ty), q0, q1, q2);
   }
 }
+
+// ---- ranks of the 5..16-tile rects (round 5) ---------------------------------------------------------------------------
+// Counting such a rect cost the fill one returning memory-side atomic per tile instance (the per-tile cursors: ~20 G line
+// operations per second chip-wide; a trained model's 3-4 % of such Gaussians made them 8 M per 30 M-Gaussian view).  The
+// batched projection now RANKS them like the rects of up to four tiles -- the serving lane's LDS atomic on the (batch,
+// tile) counter returns the instance's rank inside the batch -- and leaves the ranks of a rect in a 32-byte row of 16-bit
+// words (0xffff = tile dropped by the support cull) that the fill reads back: no cursor atomic, no second support test,
+// no record fetch.  Rows live behind the records | fill records | band indices in `geom`: batch b owns rows
+// [b * lr_mid_cap(B), ...); a batch with more such rects than rows counts the rest the old way.
+#define LR_MID_ROW 16
+__host__ __device__ inline uint32_t lr_mid_cap(uint32_t B) { return B >> 3; }
+__host__ __device__ inline size_t lr_midrank_off_bytes(size_t n) {
+  return ((sizeof(float) * LOGRAST_REC_FLOATS + 16 + 4) * n + 63) & ~(size_t)63;
+}
+// rows of all batches: batches * (B / 8) * 32 B = 4 B per Gaussian of the padded batches, and batches * B < n + 32768
+__host__ __device__ inline size_t lr_midrank_bytes(size_t n) { return 4 * n + 4 * 32768; }
 
 // ---- N4 kernel arguments (counter.hip; filled in by api.hip) ------------------------------------------
 struct CounterArgs {

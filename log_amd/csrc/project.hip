@@ -289,7 +289,8 @@ LR_DEV void lr_quad_transpose(float4& a, float4& b, float4& c, float4& d, int m)
 // Fill record (16 B, its own coalesced array behind the records): everything lr_fill_kernel needs, so that it
 // does not fetch half of every 64-byte record again.  x = depth bits; y = x0 | y0<<13 | (w-1)<<26 | (h-1)<<28 |
 // big<<30 (all ones = nothing to fill); ranked: z,w = four 16-bit ranks inside the batch (0xffff = tile dropped
-// by the support cull); big: z = x1 | y1<<16.
+// by the support cull); big: z = x1 | y1<<16, and with bit 31 of y: w = the rect's rank row (5..16 tiles, ranked by the
+// batched projection: common.hpp LR_MID_ROW).
 LR_DEV uint4 lr_fill_record(const float4& g2, const float4& g3, int rad) {
   uint4 fr = {__float_as_uint(g2.y), 0xffffffffu, 0u, 0u};
   if (rad > 0) {
@@ -465,15 +466,19 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
                           const float* __restrict__ colors, int* __restrict__ radii, float4* __restrict__ geom,
                           uint32_t* __restrict__ ranked, uint32_t* __restrict__ big, uint32_t* __restrict__ hdr,
                           uint32_t* __restrict__ basetab, uint32_t* __restrict__ hugemask, int tile_cull, int B,
-                          int S, int defer_tiles, int mid_coop LR_ABLATE_PARAM) {
+                          int S, int defer_tiles, int mid_coop, int mid_rank LR_ABLATE_PARAM) {
   // (experiment builds, LOGRAST_PROJECT_ABLATE: 1 no record stores, 2 no fill-record / radii stores, 4 no ranking atomics,
   //  8 no arithmetic -- the loop's loads and stores alone --, 16 no reservations at the end; results are garbage)
   extern __shared__ uint32_t lr_lds_ctr[];  // [S][tiles] packed (ranked | big << 16) counts, one plane per batch
   __shared__ uint32_t lr_huge_mask[LR_MAX_PLANES * LR_HUGE_WORDS];   // per batch: bit c = its 256-Gaussian chunk c deferred a rect
   __shared__ uint32_t lr_rank_dummy[64];    // where the ranking atomics of tiles that are not ranked go (see the loop)
+  __shared__ uint32_t lr_mid_cnt[LR_MAX_PLANES];   // rank rows handed out per batch (rects of 5..16 tiles: common.hpp)
   const int tiles = v.gx * v.gy;
   for (int t = threadIdx.x; t < S * tiles; t += LR_BATCH_THREADS) lr_lds_ctr[t] = 0u;
   if (threadIdx.x < LR_MAX_PLANES * LR_HUGE_WORDS) lr_huge_mask[threadIdx.x] = 0u;
+  if (threadIdx.x < LR_MAX_PLANES) lr_mid_cnt[threadIdx.x] = 0u;
+  const uint32_t midcap = lr_mid_cap((uint32_t)B);
+  uint16_t* const midrank = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(geom) + lr_midrank_off_bytes((size_t)N));
   if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[LR_HDR_CULL] = tile_cull ? 1u : 0u; hdr[LR_HDR_BATCH] = (uint32_t)B; }
   __syncthreads();
   uint32_t rect_instances = 0;
@@ -618,6 +623,7 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
     rect_instances += (uint32_t)nt;
     // ---- part 3: support cull + ranking of the rect's tiles ----
     uint32_t slot0 = 0u, slot1 = 0u, slot2 = 0u, slot3 = 0u;
+    int mrow = -1;                                             // rank row of a ranked 5..16-tile rect
     const bool small = valid && nt <= LR_RANKED_TILES;
     {
       // tile k of a rect of <= 4 tiles: one row (w >= nt), one column (w == 1) or 2x2 -- no integer division
@@ -667,7 +673,20 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
         const bool midc = mid && mid_coop && nt <= LR_COOP_TILES;
         if (mid_coop) {
           const int gxw = v.gx;
-          lr_mid_rects(midc, x0, y0, w, nt, sup, 0, 0, [&](int ty, int tx, int, int) { atomicAdd(&ctr[ty * gxw + tx], 0x10000u); });
+          // ranked (common.hpp): the owner takes a rank row of its batch; the serving lanes' LDS atomics return the ranks
+          if (midc && mid_rank) {
+            const uint32_t r = atomicAdd(&lr_mid_cnt[plane], 1u);
+            if (r < midcap) mrow = (int)r;
+          }
+          uint16_t* const rows = midrank + (size_t)(blockIdx.x * S + plane) * midcap * LR_MID_ROW;   // (wave-uniform)
+          lr_mid_rects<true>(midc, x0, y0, w, nt, sup, mrow, 0, 0, [&](int t, int ty, int tx, bool keep, int mr, int, int) {
+            if (mr >= 0) {
+              const uint32_t r = keep ? (atomicAdd(&ctr[ty * gxw + tx], 1u) & 0xffffu) : 0xffffu;
+              rows[(size_t)mr * LR_MID_ROW + t] = (uint16_t)r;
+            } else if (keep) {
+              atomicAdd(&ctr[ty * gxw + tx], 0x10000u);
+            }
+          });
         }
         if (mid && !midc) {
           for (int y = y0; y < y1; y++)
@@ -690,9 +709,9 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
       fr.x = __float_as_uint(tz);
       fr.y = !valid ? 0xffffffffu
                     : (small ? ((uint32_t)x0 | ((uint32_t)y0 << 13) | ((uint32_t)(w - 1) << 26) | ((h - 1u) << 28))
-                             : ((uint32_t)x0 | ((uint32_t)y0 << 13) | (1u << 30)));
+                             : ((uint32_t)x0 | ((uint32_t)y0 << 13) | (1u << 30) | (mrow >= 0 ? (1u << 31) : 0u)));
       fr.z = !valid ? 0u : (small ? ((slot0 & 0xffffu) | (slot1 << 16)) : r1w);
-      fr.w = (valid && small) ? ((slot2 & 0xffffu) | (slot3 << 16)) : 0u;
+      fr.w = (valid && small) ? ((slot2 & 0xffffu) | (slot3 << 16)) : (mrow >= 0 ? (uint32_t)mrow : 0u);   // bit 31 of y: w = rank row
       lr_out_store(&(fillrec + iws)[lane], fr);
     }
     if (!LR_ABLATED(1)) lr_store_records(geom + LR_REC_QUADS * iws, lane, g0, g1, g2, g3);   // (scalar base + lane offset)
@@ -1042,6 +1061,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
     uint32_t* hugecount = basetab + (size_t)batches * tiles;   // (hugemask[batches][LR_HUGE_WORDS]: common.hpp)
     LR_KNOB(mid_coop, "LOGRAST_MID_COOP", 1);
+    LR_KNOB(mid_rank, "LOGRAST_MID_RANK", 1);
 #ifdef LR_EXPERIMENTS
     static const int ablate = lr_env_int("LOGRAST_PROJECT_ABLATE", 0);   // timing experiments (tools/): see the band kernel
 #endif
@@ -1059,11 +1079,11 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
       if (v.cov3d)
         hipLaunchKernelGGL(lr_project_batched_kernel<true>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                            means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                           basetab, hugecount, tile_cull, batch, planes, defer_tiles, mid_coop LR_ABLATE_PASS(ablate));
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles, mid_coop, mid_rank LR_ABLATE_PASS(ablate));
       else
         hipLaunchKernelGGL(lr_project_batched_kernel<false>, dim3(groups), dim3(LR_BATCH_THREADS), lds * planes, s, v, N,
                            means, scales, rots, opac, colors, radii, reinterpret_cast<float4*>(geom), ranked, big, hdr,
-                           basetab, hugecount, tile_cull, batch, planes, defer_tiles, mid_coop LR_ABLATE_PASS(ablate));
+                           basetab, hugecount, tile_cull, batch, planes, defer_tiles, mid_coop, mid_rank LR_ABLATE_PASS(ablate));
     }
     lr_prof_end(LRK_PROJECT, s);
     lr_prof_begin(LRK_RESERVED, s);
@@ -1289,23 +1309,37 @@ LR_DEV bool lr_fill_verdict(uint32_t* __restrict__ state, uint32_t capacity, uin
 // per-tile cursors here.  The projection kernel's support test is repeated (same record, same code) so that the same
 // tiles are filled.  Up to LR_COOP_TILES tiles a lane expands its own rect, beyond that the whole wave expands it (ballot
 // over the lanes that hold one, record broadcast with readlane).  Every lane of the wave must call this (nt = 0: nothing).
+// slot_of(tile, owner_id): first slot of the owner's batch in `tile` (absolute): the staged row or the table look-up.
+// rmid / mrow: the rect was ranked by the batched projection (fill record bit 31): its instances go to slot + rank, the
+// ranks read back from its rank row -- no cursor atomic, no support test, no record fetch.
+template <typename SlotOf>
 LR_DEV void lr_fill_big_rect(const float4* __restrict__ geom, int i, int x0, int y0, int w, int h, int nt, uint64_t key,
                              int gx, bool tile_cull, uint32_t* __restrict__ cursor, uint64_t* __restrict__ keys, int lane,
-                             int mid_coop LR_ABLATE_PARAM) {
+                             int mid_coop, bool rmid, int mrow, const uint16_t* __restrict__ midrank, uint32_t batch,
+                             SlotOf&& slot_of LR_ABLATE_PARAM) {
   const int y1 = y0 + h, x1 = x0 + w;
   LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};  // mode 1: every tile of the rect
-  if (nt > LR_RANKED_TILES && tile_cull) {
+  if (nt > LR_RANKED_TILES && tile_cull && !rmid) {
     const float4 g0 = geom[LR_REC_QUADS * (size_t)i + 0], g1 = geom[LR_REC_QUADS * (size_t)i + 1];
     sup = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
   }
-  const bool mid = nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !LR_ABLATED(4);
+  const int klo = (int)(uint32_t)key, khi = (int)(uint32_t)(key >> 32);
+  if (__builtin_amdgcn_ballot_w64(rmid) != 0) {   // (wave-uniform) ranked rects: slot of the batch's run + rank
+    const uint32_t midcap = lr_mid_cap(batch);
+    lr_mid_rects<false>(rmid, x0, y0, w, nt, sup, mrow, klo, khi, [&](int t, int ty, int tx, bool, int mr, int lo, int hi) {
+      const uint32_t b = (uint32_t)lo / batch;             // (the key's low word is the Gaussian's index)
+      const uint32_t r = midrank[((size_t)b * midcap + (uint32_t)mr) * LR_MID_ROW + t];
+      if (r != 0xffffu) keys[slot_of(ty * gx + tx, (uint32_t)lo) + r] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+    });
+  }
+  const bool mid = !rmid && nt > LR_RANKED_TILES && nt <= LR_COOP_TILES && !LR_ABLATED(4);
   if (mid_coop) {   // the wave expands its 5..16-tile rects together, four per pass (lr_mid_rects)
     if (__builtin_amdgcn_ballot_w64(mid) != 0) {
-      const int klo = (int)(uint32_t)key, khi = (int)(uint32_t)(key >> 32);
-      lr_mid_rects(mid, x0, y0, w, nt, sup, klo, khi, [&](int ty, int tx, int lo, int hi) {
-        const uint64_t k = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-        const uint32_t pos = atomicAdd(&cursor[(ty * gx + tx) * LR_CTR_STRIDE], 1u);
-        keys[pos] = k;
+      lr_mid_rects<true>(mid, x0, y0, w, nt, sup, 0, klo, khi, [&](int, int ty, int tx, bool keep, int, int lo, int hi) {
+        if (keep) {
+          const uint32_t pos = atomicAdd(&cursor[(ty * gx + tx) * LR_CTR_STRIDE], 1u);
+          keys[pos] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+        }
       });
     }
   } else if (mid) {
@@ -1399,6 +1433,8 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
   // slots [w * span, ...), their Gaussian indices in the same slots of the array behind the fill records
   const bool sparse = batch && state[LR_HDR_SPARSE] != 0u;
   const uint32_t* __restrict__ survivor = reinterpret_cast<const uint32_t*>(fillrec + N);
+  const uint16_t* __restrict__ midrank =
+      reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(geom) + lr_midrank_off_bytes((size_t)N));
   const uint32_t span = sparse ? state[LR_HDR_SPAN] : 1u;
   const uint32_t* __restrict__ survcount =
       state + lr_survcount_off(tiles, batch ? ((uint32_t)N + batch - 1u) / batch : 0u);
@@ -1429,6 +1465,8 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       batch ? state + lr_basetab_off(tiles) + (size_t)((uint32_t)i / batch) * tiles : nullptr;
   uint32_t dbits = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  bool rmid = false;                                           // a 5..16-tile rect the projection ranked: fr.w = its rank row
+  int mrow = 0;
   uint32_t slot[LR_RANKED_TILES] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   if (vis && batch) {
     // batched projection: the 16-byte fill record (see lr_project_batched_kernel)
@@ -1438,6 +1476,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
       if (fr.y & (1u << 30)) {
         x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
+        rmid = (fr.y >> 31) != 0u; mrow = (int)fr.w;
       } else {
         x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
         const uint32_t h0 = fr.z & 0xffffu, h1 = fr.z >> 16, h2 = fr.w & 0xffffu, h3 = fr.w >> 16;
@@ -1471,7 +1510,11 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
       }
     }
   }
-  lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane, mid_coop LR_ABLATE_PASS(ablate));
+  lr_fill_big_rect(geom, i, x0, y0, w, h, nt, key, gx, tile_cull, cursor, keys, lane, mid_coop, rmid, mrow, midrank, batch,
+                   [&](int t, uint32_t owner) -> uint32_t {
+                     const uint32_t* __restrict__ bb = state + lr_basetab_off(tiles) + (size_t)(owner / batch) * tiles;
+                     return rebased ? bb[t] : offsets[t] + bb[t];
+                   } LR_ABLATE_PASS(ablate));
   }
 }
 
@@ -1535,17 +1578,22 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
   uint32_t* cursor = state + lr_cursor_off(tiles);
   const int lane = threadIdx.x & 63;
   int x0_k[K], y0_k[K], w_k[K], h_k[K], nt_k[K];
-  uint32_t hA_k[K], hB_k[K];                                     // the four 16-bit ranks of a rect of <= 4 tiles
+  uint32_t hA_k[K], hB_k[K];                                     // the four 16-bit ranks of a rect of <= 4 tiles (hB: the rank row of a ranked 5..16-tile rect)
+  bool rmid_k[K];
+  const uint16_t* __restrict__ midrank =
+      reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(geom) + lr_midrank_off_bytes((size_t)N));
 #pragma unroll
   for (int u = 0; u < K; u++) {
     const uint32_t e = first + u * LR_FILL_STAGED_ROWS + threadIdx.x;
     const uint4 fr = fr_k[u];
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     hA_k[u] = 0xffffffffu; hB_k[u] = 0xffffffffu;
+    rmid_k[u] = false;
     if (fr.y != 0xffffffffu) {
       x0 = (int)(fr.y & 0x1fffu); y0 = (int)((fr.y >> 13) & 0x1fffu);
       if (fr.y & (1u << 30)) {
         x1 = (int)(fr.z & 0xffffu); y1 = (int)(fr.z >> 16);
+        rmid_k[u] = (fr.y >> 31) != 0u; hB_k[u] = fr.w;
       } else {
         x1 = x0 + (int)((fr.y >> 26) & 3u) + 1; y1 = y0 + (int)((fr.y >> 28) & 3u) + 1;
         hA_k[u] = fr.z; hB_k[u] = fr.w;
@@ -1581,7 +1629,8 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
     // (Rects of more than four tiles, measured and removed: counting the workgroup's instances per tile in LDS first, ONE
     // cursor atomic per touched tile, a second walk placing the keys -- the C3 view's fill 426 -> 545 us: 2048 consecutive
     // rows of a level-of-detail selection do not share enough tiles to pay for two walks of support tests.)
-    lr_fill_big_rect(geom, i, x0, y0, w, h_k[u], nt, key, gx, tile_cull, cursor, keys, lane, mid_coop LR_ABLATE_PASS(ablate));
+    lr_fill_big_rect(geom, i, x0, y0, w, h_k[u], nt, key, gx, tile_cull, cursor, keys, lane, mid_coop, rmid_k[u], (int)hB_k[u],
+                     midrank, batch, [&](int t, uint32_t) -> uint32_t { return lr_slot_row[t]; } LR_ABLATE_PASS(ablate));
   }
 }
 

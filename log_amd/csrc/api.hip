@@ -101,7 +101,7 @@ struct LrKnobInfo { const char* name; int dflt, lo, hi; const char* what; };
 static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_HELPER_MIN_N", 4000000, 0, 2000000000, "Gaussians from which the helper passes (absolute slot table, touched-only dL/dconic clearing, separate zero-fill kernels) pay for their launches"},
     {"LOGRAST_MID_RANK", 1, 0, 1, "rects of 5..16 tiles are RANKED by the batched projection (LDS atomics; 32-byte rank rows in geom), so the fill places them without cursor atomics or support tests; 0 = counted only, placed through the per-tile cursors"},
-    {"LOGRAST_MID_COOP", 1, 0, 1, "rects of 5..16 tiles are counted (projection) and placed (fill) by the whole wave, four rects per pass, instead of by their lane"},
+    {"LOGRAST_MID_COOP", 16, 0, 64, "rects of 5..16 tiles are counted (projection: in waves that hold at most this many of them) and placed (fill: any non-zero value) by the whole wave, four rects per pass, instead of by their lane; 0 = per lane"},
     {"LOGRAST_DEFER_TILES", LR_COOP_TILES, 4, 4096, "rects above this many tiles are counted by lr_count_huge_kernel (one wave per rect) instead of by their lane"},
     {"LOGRAST_HUGE_CHUNK", LR_HUGE_CHUNK, 256, 8192, "Gaussians per workgroup of lr_count_huge_kernel (multiple of 256)"},
     {"LOGRAST_BATCH_PLANES", 4, 1, 4, "consecutive projection batches one workgroup owns"},

@@ -667,18 +667,23 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
         const int c = (iw - (i_begin + plane * B)) >> 8;
         atomicOr(&lr_huge_mask[plane * LR_HUGE_WORDS + (c >> 5)], 1u << (c & 31));
       }
-      if (__builtin_amdgcn_ballot_w64(mid) != 0) {   // (wave-uniform)
-        // four rects per pass, one tile per lane: lr_mid_rects (16 lanes per rect: LOGRAST_DEFER_TILES above 16 leaves
-        // the rects between to their lanes)
-        const bool midc = mid && mid_coop && nt <= LR_COOP_TILES;
-        if (mid_coop) {
-          const int gxw = v.gx;
-          // ranked (common.hpp): the owner takes a rank row of its batch; the serving lanes' LDS atomics return the ranks
-          if (midc && mid_rank) {
-            const uint32_t r = atomicAdd(&lr_mid_cnt[plane], 1u);
-            if (r < midcap) mrow = (int)r;
-          }
-          uint16_t* const rows = midrank + (size_t)(blockIdx.x * S + plane) * midcap * LR_MID_ROW;   // (wave-uniform)
+      const uint64_t midm = __builtin_amdgcn_ballot_w64(mid);
+      if (midm != 0) {   // (wave-uniform)
+        // Up to `mid_coop` such rects in the wave: four rects per pass, one tile per lane (lr_mid_rects; 16 lanes per rect:
+        // LOGRAST_DEFER_TILES above 16 leaves the rects between to their lanes).  More -- siblings of a level-of-detail
+        // tree sit in neighbouring lanes: 30 of 64 -- and every lane walks its own rect: c / 4 passes of ~170 instructions
+        // against ~12 iterations of ~75 (measured on the tree-ordered C3 view: always cooperative 331 -> 426 us).
+        const bool coop = mid_coop > 0 && (int)__popcll(midm) <= mid_coop;
+        const bool rankable = mid && nt <= LR_MID_ROW;
+        const int gxw = v.gx;
+        // ranked (common.hpp): the owner takes a rank row of its batch; the counting LDS atomics return the ranks
+        if (rankable && mid_rank) {
+          const uint32_t r = atomicAdd(&lr_mid_cnt[plane], 1u);
+          if (r < midcap) mrow = (int)r;
+        }
+        uint16_t* const rows = midrank + (size_t)(blockIdx.x * S + plane) * midcap * LR_MID_ROW;   // (wave-uniform)
+        const bool midc = rankable && coop;
+        if (coop) {
           lr_mid_rects<true>(midc, x0, y0, w, nt, sup, mrow, 0, 0, [&](int t, int ty, int tx, bool keep, int mr, int, int) {
             if (mr >= 0) {
               const uint32_t r = keep ? (atomicAdd(&ctr[ty * gxw + tx], 1u) & 0xffffu) : 0xffffu;
@@ -690,8 +695,15 @@ lr_project_batched_kernel(LrView v, int N, const float* __restrict__ means, cons
         }
         if (mid && !midc) {
           for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++)
-              if (lr_support_tile(sup, x, y)) atomicAdd(&ctr[y * v.gx + x], 0x10000u);
+            for (int x = x0; x < x1; x++) {
+              const bool keep = lr_support_tile(sup, x, y);
+              if (mrow >= 0) {   // tile t = (y - y0) w + (x - x0): the order the fill reads the row in
+                const uint32_t r = keep ? (atomicAdd(&ctr[y * gxw + x], 1u) & 0xffffu) : 0xffffu;
+                rows[(size_t)mrow * LR_MID_ROW + (y - y0) * w + (x - x0)] = (uint16_t)r;
+              } else if (keep) {
+                atomicAdd(&ctr[y * gxw + x], 0x10000u);
+              }
+            }
         }
       }
     }
@@ -1060,7 +1072,7 @@ void lr_launch_project(const LrView& v, int N, const float* means, const float* 
     const int batches = (N + batch - 1) / batch;
     const int groups = (batches + planes - 1) / planes;     // workgroups: `planes` consecutive batches each
     uint32_t* hugecount = basetab + (size_t)batches * tiles;   // (hugemask[batches][LR_HUGE_WORDS]: common.hpp)
-    LR_KNOB(mid_coop, "LOGRAST_MID_COOP", 1);
+    LR_KNOB(mid_coop, "LOGRAST_MID_COOP", 16);
     LR_KNOB(mid_rank, "LOGRAST_MID_RANK", 1);
 #ifdef LR_EXPERIMENTS
     static const int ablate = lr_env_int("LOGRAST_PROJECT_ABLATE", 0);   // timing experiments (tools/): see the band kernel
@@ -1641,7 +1653,7 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
   lr_prof_begin(LRK_FILL, s);
   LR_KNOB(xcd_order, "LOGRAST_FILL_XCD_ORDER", 1);
   LR_KNOB(fill_nt, "LOGRAST_FILL_NT", 1);
-  LR_KNOB(mid_coop, "LOGRAST_MID_COOP", 1);
+  LR_KNOB(mid_coop, "LOGRAST_MID_COOP", 16);
 #ifdef LR_EXPERIMENTS
   static const int ablate = lr_env_int("LOGRAST_FILL_ABLATE", 0);   // timing experiments (tools/): 1 no zero-fill, 2 no key stores, 4 no 5-16-tile rects, 8 no larger rects
 #endif

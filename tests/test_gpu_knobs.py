@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 SWEEP = {
     "LOGRAST_HELPER_MIN_N": (0, 4_000_000, 2_000_000_000),
     "LOGRAST_DEFER_TILES": (4, 16, 100),
-    "LOGRAST_MID_COOP": (0, 1),
+    "LOGRAST_MID_COOP": (0, 1, 16, 64),
     "LOGRAST_MID_RANK": (0, 1),
     "LOGRAST_HUGE_CHUNK": (256, 512, 2048),
     "LOGRAST_BATCH_PLANES": (1, 2, 4),

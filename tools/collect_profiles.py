@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -31,12 +31,16 @@ for n, t in (("b_default", "default"), ("b_oprand", "opacity_rand"), ("b_10M", "
         line = [l for l in open(f) if l.startswith("{")][-1]
         json.dump(json.loads(line), open(os.path.join(P, f"{tag}_bench_{t}.json"), "w"), indent=1)
 cmd = ("python bench.py --views 4 --steps 1 --warmup 0 --streams 1 --no-graphs --no-cpu-baseline --no-kernel-timing "
-       "--no-secondary --no-dropin-mode --no-rand-variant --no-forward-only")
+       "--no-secondary --no-dropin-mode --no-rand-variant --no-forward-only --no-trained-like")
 WORKLOAD = "the bench headline: 30 M random Gaussians @1080p, 4 views (stats pass + 1 step), one stream, eager launches"
 src = os.path.join(G, f"{tag}_trace", "h30_kernel_stats.csv")
 if os.path.exists(src):
     stats(src, f"rocprofv3 --kernel-trace --stats -- {cmd}; {WORKLOAD}", os.path.join(P, f"{tag}_kernel_stats.md"))
     shutil.copy(src, os.path.join(P, f"{tag}_kernel_stats.csv"))
+src_t = os.path.join(G, f"{tag}_trace_trained", "t30_kernel_stats.csv")
+if os.path.exists(src_t):
+    stats(src_t, f"rocprofv3 --kernel-trace --stats -- {cmd} --scene trained; the same step on the trained-like scene "
+                 "(log_amd.scenes.trained_like_scene, 30 M Gaussians @1080p)", os.path.join(P, f"{tag}_kernel_stats_trained.md"))
 pm = os.path.join(ROOT, "tools", "pmc_summary.py")
 sq = os.path.join(G, f"{tag}_pmc_sq", "h30_counter_collection.csv")
 fe = os.path.join(G, f"{tag}_pmc_fetch", "h30_counter_collection.csv")

@@ -102,8 +102,8 @@ const char* lograst_last_error(void);
  * order, and the per-batch slot reservations of the projection stage, which grow with n) */
 size_t lograst_tile_state_bytes(int32_t width, int32_t height, int32_t n);
 /* bytes of the projected-record array for N Gaussians (64-byte records followed by 16-byte fill records and a 4-byte
- * index each, then -- round 5 -- the rank rows of the rects of 5..16 tiles: 32 bytes per such rect, room for one in eight
- * Gaussians of every projection batch: 4 bytes per Gaussian + 128 KB).  Records of Gaussians with radii == 0 are
+ * index each, then -- round 5 -- the rank rows of the rects of 5..16 tiles: 32 bytes per such rect, room for one in four
+ * Gaussians of every projection batch: 8 bytes per Gaussian + 256 KB).  Records of Gaussians with radii == 0 are
  * undefined: a view that owns a band of tile rows does not write them (a Gaussian without a rect then costs the 40 bytes
  * its rect is computed from and its radii word). */
 size_t lograst_geom_bytes(int32_t n);

@@ -457,14 +457,14 @@ LR_DEV void lr_mid_rects(bool mid, int x0, int y0, int w, int nt, const LrSuppor
 // tile) counter returns the instance's rank inside the batch -- and leaves the ranks of a rect in a 32-byte row of 16-bit
 // words (0xffff = tile dropped by the support cull) that the fill reads back: no cursor atomic, no second support test,
 // no record fetch.  Rows live behind the records | fill records | band indices in `geom`: batch b owns rows
-// [b * lr_mid_cap(B), ...); a batch with more such rects than rows counts the rest the old way.
+// [b * lr_mid_cap(B), ...) -- one row per four Gaussians of the batch; a batch with more such rects counts the rest the old way.
 #define LR_MID_ROW 16
-__host__ __device__ inline uint32_t lr_mid_cap(uint32_t B) { return B >> 3; }
+__host__ __device__ inline uint32_t lr_mid_cap(uint32_t B) { return B >> 2; }   // (C2: 13 % of the Gaussians hold such a rect)
 __host__ __device__ inline size_t lr_midrank_off_bytes(size_t n) {
   return ((sizeof(float) * LOGRAST_REC_FLOATS + 16 + 4) * n + 63) & ~(size_t)63;
 }
-// rows of all batches: batches * (B / 8) * 32 B = 4 B per Gaussian of the padded batches, and batches * B < n + 32768
-__host__ __device__ inline size_t lr_midrank_bytes(size_t n) { return 4 * n + 4 * 32768; }
+// rows of all batches: batches * (B / 4) * 32 B = 8 B per Gaussian of the padded batches, and batches * B < n + 32768
+__host__ __device__ inline size_t lr_midrank_bytes(size_t n) { return 8 * n + 8 * 32768; }
 
 // ---- N4 kernel arguments (counter.hip; filled in by api.hip) ------------------------------------------
 struct CounterArgs {

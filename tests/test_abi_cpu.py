@@ -34,9 +34,9 @@ def test_sizing_helpers_and_error_text_work_without_gpu():
     tiles = 120 * 68
     assert L.lograst_tile_state_bytes(1920, 1080, 1000000) >= 4 * (tiles + 1)
     # records + fill records + an index each (band views), rounded up to 64 bytes, + the rank rows of the 5..16-tile rects
-    # (4 bytes per Gaussian of the padded batches: round 5)
-    assert L.lograst_geom_bytes(10) == (10 * (64 + 16 + 4) + 63) // 64 * 64 + 4 * 10 + 4 * 32768
-    assert L.lograst_geom_bytes(30_000_000) < 30_000_000 * 89 + (1 << 20)
+    # (8 bytes per Gaussian of the padded batches: round 5)
+    assert L.lograst_geom_bytes(10) == (10 * (64 + 16 + 4) + 63) // 64 * 64 + 8 * 10 + 8 * 32768
+    assert L.lograst_geom_bytes(30_000_000) < 30_000_000 * 93 + (1 << 20)
     assert L.lograst_keys_bytes(7) == 2 * 56 and L.lograst_list_bytes(7) == 28   # keys + the sort scratch half
     # argument validation happens before any device work
     rc = L.lograst_compute_radius(-1, None, None, None, None, None, 1.0, 1.0, 1.0, 1.0, None, None)

@@ -945,6 +945,7 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
 // the support tests of a rect run 64 at a time and the LDS atomics never collide; counts go through per-workgroup
 // LDS counters (one memory-side atomic per touched tile and workgroup).  A workgroup owns `chunk` Gaussians and
 // returns at once when its batches left nothing (the common case: small splats only).
+#define LR_HUGE_DIRECT 8   // deferred rects per 256-Gaussian chunk up to which they are counted without the LDS plane
 __global__ void __launch_bounds__(256)
 lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,
                      const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ hugemask, int B, int tile_cull,
@@ -981,19 +982,16 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
     __syncthreads();
   }
   const int ntodo = (int)lr_chunk_todo[256];
-  for (int q = 0; q < ntodo; q++) {
-  const int chunk_id = first + (int)lr_chunk_todo[q] * (int)gridDim.x;
-  const int base = chunk_id * chunk;
-  __syncthreads();                                           // (the previous chunk's flush has read the counters)
-  for (int t = threadIdx.x; t < tiles; t += 256) lr_lds_ctr[t] = 0u;
-  __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint4* __restrict__ fill = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)n_all);
   const uint32_t* __restrict__ survivor = reinterpret_cast<const uint32_t*>(fill + n_all);
-  for (int k = 0; k < chunk / 256; k++) {
-    const int i = base + k * 256 + (int)threadIdx.x;
-    int x0 = 0, y0 = 0, w = 0, nt = 0;
-    LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};
+  for (int q = 0; q < ntodo; q++) {
+  const int chunk_id = first + (int)lr_chunk_todo[q] * (int)gridDim.x;
+  const int base = chunk_id * chunk;
+  int x0 = 0, y0 = 0, w = 0, nt = 0;
+  LrSupport sup = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1};
+  auto load = [&](int i) {   // this thread's Gaussian (band views: slot) of the chunk: its rect, if it was deferred
+    x0 = 0; y0 = 0; w = 0; nt = 0;
     if (i < N && (!sparse || i - (i / span) * span < (int)survcount[i / span])) {
       const uint4 fr = fill[i];
       const size_t gid = sparse ? (size_t)survivor[i] : (size_t)i;
@@ -1007,6 +1005,20 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
         }
       }
     }
+  };
+  load(base + (int)threadIdx.x);
+  // A chunk with a handful of deferred rects (a trained model's few large splats, spread evenly: one or two per chunk
+  // with work) counts them straight into the dense global counters -- clearing and flushing the workgroup's 8160 LDS
+  // counters for ~40 instances was most of this kernel's 53 us there.  (The barrier also separates the previous chunk's
+  // flush from this chunk's clear.)
+  const bool direct = (chunk == 256) && __syncthreads_count(nt > defer_tiles) <= LR_HUGE_DIRECT;
+  if (!direct) {
+    if (chunk != 256) __syncthreads();
+    for (int t = threadIdx.x; t < tiles; t += 256) lr_lds_ctr[t] = 0u;
+    __syncthreads();
+  }
+  for (int k = 0; k < chunk / 256; k++) {
+    if (k > 0) load(base + k * 256 + (int)threadIdx.x);
     uint64_t m = __ballot(nt > defer_tiles);
     while (m) {
       const int src = __builtin_ctzll(m);
@@ -1021,14 +1033,19 @@ lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, 
       bs.mode = lr_readlane_i(sup.mode, src);
       for (int t = lane; t < bn; t += 64) {
         const int ty = t / bw, tx = t - ty * bw;
-        if (lr_support_tile(bs, bx0 + tx, by0 + ty)) atomicAdd(&lr_lds_ctr[(by0 + ty) * gx + (bx0 + tx)], 1u);
+        if (lr_support_tile(bs, bx0 + tx, by0 + ty)) {
+          const int tile = (by0 + ty) * gx + (bx0 + tx);
+          if (direct) atomicAdd(&big[tile], 1u); else atomicAdd(&lr_lds_ctr[tile], 1u);
+        }
       }
     }
   }
-  __syncthreads();
-  for (int t = threadIdx.x; t < tiles; t += 256) {
-    const uint32_t c = lr_lds_ctr[t];
-    if (c) atomicAdd(&big[t], c);   // dense counters in batched mode
+  if (!direct) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < tiles; t += 256) {
+      const uint32_t c = lr_lds_ctr[t];
+      if (c) atomicAdd(&big[t], c);   // dense counters in batched mode
+    }
   }
   }
   }

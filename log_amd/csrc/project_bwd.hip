@@ -121,6 +121,77 @@ LR_DEV void lr_project_bwd_row(const LrView& v, int i, const float* __restrict__
   }
 }
 
+// The chain rule of ONE live Gaussian i: reads its accumulator row (AOS) or its (dL/dmean2D, dL/dconic) pair, hands out
+// the per-view outputs and writes / adds the gradients (see lr_project_bwd_kernel for the template flags).
+template <bool ACCUMULATE, bool COV, bool AOS, bool SINKROWS>
+LR_DEV void lr_pbwd_live_row(const LrView& v, int i, const float* __restrict__ means, const float* __restrict__ scales,
+                             const float* __restrict__ rots, const float* __restrict__ g_mean2d,
+                             const float* __restrict__ g_conic, const float4* __restrict__ rows,
+                             float* __restrict__ o_mean2d, float* __restrict__ o_opac, float* __restrict__ o_col,
+                             float* __restrict__ g_means3d, float* __restrict__ g_scales, float* __restrict__ g_rots) {
+    float gm[3], gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    float gnx, gny, gA, gB, gC;
+    // running sums (ACCUMULATE): every old value is requested up front, next to the row's inputs -- the row is a chain of
+    // ~20 scattered accesses, and the read-modify-writes behind the chain rule's ~600 instructions were fully exposed
+    float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_c[3] = {0.f, 0.f, 0.f}, old_o = 0.f;
+    float4 old_q = {0.f, 0.f, 0.f, 0.f};
+    float4 sr0 = {0.f, 0.f, 0.f, 0.f}, sr1 = sr0, sr2 = sr0, sr3 = sr0;
+    float4* const srow = SINKROWS ? reinterpret_cast<float4*>(g_means3d) + 4 * (size_t)i : nullptr;
+    if (SINKROWS) {
+      sr0 = srow[0]; sr1 = srow[1]; sr2 = srow[2]; sr3 = srow[3];
+    } else if (ACCUMULATE) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) old_m[k] = g_means3d[3 * (size_t)i + k];
+      if (!COV) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) old_s[k] = g_scales[3 * (size_t)i + k];
+        old_q = reinterpret_cast<const float4*>(g_rots)[i];
+      }
+      if (AOS) {
+        old_o = o_opac[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) old_c[k] = o_col[3 * (size_t)i + k];
+      }
+    }
+    if (AOS) {
+      const float4 a0 = rows[4 * (size_t)i], a1 = rows[4 * (size_t)i + 1];
+      const float cb = reinterpret_cast<const float*>(rows + 4 * (size_t)i + 2)[0];
+      gnx = a0.x; gny = a0.y; gA = a0.z; gB = a0.w; gC = a1.x;
+      o_mean2d[3 * (size_t)i + 0] = gnx; o_mean2d[3 * (size_t)i + 1] = gny; o_mean2d[3 * (size_t)i + 2] = 0.f;
+      if (SINKROWS) {
+        sr2.z += a1.y; sr2.w += a1.z; sr3.x += a1.w; sr3.y += cb;   // slots 10 opacity, 11-13 colour
+      } else {
+        o_opac[i] = old_o + a1.y;
+        o_col[3 * (size_t)i + 0] = old_c[0] + a1.z; o_col[3 * (size_t)i + 1] = old_c[1] + a1.w; o_col[3 * (size_t)i + 2] = old_c[2] + cb;
+      }
+    } else {
+      gnx = g_mean2d[3 * (size_t)i]; gny = g_mean2d[3 * (size_t)i + 1];
+      const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
+      gA = gc4.x; gB = gc4.y; gC = gc4.z;
+    }
+    lr_project_bwd_row<ACCUMULATE, COV>(v, i, means, scales, rots, gnx, gny, gA, gB, gC, gm, gs, gq);
+    if (SINKROWS) {    // running sums over views, one row per Gaussian
+      sr0.x += gm[0]; sr0.y += gm[1]; sr0.z += gm[2]; sr0.w += gs[0];
+      sr1.x += gs[1]; sr1.y += gs[2]; sr1.z += gq[0]; sr1.w += gq[1];
+      sr2.x += gq[2]; sr2.y += gq[3];
+      srow[0] = sr0; srow[1] = sr1; srow[2] = sr2; srow[3] = sr3;
+    } else if (ACCUMULATE) {  // running sums over views (log_amd.dist)
+#pragma unroll
+      for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] = old_m[k] + gm[k];
+      if (!COV) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) g_scales[3 * (size_t)i + k] = old_s[k] + gs[k];
+        reinterpret_cast<float4*>(g_rots)[i] = float4{old_q.x + gq[0], old_q.y + gq[1], old_q.z + gq[2], old_q.w + gq[3]};
+      }
+    } else {
+      g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];
+      if (!COV) {
+        g_scales[3 * (size_t)i + 0] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2];
+        reinterpret_cast<float4*>(g_rots)[i] = float4{gq[0], gq[1], gq[2], gq[3]};
+      }
+    }
+}
+
 // One workgroup owns LR_PBWD_ROWS consecutive Gaussians.  Their live flags are read coalesced; the live rows are
 // COMPACTED into an LDS list and the chain rule (~600 VALU instructions per row) then runs on full waves: with 15 % of
 // the rows live (30 M Gaussians, opacity 0.999) every wave of a one-thread-per-Gaussian kernel still met a live lane and
@@ -232,73 +303,89 @@ lr_project_bwd_kernel(LrView v, int N, const float* __restrict__ means, const fl
   }
   __syncthreads();
   const uint32_t n = live_count;
-  for (uint32_t j = (uint32_t)tid; j < n; j += 256u) {
-    const int i = (int)live_list[j];
-    float gm[3], gs[3] = {0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-    float gnx, gny, gA, gB, gC;
-    // running sums (ACCUMULATE): every old value is requested up front, next to the row's inputs -- the row is a chain of
-    // ~20 scattered accesses, and the read-modify-writes behind the chain rule's ~600 instructions were fully exposed
-    float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_c[3] = {0.f, 0.f, 0.f}, old_o = 0.f;
-    float4 old_q = {0.f, 0.f, 0.f, 0.f};
-    float4 sr0 = {0.f, 0.f, 0.f, 0.f}, sr1 = sr0, sr2 = sr0, sr3 = sr0;
-    float4* const srow = SINKROWS ? reinterpret_cast<float4*>(g_means3d) + 4 * (size_t)i : nullptr;
-    if (SINKROWS) {
-      sr0 = srow[0]; sr1 = srow[1]; sr2 = srow[2]; sr3 = srow[3];
-    } else if (ACCUMULATE) {
+  for (uint32_t j = (uint32_t)tid; j < n; j += 256u)
+    lr_pbwd_live_row<ACCUMULATE, COV, AOS, SINKROWS>(v, (int)live_list[j], means, scales, rots, g_mean2d, g_conic, rows,
+                                                     o_mean2d, o_opac, o_col, g_means3d, g_scales, g_rots);
+}
+
+
+// ---- the chain rule over a COMPACT list of the live rows (round 5) ---------------------------------------------------------
+// On large inputs whose gradients are running sums (nothing is written for a dead row) the kernel above spends half its
+// time deciding that rows are dead: 29 K workgroups of a 30 M-row view, each a chain of flag load -> barrier -> (no live
+// row) at three resident workgroups per CU (its chain rule needs ~130 VGPRs) -- 0.21 of its 0.40 ms; a band view of 100 M
+// rows 0.5 of its 0.74.  So the decision gets a kernel of its own, shaped like a copy: `lr_pbwd_compact_kernel` streams
+// point_weight (16 bytes per lane, low registers, full occupancy) and appends the indices of the rows with weight > 0 to a
+// list, one slot-reserving atomic per 8192 rows; `lr_pbwd_list_kernel` then runs the chain rule over that list with a
+// fixed grid (the count never travels to the host) and every lane busy.  The list needs no buffer of its own: slots 12-15
+// of the reverse walk's 64-byte accumulator rows are unused (LOGRAST_BWD_ROW_FLOATS: nine sums per row), so entry j sits
+// in row 1 + j / 4, slot 12 + j % 4, and the count in row 0, slot 12 (cleared by lr_zero_words_kernel before the pass).
+// Same per-row code (lr_pbwd_live_row), so the same gradients bit for bit.
+#define LR_PBWD_CHUNK 8192             // rows per workgroup of the compaction pass (one atomic each; 32 KB of LDS for a chunk that is all live)
+LR_DEV uint32_t* lr_pbwd_list_slot(float4* rows, uint32_t j) {
+  return reinterpret_cast<uint32_t*>(rows + 4 * (size_t)(1u + (j >> 2)) + 3) + (j & 3u);
+}
+__global__ void __launch_bounds__(1024)
+lr_pbwd_compact_kernel(const float* __restrict__ pw, int N, float4* __restrict__ rows) {
+  __shared__ uint32_t live[LR_PBWD_CHUNK];                    // worst case: every row of the chunk is live
+  __shared__ uint32_t cnt, base_s;
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * LR_PBWD_CHUNK;
+  if (tid == 0) cnt = 0u;
+  __syncthreads();
+  typedef float lr_f4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int k = 0; k < 3; k++) old_m[k] = g_means3d[3 * (size_t)i + k];
-      if (!COV) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) old_s[k] = g_scales[3 * (size_t)i + k];
-        old_q = reinterpret_cast<const float4*>(g_rots)[i];
-      }
-      if (AOS) {
-        old_o = o_opac[i];
-#pragma unroll
-        for (int k = 0; k < 3; k++) old_c[k] = o_col[3 * (size_t)i + k];
-      }
-    }
-    if (AOS) {
-      const float4 a0 = rows[4 * (size_t)i], a1 = rows[4 * (size_t)i + 1];
-      const float cb = reinterpret_cast<const float*>(rows + 4 * (size_t)i + 2)[0];
-      gnx = a0.x; gny = a0.y; gA = a0.z; gB = a0.w; gC = a1.x;
-      o_mean2d[3 * (size_t)i + 0] = gnx; o_mean2d[3 * (size_t)i + 1] = gny; o_mean2d[3 * (size_t)i + 2] = 0.f;
-      if (SINKROWS) {
-        sr2.z += a1.y; sr2.w += a1.z; sr3.x += a1.w; sr3.y += cb;   // slots 10 opacity, 11-13 colour
-      } else {
-        o_opac[i] = old_o + a1.y;
-        o_col[3 * (size_t)i + 0] = old_c[0] + a1.z; o_col[3 * (size_t)i + 1] = old_c[1] + a1.w; o_col[3 * (size_t)i + 2] = old_c[2] + cb;
-      }
+  for (int k = 0; k < LR_PBWD_CHUNK / 4096; k++) {           // four rows per lane and round, all rounds requested up front
+    const int i0 = base + (k * 1024 + tid) * 4;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i0 + 3 < N && ((reinterpret_cast<uintptr_t>(pw) & 15u) == 0u)) {
+      const lr_f4v q = __builtin_nontemporal_load(reinterpret_cast<const lr_f4v*>(pw + i0));
+      w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
     } else {
-      gnx = g_mean2d[3 * (size_t)i]; gny = g_mean2d[3 * (size_t)i + 1];
-      const float4 gc4 = reinterpret_cast<const float4*>(g_conic)[i];
-      gA = gc4.x; gB = gc4.y; gC = gc4.z;
-    }
-    lr_project_bwd_row<ACCUMULATE, COV>(v, i, means, scales, rots, gnx, gny, gA, gB, gC, gm, gs, gq);
-    if (SINKROWS) {    // running sums over views, one row per Gaussian
-      sr0.x += gm[0]; sr0.y += gm[1]; sr0.z += gm[2]; sr0.w += gs[0];
-      sr1.x += gs[1]; sr1.y += gs[2]; sr1.z += gq[0]; sr1.w += gq[1];
-      sr2.x += gq[2]; sr2.y += gq[3];
-      srow[0] = sr0; srow[1] = sr1; srow[2] = sr2; srow[3] = sr3;
-    } else if (ACCUMULATE) {  // running sums over views (log_amd.dist)
 #pragma unroll
-      for (int k = 0; k < 3; k++) g_means3d[3 * (size_t)i + k] = old_m[k] + gm[k];
-      if (!COV) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) g_scales[3 * (size_t)i + k] = old_s[k] + gs[k];
-        reinterpret_cast<float4*>(g_rots)[i] = float4{old_q.x + gq[0], old_q.y + gq[1], old_q.z + gq[2], old_q.w + gq[3]};
-      }
-    } else {
-      g_means3d[3 * (size_t)i + 0] = gm[0]; g_means3d[3 * (size_t)i + 1] = gm[1]; g_means3d[3 * (size_t)i + 2] = gm[2];
-      if (!COV) {
-        g_scales[3 * (size_t)i + 0] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2];
-        reinterpret_cast<float4*>(g_rots)[i] = float4{gq[0], gq[1], gq[2], gq[3]};
-      }
+      for (int u = 0; u < 4; u++) w[u] = (i0 + u < N) ? pw[i0 + u] : 0.f;
     }
+    const int n_live = (w[0] > 0.f) + (w[1] > 0.f) + (w[2] > 0.f) + (w[3] > 0.f);
+    // position inside the chunk's list: wave prefix over the lanes' counts, one LDS atomic per wave
+    int inc = n_live;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d);
+      if ((tid & 63) >= d) inc += up;
+    }
+    uint32_t first = 0;
+    const int total = __shfl(inc, 63);
+    if ((tid & 63) == 63 && total) first = atomicAdd(&cnt, (uint32_t)total);
+    first = (uint32_t)__shfl((int)first, 63);
+    uint32_t pos = first + (uint32_t)(inc - n_live);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (w[u] > 0.f) live[pos++] = (uint32_t)(i0 + u);
+  }
+  __syncthreads();
+  const uint32_t n = cnt;
+  if (tid == 0) base_s = n ? atomicAdd(reinterpret_cast<uint32_t*>(rows + 3), n) : 0u;   // row 0, slot 12: the list's length
+  __syncthreads();
+  const uint32_t b = base_s;
+  for (uint32_t j = (uint32_t)tid; j < n; j += 1024u) *lr_pbwd_list_slot(rows, b + j) = live[j];
+}
+
+template <bool ACCUMULATE, bool SINKROWS>
+__global__ void __launch_bounds__(256)
+lr_pbwd_list_kernel(LrView v, int N, const float* __restrict__ means, const float* __restrict__ scales,
+                    const float* __restrict__ rots, float4* __restrict__ rows, float* __restrict__ o_mean2d,
+                    float* __restrict__ o_opac, float* __restrict__ o_col, float* __restrict__ g_means3d,
+                    float* __restrict__ g_scales, float* __restrict__ g_rots) {
+  const uint32_t n = min(reinterpret_cast<const uint32_t*>(rows + 3)[0], (uint32_t)N);
+  for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
+    const uint32_t i = *lr_pbwd_list_slot(rows, j);
+    if (i < (uint32_t)N)
+      lr_pbwd_live_row<ACCUMULATE, false, true, SINKROWS>(v, (int)i, means, scales, rots, nullptr, nullptr, rows, o_mean2d,
+                                                          o_opac, o_col, g_means3d, g_scales, g_rots);
   }
 }
 
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);   // project.hip
+void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);   // project.hip
 // rows != NULL: the 64-byte accumulator rows of lograst_backward (+ its three separate outputs); NULL: g_mean2d / g_conic
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
@@ -317,6 +404,23 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
   LR_KNOB(separate_min_n, "LOGRAST_HELPER_MIN_N", 4000000);
   const int clear_inside = (rows && (accumulate || sink_rows) && N >= separate_min_n) ? 0 : 1;
   if (!clear_inside) lr_launch_zero_floats(o_mean2d, 3 * (size_t)N, s);
+  // Large inputs, running sums, the forward's point_weight at hand, no cov3d_precomp: the live rows through a compact list
+  // (see lr_pbwd_compact_kernel).  LOGRAST_PBWD_LIST=0: the one-kernel form.
+  LR_KNOB(list_knob, "LOGRAST_PBWD_LIST", 1);
+  if (list_knob && !clear_inside && pw && !v.cov3d && N >= 8) {
+    float4* rows_w = const_cast<float4*>(rows4);   // (the accumulator rows are the caller's scratch: slots 12-15 are this path's)
+    lr_launch_zero_words(reinterpret_cast<uint32_t*>(rows_w + 3), 4, s);
+    hipLaunchKernelGGL(lr_pbwd_compact_kernel, dim3((N + LR_PBWD_CHUNK - 1) / LR_PBWD_CHUNK), dim3(1024), 0, s, pw, N, rows_w);
+    const dim3 lgrid(2048);
+    if (sink_rows)
+      hipLaunchKernelGGL((lr_pbwd_list_kernel<true, true>), lgrid, block, 0, s, v, N, means, scales, rots, rows_w, o_mean2d,
+                         o_opac, o_col, g_means3d, g_scales, g_rots);
+    else
+      hipLaunchKernelGGL((lr_pbwd_list_kernel<true, false>), lgrid, block, 0, s, v, N, means, scales, rots, rows_w, o_mean2d,
+                         o_opac, o_col, g_means3d, g_scales, g_rots);
+    lr_prof_end(LRK_PROJECT_BWD, s);
+    return;
+  }
   if (sink_rows) {   // (lograst_backward checked: rows != NULL, no cov3d)
     const bool band = v.ty0 > 0 || v.ty1 < v.gy;
     if (pw && band)

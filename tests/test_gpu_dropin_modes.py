@@ -274,6 +274,51 @@ def test_walk_form_can_be_pinned_by_the_host():
         GaussianRasterizer(raster_settings=st(), walk_form="columns")
 
 
+@pytest.mark.parametrize("n", [20000, 20003])
+def test_chain_rule_over_the_live_list_equals_the_one_kernel_form(n):
+    """Round 5: on large inputs with running-sum gradients the chain rule runs over a compact list of the rows with
+    point_weight > 0 (lr_pbwd_compact_kernel + lr_pbwd_list_kernel; the list lives in slots 12-15 of the accumulator rows)
+    instead of one kernel that tests every row.  Same per-row code: the running sums of three views -- row-major and
+    attribute-major -- are BIT-identical in both forms (LOGRAST_PBWD_LIST 0 / 1; LOGRAST_HELPER_MIN_N = 0 makes this
+    input "large"), and dL/dmeans2D of every view too."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    from log_amd import rasterizer as R, scenes, tune
+    from log_amd.dist import GradientBucket
+    import gpu_util as G
+    dev = torch.device(DEV)
+    cams = scenes.orbit_cameras(3, W=160, H=112, focal=170.0)
+    sc = scenes.random_scene(n, seed=13, opacity=None, smax=0.05)
+    sc["xyz"][: n // 3] += 50.0                                  # a third of the rows off screen: dead rows in every chunk
+    w = torch.tensor(np.random.default_rng(4).random((3, 112, 160), dtype=np.float32), device=dev)
+
+    def run(row_major, use_list):
+        tune.reset_knobs()
+        tune.set_knob("LOGRAST_HELPER_MIN_N", 0)
+        tune.set_knob("LOGRAST_PBWD_LIST", use_list)
+        try:
+            leaves = _leaves(sc, dev)
+            bucket = GradientBucket(n, dev, row_major=row_major)
+            m2s = []
+            with R.accumulate_grads_into(bucket.sink()):
+                for cam in cams:
+                    rast = GaussianRasterizer(raster_settings=G.settings(cam, (1, 1, 1), dev))
+                    ret, m2 = _call(rast, leaves, n, dev)
+                    (ret[0] * w).sum().backward()
+                    m2s.append(m2.grad.clone())
+            torch.cuda.synchronize()
+            return bucket.flat.clone(), m2s, float((ret[4] > 0).float().mean())
+        finally:
+            tune.reset_knobs()
+
+    for row_major in (True, False):
+        one, m2_one, live = run(row_major, 0)
+        lst, m2_lst, _ = run(row_major, 1)
+        assert 0.05 < live < 0.95 and float(one.abs().sum()) > 0
+        assert torch.equal(one, lst), row_major
+        for a, b in zip(m2_one, m2_lst):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("n", [5000, 5003])
 def test_row_major_gradient_sink_equals_the_planar_one(n):
     """LOGRAST_BWD_ACCUMULATE_ROWS: three views accumulated into ONE 64-byte row of running sums per Gaussian

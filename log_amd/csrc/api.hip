@@ -100,7 +100,7 @@ int lr_env_int(const char* name, int dflt) {
 struct LrKnobInfo { const char* name; int dflt, lo, hi; const char* what; };
 static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_HELPER_MIN_N", 4000000, 0, 2000000000, "Gaussians from which the helper passes (absolute slot table, touched-only dL/dconic clearing, separate zero-fill kernels) pay for their launches"},
-    {"LOGRAST_PBWD_LIST", 1, 0, 1, "large inputs with running-sum gradients: the chain rule runs over a compact list of the rows with point_weight > 0 (a streaming compaction pass + a list pass) instead of one kernel that tests every row"},
+    {"LOGRAST_PBWD_LIST", 1, 0, 2, "large inputs with running-sum gradients: the chain rule runs over a compact list of the rows with point_weight > 0 (a streaming compaction pass + a list pass) instead of one kernel that tests every row: 0 never, 1 on band views, 2 always"},
     {"LOGRAST_MID_RANK", 1, 0, 1, "rects of 5..16 tiles are RANKED by the batched projection (LDS atomics; 32-byte rank rows in geom), so the fill places them without cursor atomics or support tests; 0 = counted only, placed through the per-tile cursors"},
     {"LOGRAST_MID_COOP", 16, 0, 64, "rects of 5..16 tiles are counted (projection: in waves that hold at most this many of them) and placed (fill: any non-zero value) by the whole wave, four rects per pass, instead of by their lane; 0 = per lane"},
     {"LOGRAST_DEFER_TILES", LR_COOP_TILES, 4, 4096, "rects above this many tiles are counted by lr_count_huge_kernel (one wave per rect) instead of by their lane"},

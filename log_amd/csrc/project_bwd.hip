@@ -405,9 +405,14 @@ void lr_launch_project_bwd(const LrView& v, int N, const float* means, const flo
   const int clear_inside = (rows && (accumulate || sink_rows) && N >= separate_min_n) ? 0 : 1;
   if (!clear_inside) lr_launch_zero_floats(o_mean2d, 3 * (size_t)N, s);
   // Large inputs, running sums, the forward's point_weight at hand, no cov3d_precomp: the live rows through a compact list
-  // (see lr_pbwd_compact_kernel).  LOGRAST_PBWD_LIST=0: the one-kernel form.
+  // (see lr_pbwd_compact_kernel) -- on BAND views, where a per cent of the rows is live and the one-kernel form is nearly
+  // all flag pass (100 M rows, band 3 of 8: 929 -> 490 us).  On full views the chain rule is bound by its scattered lines
+  // either way (~7 lines per live row at ~50 G lines/s): measured at 30 M rows, list / one kernel: 7 % live 419 / 469 us,
+  // 7.5 % (trained-like) 451 / 481, 14 % (opacity = rand) 690 / 610 -- not worth a second form there.
+  // LOGRAST_PBWD_LIST: 0 never, 1 band views (default), 2 always.
   LR_KNOB(list_knob, "LOGRAST_PBWD_LIST", 1);
-  if (list_knob && !clear_inside && pw && !v.cov3d && N >= 8) {
+  const bool band_view = v.ty0 > 0 || v.ty1 < v.gy;
+  if ((list_knob == 2 || (list_knob == 1 && band_view)) && !clear_inside && pw && !v.cov3d && N >= 8) {
     float4* rows_w = const_cast<float4*>(rows4);   // (the accumulator rows are the caller's scratch: slots 12-15 are this path's)
     lr_launch_zero_words(reinterpret_cast<uint32_t*>(rows_w + 3), 4, s);
     hipLaunchKernelGGL(lr_pbwd_compact_kernel, dim3((N + LR_PBWD_CHUNK - 1) / LR_PBWD_CHUNK), dim3(1024), 0, s, pw, N, rows_w);

@@ -31,8 +31,10 @@ extern "C" {
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
 /* The reverse walk's accumulators: ONE 64-byte row per Gaussian -- slots 0-1 dL/d(ndc mean x, y), 2-4 dL/d(conic A, B, C),
- * 5 dL/dopacity, 6-8 dL/dcolour r g b, 9-15 unused.  A memory-side atomic costs one operation per 64-byte line whatever the
- * number of lanes in it (tools/micro/atomic_lines.hip), so a (wave, Gaussian) visit commits all nine sums as one. */
+ * 5 dL/dopacity, 6-8 dL/dcolour r g b, 9-11 unused, 12-15 scratch of the chain rule (band views keep the compact list of
+ * the live rows there: row 0 its length, rows 1.. four indices each; whatever the caller finds in bwd_rows after
+ * lograst_backward is unspecified).  A memory-side atomic costs one operation per 64-byte line whatever the number of lanes
+ * in it (tools/micro/atomic_lines.hip), so a (wave, Gaussian) visit commits all nine sums as one. */
 #define LOGRAST_BWD_ROW_FLOATS 16
 
 /* 2-D low-pass flavours */

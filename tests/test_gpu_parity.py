@@ -44,6 +44,12 @@ def _case(name):
         cam, sc = small_case(n=400000, W=160, H=112, focal=150.0, seed=13, smax=0.003)
         sc["xyz"][:300000] = sc["xyz"][:300000] * 0.004 + np.array([0.0, 0.12, -0.07], np.float32)
         return cam, sc
+    if name == "mid_rects":   # nearly every Gaussian holds a rect of 5..16 tiles: ranked by the projection (rank rows for one
+        # in four Gaussians of a batch: the rest of every batch overflows to the cursors), expanded by the wave in the fill
+        cam, sc = small_case(n=30000, W=640, H=400, focal=500.0, radius=3.0, seed=21, smax=0.02)
+        rng = np.random.default_rng(22)
+        sc["scaling"] = (0.025 + 0.02 * rng.random((30000, 3))).astype(np.float32)
+        return cam, sc
     if name.startswith("flat_depth_"):
         # all Gaussians at (almost) the same view depth, n of them inside one or two tiles: the depth-bucket sorts overflow
         # their buckets and every size class must fall back to the network (LDS class, long LDS class, hybrid)
@@ -59,7 +65,7 @@ def _case(name):
     raise KeyError(name)
 
 
-CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "dense_tile", "huge_tiles", "giant_tile", "flat_depth_3000",
+CASES = ["tiny", "ragged", "opaque", "c1", "big_splats", "mid_rects", "dense_tile", "huge_tiles", "giant_tile", "flat_depth_3000",
          "flat_depth_6000", "flat_depth_14000"]
 
 
@@ -82,7 +88,7 @@ def test_forward_bit_exact(oracle_mod, name, flavour_name):
         assert st["pid_mismatch"] == 0 and st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0, st
 
 
-@pytest.mark.parametrize("name", ["ragged", "c1", "big_splats", "huge_tiles"])
+@pytest.mark.parametrize("name", ["ragged", "c1", "big_splats", "mid_rects", "huge_tiles"])
 def test_exact_reference_lists_without_tile_cull(oracle_mod, name):
     """With the binning-stage support cull off, the tile lists ARE the reference's rect lists: offsets, order and
     n_contrib identical to the oracle's.  With it on (default) they are a result-preserving subset -- checked by

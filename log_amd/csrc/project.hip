@@ -943,8 +943,10 @@ lr_project_band_kernel(LrView v, int N, const float* __restrict__ means, const f
 
 // Rects of more than `defer_tiles` tiles, left out by lr_project_batched_kernel: one wave per rect, lanes = tiles, so
 // the support tests of a rect run 64 at a time and the LDS atomics never collide; counts go through per-workgroup
-// LDS counters (one memory-side atomic per touched tile and workgroup).  A workgroup owns `chunk` Gaussians and
-// returns at once when its batches left nothing (the common case: small splats only).
+// LDS counters (one memory-side atomic per touched tile and workgroup).  A workgroup walks chunks of `chunk` Gaussians and
+// skips those whose bit of the batch's 128-bit mask is clear (hugemask: one bit per 256 Gaussians; the common case --
+// small splats only -- returns after one read of the header flag); a chunk with a handful of deferred rects counts them
+// straight into the global counters.
 #define LR_HUGE_DIRECT 8   // deferred rects per 256-Gaussian chunk up to which they are counted without the LDS plane
 __global__ void __launch_bounds__(256)
 lr_count_huge_kernel(int N, int gx, int tiles, const float4* __restrict__ geom, uint32_t* __restrict__ big,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LOGRAST_VERSION 3   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows); lograst_view gained walk_form.  Added since without a version change (new entry points only): lograst_sparse_segment_floats / lograst_pack_rows / lograst_unpack_rows */
+#define LOGRAST_VERSION 3   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows); lograst_view gained walk_form.  Added since without a version change (new entry points only): lograst_sparse_segment_floats / lograst_pack_rows / lograst_unpack_rows / lograst_ordered_lengths / lograst_finish_lists */
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
 /* The reverse walk's accumulators: ONE 64-byte row per Gaussian -- slots 0-1 dL/d(ndc mean x, y), 2-4 dL/d(conic A, B, C),
@@ -333,6 +333,20 @@ int lograst_sh_backward(int32_t n, int32_t degree, int32_t max_coeffs, const flo
 /* ---- debugging / test access to intermediates --------------------------------------------------
  * Pointers into a tile_state block (device): offsets has tiles+1 entries. */
 const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height);
+/* Lazily ordered tile lists (knob LOGRAST_LAZY_SORT, default on).  The third-party package sorts every (tile, depth) key
+ * of a view (one global radix sort) before it composites; this library orders, of a list of more than 4096 keys, only
+ * the first window (7680 positions, cut at a depth-bucket boundary) before the compositing pass, lets that pass mark the
+ * tiles in which a pixel was still open at the end of the ordered part, and then orders the rest of exactly those lists
+ * and composites their tiles again.  Images, fork maps, n_contrib, point_weight and every gradient are the same bit for
+ * bit either way (tests/test_gpu_knobs.py); what differs is point_list behind the ordered part of a list nobody walked:
+ * those entries are unspecified until lograst_finish_lists has run.
+ *   lograst_ordered_lengths: lengths_out[t] (device, tiles entries) = leading positions of tile t's list that are in
+ *     final order (the whole list for lists of up to 4096 keys, and for every list when the knob is 0);
+ *   lograst_finish_lists: orders every list to its end (same tile_state / keys / point_list / capacity as the forward
+ *     call, before any other forward reuses the keys buffer).  The lists are then what LOGRAST_LAZY_SORT=0 produces. */
+int lograst_ordered_lengths(const void* tile_state, int32_t width, int32_t height, uint32_t* lengths_out, void* stream);
+int lograst_finish_lists(void* tile_state, int32_t width, int32_t height, void* keys, uint32_t* point_list,
+                         uint32_t capacity, void* stream);
 
 /* ---- "next" row N3: level-of-detail selection ------------------------------------------------------------
  * Replaces TensorTree.traverse + TensorTree._query_tree_torch (/root/reference/LoG/model/tensor_tree.py:131-185;

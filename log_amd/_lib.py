@@ -51,6 +51,8 @@ _SIGNATURES = {
     "lograst_keys_bytes": (c_size_t, [c_uint32]),
     "lograst_list_bytes": (c_size_t, [c_uint32]),
     "lograst_tile_offsets": (c_void_p, [c_void_p, c_int32, c_int32]),
+    "lograst_ordered_lengths": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "lograst_finish_lists": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_uint32, c_void_p]),
     "lograst_compute_radius": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                               c_float, c_float, c_float, c_void_p, c_void_p]),
     "lograst_forward_project": (ctypes.c_int, [ctypes.POINTER(LograstView), c_int32, c_void_p, c_void_p, c_void_p,

@@ -39,10 +39,13 @@ void lr_launch_tile_rows(const LrView& v, int N, const float* means, const float
                          uint32_t* rows, hipStream_t s);
 void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s);
 void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
-                    uint32_t max_len, hipStream_t s);
+                    uint32_t max_len, int lazy, hipStream_t s);
+void lr_launch_sort_rest(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
+                         uint32_t max_len, int mode, hipStream_t s);
+void lr_launch_ordered_lengths(const uint32_t* state, uint32_t tiles, uint32_t* out, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, hipStream_t s);
+                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, int lazy, hipStream_t s);
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
                          const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s);
@@ -100,6 +103,7 @@ int lr_env_int(const char* name, int dflt) {
 struct LrKnobInfo { const char* name; int dflt, lo, hi; const char* what; };
 static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_HELPER_MIN_N", 4000000, 0, 2000000000, "Gaussians from which the helper passes (absolute slot table, touched-only dL/dconic clearing, separate zero-fill kernels) pay for their launches"},
+    {"LOGRAST_LAZY_SORT", 1, 0, 1, "lists of more than 4096 keys are ordered over their first window (7680 positions) only; tiles whose walk needs more are marked by the compositing kernels and finished by a second, normally idle sort + compositing pair; 0 = every list to its end up front"},
     {"LOGRAST_PBWD_LIST", 1, 0, 2, "large inputs with running-sum gradients: the chain rule runs over a compact list of the rows with point_weight > 0 (a streaming compaction pass + a list pass) instead of one kernel that tests every row: 0 never, 1 on band views, 2 always"},
     {"LOGRAST_MID_RANK", 1, 0, 1, "rects of 5..16 tiles are RANKED by the batched projection (LDS atomics; 32-byte rank rows in geom), so the fill places them without cursor atomics or support tests; 0 = counted only, placed through the per-tile cursors"},
     {"LOGRAST_MID_COOP", 16, 0, 64, "rects of 5..16 tiles are counted (projection: in waves that hold at most this many of them) and placed (fill: any non-zero value) by the whole wave, four rects per pass, instead of by their lane; 0 = per lane"},
@@ -205,7 +209,7 @@ static int lr_tile_cull() {
 static const char* kKernelNames[LOGRAST_NUM_KERNELS] = {
     "compute_radius", "project", "scan_tiles", "fill_keys", "sort_small", "sort_large", "sort_huge",
     "blend_fwd", "blend_bwd", "project_bwd", "knn3", "lod_traverse", "counter_update", "sparse_adam",
-    "id_histogram", "gather_activate", "activate_bwd", "count_huge", "rebase_slots", "reserved"};
+    "id_histogram", "gather_activate", "activate_bwd", "count_huge", "rebase_slots", "lazy_tail"};
 struct ProfRec { int slot; hipEvent_t a, b; bool own_a; };
 // Consecutive launches inside one entry point share an event: the end of kernel k is the begin of kernel k+1 (N+1
 // events for a chain of N kernels instead of 2N; every recorded event costs ~1.4 us of stream time).
@@ -316,6 +320,31 @@ const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int3
   return reinterpret_cast<const uint32_t*>(tile_state) + lr_offsets_off(gx * gy);
 }
 
+// Lazily ordered lists (LOGRAST_LAZY_SORT; common.hpp: sorted[]): how much of every tile's list is in final order, and
+// the call that orders the rest -- for callers that want the complete lists (the parity tests do).
+int lograst_ordered_lengths(const void* tile_state, int32_t width, int32_t height, uint32_t* lengths_out, void* stream) {
+  g_prof_call++;
+  if (!tile_state || !lengths_out) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (width <= 0 || height <= 0) return lr_fail(LOGRAST_ERR_ARG, "bad image size");
+  const uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  lr_launch_ordered_lengths(reinterpret_cast<const uint32_t*>(tile_state), gx * gy, lengths_out, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+int lograst_finish_lists(void* tile_state, int32_t width, int32_t height, void* keys, uint32_t* point_list,
+                         uint32_t capacity, void* stream) {
+  g_prof_call++;
+  if (!tile_state) return lr_fail(LOGRAST_ERR_ARG, "tile_state is NULL");
+  if (width <= 0 || height <= 0) return lr_fail(LOGRAST_ERR_ARG, "bad image size");
+  if (capacity == 0) return LOGRAST_OK;
+  if (!keys || !point_list) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  const uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  lr_launch_sort_rest(reinterpret_cast<uint32_t*>(tile_state), gx * gy, reinterpret_cast<uint64_t*>(keys), point_list,
+                      capacity, 0, 3, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+
 int lograst_compute_radius(int32_t p, const float* means3d, const float* scales, const float* rotations,
                            const float* projmatrix, const float* viewmatrix, float focal_x, float focal_y,
                            float tanfovx, float tanfovy, float* radii_out, void* stream) {
@@ -352,6 +381,13 @@ static int lr_stage1(const LrView& v, int32_t n, const float* means3d, const flo
   return LOGRAST_OK;
 }
 
+// (a list is streamed -- and may be left at its first window -- only above LR_LONG_LIST keys: with a smaller bound on the
+// longest list known to the host the lazy machinery is not launched at all)
+static inline bool max_tile_len_allows_streaming(uint32_t max_tile_len, uint32_t capacity) {
+  const uint32_t m = (max_tile_len == 0 || max_tile_len > capacity) ? capacity : max_tile_len;
+  return m > LR_LONG_LIST;
+}
+
 // stage 2 launches: bucket fill (+ zero-fills), per-tile sort, compositing
 static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st, uint64_t* keys, uint32_t* point_list,
                      uint32_t capacity, uint32_t max_tile_len, float* image, float* final_t, int32_t* n_contrib,
@@ -385,9 +421,23 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
                  (lr_big_input(n) && staged_k == 0) ? 1 : 0, speculative, lr_band_sparse(v, (int)fill_batch) ? 1 : 0, staged_k, s);
   static const int stop_after_fill = LR_EXPERIMENT_INT("LOGRAST_STOP_AFTER_FILL", 0);   // experiment builds (tools/fill_probe.py)
   if (stop_after_fill) return LOGRAST_OK;
-  lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, s);
+  // LOGRAST_LAZY_SORT (default 1): lists of more than 4096 keys are ordered over their first window only (7680 positions;
+  // the walk of a view ends far in front of that: common.hpp, sorted[]); the compositing kernels mark the tiles that needed
+  // more, and the second pair of launches -- idle in every benched view -- finishes exactly those.  0: every list to its
+  // end before the first compositing pass (what lograst_finish_lists produces afterwards).
+  LR_KNOB(lazy_knob, "LOGRAST_LAZY_SORT", 1);
+  const int lazy = (lazy_knob && max_tile_len_allows_streaming(max_tile_len, capacity)) ? 1 : 0;
+  lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, lazy, s);
+  float* const zrows = touched_only ? bwd_scratch : nullptr;
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
-                      point_weight_pixel, point_weight, touched_only ? bwd_scratch : nullptr, lr_big_input(n) ? 1 : 0, s);
+                      point_weight_pixel, point_weight, zrows, lr_big_input(n) ? 1 : 0, lazy, s);
+  if (lazy) {
+    lr_prof_begin(LRK_LAZY_TAIL, s);
+    lr_launch_sort_rest(st, tiles, keys, point_list, capacity, max_tile_len, 2, s);
+    lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
+                        point_weight_pixel, point_weight, zrows, lr_big_input(n) ? 1 : 0, 2, s);
+    lr_prof_end(LRK_LAZY_TAIL, s);
+  }
   return LOGRAST_OK;
 }
 

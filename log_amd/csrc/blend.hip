@@ -116,18 +116,37 @@ LR_DEV bool lr_support_hits(const float4 g0, const float2 g1, float x0, float x1
   return !(best > tau);
 }
 
+// Lazily ordered lists (common.hpp: sorted[]; sort.hip).  lazy = 1: the first compositing pass -- a streamed list is walked
+// over its ordered prefix only (`end` comes back clamped); a wave that gets there with a pixel still open raises
+// LR_SORTED_OPEN on the tile, whose outputs of this pass are then provisional.  lazy = 2: the second pass, after
+// lr_launch_sort_rest ordered those lists to their end -- only their tiles run (false = nothing to do for this one), from
+// the start of the list: whatever the first pass stored for them is overwritten (per-pixel outputs) or stored again with
+// the same value (point_weight's atomicMax over a superset of the first pass's visits, zeros into accumulator rows).
+LR_DEV bool lr_lazy_range(const uint32_t* sorted, int lazy, uint32_t tile, uint32_t beg, uint32_t& end, bool& clamped) {
+  if (!lazy) return true;
+  if (end - beg <= LR_LONG_LIST) return lazy == 1;
+  const uint32_t w = sorted[tile];
+  if (lazy == 2 && !(w & LR_SORTED_OPEN)) return false;
+  const uint32_t ordered = w & ~LR_SORTED_OPEN;
+  if (ordered < end - beg) { end = beg + ordered; clamped = true; }
+  return true;
+}
+
 template <bool EXTRAS>
 __global__ void __launch_bounds__(256) LR_OCC_FWD
 lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
-                    float4* __restrict__ zero_conic, int xcd_mode, int cull) {
+                    float4* __restrict__ zero_conic, int xcd_mode, int cull, uint32_t* __restrict__ sorted, int lazy) {
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
-  const uint32_t beg = offsets[tile], end = offsets[tile + 1];
+  const uint32_t beg = offsets[tile];
+  uint32_t end = offsets[tile + 1];
+  bool clamped = false;
+  if (!lr_lazy_range(sorted, lazy, tile, beg, end, clamped)) return;
   const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
@@ -244,6 +263,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       if (!(hit0 | hit1) && __all(done)) break;
     }
   }
+  if (clamped && !__all(done) && lane == 0) atomicOr(sorted + tile, LR_SORTED_OPEN);   // out of ordered entries: see lr_lazy_range
 
   if (inside) {
     const size_t plane = (size_t)v.W * v.H;
@@ -689,13 +709,17 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                          int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
-                         float4* __restrict__ zero_rows, int xcd_mode, int cull LR_ABLATE_PARAM) {
+                         float4* __restrict__ zero_rows, int xcd_mode, int cull, uint32_t* __restrict__ sorted,
+                         int lazy LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
-  const uint32_t beg = offsets[tile], end = offsets[tile + 1];
+  const uint32_t beg = offsets[tile];
+  uint32_t end = offsets[tile + 1];
+  bool clamped = false;
+  if (!lr_lazy_range(sorted, lazy, tile, beg, end, clamped)) return;
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
   const int row = lane >> 4, li = lane & 15;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
@@ -820,6 +844,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       }
     }
   }
+  if (clamped && !__all(done) && lane == 0) atomicOr(sorted + tile, LR_SORTED_OPEN);   // out of ordered entries: see lr_lazy_range
 
   if (inside) {
     const size_t plane = (size_t)v.W * v.H;
@@ -835,8 +860,10 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
 
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, hipStream_t s) {
-  LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
+                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, int lazy, hipStream_t s) {
+  uint32_t* const sorted = lazy ? const_cast<uint32_t*>(state) + lr_sorted_off(tiles) : nullptr;   // (the one word of the tile state a compositing kernel writes)
+  LR_KNOB(xcd_knob, "LOGRAST_XCD_MODE", 3);
+  int xcd_mode = xcd_knob;
   static const int cull = LR_EXPERIMENT_INT("LOGRAST_CULL", 1);   // experiment builds: 0 = no per-quadrant support test
   static const size_t lds_fwd = (size_t)LR_EXPERIMENT_INT("LOGRAST_BLEND_FWD_LDS_KB", 0) * 1024;   // experiment builds: occupancy cap
   // LOGRAST_FWD_ROWS: 1 = row-split form (lr_blend_fwd_rows_kernel), 0 = one quadrant per wave, 2 (default) = the caller's
@@ -849,25 +876,29 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   const int rows = rows_knob != 2 ? rows_knob
                    : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : (v.walk_form == LOGRAST_FORM_QUADRANT ? 0 : 0));   // no hint: quadrant
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
+  if (lazy == 2) {   // only streamed lists can be open: in the scan's longest-first order they sit in front of every shorter one
+    xcd_mode = 3;
+    grid = min(tiles, capacity / (uint32_t)LR_LONG_LIST + 1u);
+  }
   const float4* g4 = reinterpret_cast<const float4*>(geom);
   float4* z4 = reinterpret_cast<float4*>(zero_conic);
-  lr_prof_begin(LRK_BLEND_FWD, s);
+  if (lazy != 2) lr_prof_begin(LRK_BLEND_FWD, s);           // (the second pass is timed by its caller, with the sort of the tails)
   if (rows) {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy LR_ABLATE_PASS(fwd_ablate));
     else
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy LR_ABLATE_PASS(fwd_ablate));
   } else {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy);
     else
       hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy);
   }
-  lr_prof_end(LRK_BLEND_FWD, s);
+  if (lazy != 2) lr_prof_end(LRK_BLEND_FWD, s);
 }
 
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,

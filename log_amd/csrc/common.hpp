@@ -43,6 +43,7 @@
 #define LR_HDR_SPARSE 3  // band view (lr_project_band_kernel): only Gaussians with a rect have a record; their fill records are compacted per projection workgroup:
 #define LR_HDR_SPAN 8    // workgroup w owns fill-record slots [w * span, w * span + survcount[w]), the Gaussians' indices behind the fill records
 #define LR_HDR_HUGE 7  // batched projection: some workgroup deferred a rect to lr_count_huge_kernel (else that kernel returns at once)
+#define LR_HDR_LAZY 9  // the per-tile sort ordered only the first window of the streamed lists (sorted[] below is valid)
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_LONG_LIST 4096   // longer lists are sorted with their keys streamed from memory (shorter ones: LDS-resident)
 #define LR_REC_QUADS 4  // float4 per projected record (64 B)
@@ -53,6 +54,16 @@ __host__ __device__ inline uint32_t lr_big_off(uint32_t tiles) { return lr_ranke
 __host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { return lr_big_off(tiles) + tiles * LR_CTR_STRIDE; }
 __host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_offsets_off(tiles) + lr_tpad(tiles); }
 __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
+// sorted[T]: once the fill is done its cursors are dead, and the first T words of their array say how much of each STREAMED
+// list (more than LR_LONG_LIST keys) is in final order: its first `sorted[t] & ~LR_SORTED_OPEN` positions.  The walk of a
+// view almost never leaves a long list's first window (30 M Gaussians @1080p: 2116 lists of 19.6 K keys each, the deepest
+// pixel of any of them stops after 1.4 K entries, 2.8 K with random opacities: tools/walk_depth_probe.py), so the sort
+// orders that window only (sort.hip, lazy = 1); a compositing wave that runs out of ordered entries with a pixel still
+// open raises LR_SORTED_OPEN, and a second, normally idle pair of launches orders the rest of exactly those lists and
+// composites their tiles again from the start (every store of the compositing kernels is idempotent: per-pixel outputs,
+// atomicMax on point_weight, zeros into accumulator rows).
+__host__ __device__ inline uint32_t lr_sorted_off(uint32_t tiles) { return lr_cursor_off(tiles); }
+#define LR_SORTED_OPEN 0x80000000u
 // then basetab[batches][T]: start of every projection batch's reservation inside each tile's ranked range
 __host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
 // then hugemask[batches][LR_HUGE_WORDS]: which 256-Gaussian chunks of the batch hold a Gaussian that left its (more than
@@ -520,7 +531,7 @@ struct ActBwdArgs {
 enum LrKernelSlot {
   LRK_RADIUS = 0, LRK_PROJECT, LRK_SCAN, LRK_FILL, LRK_SORT_SMALL, LRK_SORT_LARGE, LRK_SORT_HUGE,
   LRK_BLEND_FWD, LRK_BLEND_BWD, LRK_PROJECT_BWD, LRK_MISC, LRK_LOD, LRK_COUNTER, LRK_ADAM, LRK_HIST, LRK_GATHER, LRK_GATHER_BWD, LRK_RESERVED,
-  LRK_REBASE, LRK_SPARE
+  LRK_REBASE, LRK_LAZY_TAIL   // LRK_LAZY_TAIL: the second sort + compositing pair of lazily ordered lists (normally idle)
 };
 // ---- experiment switches ---------------------------------------------------------------------------------------
 // Timing ablations (kernels that SKIP part of their work) and alternative algorithms kept for A/B measurements exist only

@@ -458,7 +458,7 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap) {
 __global__ void __launch_bounds__(1024, 8)   // two workgroups per CU: 64 VGPRs (at 77 the kernel ran one per CU: 0.62 -> 0.86 ms at 30 M)
 lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
                     uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity, int equalize,
-                    int network_only) {
+                    int network_only, int lazy) {
   constexpr uint32_t LR_LONG_WIN = LR_LONG_WIN_BYTES / sizeof(uint64_t);
   extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
   uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
@@ -470,6 +470,19 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg, tid = threadIdx.x;
   if (L <= 1024u) return;                                   // lr_sort_small_kernel's
+  // lazy (streamed lists only; common.hpp: sorted[]): 0 = every list to its end; 1 = the first window, the ordered length
+  // goes to sorted[tile]; 2 = the lists whose compositing ran out of ordered entries (LR_SORTED_OPEN), to their end;
+  // 3 = every list that is not ordered to its end (lograst_finish_lists).  2 and 3 redo the list from its keys (the
+  // bucket path never moves them): the same values land on the positions that were ordered already.
+  uint32_t* const sorted = state + lr_sorted_off(tiles) + tile;
+  uint32_t keep = 0u;
+  if (lazy >= 2) {
+    if (L <= LR_LONG_LIST || !state[LR_HDR_LAZY]) return;
+    const uint32_t w = *sorted;
+    if (lazy == 2 ? !(w & LR_SORTED_OPEN) : (w & ~LR_SORTED_OPEN) >= L) return;
+    keep = w & LR_SORTED_OPEN;
+    __syncthreads();                                        // (everybody has read the word that thread 0 rewrites at the end)
+  }
   const uint64_t* k = keys + beg;
   uint16_t* rk = reinterpret_cast<uint16_t*>(ranks) + beg;   // one 16-bit bucket id per key (nb <= 4096)
   uint32_t* pl = plist + beg;
@@ -479,6 +492,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
     __syncthreads();
     lr_wg_hybrid_sort<1024>(keys + beg, L, reinterpret_cast<uint64_t*>(lcnt), tid);
     for (uint32_t i = tid; i < L; i += 1024u) pl[i] = (uint32_t)k[i];
+    if (lazy && tid == 0 && L > LR_LONG_LIST) *sorted = L | keep;
   };
   if (network_only) {                                       // (lists up to one block were sorted by lr_sort_rb_kernel)
     if (L > LR_SORT_BLOCK) network();
@@ -494,6 +508,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
 #define LR_TICK() do { } while (0)
 #endif
   LR_TICK();
+  if (lazy == 1 && tid == 0) state[LR_HDR_LAZY] = 1u;       // (every streamed list's workgroup stores the same word)
   uint32_t P2 = 8;
   while (P2 < L) P2 <<= 1;
   const uint32_t nb = min((uint32_t)LR_LONG_NB, P2 >> 1);
@@ -665,8 +680,13 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
     }
     __syncthreads();
     LR_TICK();
+    if (lazy == 1 && b1 < nb) {                              // the first window is what a view walks; the rest on demand
+      if (tid == 0) *sorted = lcnt[b1];                      // (bucket b1 is untouched: lcnt[b1] is still its first position)
+      return;
+    }
     b0 = b1;
   }
+  if (lazy && tid == 0) *sorted = L | keep;
 
 #if defined(LR_EXPERIMENTS) && defined(LR_LONG_TICKS)
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700 || blockIdx.x == 2000)) {
@@ -694,7 +714,7 @@ static_assert(sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_
 // max_len: upper bound on the longest tile list known to the HOST (exact count from stage 1, a hint in sync-free
 // operation, or 0 = unknown -> assume `capacity`).  It only decides how many multi-block levels are launched.
 void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
-                    uint32_t max_len, hipStream_t s) {
+                    uint32_t max_len, int lazy, hipStream_t s) {
   if (tiles == 0) return;
   static bool attr_set = false;
   if (!attr_set) {
@@ -737,7 +757,37 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
     lr_prof_begin(LRK_SORT_HUGE, s);
     hipLaunchKernelGGL(lr_sort_long_kernel, dim3(min(tiles, capacity / 1024u + 1u)), dim3(1024), lr_long_lds_bytes(), s,
                        state, tiles, keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize,
-                       bucket ? 0 : 1);
+                       bucket ? 0 : 1, (bucket && lazy) ? 1 : 0);
     lr_prof_end(LRK_SORT_HUGE, s);
   }
+}
+
+// out[t] = leading positions of tile t's list that are in final order (lograst_ordered_lengths)
+__global__ void __launch_bounds__(256)
+lr_ordered_lengths_kernel(const uint32_t* __restrict__ state, uint32_t tiles, uint32_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= tiles) return;
+  const uint32_t* offsets = state + lr_offsets_off(tiles);
+  const uint32_t L = offsets[t + 1] - offsets[t];
+  const bool lazy = state[LR_HDR_LAZY] != 0u && L > LR_LONG_LIST;
+  out[t] = lazy ? min(state[lr_sorted_off(tiles) + t] & ~LR_SORTED_OPEN, L) : L;
+}
+void lr_launch_ordered_lengths(const uint32_t* state, uint32_t tiles, uint32_t* out, hipStream_t s) {
+  if (tiles == 0) return;
+  hipLaunchKernelGGL(lr_ordered_lengths_kernel, dim3((tiles + 255u) / 256u), dim3(256), 0, s, state, tiles, out);
+}
+
+// The rest of the lists that lr_launch_sort(lazy = 1) left at their first window: mode 2 = those whose compositing asked for
+// it (LR_SORTED_OPEN), mode 3 = all of them (lograst_finish_lists).  Same grid as the first pass; a workgroup whose list
+// needs nothing returns after two loads.
+void lr_launch_sort_rest(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
+                         uint32_t max_len, int mode, hipStream_t s) {
+  if (tiles == 0) return;
+  if (max_len == 0 || max_len > capacity) max_len = capacity;
+  if (max_len <= LR_LONG_LIST) return;
+  static const int equalize = LR_EXPERIMENT_INT("LOGRAST_EQUALIZE", 1);
+  // (every tile in front of a streamed list in order[] holds at least LR_LONG_LIST keys itself: lr_scan_kernel's buckets)
+  hipLaunchKernelGGL(lr_sort_long_kernel, dim3(min(tiles, capacity / (uint32_t)LR_LONG_LIST + 1u)), dim3(1024),
+                     lr_long_lds_bytes(), s, state, tiles, keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity,
+                     equalize, 0, mode);
 }

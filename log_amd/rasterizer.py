@@ -80,6 +80,7 @@ _inplace_leaf_grads = False
 _INPLACE_TAG = "_lograst_inplace_grad"   # attribute set on leaves whose owner asked for the in-place route
 _status = {}          # device -> int32[8] status block (sticky across forwards, all streams)
 _debug_keep = False   # tests: keep dL/dconic of the last backward (HipBackend.last_conic_grad)
+_keep_keys = False    # tests: the forward's key buffer stays alive in `saved` (finish_lists below needs it)
 _DEBUG_ADDR = bool(int(__import__('os').environ.get('LOGRAST_DEBUG_ADDR', '0')))
 
 
@@ -489,11 +490,14 @@ class HipBackend:
             instances = capacity          # exact mode: the real count; sync-free: the caller's (tight) upper bound
         if _DEBUG_ADDR:
             print("fwd state@%x keys@%x capacity=%d stream=%x" % (k["state"].data_ptr(), keys.data_ptr(), capacity, stream.value or 0), flush=True)
+        kept_keys = (keys, capacity) if _keep_keys else None
         del keys, keep
         saved = dict(radii=o["radii"], geom=k["geom"].view(f32), state=k["state"].view(i32), plist=plist,
                      final_T=k["final_T"], n_contrib=k["n_contrib"], bwd_scratch=k.get("bwd_scratch"),
                      point_weight=o.get("pw"), tile_rows=(view.tile_row_begin, view.tile_row_end), instances=int(instances),
                      walk_form_pin=pin)
+        if kept_keys is not None:
+            saved["keys"], saved["capacity"] = kept_keys
         return o["image"], o["radii"], o.get("pid"), o.get("pwp"), o.get("pw"), saved
 
     def backward(self, rs, flavour, use_filter, means3D, scales, rotations, saved, grad_image, sink=None, cov3D=None):
@@ -1058,6 +1062,35 @@ class GaussianRasterizer(nn.Module):
 
 class UpstreamGaussianRasterizer(GaussianRasterizer):
     FLAVOUR = UPSTREAM
+
+
+def keep_keys(enabled):
+    """Test/debug switch: forwards keep their (depth, id) key buffer in `saved` (16 bytes per tile instance, otherwise
+    released when the forward returns) so that finish_lists can order the lists' tails.  Returns the previous setting."""
+    global _keep_keys
+    prev, _keep_keys = _keep_keys, bool(enabled)
+    return prev
+
+
+def ordered_lengths_of(saved, width, height):
+    """Test/debug accessor: per tile, how many leading positions of its list are in final order (lists of more than
+    4096 keys are ordered over their first window only unless a pixel needed more: include/lograst.h,
+    lograst_ordered_lengths)."""
+    tiles = ((int(width) + 15) // 16) * ((int(height) + 15) // 16)
+    st = saved["state"]
+    out = torch.empty(tiles, dtype=torch.int32, device=st.device)
+    with torch.cuda.device(st.device):
+        _lib.check(_lib.lib().lograst_ordered_lengths(_ptr(st), int(width), int(height), _ptr(out), _stream_ptr(st.device)))
+    return out
+
+
+def finish_lists(saved, width, height):
+    """Test/debug: orders every tile list of a forward made under keep_keys(True) to its end, in place
+    (lograst_finish_lists): saved["plist"] is then what LOGRAST_LAZY_SORT=0 would have produced."""
+    st = saved["state"]
+    with torch.cuda.device(st.device):
+        _lib.check(_lib.lib().lograst_finish_lists(_ptr(st), int(width), int(height), _ptr(saved["keys"]), _ptr(saved["plist"]),
+                                                  int(saved["capacity"]), _stream_ptr(st.device)))
 
 
 def tile_offsets_of(saved, width, height):

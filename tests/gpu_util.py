@@ -41,12 +41,21 @@ def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", 
     rs = settings(cam, bg, dev, scale_modifier)
     t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
     m, s, r, o, c = t(sc["xyz"]), t(sc["scaling"]), t(sc["rotation"]), t(sc["opacity"]).reshape(-1), t(sc["colors"])
-    image, radii, pid, pwp, pw, saved = R._backend.forward(rs, flavour, use_filter, m, s, r, o, c,
-                                                           scratch_floats=scratch_floats)
+    prev_keep = R.keep_keys(True)
+    try:
+        image, radii, pid, pwp, pw, saved = R._backend.forward(rs, flavour, use_filter, m, s, r, o, c,
+                                                               scratch_floats=scratch_floats)
+    finally:
+        R.keep_keys(prev_keep)
     torch.cuda.synchronize()
     W, H = cam["image_width"], cam["image_height"]
     offs = R.tile_offsets_of(saved, W, H).cpu().numpy().astype(np.uint32)
     I = int(offs[-1])
+    # Lazily ordered lists (include/lograst.h: lograst_ordered_lengths): the forward above ordered the lists of more than
+    # 4096 keys as far as its walk needed.  The comparisons below want the COMPLETE lists, so the tails are ordered now --
+    # after noting (a) that the part the forward called ordered does not change by that, (b) that no pixel's walk went past
+    # it; both counts go into compare_forward's list_mismatch.
+    lazy = _lazy_list_check(saved, offs, I, W, H)
     out = dict(image=image.cpu().numpy(), radii=radii.cpu().numpy(),
                rec=saved["geom"][:16 * len(radii)].cpu().numpy().reshape(-1, 16)[:, :12], tile_offsets=offs,
                point_list=saved["plist"].cpu().numpy().astype(np.uint32)[:I], I=I,
@@ -56,7 +65,29 @@ def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", 
                    point_weight=pw.cpu().numpy())
     out["_torch"] = (rs, flavour, use_filter, m, s, r, saved)
     out["fwd_form"] = R._backend.last_forms["fwd"]
+    out.update(lazy)
     return out
+
+
+def _lazy_list_check(saved, offs, I, W, H):
+    """-> dict(ordered_len[tiles], lazy_lists, lazy_prefix_mismatch, walk_beyond_ordered); finishes saved["plist"]."""
+    ordered = R.ordered_lengths_of(saved, W, H).cpu().numpy().astype(np.int64)
+    lens = np.diff(offs.astype(np.int64))[: len(ordered)]
+    before = saved["plist"][:I].cpu().numpy().astype(np.uint32)
+    R.finish_lists(saved, W, H)
+    torch.cuda.synchronize()
+    after = saved["plist"][:I].cpu().numpy().astype(np.uint32)
+    assert (R.ordered_lengths_of(saved, W, H).cpu().numpy().astype(np.int64) == lens).all()
+    partly = ordered < lens
+    mismatch = 0
+    for t in np.nonzero(partly | (lens > 4096))[0]:            # the streamed lists: ordered part before == after
+        b, n = int(offs[t]), int(ordered[t])
+        mismatch += int((before[b:b + n] != after[b:b + n]).sum())
+    gx = (W + 15) // 16
+    ys, xs = np.mgrid[0:H, 0:W]
+    nc = saved["n_contrib"].cpu().numpy().astype(np.int64)
+    beyond = int((nc > ordered[(ys // 16) * gx + xs // 16]).sum())
+    return dict(ordered_len=ordered, lazy_lists=int(partly.sum()), lazy_prefix_mismatch=mismatch, walk_beyond_ordered=beyond)
 
 
 def hip_backward(hf, dL):
@@ -158,6 +189,10 @@ def compare_forward(hf, of):
         st["culled_instances"] = 0
     else:
         st.update(_compare_culled_lists(hf, of))
+    st["lazy_lists"] = int(hf.get("lazy_lists", 0))
+    st["lazy_prefix_mismatch"] = int(hf.get("lazy_prefix_mismatch", 0))
+    st["walk_beyond_ordered"] = int(hf.get("walk_beyond_ordered", 0))
+    st["list_mismatch"] += st["lazy_prefix_mismatch"] + st["walk_beyond_ordered"]
     for k in ("image", "final_T"):
         st[k + "_bits_mismatch"] = int((hf[k].view(np.uint32) != of[k].view(np.uint32)).sum())
         st[k + "_max_abs"] = float(np.abs(hf[k] - of[k]).max())

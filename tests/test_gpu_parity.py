@@ -126,6 +126,88 @@ def test_exact_reference_lists_without_tile_cull(oracle_mod, name):
         assert rel_l2(g_on[k], g_off[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("kind", ["closed", "open"])
+@pytest.mark.parametrize("form", ["quadrant", "rows"])
+def test_lazily_ordered_lists_both_ways(oracle_mod, kind, form):
+    """Lists of more than 4096 keys are ordered over their first window (7680 positions) before the compositing pass and
+    to their end only where a pixel was still open there (include/lograst.h: lograst_ordered_lengths).  `closed`: screen-
+    filling opaque splats -- every pixel stops after a few entries, the tails stay unordered (and the image, maps and
+    gradients are the oracle's all the same).  `open`: the same lists with faint pinpoint splats -- no pixel ever stops, the
+    second sort + compositing pair must finish and redo every such tile.  Both compositing forms; with the knob off the
+    outputs are the same bits."""
+    from log_amd import tune
+    import gpu_util as G
+    rng = np.random.default_rng(31)
+    n = 11000
+    cam, sc = small_case(n=n, W=64, H=48, focal=70.0, seed=30, opacity=(0.999 if kind == "closed" else 0.05),
+                         smax=(0.6 if kind == "closed" else 0.004))
+    if kind == "closed":
+        sc["scaling"] = (0.3 + 0.3 * rng.random((n, 3))).astype(np.float32)     # every rect covers every tile
+    else:
+        sc["xyz"] = (sc["xyz"] * 0.06).astype(np.float32)                        # all of them inside the middle tiles
+    bg = (0.3, 0.6, 0.9)
+    _, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    hf = G.hip_forward(cam, sc, bg, fwd_form=form, scratch_floats=16)
+    lens = np.diff(hf["tile_offsets"].astype(np.int64))
+    long_lists = int((lens > 7680).sum())
+    assert long_lists > 0, lens.max()
+    if kind == "closed":
+        assert hf["lazy_lists"] == long_lists and (hf["ordered_len"][lens > 7680] <= 7680).all()
+    else:
+        assert hf["lazy_lists"] < long_lists                                     # somebody asked for the tails
+        assert (hf["n_contrib"].astype(np.int64).max() > 7680)                   # ... because the walk went there
+    st = G.compare_forward(hf, of)
+    for k in ("radii_mismatch", "rec_bits_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch",
+              "image_bits_mismatch", "final_T_bits_mismatch", "pid_mismatch"):
+        assert st[k] == 0, (k, st)
+    assert st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0, st
+    dL = np.random.default_rng(2).standard_normal(hf["image"].shape).astype(np.float32)
+    g = G.hip_backward(hf, dL)
+    tune.set_knob("LOGRAST_LAZY_SORT", 0)
+    try:
+        hf0 = G.hip_forward(cam, sc, bg, fwd_form=form, scratch_floats=16)
+        assert hf0["lazy_lists"] == 0
+        for k in ("image", "final_T", "point_weight_pixel", "point_weight"):
+            assert (hf0[k].view(np.uint32) == hf[k].view(np.uint32)).all(), k
+        for k in ("radii", "tile_offsets", "point_list", "n_contrib", "point_id_pixel"):
+            assert (hf0[k] == hf[k]).all(), k
+        g0 = G.hip_backward(hf0, dL)
+    finally:
+        tune.reset_knobs()
+    for k in ("means2D", "conic", "opacities", "colors"):
+        assert rel_l2(g[k], g0[k]) < 1e-5, k
+
+
+def test_backward_reads_only_the_ordered_part_of_a_lazily_ordered_list(oracle_mod):
+    """The reverse walk of a view whose lists were left at their first window (the product path: nobody calls
+    lograst_finish_lists there) against the oracle's gradients: through the autograd Function, whose forward keeps no keys
+    and finishes nothing."""
+    from diff_gaussian_rasterization_wodilate import GaussianRasterizer
+    import gpu_util as G
+    rng = np.random.default_rng(31)
+    n = 11000
+    cam, sc = small_case(n=n, W=64, H=48, focal=70.0, seed=30, opacity=0.999, smax=0.6)
+    sc["scaling"] = (0.3 + 0.3 * rng.random((n, 3))).astype(np.float32)
+    bg = (0.3, 0.6, 0.9)
+    dev = torch.device("cuda:0")
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    assert np.diff(of["tile_offsets"].astype(np.int64)).max() > 7680
+    dL = np.random.default_rng(2).standard_normal(of["image"].shape).astype(np.float32)
+    og = oracle_mod.backward(v, of, dL)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev).requires_grad_(True)
+    leaves = dict(means3D=t(sc["xyz"]), scales=t(sc["scaling"]), rotations=t(sc["rotation"]),
+                  opacities=t(sc["opacity"]), colors=t(sc["colors"]))
+    rast = GaussianRasterizer(raster_settings=G.settings(cam, bg, dev))
+    means2D = torch.zeros(n, 3, device=dev, requires_grad=True)
+    out = rast(means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors"],
+               opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+    assert (out[0].detach().cpu().numpy().view(np.uint32) == of["image"].view(np.uint32)).all()
+    out[0].backward(gradient=torch.from_numpy(dL).to(dev))
+    assert rel_l2(leaves["colors"].grad.cpu().numpy(), og["colors"]) < GRAD_TOL
+    assert rel_l2(leaves["opacities"].grad.cpu().numpy().reshape(-1), np.asarray(og["opacities"]).reshape(-1)) < GRAD_TOL
+    assert rel_l2(means2D.grad.cpu().numpy()[:, :2], np.asarray(og["means2D"])[:, :2]) < GRAD_TOL
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_backward_vs_oracle(oracle_mod, name):
     import gpu_util as G

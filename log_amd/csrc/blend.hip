@@ -116,20 +116,49 @@ LR_DEV bool lr_support_hits(const float4 g0, const float2 g1, float x0, float x1
   return !(best > tau);
 }
 
-// Lazily ordered lists (common.hpp: sorted[]; sort.hip).  lazy = 1: the first compositing pass -- a streamed list is walked
-// over its ordered prefix only (`end` comes back clamped); a wave that gets there with a pixel still open raises
-// LR_SORTED_OPEN on the tile, whose outputs of this pass are then provisional.  lazy = 2: the second pass, after
-// lr_launch_sort_rest ordered those lists to their end -- only their tiles run (false = nothing to do for this one), from
-// the start of the list: whatever the first pass stored for them is overwritten (per-pixel outputs) or stored again with
-// the same value (point_weight's atomicMax over a superset of the first pass's visits, zeros into accumulator rows).
-LR_DEV bool lr_lazy_range(const uint32_t* sorted, int lazy, uint32_t tile, uint32_t beg, uint32_t& end, bool& clamped) {
+// Lazily ordered lists (common.hpp: sorted[] / open[]; sort.hip).  lazy = 1: the first compositing pass -- a streamed list
+// is walked over its ordered part only (`end` comes back clamped); a wave that gets there with a pixel still open parks
+// its pixels' state in the outputs (lr_lazy_park) and sets its bit in open[tile].  lazy = 2: the second pass, after
+// lr_launch_sort_rest ordered those lists to their end -- only the waves that parked run (false = nothing to do for this
+// one): they pick their state up again and go on at list position `first`, entry for entry what an uninterrupted walk does.
+LR_DEV bool lr_lazy_range(const uint32_t* sorted, uint32_t tiles, int lazy, uint32_t tile, int wave, uint32_t beg,
+                          uint32_t& end, uint32_t& first, bool& clamped) {
+  first = 0u;
+  clamped = false;
   if (!lazy) return true;
   if (end - beg <= LR_LONG_LIST) return lazy == 1;
-  const uint32_t w = sorted[tile];
-  if (lazy == 2 && !(w & LR_SORTED_OPEN)) return false;
-  const uint32_t ordered = w & ~LR_SORTED_OPEN;
-  if (ordered < end - beg) { end = beg + ordered; clamped = true; }
+  const uint32_t ordered = sorted[tile];
+  if (lazy == 1) {
+    if (ordered < end - beg) { end = beg + ordered; clamped = true; }
+    return true;
+  }
+  if (!((sorted[tiles + tile] >> wave) & 1u)) return false;
+  first = ordered;
   return true;
+}
+// A pixel's compositing state between the two passes lives in its own outputs: T in final_T (negative = the pixel has
+// stopped: T itself never drops below 1e-4), the colour sums WITHOUT the background term in the image, the last contributor
+// and the fork maps' running maximum where they will end up anyway.
+template <bool EXTRAS>
+LR_DEV void lr_lazy_park(const LrView& v, size_t pix, bool done, float T, float C0, float C1, float C2, int last, int wid,
+                         float wmax, float* image, float* final_T, int* n_contrib, int* pid, float* pwp) {
+  const size_t plane = (size_t)v.W * v.H;
+  final_T[pix] = done ? -T : T;
+  n_contrib[pix] = last;
+  image[pix] = C0; image[plane + pix] = C1; image[2 * plane + pix] = C2;
+  if (EXTRAS) { pid[pix] = wid; pwp[pix] = wmax; }
+}
+template <bool EXTRAS>
+LR_DEV void lr_lazy_resume(const LrView& v, size_t pix, bool& done, float& T, float& C0, float& C1, float& C2, int& last,
+                           int& wid, float& wmax, const float* image, const float* final_T, const int* n_contrib,
+                           const int* pid, const float* pwp) {
+  const size_t plane = (size_t)v.W * v.H;
+  const float t = final_T[pix];
+  done = t < 0.f;
+  T = fabsf(t);
+  last = n_contrib[pix];
+  C0 = image[pix]; C1 = image[plane + pix]; C2 = image[2 * plane + pix];
+  if (EXTRAS) { wid = pid[pix]; wmax = pwp[pix]; }
 }
 
 template <bool EXTRAS>
@@ -143,20 +172,25 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
-  const uint32_t beg = offsets[tile];
-  uint32_t end = offsets[tile + 1];
-  bool clamped = false;
-  if (!lr_lazy_range(sorted, lazy, tile, beg, end, clamped)) return;
+  uint32_t beg = offsets[tile];
+  uint32_t end = offsets[tile + 1], first;
+  bool clamped;
   const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
+  if (!lr_lazy_range(sorted, tiles, lazy, tile, quad, beg, end, first, clamped)) return;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const float pxf = (float)px, pyf = (float)py;
   const float bx0 = (float)qx0, bx1 = (float)(qx0 + 7), by0 = (float)qy0, by1 = (float)(qy0 + 7);
   const bool inside = (px < v.W) && (py < v.H);
+  const size_t pix = inside ? (size_t)py * v.W + px : 0;
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, wmax = 0.f;
   int wid = -1, last = 0;
+  if (lazy == 2) {                                           // second pass: this wave parked at list position `first`
+    if (inside) lr_lazy_resume<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
+    beg += first;
+  }
 
   // Software pipeline over 64-entry chunks: ids are fetched two chunks ahead and records one chunk ahead, so
   // the dependent id -> record gather of chunk c+1 is in flight while chunk c is composited.
@@ -180,7 +214,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
     const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
-    const int pos0 = (int)(ch * 64u);
+    const int pos0 = (int)(first + ch * 64u);
     // Two list entries per iteration, branch-free: the two alpha evaluations (power + exp polynomial, ~20 VALU
     // each) are independent, so one wave can issue them back to back instead of waiting out each dependent
     // result; T / done / last are then applied in list order.  Lane predicates stay in SGPR lane masks
@@ -263,11 +297,14 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
       if (!(hit0 | hit1) && __all(done)) break;
     }
   }
-  if (clamped && !__all(done) && lane == 0) atomicOr(sorted + tile, LR_SORTED_OPEN);   // out of ordered entries: see lr_lazy_range
+  if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
+    if (lane == 0) atomicOr(sorted + tiles + tile, 1u << quad);
+    if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
+    return;
+  }
 
   if (inside) {
     const size_t plane = (size_t)v.W * v.H;
-    const size_t pix = (size_t)py * v.W + px;
     final_T[pix] = T;
     n_contrib[pix] = last;
     image[pix] = lr_fma(T, v.bg[0], C0);
@@ -716,20 +753,25 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
-  const uint32_t beg = offsets[tile];
-  uint32_t end = offsets[tile + 1];
-  bool clamped = false;
-  if (!lr_lazy_range(sorted, lazy, tile, beg, end, clamped)) return;
+  uint32_t beg = offsets[tile];
+  uint32_t end = offsets[tile + 1], first;
+  bool clamped;
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  if (!lr_lazy_range(sorted, tiles, lazy, tile, wq, beg, end, first, clamped)) return;
   const int row = lane >> 4, li = lane & 15;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (wq & 1) * 8, qy0 = ty * 16 + (wq >> 1) * 8;
   const int px = qx0 + (row & 1) * 4 + (li & 3), py = qy0 + (row >> 1) * 4 + (li >> 2);
   const float pxf = (float)px, pyf = (float)py;
   const bool inside = (px < v.W) && (py < v.H);
+  const size_t pix = inside ? (size_t)py * v.W + px : 0;
   bool done = !inside;
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, wmax = 0.f;
   int wid = -1, last = 0;
+  if (lazy == 2) {                                           // second pass: this wave parked at list position `first`
+    if (inside) lr_lazy_resume<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
+    beg += first;
+  }
   float4* const stage = lr_stage[wq];
   if (lane < LR_RB_SLOT) stage[64 * LR_RB_SLOT + lane] = float4{0.f, 0.f, 0.f, 0.f};
   if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
@@ -782,7 +824,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     }
     uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
     if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone (gathers, staging, support tests), every list to its end
-    const int pos0 = (int)(ch * 64u);
+    const int pos0 = (int)(first + ch * 64u);
     while (true) {
       // a row whose 16 pixels are all saturated takes no more entries
       const uint64_t dm = __ballot(done);
@@ -844,11 +886,14 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       }
     }
   }
-  if (clamped && !__all(done) && lane == 0) atomicOr(sorted + tile, LR_SORTED_OPEN);   // out of ordered entries: see lr_lazy_range
+  if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
+    if (lane == 0) atomicOr(sorted + tiles + tile, 1u << wq);
+    if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
+    return;
+  }
 
   if (inside) {
     const size_t plane = (size_t)v.W * v.H;
-    const size_t pix = (size_t)py * v.W + px;
     final_T[pix] = T;
     n_contrib[pix] = last;
     image[pix] = lr_fma(T, v.bg[0], C0);

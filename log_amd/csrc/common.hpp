@@ -54,16 +54,15 @@ __host__ __device__ inline uint32_t lr_big_off(uint32_t tiles) { return lr_ranke
 __host__ __device__ inline uint32_t lr_offsets_off(uint32_t tiles) { return lr_big_off(tiles) + tiles * LR_CTR_STRIDE; }
 __host__ __device__ inline uint32_t lr_cursor_off(uint32_t tiles) { return lr_offsets_off(tiles) + lr_tpad(tiles); }
 __host__ __device__ inline uint32_t lr_order_off(uint32_t tiles) { return lr_cursor_off(tiles) + tiles * LR_CTR_STRIDE; }
-// sorted[T]: once the fill is done its cursors are dead, and the first T words of their array say how much of each STREAMED
-// list (more than LR_LONG_LIST keys) is in final order: its first `sorted[t] & ~LR_SORTED_OPEN` positions.  The walk of a
-// view almost never leaves a long list's first window (30 M Gaussians @1080p: 2116 lists of 19.6 K keys each, the deepest
-// pixel of any of them stops after 1.4 K entries, 2.8 K with random opacities: tools/walk_depth_probe.py), so the sort
-// orders that window only (sort.hip, lazy = 1); a compositing wave that runs out of ordered entries with a pixel still
-// open raises LR_SORTED_OPEN, and a second, normally idle pair of launches orders the rest of exactly those lists and
-// composites their tiles again from the start (every store of the compositing kernels is idempotent: per-pixel outputs,
-// atomicMax on point_weight, zeros into accumulator rows).
+// sorted[T] | open[T]: once the fill is done its cursors are dead, and the first 2 T words of their array say how much of
+// each STREAMED list (more than LR_LONG_LIST keys) is in final order -- its first sorted[t] positions -- and which of the
+// tile's four compositing waves ran out of ordered entries with a pixel still open (open[t], one bit per wave).  The walk
+// of a view almost never leaves a long list's first window (30 M Gaussians @1080p: 2116 lists of 19.6 K keys each, the
+// deepest pixel of any of them stops after 1.4 K entries, 2.8 K with random opacities: tools/walk_depth_probe.py), so the
+// sort orders that window only (sort.hip, lazy = 1); a compositing wave that gets to its end with a pixel open parks its
+// pixels' state in their outputs and sets its bit, and a second, normally idle pair of launches orders the rest of exactly
+// those lists and lets exactly those waves go on where they stopped (blend.hip: lr_lazy_range).
 __host__ __device__ inline uint32_t lr_sorted_off(uint32_t tiles) { return lr_cursor_off(tiles); }
-#define LR_SORTED_OPEN 0x80000000u
 // then basetab[batches][T]: start of every projection batch's reservation inside each tile's ranked range
 __host__ __device__ inline uint32_t lr_basetab_off(uint32_t tiles) { return lr_order_off(tiles) + lr_tpad(tiles); }
 // then hugemask[batches][LR_HUGE_WORDS]: which 256-Gaussian chunks of the batch hold a Gaussian that left its (more than

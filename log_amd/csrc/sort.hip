@@ -470,18 +470,18 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg, tid = threadIdx.x;
   if (L <= 1024u) return;                                   // lr_sort_small_kernel's
-  // lazy (streamed lists only; common.hpp: sorted[]): 0 = every list to its end; 1 = the first window, the ordered length
-  // goes to sorted[tile]; 2 = the lists whose compositing ran out of ordered entries (LR_SORTED_OPEN), to their end;
-  // 3 = every list that is not ordered to its end (lograst_finish_lists).  2 and 3 redo the list from its keys (the
-  // bucket path never moves them): the same values land on the positions that were ordered already.
+  // lazy (streamed lists only; common.hpp: sorted[] / open[]): 0 = every list to its end; 1 = the first window, the ordered
+  // length goes to sorted[tile] (and open[tile] = 0); 2 = the lists whose compositing ran out of ordered entries (open[tile]
+  // != 0), to their end; 3 = every list that is not ordered to its end (lograst_finish_lists).  2 and 3 run the list again
+  // from its keys (the bucket path never moves them) and skip the windows that are in place.
   uint32_t* const sorted = state + lr_sorted_off(tiles) + tile;
-  uint32_t keep = 0u;
+  uint32_t* const open = sorted + tiles;
+  uint32_t in_place = 0u;                                   // leading positions a previous pass left in final order
   if (lazy >= 2) {
     if (L <= LR_LONG_LIST || !state[LR_HDR_LAZY]) return;
-    const uint32_t w = *sorted;
-    if (lazy == 2 ? !(w & LR_SORTED_OPEN) : (w & ~LR_SORTED_OPEN) >= L) return;
-    keep = w & LR_SORTED_OPEN;
-    __syncthreads();                                        // (everybody has read the word that thread 0 rewrites at the end)
+    in_place = *sorted;
+    if (lazy == 2 ? *open == 0u : (*open != 0u || in_place >= L)) return;
+    __syncthreads();                                        // (everybody has read the word that thread 0 may rewrite at the end)
   }
   const uint64_t* k = keys + beg;
   uint16_t* rk = reinterpret_cast<uint16_t*>(ranks) + beg;   // one 16-bit bucket id per key (nb <= 4096)
@@ -492,7 +492,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
     __syncthreads();
     lr_wg_hybrid_sort<1024>(keys + beg, L, reinterpret_cast<uint64_t*>(lcnt), tid);
     for (uint32_t i = tid; i < L; i += 1024u) pl[i] = (uint32_t)k[i];
-    if (lazy && tid == 0 && L > LR_LONG_LIST) *sorted = L | keep;
+    if (lazy && lazy != 2 && tid == 0 && L > LR_LONG_LIST) { *sorted = L; if (lazy == 1) *open = 0u; }
   };
   if (network_only) {                                       // (lists up to one block were sorted by lr_sort_rb_kernel)
     if (L > LR_SORT_BLOCK) network();
@@ -637,6 +637,7 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
       if (st_mid <= w0 + (uint32_t)LR_LONG_WIN) lo_b = mid; else hi_b = mid - 1u;
     }
     const uint32_t b1 = lo_b;                              // window = list positions [start(b0), start(b1))
+    if ((b1 < nb ? lcnt[b1] : L) <= in_place) { b0 = b1; continue; }   // ordered by an earlier pass (same cuts: same keys, same map)
     for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // 2 B per key; the 8-byte key only if it lands in this window
       uint32_t cc[LR_LONG_UNR];
 #pragma unroll
@@ -681,12 +682,12 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
     __syncthreads();
     LR_TICK();
     if (lazy == 1 && b1 < nb) {                              // the first window is what a view walks; the rest on demand
-      if (tid == 0) *sorted = lcnt[b1];                      // (bucket b1 is untouched: lcnt[b1] is still its first position)
+      if (tid == 0) { *sorted = lcnt[b1]; *open = 0u; }      // (bucket b1 is untouched: lcnt[b1] is still its first position)
       return;
     }
     b0 = b1;
   }
-  if (lazy && tid == 0) *sorted = L | keep;
+  if (lazy && lazy != 2 && tid == 0) { *sorted = L; if (lazy == 1) *open = 0u; }   // (2: sorted[] stays where the parked waves resume)
 
 #if defined(LR_EXPERIMENTS) && defined(LR_LONG_TICKS)
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700 || blockIdx.x == 2000)) {
@@ -770,7 +771,8 @@ lr_ordered_lengths_kernel(const uint32_t* __restrict__ state, uint32_t tiles, ui
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t L = offsets[t + 1] - offsets[t];
   const bool lazy = state[LR_HDR_LAZY] != 0u && L > LR_LONG_LIST;
-  out[t] = lazy ? min(state[lr_sorted_off(tiles) + t] & ~LR_SORTED_OPEN, L) : L;
+  const uint32_t* sorted = state + lr_sorted_off(tiles);
+  out[t] = (lazy && sorted[tiles + t] == 0u) ? min(sorted[t], L) : L;   // (open[t] != 0: the second pass ordered it to its end)
 }
 void lr_launch_ordered_lengths(const uint32_t* state, uint32_t tiles, uint32_t* out, hipStream_t s) {
   if (tiles == 0) return;
@@ -778,7 +780,7 @@ void lr_launch_ordered_lengths(const uint32_t* state, uint32_t tiles, uint32_t* 
 }
 
 // The rest of the lists that lr_launch_sort(lazy = 1) left at their first window: mode 2 = those whose compositing asked for
-// it (LR_SORTED_OPEN), mode 3 = all of them (lograst_finish_lists).  Same grid as the first pass; a workgroup whose list
+// it (open[tile] != 0), mode 3 = all of them (lograst_finish_lists).  Same grid as the first pass; a workgroup whose list
 // needs nothing returns after two loads.
 void lr_launch_sort_rest(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                          uint32_t max_len, int mode, hipStream_t s) {

@@ -126,15 +126,16 @@ def test_exact_reference_lists_without_tile_cull(oracle_mod, name):
         assert rel_l2(g_on[k], g_off[k]) < 1e-5, k
 
 
-@pytest.mark.parametrize("kind", ["closed", "open"])
+@pytest.mark.parametrize("kind", ["closed", "open", "mixed"])
 @pytest.mark.parametrize("form", ["quadrant", "rows"])
 def test_lazily_ordered_lists_both_ways(oracle_mod, kind, form):
     """Lists of more than 4096 keys are ordered over their first window (7680 positions) before the compositing pass and
     to their end only where a pixel was still open there (include/lograst.h: lograst_ordered_lengths).  `closed`: screen-
     filling opaque splats -- every pixel stops after a few entries, the tails stay unordered (and the image, maps and
     gradients are the oracle's all the same).  `open`: the same lists with faint pinpoint splats -- no pixel ever stops, the
-    second sort + compositing pair must finish and redo every such tile.  Both compositing forms; with the knob off the
-    outputs are the same bits."""
+    second sort + compositing pair must order the tails and the parked waves go on where they stopped.  `mixed`: the same
+    plus opaque blobs over part of the image in the middle of the depth range -- waves park with some pixels stopped and
+    others open.  Both compositing forms; with the knob off the outputs are the same bits."""
     from log_amd import tune
     import gpu_util as G
     rng = np.random.default_rng(31)
@@ -145,6 +146,11 @@ def test_lazily_ordered_lists_both_ways(oracle_mod, kind, form):
         sc["scaling"] = (0.3 + 0.3 * rng.random((n, 3))).astype(np.float32)     # every rect covers every tile
     else:
         sc["xyz"] = (sc["xyz"] * 0.06).astype(np.float32)                        # all of them inside the middle tiles
+    if kind == "mixed":
+        k = 60
+        sc["xyz"][:k] = (0.02 * rng.standard_normal((k, 3)) + np.array([0.03, 0.0, 0.0])).astype(np.float32)
+        sc["scaling"][:k] = 0.05
+        sc["opacity"][:k] = 0.999
     bg = (0.3, 0.6, 0.9)
     _, of = G.oracle_forward(oracle_mod, cam, sc, bg)
     hf = G.hip_forward(cam, sc, bg, fwd_form=form, scratch_floats=16)
@@ -156,6 +162,15 @@ def test_lazily_ordered_lists_both_ways(oracle_mod, kind, form):
     else:
         assert hf["lazy_lists"] < long_lists                                     # somebody asked for the tails
         assert (hf["n_contrib"].astype(np.int64).max() > 7680)                   # ... because the walk went there
+        if kind == "mixed":   # inside a tile whose walk went into the tail, some pixels had stopped before it (alpha <= 0.99: a stopped pixel has T < 0.01)
+            H, W = hf["n_contrib"].shape
+            gx = (W + 15) // 16
+            ys, xs = np.mgrid[0:H, 0:W]
+            tile = (ys // 16) * gx + xs // 16
+            deep = np.zeros(len(lens), bool)
+            deep[np.unique(tile[hf["n_contrib"] > 7680])] = True
+            stopped_early = deep[tile] & (hf["final_T"] < 0.01) & (hf["n_contrib"] < 7000)   # (a first window ends past 7648)
+            assert stopped_early.sum() > 10, int(stopped_early.sum())
     st = G.compare_forward(hf, of)
     for k in ("radii_mismatch", "rec_bits_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch",
               "image_bits_mismatch", "final_T_bits_mismatch", "pid_mismatch"):

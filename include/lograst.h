@@ -137,8 +137,10 @@ int lograst_forward_project(const lograst_view* view, int32_t n, const float* me
                             uint32_t* max_tile_len_host, void* stream);
 
 /* ---- forward, stage 2: per-tile bucketing + per-tile depth sort + compositing (A3, A4, A5, A7, A8)
- * keys: scratch of lograst_keys_bytes(capacity) (dead after the call); point_list: lograst_list_bytes
- * (capacity), kept for backward.  `capacity` = number of tile instances the two buffers can hold.  With the
+ * keys: scratch of lograst_keys_bytes(capacity) (dead after the call -- unless lograst_finish_lists is to complete
+ * lazily ordered lists, see there); point_list: lograst_list_bytes(capacity), kept for backward: the ids of every tile
+ * list in (depth, id) order as far as the view's walk needed them (all of a list of up to 4096 keys; at least the first
+ * window of a longer one: lograst_ordered_lengths).  `capacity` = number of tile instances the two buffers can hold.  With the
  * exact count from stage 1 it always suffices.  With a guess (sync-free operation) the kernels never write past
  * it: if the real count is larger NOTHING is rendered, the overflow flag in tile_state is raised, and the
  * caller finds out from lograst_read_state() (the call itself cannot know without a host sync).

@@ -169,6 +169,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
                     float4* __restrict__ zero_conic, int xcd_mode, int cull, uint32_t* __restrict__ sorted, int lazy) {
   if (lr_bail(state, capacity)) return;
+  if (lazy == 2 && !sorted[LR_HDR_OPEN - (int)lr_sorted_off(tiles)]) return;   // nobody parked (read through the pointer the flag is written through)
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -298,7 +299,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     }
   }
   if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
-    if (lane == 0) atomicOr(sorted + tiles + tile, 1u << quad);
+    if (lane == 0) { atomicOr(sorted + tiles + tile, 1u << quad); atomicOr(sorted - lr_sorted_off(tiles) + LR_HDR_OPEN, 1u); }
     if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
     return;
   }
@@ -750,6 +751,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          int lazy LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
+  if (lazy == 2 && !sorted[LR_HDR_OPEN - (int)lr_sorted_off(tiles)]) return;   // nobody parked (read through the pointer the flag is written through)
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -887,7 +889,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     }
   }
   if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
-    if (lane == 0) atomicOr(sorted + tiles + tile, 1u << wq);
+    if (lane == 0) { atomicOr(sorted + tiles + tile, 1u << wq); atomicOr(sorted - lr_sorted_off(tiles) + LR_HDR_OPEN, 1u); }
     if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
     return;
   }

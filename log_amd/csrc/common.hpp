@@ -44,6 +44,7 @@
 #define LR_HDR_SPAN 8    // workgroup w owns fill-record slots [w * span, w * span + survcount[w]), the Gaussians' indices behind the fill records
 #define LR_HDR_HUGE 7  // batched projection: some workgroup deferred a rect to lr_count_huge_kernel (else that kernel returns at once)
 #define LR_HDR_LAZY 9  // the per-tile sort ordered only the first window of the streamed lists (sorted[] below is valid)
+#define LR_HDR_OPEN 10 // some compositing wave parked at the end of an ordered part (else the second sort / compositing pair returns at once)
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_LONG_LIST 4096   // longer lists are sorted with their keys streamed from memory (shorter ones: LDS-resident)
 #define LR_REC_QUADS 4  // float4 per projected record (64 B)

@@ -455,18 +455,17 @@ static inline size_t lr_bucket_lds_bytes(uint32_t cap) {
 #define LR_LONG_NB 4096     // bucket counters in LDS
 #define LR_LONG_WIN_BYTES 61440   // LDS window: 7680 keys staged at a time (16 KB counters + this: two workgroups per CU)
 #define LR_LONG_UNR 8       // independent loads in flight per thread in the streaming passes (64 VGPRs: two workgroups per CU, no spills)
-__global__ void __launch_bounds__(1024, 8)   // two workgroups per CU: 64 VGPRs (at 77 the kernel ran one per CU: 0.62 -> 0.86 ms at 30 M)
-lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
-                    uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity, int equalize,
-                    int network_only, int lazy) {
+// One list, by the whole workgroup (lr_sort_long_kernel below); blk = its position in the longest-first order.
+LR_DEV void lr_sort_long_list(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
+                              uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, int equalize,
+                              int network_only, int lazy, uint32_t blk) {
   constexpr uint32_t LR_LONG_WIN = LR_LONG_WIN_BYTES / sizeof(uint64_t);
   extern __shared__ uint32_t lcnt[];  // LR_LONG_NB bucket counters (then their starts) | LR_LONG_WIN + LR_BUCKET_MAX staged keys
   uint64_t* const win = reinterpret_cast<uint64_t*>(lcnt + LR_LONG_NB);
   __shared__ uint32_t sh_min, sh_max, sh_maxcnt, wave_tot[16], cellcnt[LR_CELLS], celltab[LR_CELLS];
-  if (lr_bail(state, capacity)) return;
-  // blockIdx.x walks the longest-first dispatch order: every tile in front of a list of more than 1024 keys holds at
+  // blk walks the longest-first dispatch order: every tile in front of a list of more than 1024 keys holds at
   // least 1024 itself (lr_scan_kernel's length buckets), so capacity / 1024 + 1 workgroups reach all of them
-  const uint32_t tile = state[lr_order_off(tiles) + blockIdx.x];
+  const uint32_t tile = state[lr_order_off(tiles) + blk];
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile], L = offsets[tile + 1] - beg, tid = threadIdx.x;
   if (L <= 1024u) return;                                   // lr_sort_small_kernel's
@@ -690,13 +689,34 @@ lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __re
   if (lazy && lazy != 2 && tid == 0) { *sorted = L; if (lazy == 1) *open = 0u; }   // (2: sorted[] stays where the parked waves resume)
 
 #if defined(LR_EXPERIMENTS) && defined(LR_LONG_TICKS)
-  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700 || blockIdx.x == 2000)) {
-    printf("longsort blk %u L %u nb %u ticks(10ns):", blockIdx.x, L, nb);
+  if (tid == 0 && (blk == 0 || blk == 700 || blk == 2000)) {
+    printf("longsort blk %u L %u nb %u ticks(10ns):", blk, L, nb);
     for (int q = 1; q < tn; q++) printf(" %llu", (unsigned long long)(tk[q] - tk[q - 1]));
     printf("\n");
   }
 #endif
 #undef LR_TICK
+}
+// First pass (lazy 0 / 1): one workgroup per list, handed out longest first by the dispatcher.  The passes over the tails
+// (lazy 2 / 3) run a small resident grid that loops over the lists: the per-view launch of mode 2 finds nothing to do in
+// nearly every view (LR_HDR_OPEN: no wave parked), and 512 workgroups that return after two loads cost a tenth of 8160.
+// (Two instantiations: wrapped in the loop the list code keeps its arguments live across iterations and spills -- 148 bytes
+// of scratch per lane against 8 -- which the first pass, the one every view pays for, must not inherit.)
+template <bool REST>
+__global__ void __launch_bounds__(1024, 8)   // two workgroups per CU: 64 VGPRs (at 77 the kernel ran one per CU: 0.62 -> 0.86 ms at 30 M)
+lr_sort_long_kernel(uint32_t* __restrict__ state, uint32_t tiles, uint64_t* __restrict__ keys,
+                    uint32_t* __restrict__ ranks, uint32_t* __restrict__ plist, uint32_t capacity, int equalize,
+                    int network_only, int lazy, uint32_t nblk) {
+  if (lr_bail(state, capacity)) return;
+  if (!REST) {
+    lr_sort_long_list(state, tiles, keys, ranks, plist, equalize, network_only, lazy, blockIdx.x);
+    return;
+  }
+  if (lazy == 2 && !state[LR_HDR_OPEN]) return;
+  for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    lr_sort_long_list(state, tiles, keys, ranks, plist, equalize, network_only, lazy, blk);
+    __syncthreads();                                        // (the next list reuses the LDS)
+  }
 }
 
 static inline size_t lr_sort_lds_bytes(uint32_t cap) { return sizeof(uint64_t) * (size_t)(cap + (cap >> 3)); }
@@ -722,7 +742,9 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
     const int big = (int)lr_sort_lds_bytes(LR_SORT_BLOCK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_rb_kernel<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_long_lds_bytes());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_long_lds_bytes());
     attr_set = true;
   }
@@ -756,9 +778,10 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
   }
   if (bucket ? max_len > 1024u : max_len > LR_SORT_BLOCK) {
     lr_prof_begin(LRK_SORT_HUGE, s);
-    hipLaunchKernelGGL(lr_sort_long_kernel, dim3(min(tiles, capacity / 1024u + 1u)), dim3(1024), lr_long_lds_bytes(), s,
+    const uint32_t nblk = min(tiles, capacity / 1024u + 1u);
+    hipLaunchKernelGGL(lr_sort_long_kernel<false>, dim3(nblk), dim3(1024), lr_long_lds_bytes(), s,
                        state, tiles, keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize,
-                       bucket ? 0 : 1, (bucket && lazy) ? 1 : 0);
+                       bucket ? 0 : 1, (bucket && lazy) ? 1 : 0, nblk);
     lr_prof_end(LRK_SORT_HUGE, s);
   }
 }
@@ -789,7 +812,7 @@ void lr_launch_sort_rest(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32
   if (max_len <= LR_LONG_LIST) return;
   static const int equalize = LR_EXPERIMENT_INT("LOGRAST_EQUALIZE", 1);
   // (every tile in front of a streamed list in order[] holds at least LR_LONG_LIST keys itself: lr_scan_kernel's buckets)
-  hipLaunchKernelGGL(lr_sort_long_kernel, dim3(min(tiles, capacity / (uint32_t)LR_LONG_LIST + 1u)), dim3(1024),
-                     lr_long_lds_bytes(), s, state, tiles, keys, reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity,
-                     equalize, 0, mode);
+  const uint32_t nblk = min(tiles, capacity / (uint32_t)LR_LONG_LIST + 1u);
+  hipLaunchKernelGGL(lr_sort_long_kernel<true>, dim3(min(nblk, 512u)), dim3(1024), lr_long_lds_bytes(), s, state, tiles, keys,
+                     reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize, 0, mode, nblk);
 }

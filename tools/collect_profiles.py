@@ -22,6 +22,10 @@ def stats(path, title, out):
         o.append(f"| `{name[:60]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
                  f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | "
                  f"{float(r['Percentage']):.2f} |")
+    o += ["", "(The forward compositing kernel is launched TWICE per view since round 5's lazily ordered lists: the first "
+          "launch does the work, the second -- with `lr_sort_long_kernel<true>` in front of it: the tails of lists whose walk "
+          "ran out of ordered entries -- finds nothing to do in this workload (min us column); its per-view time is avg x 2, "
+          "which is what `bench.py`'s HIP events report as blend_fwd + lazy_tail.)"]
     open(out, "w").write("\n".join(o) + "\n")
 
 
@@ -46,7 +50,9 @@ sq = os.path.join(G, f"{tag}_pmc_sq", "h30_counter_collection.csv")
 fe = os.path.join(G, f"{tag}_pmc_fetch", "h30_counter_collection.csv")
 wr = os.path.join(G, f"{tag}_pmc_write", "h30_counter_collection.csv")
 if all(os.path.exists(x) for x in (sq, fe, wr)):
-    out = ["# rocprofv3 --pmc (separate passes), mean per launch; " + WORKLOAD, "", "## SQ",
+    out = ["# rocprofv3 --pmc (separate passes), mean per launch; " + WORKLOAD, "",
+           "(The forward compositing kernel runs twice per view -- the second launch, the tails of lazily ordered lists, is "
+           "idle here: its per-launch means below are HALF its per-view sums.)", "", "## SQ",
            subprocess.check_output([sys.executable, pm, sq], text=True), "",
            "## TCC FETCH_SIZE / WRITE_SIZE (KB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, see "
            "MI355X_MICROARCH.md)", subprocess.check_output([sys.executable, pm, fe, wr], text=True)]
@@ -64,7 +70,9 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
                 k = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 agg[k] += float(r["Counter_Value"])
                 cnt[k] += 1
-        return {k: agg[k] / cnt[k] for k in agg}
+        # per launch -- except the two kernels the lazily ordered lists launch twice per view (second launch idle): per view
+        twice = lambda k: k.startswith("lr_blend_fwd")
+        return {k: agg[k] / (cnt[k] / 2 if twice(k) and cnt[k] % 2 == 0 else cnt[k]) for k in agg}
     f, w = load(fe, "FETCH_SIZE"), load(wr, "WRITE_SIZE")
     names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_bwd_rows_kernel": "blend_bwd", "lr_blend_fwd_kernel<true>": "blend_fwd",
              "lr_blend_fwd_rows_kernel<true>": "blend_fwd", "lr_project_kernel": "project", "lr_project_batched_kernel": "project",
@@ -74,7 +82,7 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
              "lr_project_bwd_kernel<true, true, false, true, true>": "project_bwd",
              "lr_project_bwd_kernel<true, true, false, true, true, 1>": "project_bwd",
              "lr_fill_staged_kernel<2>": "fill_keys", "lr_fill_staged_kernel<1>": "fill_keys", "lr_fill_staged_kernel<3>": "fill_keys",
-             "lr_sort_long_kernel": "sort"}
+             "lr_sort_long_kernel": "sort", "lr_sort_long_kernel<false>": "sort"}
     tj = os.path.join(P, f"{tag}_traffic_30M.json")
     d = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): " + cmd,
          "correction": "traffic_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE "

@@ -636,7 +636,11 @@ LR_DEV void lr_sort_long_list(uint32_t* __restrict__ state, uint32_t tiles, uint
       if (st_mid <= w0 + (uint32_t)LR_LONG_WIN) lo_b = mid; else hi_b = mid - 1u;
     }
     const uint32_t b1 = lo_b;                              // window = list positions [start(b0), start(b1))
-    if ((b1 < nb ? lcnt[b1] : L) <= in_place) { b0 = b1; continue; }   // ordered by an earlier pass (same cuts: same keys, same map)
+    if (lazy >= 2) {   // windows an earlier pass left in place are skipped (same cuts: same keys, same map)
+      const uint32_t wend = b1 < nb ? lcnt[b1] : L;
+      __syncthreads();   // everybody has read it: a thread that skips goes straight on to the NEXT window, whose scatter bumps lcnt[b1]
+      if (wend <= in_place) { b0 = b1; continue; }
+    }
     for (uint32_t i = tid; i < L; i += LR_LONG_UNR * 1024u) {  // 2 B per key; the 8-byte key only if it lands in this window
       uint32_t cc[LR_LONG_UNR];
 #pragma unroll
@@ -812,6 +816,12 @@ void lr_launch_sort_rest(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32
   if (max_len <= LR_LONG_LIST) return;
   static const int equalize = LR_EXPERIMENT_INT("LOGRAST_EQUALIZE", 1);
   // (every tile in front of a streamed list in order[] holds at least LR_LONG_LIST keys itself: lr_scan_kernel's buckets)
+  static bool attr_set = false;   // (lograst_finish_lists may be the first caller in a process that only inspects buffers)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lr_sort_long_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr_long_lds_bytes());
+    attr_set = true;
+  }
   const uint32_t nblk = min(tiles, capacity / (uint32_t)LR_LONG_LIST + 1u);
   hipLaunchKernelGGL(lr_sort_long_kernel<true>, dim3(min(nblk, 512u)), dim3(1024), lr_long_lds_bytes(), s, state, tiles, keys,
                      reinterpret_cast<uint32_t*>(keys + capacity), plist, capacity, equalize, 0, mode, nblk);

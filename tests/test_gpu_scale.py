@@ -259,6 +259,35 @@ def test_c5_band_full_size_vs_oracle(oracle_mod):
         assert rel_l2(got[vis][:, c0:c1], want) < tol, (k, rel_l2(got[vis][:, c0:c1], want))
 
 
+def test_every_long_list_needs_its_tail(oracle_mod):
+    """The worst case of the lazily ordered lists (include/lograst.h: lograst_ordered_lengths), at a size where hundreds of
+    workgroups take the rare path at once: 3 M faint Gaussians on a 320x240 image -- every tile's list holds 10-20 K keys and
+    no pixel ever stops, so every compositing wave parks at the end of the first window, the second sort pass orders every
+    tail (skipping the window that is in place) and every wave resumes.  Against the oracle, both compositing forms, bit for
+    bit, and the reverse walk's gradients."""
+    import gpu_util as G
+    from log_amd import scenes
+    W, H = 320, 240
+    cam = scenes.orbit_cameras(8, W=W, H=H, focal=2139.0 * W / 1920.0)[1]
+    sc = scenes.random_scene(3_000_000, seed=4, opacity=0.02)
+    bg = (0.2, 0.5, 0.8)
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    lens = np.diff(of["tile_offsets"].astype(np.int64))
+    for form in ("rows", "quadrant"):
+        hf = G.hip_forward(cam, sc, bg, scratch_floats=16, fwd_form=form)
+        hl = np.diff(hf["tile_offsets"].astype(np.int64))
+        long_lists = int((hl > 7680).sum())
+        assert long_lists > 50, (long_lists, hl.max())        # (the cloud covers a quarter of the image)
+        assert hf["lazy_lists"] < long_lists // 10, (hf["lazy_lists"], long_lists)     # (nearly) every one was finished by the second pass
+        assert hf["n_contrib"].max() > 7680
+        _assert_forward(hf, of, True, form)
+    dL = np.random.default_rng(9).random(of["image"].shape, dtype=np.float32)
+    hg = G.hip_backward(hf, dL)
+    og = oracle_mod.backward(v, of, dL)
+    for k in ("means2D", "conic", "opacities", "colors"):
+        assert rel_l2(hg[k], og[k]) < 1e-4, (k, rel_l2(hg[k], og[k]))
+
+
 @pytest.mark.parametrize("n,W,H", [(2_000_000, 3840, 2160), (10_000_000, 1920, 1080)],
                          ids=["c5_tile_grid_4k_2M", "c3_scale_10M_1080p"])
 def test_properties_at_scale(n, W, H):

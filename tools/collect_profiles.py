@@ -99,7 +99,10 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
         durs[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
     for k, sname in names.items():
         if k in act and sname in d["kernels"] and durs.get(k):
-            avg = sum(durs[k]) / len(durs[k])
+            # (time and counter over the SAME set of launches: load() reports per view for the twice-launched compositing kernel)
+            rows = len({(r["Dispatch_Id"]) for r in csv.DictReader(open(sq)) if r["Kernel_Name"].split("(")[0].replace("void ", "") == k})
+            per = rows // 2 if (k.startswith("lr_blend_fwd") and rows % 2 == 0) else rows
+            avg = (sum(durs[k]) / len(durs[k])) * rows / per
             d["kernels"][sname]["valu_active_frac_at_2p4GHz"] = act[k] * 4.0 / (1024 * avg * 2.4e9)
     json.dump(d, open(tj, "w"), indent=1)
 print(sorted(os.listdir(P)))

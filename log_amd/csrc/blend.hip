@@ -167,9 +167,9 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
-                    float4* __restrict__ zero_conic, int xcd_mode, int cull, uint32_t* __restrict__ sorted, int lazy) {
+                    float4* __restrict__ zero_conic, int xcd_mode, int cull, uint32_t* __restrict__ lazy_state, int lazy) {
   if (lr_bail(state, capacity)) return;
-  if (lazy == 2 && !sorted[LR_HDR_OPEN - (int)lr_sorted_off(tiles)]) return;   // nobody parked (read through the pointer the flag is written through)
+  if (lazy == 2 && !lazy_state[LR_HDR_OPEN]) return;         // nobody parked (lazy_state: the tile state again, through the pointer these kernels WRITE sorted[] / open[] / the flag with)
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -177,7 +177,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   uint32_t end = offsets[tile + 1], first;
   bool clamped;
   const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
-  if (!lr_lazy_range(sorted, tiles, lazy, tile, quad, beg, end, first, clamped)) return;
+  if (!lr_lazy_range(lazy_state + lr_sorted_off(tiles), tiles, lazy, tile, quad, beg, end, first, clamped)) return;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -299,7 +299,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     }
   }
   if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
-    if (lane == 0) { atomicOr(sorted + tiles + tile, 1u << quad); atomicOr(sorted - lr_sorted_off(tiles) + LR_HDR_OPEN, 1u); }
+    if (lane == 0) { atomicOr(lazy_state + lr_sorted_off(tiles) + tiles + tile, 1u << quad); atomicOr(lazy_state + LR_HDR_OPEN, 1u); }   // open[tile], header
     if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
     return;
   }
@@ -747,11 +747,11 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                          int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
-                         float4* __restrict__ zero_rows, int xcd_mode, int cull, uint32_t* __restrict__ sorted,
+                         float4* __restrict__ zero_rows, int xcd_mode, int cull, uint32_t* __restrict__ lazy_state,
                          int lazy LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
-  if (lazy == 2 && !sorted[LR_HDR_OPEN - (int)lr_sorted_off(tiles)]) return;   // nobody parked (read through the pointer the flag is written through)
+  if (lazy == 2 && !lazy_state[LR_HDR_OPEN]) return;         // nobody parked (lazy_state: the tile state again, through the pointer these kernels WRITE sorted[] / open[] / the flag with)
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -759,7 +759,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   uint32_t end = offsets[tile + 1], first;
   bool clamped;
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
-  if (!lr_lazy_range(sorted, tiles, lazy, tile, wq, beg, end, first, clamped)) return;
+  if (!lr_lazy_range(lazy_state + lr_sorted_off(tiles), tiles, lazy, tile, wq, beg, end, first, clamped)) return;
   const int row = lane >> 4, li = lane & 15;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (wq & 1) * 8, qy0 = ty * 16 + (wq >> 1) * 8;
@@ -889,7 +889,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     }
   }
   if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
-    if (lane == 0) { atomicOr(sorted + tiles + tile, 1u << wq); atomicOr(sorted - lr_sorted_off(tiles) + LR_HDR_OPEN, 1u); }
+    if (lane == 0) { atomicOr(lazy_state + lr_sorted_off(tiles) + tiles + tile, 1u << wq); atomicOr(lazy_state + LR_HDR_OPEN, 1u); }   // open[tile], header
     if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
     return;
   }
@@ -908,7 +908,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
                          int* pid, float* pwp, float* pw, float* zero_conic, int big_input, int lazy, hipStream_t s) {
-  uint32_t* const sorted = lazy ? const_cast<uint32_t*>(state) + lr_sorted_off(tiles) : nullptr;   // (the one word of the tile state a compositing kernel writes)
+  uint32_t* const lazy_state = lazy ? const_cast<uint32_t*>(state) : nullptr;   // (the tile state once more, writable: open[] and header word LR_HDR_OPEN are all a compositing kernel writes there)
   LR_KNOB(xcd_knob, "LOGRAST_XCD_MODE", 3);
   int xcd_mode = xcd_knob;
   static const int cull = LR_EXPERIMENT_INT("LOGRAST_CULL", 1);   // experiment builds: 0 = no per-quadrant support test
@@ -933,17 +933,17 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   if (rows) {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy LR_ABLATE_PASS(fwd_ablate));
     else
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy LR_ABLATE_PASS(fwd_ablate));
   } else {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy);
     else
       hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, sorted, lazy);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy);
   }
   if (lazy != 2) lr_prof_end(LRK_BLEND_FWD, s);
 }

@@ -151,3 +151,16 @@ def test_ctypes_signatures_match_the_header_prototypes():
         want = [] if params.strip() in ("", "void") else [c_class(p) for p in params.split(",")]
         got = [py_class(t) for t in _lib._SIGNATURES[name][1]]
         assert got == want, (name, got, want)
+
+
+def test_every_tunable_knob_is_documented():
+    """The knob table of the library (api.hip: kKnobs -- what lograst_knob_info enumerates) against INTEGRATION.md: a knob
+    a host can move must be described where a host looks."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "log_amd", "csrc", "api.hip")).read()
+    i = src.index("static const LrKnobInfo kKnobs[]")
+    names = re.findall(r'\{"(LOGRAST_[A-Z_]+)"', src[i:src.index("};", i)])
+    assert len(names) >= 20
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert [n for n in names if n not in doc] == []

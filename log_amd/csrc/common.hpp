@@ -18,7 +18,8 @@
 // [0] num_instances  [1] overflow flag  [2] longest tile list  [3] reserved
 // [4] tile instances of the plain rect rule (before the support cull; reporting only)
 // [5] support cull applied by the projection kernel (0/1)  [6] projection batch size (0 = unbatched)
-// [7] some rect was deferred to lr_count_huge_kernel  [8] band views: fill-record slots per projection workgroup  [9..15] reserved
+// [7] some rect was deferred to lr_count_huge_kernel  [8] band views: fill-record slots per projection workgroup
+// [9] the long-list sort left lists at their first window (sorted[] / open[] below are valid)  [10] a compositing wave parked at the end of an ordered part  [11..15] reserved
 // then per-tile counter arrays, one counter every S = LR_CTR_STRIDE words (64 B apart: the atomic targets
 // spread over the memory channels instead of 8160 counters sharing 32 KB); header, ranked and big are
 // contiguous so that ONE memset prepares a forward:

@@ -27,7 +27,13 @@
 extern "C" {
 #endif
 
-#define LOGRAST_VERSION 3   /* 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows); lograst_view gained walk_form.  Added since without a version change (new entry points only): lograst_sparse_segment_floats / lograst_pack_rows / lograst_unpack_rows / lograst_ordered_lengths / lograst_finish_lists */
+#define LOGRAST_VERSION 4   /* 4 (round 6): contracts that changed since 3 -- (a) lograst_geom_bytes grew by 8 B per Gaussian + 256 KB (the
+ * rank rows of the 5-16-tile rects behind the fill records and indices: a caller that sized `geom` as 84 B per Gaussian gets
+ * out-of-bounds writes; always size it with lograst_geom_bytes); (b) bwd_rows slots 12-15 are scratch of the chain rule
+ * (band views keep the compact live-row list there); (c) point_list tails of streamed lists (> 4096 keys) are unspecified
+ * until lograst_finish_lists, which now checks that `keys` is the buffer the forward filled and synchronises the stream;
+ * (d) the forward takes an optional hit-mask buffer for the reverse walk (lograst_view.hit_masks, see below).
+ * 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows); lograst_view gained walk_form.  Added since without a version change (new entry points only): lograst_sparse_segment_floats / lograst_pack_rows / lograst_unpack_rows / lograst_ordered_lengths / lograst_finish_lists */
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
 /* The reverse walk's accumulators: ONE 64-byte row per Gaussian -- slots 0-1 dL/d(ndc mean x, y), 2-4 dL/d(conic A, B, C),
@@ -94,6 +100,17 @@ typedef struct lograst_view {
    * LOGRAST_FORM_QUADRANT = the whole wave walks its 8x8 quadrant.  The caller knows the view's instances per Gaussian
    * from earlier forwards (forward) or from this view's forward (backward). */
   int32_t walk_form;
+  /* Optional (version 4; NULL = off): a buffer in which the forward's compositing kernels leave, per wave and 64-entry chunk
+   * of a tile list they walked, the ballot of their support tests, and from which the reverse walk of lograst_backward
+   * takes its visits instead of running the tests (and gathering every record of a chunk) again -- same decisions, same
+   * sums.  Device, 32-byte aligned, hit_mask_words 64-bit words >= lograst_hit_mask_bytes(capacity, width, height) / 8,
+   * uninitialised; the backward must be given the very buffer (contents untouched) of the forward whose tile_state it is
+   * handed.  Speed only: 30 M Gaussians, reverse walk 640 -> see DESIGN.md section 4. */
+  uint64_t* hit_masks;
+  uint64_t hit_mask_words;
+  /* lograst_backward only: what lograst_forward_form() returned for the forward's view (1 row-split, 2 quadrant; 0 = do not
+   * use the masks).  The reverse walk takes the masks only when it runs in that same form (walk_form / LOGRAST_BWD_ROWS). */
+  int32_t hit_mask_form;
 } lograst_view;
 
 int lograst_version(void);
@@ -112,6 +129,12 @@ size_t lograst_geom_bytes(int32_t n);
 /* bytes of the (depth,id) key buffer (keys + an equally large scratch half used by the long-list sort) / of the
  * sorted id list, for `capacity` tile instances */
 size_t lograst_keys_bytes(uint32_t capacity);
+/* bytes of lograst_view.hit_masks for `capacity` tile instances on a width x height image: 128 per (tile, 64-entry chunk)
+ * slot, capacity / 64 + tiles + 1 slots (only the chunks a view walks are ever written or read) */
+size_t lograst_hit_mask_bytes(uint32_t capacity, int32_t width, int32_t height);
+/* which form the forward's compositing kernels take for this view (its walk_form + the LOGRAST_FWD_ROWS knob): 1 = row-split,
+ * 2 = quadrant, negative = error.  Pass it back as hit_mask_form of the backward's view. */
+int lograst_forward_form(const lograst_view* view);
 size_t lograst_list_bytes(uint32_t capacity);
 
 /* ---- A0: LoG/cuda compute_radius --------------------------------------------------------------

@@ -28,6 +28,7 @@ class LograstView(ctypes.Structure):
         ("tile_row_begin", c_int32), ("tile_row_end", c_int32),
         ("cov3d_precomp", c_void_p), ("dl_dcov3d", c_void_p),
         ("walk_form", c_int32),
+        ("hit_masks", c_void_p), ("hit_mask_words", ctypes.c_uint64), ("hit_mask_form", c_int32),
     ]
 
 
@@ -49,6 +50,8 @@ _SIGNATURES = {
     "lograst_tile_state_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "lograst_geom_bytes": (c_size_t, [c_int32]),
     "lograst_keys_bytes": (c_size_t, [c_uint32]),
+    "lograst_hit_mask_bytes": (c_size_t, [c_uint32, c_int32, c_int32]),
+    "lograst_forward_form": (ctypes.c_int, [ctypes.POINTER(LograstView)]),
     "lograst_list_bytes": (c_size_t, [c_uint32]),
     "lograst_tile_offsets": (c_void_p, [c_void_p, c_int32, c_int32]),
     "lograst_ordered_lengths": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
@@ -127,7 +130,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.lograst_version() != 3:
+        if L.lograst_version() != 4:
             raise LograstError("liblograst.so version mismatch; rebuild")
         _lib = L
     return _lib

@@ -38,17 +38,19 @@ void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t t
 void lr_launch_tile_rows(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                          uint32_t* rows, hipStream_t s);
 void lr_launch_stream_copy(const void* src, void* dst, size_t bytes, int blocks, hipStream_t s);
-void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
-                    uint32_t max_len, int lazy, hipStream_t s);
+int lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
+                   uint32_t max_len, int lazy, hipStream_t s);
 void lr_launch_sort_rest(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
                          uint32_t max_len, int mode, hipStream_t s);
 void lr_launch_ordered_lengths(const uint32_t* state, uint32_t tiles, uint32_t* out, hipStream_t s);
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, int lazy, hipStream_t s);
+                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, int lazy, uint64_t* masks,
+                         hipStream_t s);
+int lr_blend_fwd_form(const LrView& v);
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
-                         const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s);
+                         const float* dL_dimage, float* acc_rows, int big_input, const uint64_t* masks, hipStream_t s);
 void lr_launch_project_bwd(const LrView& v, int N, const float* means, const float* scales, const float* rots,
                            const int* radii, const float* g_mean2d, const float* g_conic, const float* rows,
                            float* o_mean2d, float* o_opac, float* o_col, const float* pw,
@@ -103,6 +105,7 @@ int lr_env_int(const char* name, int dflt) {
 struct LrKnobInfo { const char* name; int dflt, lo, hi; const char* what; };
 static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_HELPER_MIN_N", 4000000, 0, 2000000000, "Gaussians from which the helper passes (absolute slot table, touched-only dL/dconic clearing, separate zero-fill kernels) pay for their launches"},
+    {"LOGRAST_HIT_MASKS", 1, 0, 1, "the compositing kernels leave their per-chunk support ballots in lograst_view.hit_masks (when the caller provides it) and the reverse walk reads them instead of running the tests again; 0 = ignore the buffer"},
     {"LOGRAST_LAZY_SORT", 1, 0, 1, "lists of more than 4096 keys are ordered over their first window (7680 positions) only; tiles whose walk needs more are marked by the compositing kernels and finished by a second, normally idle sort + compositing pair; 0 = every list to its end up front"},
     {"LOGRAST_PBWD_LIST", 1, 0, 2, "large inputs with running-sum gradients: the chain rule runs over a compact list of the rows with point_weight > 0 (a streaming compaction pass + a list pass) instead of one kernel that tests every row: 0 never, 1 on band views, 2 always"},
     {"LOGRAST_MID_RANK", 1, 0, 1, "rects of 5..16 tiles are RANKED by the batched projection (LDS atomics; 32-byte rank rows in geom), so the fill places them without cursor atomics or support tests; 0 = counted only, placed through the per-tile cursors"},
@@ -296,6 +299,12 @@ static int lr_make_view(const lograst_view* in, LrView* out) {
   out->cov3d = in->cov3d_precomp; out->g_cov3d = in->dl_dcov3d;
   if (in->walk_form < LOGRAST_FORM_AUTO || in->walk_form > LOGRAST_FORM_QUADRANT) return lr_fail(LOGRAST_ERR_ARG, "bad walk_form");
   out->walk_form = in->walk_form;
+  LR_KNOB(hit_masks, "LOGRAST_HIT_MASKS", 1);
+  if (in->hit_masks && (reinterpret_cast<uintptr_t>(in->hit_masks) & 31u)) return lr_fail(LOGRAST_ERR_ARG, "hit_masks must be 32-byte aligned");
+  out->masks = hit_masks ? in->hit_masks : nullptr;
+  out->mask_words = in->hit_mask_words;
+  if (in->hit_mask_form < 0 || in->hit_mask_form > 2) return lr_fail(LOGRAST_ERR_ARG, "bad hit_mask_form");
+  out->mask_form = in->hit_mask_form;
   return LOGRAST_OK;
 }
 
@@ -313,6 +322,16 @@ size_t lograst_geom_bytes(int32_t n) {  // 64-byte records + the 16-byte fill re
   return lr_midrank_off_bytes(nn) + lr_midrank_bytes(nn);
 }
 size_t lograst_keys_bytes(uint32_t capacity) { return 2 * sizeof(uint64_t) * (size_t)capacity; }  // keys + sort scratch
+int lograst_forward_form(const lograst_view* view) {
+  LrView v;
+  int rc = lr_make_view(view, &v);
+  if (rc) return rc;
+  return lr_blend_fwd_form(v);
+}
+size_t lograst_hit_mask_bytes(uint32_t capacity, int32_t width, int32_t height) {   // blend.hip: 16 words per (tile, 64-entry chunk) slot
+  const size_t gx = (size_t)(width > 0 ? (width + LOGRAST_TILE - 1) / LOGRAST_TILE : 0), gy = (size_t)(height > 0 ? (height + LOGRAST_TILE - 1) / LOGRAST_TILE : 0);
+  return 16 * sizeof(uint64_t) * ((size_t)capacity / 64 + gx * gy + 1);
+}
 size_t lograst_list_bytes(uint32_t capacity) { return sizeof(uint32_t) * (size_t)capacity; }
 
 const uint32_t* lograst_tile_offsets(const void* tile_state, int32_t width, int32_t height) {
@@ -339,6 +358,15 @@ int lograst_finish_lists(void* tile_state, int32_t width, int32_t height, void* 
   if (capacity == 0) return LOGRAST_OK;
   if (!keys || !point_list) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   const uint32_t gx = (uint32_t)(width + LOGRAST_TILE - 1) / LOGRAST_TILE, gy = (uint32_t)(height + LOGRAST_TILE - 1) / LOGRAST_TILE;
+  // The forward documents `keys` as dead after the call; what this entry point orders from must be the very buffer that
+  // forward's fill wrote (round-5 advisory: a stale or reused buffer silently corrupted point_list and marked it ordered).
+  // The fill left (pointer, capacity) in the header; this diagnostic call reads them back (it synchronises `stream`).
+  uint32_t hdr[LR_HDR_WORDS];
+  LR_HIP(hipMemcpyAsync(hdr, tile_state, sizeof(hdr), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  LR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  const uint64_t kp = (uint64_t)reinterpret_cast<uintptr_t>(keys);
+  if (hdr[LR_HDR_KEYS_LO] != (uint32_t)kp || hdr[LR_HDR_KEYS_HI] != (uint32_t)(kp >> 32) || hdr[LR_HDR_KEYS_CAP] != capacity)
+    return lr_fail(LOGRAST_ERR_ARG, "keys / capacity are not the buffer this tile_state's forward filled");
   lr_launch_sort_rest(reinterpret_cast<uint32_t*>(tile_state), gx * gy, reinterpret_cast<uint64_t*>(keys), point_list,
                       capacity, 0, 3, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
@@ -426,16 +454,16 @@ static int lr_stage2(const LrView& v, int32_t n, const void* geom, uint32_t* st,
   // more, and the second pair of launches -- idle in every benched view -- finishes exactly those.  0: every list to its
   // end before the first compositing pass (what lograst_finish_lists produces afterwards).
   LR_KNOB(lazy_knob, "LOGRAST_LAZY_SORT", 1);
-  const int lazy = (lazy_knob && max_tile_len_allows_streaming(max_tile_len, capacity)) ? 1 : 0;
-  lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, lazy, s);
+  const int lazy_asked = (lazy_knob && max_tile_len_allows_streaming(max_tile_len, capacity)) ? 1 : 0;
+  const int lazy = lr_launch_sort(st, tiles, keys, point_list, capacity, max_tile_len, lazy_asked, s);
   float* const zrows = touched_only ? bwd_scratch : nullptr;
   lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
-                      point_weight_pixel, point_weight, zrows, lr_big_input(n) ? 1 : 0, lazy, s);
+                      point_weight_pixel, point_weight, zrows, lr_big_input(n) ? 1 : 0, lazy, v.masks, s);
   if (lazy) {
     lr_prof_begin(LRK_LAZY_TAIL, s);
     lr_launch_sort_rest(st, tiles, keys, point_list, capacity, max_tile_len, 2, s);
     lr_launch_blend_fwd(v, geom, st, tiles, point_list, capacity, image, final_t, n_contrib, point_id_pixel,
-                        point_weight_pixel, point_weight, zrows, lr_big_input(n) ? 1 : 0, 2, s);
+                        point_weight_pixel, point_weight, zrows, lr_big_input(n) ? 1 : 0, 2, v.masks, s);
     lr_prof_end(LRK_LAZY_TAIL, s);
   }
   return LOGRAST_OK;
@@ -480,6 +508,8 @@ static int lr_check_stage2_args(const LrView& v, int32_t n, const void* tile_sta
     return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch: 0 or LOGRAST_BWD_ROW_FLOATS (16) floats per Gaussian and a non-NULL block");
   if (bwd_scratch_floats > 0 && (reinterpret_cast<uintptr_t>(bwd_scratch) & 63u))
     return lr_fail(LOGRAST_ERR_ARG, "bwd_scratch must be 64-byte aligned (one accumulator row per line)");
+  if (v.masks && (size_t)v.mask_words * sizeof(uint64_t) < lograst_hit_mask_bytes(capacity, v.W, v.H))
+    return lr_fail(LOGRAST_ERR_ARG, "hit_mask_words is smaller than lograst_hit_mask_bytes(capacity, width, height) / 8");
   return LOGRAST_OK;
 }
 
@@ -781,7 +811,7 @@ int lograst_backward(const lograst_view* view, int32_t n, const float* means3d, 
     LR_HIP(hipMemsetAsync(dl_dconic, 0, sizeof(float) * LOGRAST_BWD_ROW_FLOATS * (size_t)n, s));
   // capacity check is a forward concern: a list that rendered is by construction within capacity
   lr_launch_blend_bwd(v, geom, st, tiles, point_list, 0xffffffffu, final_t, n_contrib, dl_dimage, dl_dconic,
-                      lr_big_input(n) ? 1 : 0, s);
+                      lr_big_input(n) ? 1 : 0, v.masks, s);
   // the chain rule reads every live Gaussian's accumulator row and hands out the separate outputs: dL/dmeans2D (written
   // for all rows), dL/dopacities and dL/dcolors (written, or added to the caller's running sums)
   lr_launch_project_bwd(v, n, means3d, scales, rotations, radii, nullptr, nullptr, dl_dconic, dl_dmeans2d, dl_dopacities,

@@ -127,7 +127,9 @@ LR_DEV bool lr_lazy_range(const uint32_t* sorted, uint32_t tiles, int lazy, uint
   clamped = false;
   if (!lazy) return true;
   if (end - beg <= LR_LONG_LIST) return lazy == 1;
-  const uint32_t ordered = sorted[tile];
+  // (down to a whole number of 64-entry chunks: the chunks of both passes are then the chunks of an uninterrupted walk,
+  // which is what the hit masks handed to the reverse walk are indexed by; the entries in between are simply walked later)
+  const uint32_t ordered = sorted[tile] & ~63u;
   if (lazy == 1) {
     if (ordered < end - beg) { end = beg + ordered; clamped = true; }
     return true;
@@ -161,15 +163,40 @@ LR_DEV void lr_lazy_resume(const LrView& v, size_t pix, bool& done, float& T, fl
   if (EXTRAS) { wid = pid[pix]; wmax = pwp[pix]; }
 }
 
+// ---- hit masks: the forward's support decisions handed to the reverse walk (round 6) ------------------------------------
+// Per 64-entry chunk of a tile's list a compositing wave ballots which entries can reach the alpha floor inside its
+// quadrant (quadrant form: one 64-bit mask) or inside each of its four 4x4 blocks (row-split form: four masks).  The reverse
+// walk visits the same (wave, chunk) pairs and used to run the same tests again -- lr_support_prepare + two lr_support_box2
+// per entry, ~190 VALU: a third of lr_blend_bwd_rows_kernel -- and to gather all 64 records of a chunk to run them on.  When
+// the caller provides lograst_view.hit_masks the forward stores its ballots (8 B per wave and chunk, 4 x 8 B in the row-split
+// form; only the chunks it really walked: a few per cent of a long list) and the reverse walk, now walking the list in the
+// forward's chunks (aligned to multiples of 64 instead of to its deepest contributor), loads them through the scalar cache,
+// gathers only the records whose bit is set and runs no support test.  Same decisions, so the same visits and the same sums.
+// Slot of (tile, chunk c): (offsets[tile] >> 6) + tile + c -- disjoint for all tiles (floor(L / 64) + 1 >= ceil(L / 64)),
+// at most capacity / 64 + tiles + 1 slots; a slot holds 16 words (row-split: [wave][block]) or 4 (quadrant: [wave]).
+// Which form wrote them: lograst_view.hit_mask_form of the backward's view (the caller knows what its forward launched:
+// lograst_forward_form); a reverse walk of the other form ignores the buffer and runs the tests as before.  The forward also
+// leaves the form in header word LR_HDR_MASKS (diagnostics).
+#define LR_MASK_FORM_ROWS 1u
+#define LR_MASK_FORM_QUAD 2u
+LR_DEV size_t lr_mask_slot(uint32_t list_begin, uint32_t tile) { return (size_t)(list_begin >> 6) + tile; }
+// bits of a REVERSED chunk mask (bit j = list position hi - 1 - j) whose position lies in front of `limit`
+LR_DEV uint64_t lr_mask_before(uint64_t m, int hi, int limit) {
+  const int sh = hi - limit;                                 // positions hi - 1 - j < limit  <=>  j >= sh
+  return sh <= 0 ? m : (sh >= 64 ? 0ull : (m & (~0ull << sh)));
+}
+
 template <bool EXTRAS>
 __global__ void __launch_bounds__(256) LR_OCC_FWD
 lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                     int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
-                    float4* __restrict__ zero_conic, int xcd_mode, int cull, uint32_t* __restrict__ lazy_state, int lazy) {
+                    float4* __restrict__ zero_conic, int xcd_mode, int cull, uint32_t* __restrict__ lazy_state, int lazy,
+                    uint64_t* __restrict__ masks, uint32_t* __restrict__ hdr_w) {
   if (lr_bail(state, capacity)) return;
   if (lazy == 2 && !lazy_state[LR_HDR_OPEN]) return;         // nobody parked (lazy_state: the tile state again, through the pointer these kernels WRITE sorted[] / open[] / the flag with)
+  if (masks && blockIdx.x == 0 && threadIdx.x == 0) hdr_w[LR_HDR_MASKS] = LR_MASK_FORM_QUAD;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -177,6 +204,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   uint32_t end = offsets[tile + 1], first;
   bool clamped;
   const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
+  uint64_t* const mrow_out = masks ? masks + 4 * lr_mask_slot(beg, tile) + quad : nullptr;
   if (!lr_lazy_range(lazy_state + lr_sorted_off(tiles), tiles, lazy, tile, quad, beg, end, first, clamped)) return;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
@@ -216,6 +244,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
     const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
     uint64_t todo = __ballot(rel);
     const int pos0 = (int)(first + ch * 64u);
+    if (mrow_out && lane == 0) mrow_out[4 * (size_t)(pos0 >> 6)] = todo;   // for the reverse walk (hit masks, above)
     // Two list entries per iteration, branch-free: the two alpha evaluations (power + exp polynomial, ~20 VALU
     // each) are independent, so one wave can issue them back to back instead of waiting out each dependent
     // result; T / done / last are then applied in list order.  Lane predicates stay in SGPR lane masks
@@ -350,18 +379,20 @@ LR_DEV void lr_reduce9(const float v[9], float& r0, float& r1, float& r2) {
   r2 = lr_row_sum(lr_swap_add16(s8, s8));
 }
 
+template <bool MASKS>
 __global__ void __launch_bounds__(256) LR_OCC_BWD
 lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                     uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                     const float* __restrict__ final_T, const int* __restrict__ n_contrib,
                     const float* __restrict__ dL_dimage, float* __restrict__ acc_rows,
-                    int xcd_mode, int cull) {
+                    int xcd_mode, int cull, const uint64_t* __restrict__ masks) {
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile];
   const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
+  constexpr bool use_masks = MASKS;   // the forward left its quadrant ballots in `masks` (the host checked the form: lr_launch_blend_bwd)
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -395,27 +426,43 @@ lr_blend_bwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   const bool lead = (lane & 15) == 0;
 
   // Reverse walk in 64-entry chunks from the deepest contributor; lane l of chunk ch holds list position
-  // maxc-1 - 64*ch - l.  Same two-stage prefetch as the forward pass.
-  const uint32_t nchunks = ((uint32_t)maxc + 63u) >> 6;
+  // top-1 - 64*ch - l, top = maxc -- or, with the forward's hit masks, maxc rounded up to the forward's chunk grid: chunk ch
+  // is then the forward's chunk top/64 - 1 - ch with its lanes reversed, and its visits are the set bits of the forward's
+  // (bit-reversed) ballot in front of maxc: no record is gathered per lane, no support test runs.
+  const int top = use_masks ? ((maxc + 63) & ~63) : maxc;
+  const uint32_t nchunks = ((uint32_t)top + 63u) >> 6;
   auto load_id = [&](uint32_t c) -> uint32_t {
-    const int pos = maxc - 1 - (int)(c * 64u) - lane;
-    return (c < nchunks && pos >= 0) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
+    const int pos = top - 1 - (int)(c * 64u) - lane;
+    return (c < nchunks && pos >= 0 && pos < maxc) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
+  };
+  const uint64_t* const mbase = use_masks ? masks + 4 * lr_mask_slot(beg, tile) + __builtin_amdgcn_readfirstlane(quad) : nullptr;
+  auto load_mask = [&](uint32_t c) -> uint64_t {             // (uniform address: a scalar load)
+    return (use_masks && c < nchunks) ? mbase[4 * (size_t)(((uint32_t)top >> 6) - 1u - c)] : 0ull;
   };
   uint32_t id_n = load_id(0), id_nn = load_id(1);
+  uint64_t mk_n = load_mask(0), mk_nn = load_mask(1);
   float4 g0_n = {0.f, 0.f, 0.f, 0.f};
   float2 g1_n = {0.f, 0.f};  // (conic C, opacity): all the support test needs of q1
-  if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
+  if (!use_masks && id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
-    const int hi = maxc - (int)(ch * 64u);
+    const int hi = top - (int)(ch * 64u);
     const uint32_t id = id_n;
     const float4 g0 = g0_n;
     const float2 g1 = g1_n;
+    const uint64_t mk = mk_n;
     id_n = id_nn;
     id_nn = load_id(ch + 2);
-    if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
-    const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
-    uint64_t todo = __ballot(rel);
+    mk_n = mk_nn;
+    mk_nn = load_mask(ch + 2);
+    uint64_t todo;
+    if (use_masks) {
+      todo = lr_mask_before(__builtin_bitreverse64(mk), hi, maxc);
+    } else {
+      if (id_n != 0xffffffffu) { g0_n = geom[LR_REC_QUADS * (size_t)id_n]; g1_n = *reinterpret_cast<const float2*>(geom + LR_REC_QUADS * (size_t)id_n + 1); }
+      const bool rel = (id != 0xffffffffu) && (cull ? lr_support_hits(g0, g1, bx0, bx1, by0, by1) : true);
+      todo = __ballot(rel);
+    }
     // Two entries per iteration: both alpha evaluations are issued together (independent chains), the
     // gradient bodies then run in list order.
     while (todo) {
@@ -554,12 +601,13 @@ LR_DEV uint64_t lr_row_mask(int row, uint64_t m0, uint64_t m1, uint64_t m2, uint
   return row == 0 ? m0 : (row == 1 ? m1 : (row == 2 ? m2 : m3));
 }
 
+template <bool MASKS>
 __global__ void __launch_bounds__(256) LR_OCC_BWD_ROWS
 lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
                          uint32_t tiles, const uint32_t* __restrict__ plist, uint32_t capacity,
                          const float* __restrict__ final_T, const int* __restrict__ n_contrib,
                          const float* __restrict__ dL_dimage, float* __restrict__ acc_rows,
-                         int xcd_mode, int cull, int block_test LR_ABLATE_PARAM) {
+                         int xcd_mode, int cull, int block_test, const uint64_t* __restrict__ masks LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
@@ -567,6 +615,8 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   const uint32_t* offsets = state + lr_offsets_off(tiles);
   const uint32_t beg = offsets[tile];
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  // the forward's block masks of this wave's chunks (hit masks, above), if it left any in this form
+  constexpr bool use_masks = MASKS;   // the forward left its block ballots in `masks` (the host checked the form: lr_launch_blend_bwd)
   const int row = lane >> 4, li = lane & 15;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (wq & 1) * 8, qy0 = ty * 16 + (wq >> 1) * 8;
@@ -610,36 +660,60 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   // the four blocks of this quadrant (wave-uniform), for the support tests
   const float bx[2] = {(float)qx0, (float)(qx0 + 4)}, by[2] = {(float)qy0, (float)(qy0 + 4)};
 
-  const uint32_t nchunks = ((uint32_t)maxc + 63u) >> 6;
+  // With the forward's masks the walk runs on the forward's chunk grid: top = maxc rounded up to a multiple of 64, chunk ch
+  // = the forward's chunk top/64 - 1 - ch with its lanes reversed (lane l: list position top-1 - 64 ch - l), a row's visits =
+  // the set bits of its (bit-reversed) block mask in front of the row's deepest contributor; only entries with a bit in
+  // one of the four masks are gathered and staged.  Without masks: top = maxc and the tests run here, as before.
+  const int top = use_masks ? ((maxc + 63) & ~63) : maxc;
+  const uint32_t nchunks = ((uint32_t)top + 63u) >> 6;
   auto load_id = [&](uint32_t c) -> uint32_t {
-    const int pos = maxc - 1 - (int)(c * 64u) - lane;
-    return (c < nchunks && pos >= 0) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
+    const int pos = top - 1 - (int)(c * 64u) - lane;
+    return (c < nchunks && pos >= 0 && pos < maxc) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
+  };
+  const uint4* const mbase = use_masks ? reinterpret_cast<const uint4*>(masks + 16 * lr_mask_slot(beg, tile) +
+                                                                        4 * __builtin_amdgcn_readfirstlane(wq)) : nullptr;
+  struct Masks4 { uint64_t m0, m1, m2, m3; };
+  auto load_masks = [&](uint32_t c) -> Masks4 {              // (uniform address: scalar loads, 32 bytes per wave and chunk)
+    if (!use_masks || c >= nchunks) return Masks4{0ull, 0ull, 0ull, 0ull};
+    const uint4* mp = mbase + 8 * (size_t)(((uint32_t)top >> 6) - 1u - c);   // (16 words = 8 uint4 per slot)
+    const uint4 lo = mp[0], hi4 = mp[1];
+    return Masks4{__builtin_bitreverse64(((uint64_t)lo.y << 32) | lo.x), __builtin_bitreverse64(((uint64_t)lo.w << 32) | lo.z),
+                  __builtin_bitreverse64(((uint64_t)hi4.y << 32) | hi4.x), __builtin_bitreverse64(((uint64_t)hi4.w << 32) | hi4.z)};
   };
   uint32_t id_n = load_id(0), id_nn = load_id(1);
+  Masks4 mk_n = load_masks(0), mk_nn = load_masks(1);
   float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
   float cb_n = 0.f;
-  if (id_n != 0xffffffffu) {
+  auto wanted = [&](const Masks4& m) -> bool {               // does any row of this wave visit lane's entry?
+    return !use_masks || (((m.m0 | m.m1 | m.m2 | m.m3) >> lane) & 1ull) != 0ull;
+  };
+  if (id_n != 0xffffffffu && wanted(mk_n)) {
     const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
     g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
   }
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
-    const int hi = maxc - (int)(ch * 64u);
+    const int hi = top - (int)(ch * 64u);
     const uint32_t id = id_n;
     const float4 g0 = g0_n, g1 = g1_n;
     const float cb = cb_n;
+    const Masks4 mk = mk_n;
     id_n = id_nn;
     id_nn = load_id(ch + 2);
-    if (id_n != 0xffffffffu) {
+    mk_n = mk_nn;
+    mk_nn = load_masks(ch + 2);
+    if (id_n != 0xffffffffu && wanted(mk_n)) {
       const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
       g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
     }
     // this chunk's entries -> LDS (the wave's own slots; the previous chunk's reads have all returned)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    stage[lane * LR_RB_SLOT + 0] = g0;
-    stage[lane * LR_RB_SLOT + 1] = g1;
-    stage[lane * LR_RB_SLOT + 2] = float4{cb, __uint_as_float(id), 0.f, 0.f};
+    if (wanted(mk)) {
+      stage[lane * LR_RB_SLOT + 0] = g0;
+      stage[lane * LR_RB_SLOT + 1] = g1;
+      stage[lane * LR_RB_SLOT + 2] = float4{cb, __uint_as_float(id), 0.f, 0.f};
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -648,7 +722,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     const bool valid = id != 0xffffffffu;
     const int pos = hi - 1 - lane;
     bool r0 = valid & (pos < rm0), r1 = valid & (pos < rm1), r2 = valid & (pos < rm2), r3 = valid & (pos < rm3);
-    if (cull) {
+    if (cull && !use_masks) {
       const LrSupport sp = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
       if (block_test) {   // the exact ellipse-vs-box test for each of the four blocks (~75 VALU each)
         bool k0, k1, k2, k3;   // (two blocks at a time: lr_support_box2, the decisions of four lr_support_box calls)
@@ -667,7 +741,9 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
         r3 = r3 && q && x_hi && y_hi;
       }
     }
-    uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
+    uint64_t mrow;                                            // this lane's row's hit mask
+    if (use_masks) mrow = lr_mask_before(lr_row_mask(row, mk.m0, mk.m1, mk.m2, mk.m3), hi, rmax);   // (rmax: this lane's row's deepest contributor)
+    else mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));
     if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone
     while (__builtin_amdgcn_ballot_w64(mrow != 0ull) != 0) {
       // every row's next two entries (64 = none: the all-zero slot)
@@ -748,10 +824,11 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                          int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
                          float4* __restrict__ zero_rows, int xcd_mode, int cull, uint32_t* __restrict__ lazy_state,
-                         int lazy LR_ABLATE_PARAM) {
+                         int lazy, uint64_t* __restrict__ masks, uint32_t* __restrict__ hdr_w LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
   if (lazy == 2 && !lazy_state[LR_HDR_OPEN]) return;         // nobody parked (lazy_state: the tile state again, through the pointer these kernels WRITE sorted[] / open[] / the flag with)
+  if (masks && blockIdx.x == 0 && threadIdx.x == 0) hdr_w[LR_HDR_MASKS] = LR_MASK_FORM_ROWS;
   const uint32_t tile = lr_tile_of_block(blockIdx.x, tiles, v.gx, v.gy, xcd_mode, state);
   if (tile >= tiles) return;
   const uint32_t* offsets = state + lr_offsets_off(tiles);
@@ -759,6 +836,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   uint32_t end = offsets[tile + 1], first;
   bool clamped;
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  uint64_t* const mrow_out = masks ? masks + 16 * lr_mask_slot(beg, tile) + 4 * wq + (lane >> 4) : nullptr;
   if (!lr_lazy_range(lazy_state + lr_sorted_off(tiles), tiles, lazy, tile, wq, beg, end, first, clamped)) return;
   const int row = lane >> 4, li = lane & 15;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
@@ -825,8 +903,9 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       r0 = r0 && k0; r1 = r1 && k1; r2 = r2 && k2; r3 = r3 && k3;
     }
     uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
-    if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone (gathers, staging, support tests), every list to its end
     const int pos0 = (int)(first + ch * 64u);
+    if (mrow_out && li == 0) mrow_out[16 * (size_t)(pos0 >> 6)] = mrow;   // four lanes, 32 adjacent bytes: for the reverse walk (hit masks, above)
+    if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone (gathers, staging, support tests), every list to its end
     while (true) {
       // a row whose 16 pixels are all saturated takes no more entries
       const uint64_t dm = __ballot(done);
@@ -905,9 +984,19 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   }
 }
 
+// Which form the forward's compositing launches for this view (1 = row-split, 2 = quadrant): lr_launch_blend_fwd's rule,
+// also behind lograst_forward_form (the caller of lograst_backward passes it back as lograst_view.hit_mask_form).
+int lr_blend_fwd_form(const LrView& v) {
+  LR_KNOB(rows_knob, "LOGRAST_FWD_ROWS", 2);
+  const int rows = rows_knob != 2 ? rows_knob : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : 0);   // no hint: quadrant
+  return rows ? (int)LR_MASK_FORM_ROWS : (int)LR_MASK_FORM_QUAD;
+}
+
 void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, float* image, float* final_T, int* n_contrib,
-                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, int lazy, hipStream_t s) {
+                         int* pid, float* pwp, float* pw, float* zero_conic, int big_input, int lazy, uint64_t* masks,
+                         hipStream_t s) {
+  uint32_t* const hdr_w = const_cast<uint32_t*>(state);     // (header word LR_HDR_MASKS: which form left hit masks)
   uint32_t* const lazy_state = lazy ? const_cast<uint32_t*>(state) : nullptr;   // (the tile state once more, writable: open[] and header word LR_HDR_OPEN are all a compositing kernel writes there)
   LR_KNOB(xcd_knob, "LOGRAST_XCD_MODE", 3);
   int xcd_mode = xcd_knob;
@@ -916,12 +1005,11 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   // LOGRAST_FWD_ROWS: 1 = row-split form (lr_blend_fwd_rows_kernel), 0 = one quadrant per wave, 2 (default) = the caller's
   // hint (lograst_view.walk_form), quadrant without one.  Measured, MI355X: 30 M tiny splats 706 -> 658 us (random
   // opacities 1267 -> 1188); C2's 1 M 174 -> 193; a tree-ordered heavy-tailed view 278 -> 347.
-  LR_KNOB(rows_knob, "LOGRAST_FWD_ROWS", 2);
 #ifdef LR_EXPERIMENTS
   static const int fwd_ablate = lr_env_int("LOGRAST_FWD_ABLATE", 0);   // timing experiments (row-split form): 1 no point_weight atomics, 2 no row clears
 #endif
-  const int rows = rows_knob != 2 ? rows_knob
-                   : (v.walk_form == LOGRAST_FORM_ROWS ? 1 : (v.walk_form == LOGRAST_FORM_QUADRANT ? 0 : 0));   // no hint: quadrant
+  const int rows = lr_blend_fwd_form(v) == (int)LR_MASK_FORM_ROWS;
+  if (!cull) masks = nullptr;                                // (experiment builds without support tests: nothing to hand over)
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   if (lazy == 2) {   // only streamed lists can be open: in the scan's longest-first order they sit in front of every shorter one
     xcd_mode = 3;
@@ -933,24 +1021,24 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   if (rows) {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w LR_ABLATE_PASS(fwd_ablate));
     else
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w LR_ABLATE_PASS(fwd_ablate));
   } else {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w);
     else
       hipLaunchKernelGGL(lr_blend_fwd_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy);
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w);
   }
   if (lazy != 2) lr_prof_end(LRK_BLEND_FWD, s);
 }
 
 void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* state, uint32_t tiles,
                          const uint32_t* plist, uint32_t capacity, const float* final_T, const int* n_contrib,
-                         const float* dL_dimage, float* acc_rows, int big_input, hipStream_t s) {
+                         const float* dL_dimage, float* acc_rows, int big_input, const uint64_t* masks, hipStream_t s) {
   LR_KNOB(xcd_mode, "LOGRAST_XCD_MODE", 3);
   static const int cull = LR_EXPERIMENT_INT("LOGRAST_CULL", 1);   // experiment builds: 0 = no per-quadrant support test
   static const size_t lds_bwd = (size_t)LR_EXPERIMENT_INT("LOGRAST_BLEND_BWD_LDS_KB", 0) * 1024;   // experiment builds: occupancy cap
@@ -967,12 +1055,20 @@ void lr_launch_blend_bwd(const LrView& v, const void* geom, const uint32_t* stat
 #endif
   LR_KNOB(block_test, "LOGRAST_BWD_BLOCK_TEST", 1);
   lr_prof_begin(LRK_BLEND_BWD, s);
-  if (rows)
-    hipLaunchKernelGGL(lr_blend_bwd_rows_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom),
-                       state, tiles, plist, capacity, final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull,
-                       block_test LR_ABLATE_PASS(ablate));
+  // the forward's hit masks serve a reverse walk of the SAME form only (v.mask_form: what the caller says its forward launched)
+  const bool use_masks = masks != nullptr && cull && v.mask_form == (rows ? (int)LR_MASK_FORM_ROWS : (int)LR_MASK_FORM_QUAD);
+  const float4* g4 = reinterpret_cast<const float4*>(geom);
+  if (rows && use_masks)
+    hipLaunchKernelGGL(lr_blend_bwd_rows_kernel<true>, dim3(grid), dim3(256), lds_bwd, s, v, g4, state, tiles, plist, capacity,
+                       final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull, block_test, masks LR_ABLATE_PASS(ablate));
+  else if (rows)
+    hipLaunchKernelGGL(lr_blend_bwd_rows_kernel<false>, dim3(grid), dim3(256), lds_bwd, s, v, g4, state, tiles, plist, capacity,
+                       final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull, block_test, masks LR_ABLATE_PASS(ablate));
+  else if (use_masks)
+    hipLaunchKernelGGL(lr_blend_bwd_kernel<true>, dim3(grid), dim3(256), lds_bwd, s, v, g4, state, tiles, plist, capacity,
+                       final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull, masks);
   else
-    hipLaunchKernelGGL(lr_blend_bwd_kernel, dim3(grid), dim3(256), lds_bwd, s, v, reinterpret_cast<const float4*>(geom), state,
-                       tiles, plist, capacity, final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull);
+    hipLaunchKernelGGL(lr_blend_bwd_kernel<false>, dim3(grid), dim3(256), lds_bwd, s, v, g4, state, tiles, plist, capacity,
+                       final_T, n_contrib, dL_dimage, acc_rows, xcd_mode, cull, masks);
   lr_prof_end(LRK_BLEND_BWD, s);
 }

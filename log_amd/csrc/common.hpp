@@ -45,6 +45,10 @@
 #define LR_HDR_SPAN 8    // workgroup w owns fill-record slots [w * span, w * span + survcount[w]), the Gaussians' indices behind the fill records
 #define LR_HDR_HUGE 7  // batched projection: some workgroup deferred a rect to lr_count_huge_kernel (else that kernel returns at once)
 #define LR_HDR_LAZY 9  // the per-tile sort ordered only the first window of the streamed lists (sorted[] below is valid)
+#define LR_HDR_KEYS_LO 11 // fingerprint of the key buffer the fill wrote into (pointer, capacity): lograst_finish_lists refuses any other
+#define LR_HDR_KEYS_HI 12
+#define LR_HDR_KEYS_CAP 13
+#define LR_HDR_MASKS 14 // which compositing form left its per-chunk support ballots in the caller's hit-mask buffer (0 none, 1 row-split, 2 quadrant: blend.hip)
 #define LR_HDR_OPEN 10 // some compositing wave parked at the end of an ordered part (else the second sort / compositing pair returns at once)
 #define LR_SORT_BLOCK 8192  // keys one workgroup sorts in LDS
 #define LR_LONG_LIST 4096   // longer lists are sorted with their keys streamed from memory (shorter ones: LDS-resident)
@@ -109,6 +113,9 @@ struct LrView {
   const float* bg;
   const float* cov3d;   // precomputed world-space covariances (n x 6) instead of scales + rotations, or nullptr
   float* g_cov3d;       // backward: dL/dcov3D (n x 6) when cov3d is set
+  uint64_t* masks;      // hit masks: written by the forward's compositing, read by the reverse walk (blend.hip), or nullptr
+  uint64_t mask_words;
+  int mask_form;        // backward: which compositing form of the forward wrote `masks` (0 unknown / none, 1 row-split, 2 quadrant)
 };
 
 #define LR_DEV __device__ __forceinline__
@@ -471,6 +478,9 @@ LR_DEV void lr_mid_rects(bool mid, int x0, int y0, int w, int nt, const LrSuppor
 // no record fetch.  Rows live behind the records | fill records | band indices in `geom`: batch b owns rows
 // [b * lr_mid_cap(B), ...) -- one row per four Gaussians of the batch; a batch with more such rects counts the rest the old way.
 #define LR_MID_ROW 16
+// lr_mid_rects serves a rect with 16 lanes (t = lane & 15, four rects per pass) and a rank row holds 16 ranks: a rect handed to
+// either must not have more tiles than that (round-5 advisory: nothing enforced it).
+static_assert(LR_COOP_TILES <= 16 && LR_MID_ROW == 16, "lr_mid_rects / rank rows serve at most 16 tiles per rect");
 __host__ __device__ inline uint32_t lr_mid_cap(uint32_t B) { return B >> 2; }   // (C2: 13 % of the Gaussians hold such a rect)
 __host__ __device__ inline size_t lr_midrank_off_bytes(size_t n) {
   return ((sizeof(float) * LOGRAST_REC_FLOATS + 16 + 4) * n + 63) & ~(size_t)63;

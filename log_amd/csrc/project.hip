@@ -1314,13 +1314,15 @@ void lr_launch_rebase(uint32_t* state, uint32_t tiles, uint32_t batches, uint32_
 // kernels return at once (lr_bail), and the caller's status block (optional, include/lograst.h: LOGRAST_STATUS_*) records
 // this forward and the running maxima / sticky overflow bit across forwards (written by one thread of the grid).
 LR_DEV bool lr_fill_verdict(uint32_t* __restrict__ state, uint32_t capacity, uint32_t max_len_hint,
-                            uint32_t* __restrict__ status, int speculative) {
+                            uint32_t* __restrict__ status, int speculative, const void* keys) {
   const uint32_t total = state[LR_HDR_NUM], maxlen = state[LR_HDR_MAXLEN];
   const bool over = total > capacity || (max_len_hint != 0u && maxlen > max_len_hint);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // (written either way: a second stage-2 pass over the same tile_state with larger buffers -- the retry of a
     // speculative forward, lograst_forward_speculative -- must find the flag of the failed attempt cleared)
     state[LR_HDR_OVERFLOW] = over ? 1u : 0u;
+    const uint64_t kp = (uint64_t)reinterpret_cast<uintptr_t>(keys);
+    state[LR_HDR_KEYS_LO] = (uint32_t)kp; state[LR_HDR_KEYS_HI] = (uint32_t)(kp >> 32); state[LR_HDR_KEYS_CAP] = capacity;
     // a speculative attempt that overflows is repeated by the caller with exact buffers: only that pass is recorded
     if (status && !(speculative && over)) {
       status[LOGRAST_STATUS_LAST_INSTANCES] = total;
@@ -1447,7 +1449,7 @@ lr_fill_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* __restr
     }
   }
   const bool tile_cull = state[LR_HDR_CULL] != 0u;
-  const bool over = lr_fill_verdict(state, capacity, max_len_hint, status, speculative);
+  const bool over = lr_fill_verdict(state, capacity, max_len_hint, status, speculative, keys);
   if (over) return;
   const uint32_t* __restrict__ offsets = state + lr_offsets_off(tiles);
   uint32_t* cursor = state + lr_cursor_off(tiles);
@@ -1568,7 +1570,7 @@ lr_fill_staged_kernel(int N, int gx, const float4* __restrict__ geom, uint32_t* 
   const uint32_t vblock = xcd_order ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t first = vblock * (LR_FILL_STAGED_ROWS * K);      // the workgroup's first Gaussian (< N unless the grid's padding)
   const bool tile_cull = state[LR_HDR_CULL] != 0u;
-  const bool over = lr_fill_verdict(state, capacity, max_len_hint, status, speculative);
+  const bool over = lr_fill_verdict(state, capacity, max_len_hint, status, speculative, keys);
   const uint32_t batch = state[LR_HDR_BATCH];
   const uint4* __restrict__ fillrec = reinterpret_cast<const uint4*>(geom + LR_REC_QUADS * (size_t)N);
   uint4 fr_k[K];

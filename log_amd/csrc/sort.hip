@@ -738,9 +738,11 @@ static_assert(sizeof(uint32_t) * LR_LONG_NB + LR_LONG_WIN_BYTES + sizeof(uint64_
 
 // max_len: upper bound on the longest tile list known to the HOST (exact count from stage 1, a hint in sync-free
 // operation, or 0 = unknown -> assume `capacity`).  It only decides how many multi-block levels are launched.
-void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
-                    uint32_t max_len, int lazy, hipStream_t s) {
-  if (tiles == 0) return;
+// -> the lazy mode that is really in effect (experiment builds with LOGRAST_BUCKET_SORT=0 order every list to its end: the
+// compositing passes must then not read sorted[] / open[], which still hold dead fill cursors -- round-5 advisory).
+int lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* plist, uint32_t capacity,
+                   uint32_t max_len, int lazy, hipStream_t s) {
+  if (tiles == 0) return 0;
   static bool attr_set = false;
   if (!attr_set) {
     const int big = (int)lr_sort_lds_bytes(LR_SORT_BLOCK);
@@ -788,6 +790,7 @@ void lr_launch_sort(uint32_t* state, uint32_t tiles, uint64_t* keys, uint32_t* p
                        bucket ? 0 : 1, (bucket && lazy) ? 1 : 0, nblk);
     lr_prof_end(LRK_SORT_HUGE, s);
   }
+  return (bucket && lazy) ? 1 : 0;
 }
 
 // out[t] = leading positions of tile t's list that are in final order (lograst_ordered_lengths)

@@ -80,6 +80,7 @@ _inplace_leaf_grads = False
 _INPLACE_TAG = "_lograst_inplace_grad"   # attribute set on leaves whose owner asked for the in-place route
 _status = {}          # device -> int32[8] status block (sticky across forwards, all streams)
 _debug_keep = False   # tests: keep dL/dconic of the last backward (HipBackend.last_conic_grad)
+_hit_masks = True     # a training forward hands its compositing kernels a hit-mask buffer for the reverse walk (blend.hip)
 _keep_keys = False    # tests: the forward's key buffer stays alive in `saved` (finish_lists below needs it)
 _DEBUG_ADDR = bool(int(__import__('os').environ.get('LOGRAST_DEBUG_ADDR', '0')))
 
@@ -92,6 +93,14 @@ def set_instance_capacity(n, max_tile_len=0):
     global _capacity_hint, _max_len_hint
     _capacity_hint = None if n is None else int(n)
     _max_len_hint = int(max_tile_len) if n is not None else 0
+
+
+def set_hit_masks(enabled):
+    """Training forwards allocate lograst_view.hit_masks (128 B per walked (tile, 64-entry chunk)) so that the reverse walk
+    reuses the forward's support decisions instead of recomputing them (default on; speed only).  -> previous value."""
+    global _hit_masks
+    prev, _hit_masks = _hit_masks, bool(enabled)
+    return prev
 
 
 def set_speculative(enabled):
@@ -425,6 +434,19 @@ class HipBackend:
         if scratch_floats and N:
             kept.append(("bwd_scratch", f32, (N * scratch_floats,)))
         instances = None
+        want_masks = bool(_hit_masks and scratch_floats and N)
+        if want_masks:   # (knob LOGRAST_HIT_MASKS = 0: the library would ignore the buffer, and a backward under a different
+            kv = ctypes.c_int32(1)   # knob value must not find an unwritten one)
+            L.lograst_get_knob(b"LOGRAST_HIT_MASKS", ctypes.byref(kv))
+            want_masks = kv.value != 0
+
+        def masks_for(cap):
+            """The hit-mask buffer of a training forward with room for `cap` tile instances (uninitialised)."""
+            if not want_masks:
+                return None
+            m = torch.empty(L.lograst_hit_mask_bytes(cap, W, H) // 8, dtype=torch.int64, device=device)
+            view.hit_masks, view.hit_mask_words = m.data_ptr(), m.numel()
+            return m
         ckey = (device.index, W, H, _tile_rows.get())
         hist_ratio = _cap_model.ratio(ckey)
         # which form the compositing kernel takes: instances per Gaussian as the recent forwards of this resolution had
@@ -441,6 +463,7 @@ class HipBackend:
                 k = self._carve(device, kept)
                 plist = torch.empty(capacity, dtype=i32, device=device)
                 keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                masks = masks_for(capacity)
                 n_host, m_host = ctypes.c_uint32(0), ctypes.c_uint32(0)
                 _lib.check(L.lograst_forward_speculative(
                     ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(colors),
@@ -456,6 +479,7 @@ class HipBackend:
                     capacity, max_len = n_inst, max(n_len, 1)
                     plist = torch.empty(capacity, dtype=i32, device=device)
                     keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                    masks = masks_for(capacity)
                     _lib.check(L.lograst_forward_render(
                         ctypes.byref(view), N, _ptr(k["geom"]), _ptr(k["state"]), _ptr(keys), _ptr(plist), capacity, max_len,
                         _ptr(o["image"]), _ptr(k["final_T"]), _ptr(k["n_contrib"]), _ptr(o.get("pid")), _ptr(o.get("pwp")),
@@ -470,6 +494,7 @@ class HipBackend:
                 capacity, max_len = int(n_host.value), max(int(m_host.value), 1)
                 plist = torch.empty(capacity, dtype=i32, device=device)
                 keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                masks = masks_for(capacity)
                 _lib.check(L.lograst_forward_render(
                     ctypes.byref(view), N, _ptr(k["geom"]), _ptr(k["state"]), _ptr(keys), _ptr(plist), capacity, max_len,
                     _ptr(o["image"]), _ptr(k["final_T"]), _ptr(k["n_contrib"]), _ptr(o.get("pid")), _ptr(o.get("pwp")),
@@ -480,6 +505,7 @@ class HipBackend:
                 k = self._carve(device, kept + [("plist", i32, (capacity,))])
                 plist = k["plist"]
                 keys = torch.empty(L.lograst_keys_bytes(capacity), dtype=u8, device=device)
+                masks = masks_for(capacity)
                 _lib.check(L.lograst_forward(
                     ctypes.byref(view), N, _ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(colors),
                     _ptr(o["radii"]), _ptr(k["geom"]), _ptr(k["state"]), _ptr(keys), _ptr(plist), capacity, max_len,
@@ -495,7 +521,8 @@ class HipBackend:
         saved = dict(radii=o["radii"], geom=k["geom"].view(f32), state=k["state"].view(i32), plist=plist,
                      final_T=k["final_T"], n_contrib=k["n_contrib"], bwd_scratch=k.get("bwd_scratch"),
                      point_weight=o.get("pw"), tile_rows=(view.tile_row_begin, view.tile_row_end), instances=int(instances),
-                     walk_form_pin=pin)
+                     walk_form_pin=pin, hit_masks=masks if want_masks else None,
+                     hit_mask_form=int(L.lograst_forward_form(ctypes.byref(view))) if want_masks else 0)
         if kept_keys is not None:
             saved["keys"], saved["capacity"] = kept_keys
         return o["image"], o["radii"], o.get("pid"), o.get("pwp"), o.get("pw"), saved
@@ -532,6 +559,10 @@ class HipBackend:
         # tiny splats -> the row-split reverse walk; a form pinned for the forward holds for its backward
         view.walk_form = saved.get("walk_form_pin", 0) or self.walk_form(saved.get("instances", 0), N)
         self._note_form("bwd", view.walk_form, N)
+        hm = saved.get("hit_masks")      # the forward's support ballots (lograst_view.hit_masks): the reverse walk reads them
+        if hm is not None:
+            view.hit_masks, view.hit_mask_words = hm.data_ptr(), hm.numel()
+            view.hit_mask_form = max(int(saved.get("hit_mask_form", 0)), 0)
         g_conic = acc          # (the C ABI's `bwd_rows`)
         g_means2D = torch.empty(N, 3, **f32)
         if sink is None:
@@ -1088,6 +1119,9 @@ def finish_lists(saved, width, height):
     """Test/debug: orders every tile list of a forward made under keep_keys(True) to its end, in place
     (lograst_finish_lists): saved["plist"] is then what LOGRAST_LAZY_SORT=0 would have produced."""
     st = saved["state"]
+    if saved.get("keys") is None:
+        raise RuntimeError("finish_lists: this forward did not keep its key buffer -- run it under keep_keys(True) "
+                           "(the forward treats `keys` as dead scratch otherwise)")
     with torch.cuda.device(st.device):
         _lib.check(_lib.lib().lograst_finish_lists(_ptr(st), int(width), int(height), _ptr(saved["keys"]), _ptr(saved["plist"]),
                                                   int(saved["capacity"]), _stream_ptr(st.device)))

@@ -27,6 +27,7 @@ CANDIDATES = {
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
     "LOGRAST_MID_COOP": (0, 8, 16, 32),       # rects of 5..16 tiles: wave-cooperative counting up to this many per wave
     "LOGRAST_MID_RANK": (0, 1),
+    "LOGRAST_HIT_MASKS": (0, 1),              # the forward's support ballots handed to the reverse walk
     "LOGRAST_LAZY_SORT": (0, 1),              # long lists ordered over their first window only (loses where every walk needs the tails: fog)
 }
 HELPER_KNOBS = ("LOGRAST_HELPER_MIN_N",)      # thresholds on the input size: tuned by helper_threshold()

@@ -22,12 +22,20 @@ def settings(cam, bg, dev, scale_modifier=1.0):
 
 
 def hip_forward(cam, sc, bg, flavour=R.WODILATE, use_filter=True, dev="cuda:0", scale_modifier=1.0, scratch_floats=0,
-                fwd_form=None):
+                fwd_form=None, hit_masks=None):
     """Raw backend call (keeps the intermediates).  Returns dict of numpy arrays + the torch `saved`.
     scratch_floats=16: have the forward prepare the backward's accumulator rows, as the autograd path does.
     fwd_form: "rows" / "quadrant" forces the compositing kernel's form (knob LOGRAST_FWD_ROWS) for this call; None = what
-    the package would pick (the resolution's history).  out["fwd_form"] says which one ran."""
+    the package would pick (the resolution's history).  out["fwd_form"] says which one ran.
+    hit_masks: False = a training forward (scratch_floats=16) WITHOUT the hit-mask buffer for the reverse walk
+    (log_amd.rasterizer.set_hit_masks); None / True = the package's default (on)."""
     from log_amd import tune
+    if hit_masks is not None:
+        prev = R.set_hit_masks(bool(hit_masks))
+        try:
+            return hip_forward(cam, sc, bg, flavour, use_filter, dev, scale_modifier, scratch_floats, fwd_form)
+        finally:
+            R.set_hit_masks(prev)
     if fwd_form is not None:
         prev = tune.get_knob("LOGRAST_FWD_ROWS")
         tune.set_knob("LOGRAST_FWD_ROWS", {"rows": 1, "quadrant": 0}[fwd_form])
@@ -90,18 +98,32 @@ def _lazy_list_check(saved, offs, I, W, H):
     return dict(ordered_len=ordered, lazy_lists=int(partly.sum()), lazy_prefix_mismatch=mismatch, walk_beyond_ordered=beyond)
 
 
-def hip_backward(hf, dL):
+def hip_backward(hf, dL, bwd_form=None):
+    """bwd_form: "rows" / "quadrant" forces the reverse walk's form (knob LOGRAST_BWD_ROWS) for this call; None = the
+    package's choice (from the forward's own instance count).  out["bwd_form"] says which one ran, out["bwd_masks"] whether
+    it took its visits from the forward's hit masks (same form as the forward that left them)."""
+    from log_amd import tune
     rs, flavour, use_filter, m, s, r, saved = hf["_torch"]
     g = torch.tensor(np.ascontiguousarray(dL, np.float32), device=m.device)
-    g_m3, g_m2, g_c, g_o, g_s, g_r = R._backend.backward(rs, flavour, use_filter, m, s, r, saved, g)
+    prev = tune.get_knob("LOGRAST_BWD_ROWS")
+    if bwd_form is not None:
+        tune.set_knob("LOGRAST_BWD_ROWS", {"rows": 1, "quadrant": 0}[bwd_form])
+    try:
+        g_m3, g_m2, g_c, g_o, g_s, g_r = R._backend.backward(rs, flavour, use_filter, m, s, r, saved, g)
+    finally:
+        tune.set_knob("LOGRAST_BWD_ROWS", prev)
     torch.cuda.synchronize()
+    ran = R._backend.last_forms["bwd"]
+    assert bwd_form is None or ran == bwd_form
     conic = R._backend.last_conic_grad.clone()
     if saved.get("point_weight") is not None:
         # rows of Gaussians that contributed to no pixel are neither cleared nor read on large inputs (their dL/dconic
         # is zero by construction; lograst.h: LOGRAST_BWD_CONIC_TOUCHED_ONLY)
         conic[saved["point_weight"] == 0] = 0
+    masks = saved.get("hit_masks") is not None and {1: "rows", 2: "quadrant"}.get(saved.get("hit_mask_form")) == ran
     return dict(conic=conic.cpu().numpy(), means3D=g_m3.cpu().numpy(), means2D=g_m2.cpu().numpy(), colors=g_c.cpu().numpy(),
-                opacities=g_o.cpu().numpy().reshape(-1, 1), scales=g_s.cpu().numpy(), rotations=g_r.cpu().numpy())
+                opacities=g_o.cpu().numpy().reshape(-1, 1), scales=g_s.cpu().numpy(), rotations=g_r.cpu().numpy(),
+                bwd_form=ran, bwd_masks=bool(masks))
 
 
 def hip_project_backward(hf, g_mean2d, g_conic):

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_sizing_helpers_and_error_text_work_without_gpu():
     from log_amd import _lib
     L = _lib.lib()
-    assert L.lograst_version() == 3
+    assert L.lograst_version() == 4
     tiles = 120 * 68
     assert L.lograst_tile_state_bytes(1920, 1080, 1000000) >= 4 * (tiles + 1)
     # records + fill records + an index each (band views), rounded up to 64 bytes, + the rank rows of the 5..16-tile rects

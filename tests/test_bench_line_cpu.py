@@ -1,0 +1,113 @@
+"""The bench line the driver parses (round-5 verdict, next #1: BENCH_r05.json.parsed was null because the single line had
+grown to 26 KB).  bench.compact_line() builds the LAST stdout line from the full result; here it is built from committed
+full results of earlier runs (profiles/r0*_bench_default.json: what bench.py printed then) and from a minimal one."""
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+ROOFLINE = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")
+CPU = ("value", "unit", "cores", "kind", "sample")
+
+
+def _full_results():
+    out = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_bench_default.json")) +
+                       glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_full.json"))):
+        with open(path) as f:
+            text = f.read().strip()
+        try:
+            d = json.loads(text)                            # pretty-printed copy
+        except ValueError:
+            d = json.loads(text.splitlines()[-1])           # raw stdout of a run
+        if "modes" in d:
+            out.append((os.path.basename(path), d))
+    return out
+
+
+def _check(line, full):
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    assert "\n" not in text
+    back = json.loads(text)
+    assert back == line
+    for k in CONTRACT:
+        assert k in back, k
+    assert back["value"] == pytest.approx(full["value"], rel=1e-6)
+    assert back["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert isinstance(back["config"]["workload"], str) and back["config"]["workload"]
+    assert "model" not in back["config"]
+    # the driver's record truncates keys at 40 characters and strings at ~128
+    def walk(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                assert len(k) <= 40, k
+                walk(v)
+        elif isinstance(o, str):
+            assert len(o) <= 120, o
+    walk({k: v for k, v in back.items() if k != "mode"})
+    assert len(back["mode"]) <= 160
+    assert text.index('"mode"') < 120          # which mode `value` is, inside the first 200 characters
+    return back
+
+
+@pytest.mark.parametrize("name,full", _full_results())
+def test_compact_line_from_committed_full_results(name, full):
+    bench.flatten_for_the_driver(full)
+    back = _check(bench.compact_line(full), full)
+    for k in ROOFLINE:
+        assert k in back["roofline"], k
+    assert back["roofline"]["frac"] == pytest.approx(back["roofline"]["achieved"] / back["roofline"]["peak"], rel=1e-3)
+    for k in CPU:
+        assert k in back["cpu_baseline"], k
+    assert back["config"]["ms_per_view"] > 0
+    if "dropin_default" in full["modes"]:
+        assert back["config"]["dropin_default_ms_per_view"] >= back["config"]["ms_per_view"] * 0.9
+
+
+def test_there_is_a_committed_full_result_to_test_with():
+    assert _full_results(), "profiles/ holds no full bench result"
+
+
+def test_compact_line_survives_a_result_without_optional_legs():
+    full = {"metric": "Gaussians/sec fwd+bwd @1080p", "value": 1.0e9, "unit": "Gaussians/s", "n_gpus": 2, "steps": 3,
+            "warmup": 1, "ms_per_step": 12.5, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "x" * 500, "gaussians": 1000, "width": 64, "height": 64, "views_per_gpu": 2,
+                       "parallelism": "p" * 500},
+            "modes": {"pipelined": {"ms_per_view": 6.25}},
+            "exchange": {"mode": "sparse", "parts": 2, "exchange_only_ms_per_step": 1.25,
+                         "bytes_moved_per_rank_per_step": 12345}}
+    back = _check(bench.compact_line(full), full)
+    assert "roofline" not in back and "cpu_baseline" not in back
+    assert back["config"]["exchange_mode"] == "sparse" and back["config"]["exchange_parts"] == 2
+
+
+def test_an_oversized_kernel_table_is_shed_not_printed():
+    name, full = _full_results()[-1]
+    bench.flatten_for_the_driver(full)
+    for i in range(400):
+        full["roofline"]["kernel_us_made_up_kernel_%03d" % i] = 1.0 + i
+    line = bench.compact_line(full)
+    assert len(json.dumps(line, separators=(",", ":"))) < bench.LINE_LIMIT
+    assert "frac" in line["roofline"]
+
+
+def test_emit_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):
+    name, full = _full_results()[-1]
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.flatten_for_the_driver(full)
+    bench.emit(full)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert json.loads(out[-1])["value"] == pytest.approx(full["value"], rel=1e-6)
+    assert len(out[-1]) < bench.LINE_LIMIT
+    with open(tmp_path / "bench_full.json") as f:
+        assert json.load(f)["value"] == full["value"]

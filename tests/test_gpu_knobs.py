@@ -19,6 +19,7 @@ SWEEP = {
     "LOGRAST_MID_RANK": (0, 1),
     "LOGRAST_PBWD_LIST": (0, 1, 2),
     "LOGRAST_LAZY_SORT": (0, 1),
+    "LOGRAST_HIT_MASKS": (0, 1),
     "LOGRAST_HUGE_CHUNK": (256, 512, 2048),
     "LOGRAST_BATCH_PLANES": (1, 2, 4),
     "LOGRAST_BATCH_SLOTS": (64, 256, 1024),

@@ -177,7 +177,11 @@ def test_lazily_ordered_lists_both_ways(oracle_mod, kind, form):
         assert st[k] == 0, (k, st)
     assert st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0, st
     dL = np.random.default_rng(2).standard_normal(hf["image"].shape).astype(np.float32)
-    g = G.hip_backward(hf, dL)
+    g = G.hip_backward(hf, dL, bwd_form=form)        # (same form: its visits come from the forward's hit masks, written by
+    assert g["bwd_masks"]                             # both compositing passes where waves parked)
+    og = oracle_mod.backward(of["_view"], of, dL)
+    for k in ("means2D", "conic", "opacities", "colors"):
+        assert rel_l2(g[k], og[k]) < GRAD_TOL, (k, rel_l2(g[k], og[k]))
     tune.set_knob("LOGRAST_LAZY_SORT", 0)
     try:
         hf0 = G.hip_forward(cam, sc, bg, fwd_form=form, scratch_floats=16)
@@ -186,7 +190,7 @@ def test_lazily_ordered_lists_both_ways(oracle_mod, kind, form):
             assert (hf0[k].view(np.uint32) == hf[k].view(np.uint32)).all(), k
         for k in ("radii", "tile_offsets", "point_list", "n_contrib", "point_id_pixel"):
             assert (hf0[k] == hf[k]).all(), k
-        g0 = G.hip_backward(hf0, dL)
+        g0 = G.hip_backward(hf0, dL, bwd_form=form)
     finally:
         tune.reset_knobs()
     for k in ("means2D", "conic", "opacities", "colors"):
@@ -223,15 +227,28 @@ def test_backward_reads_only_the_ordered_part_of_a_lazily_ordered_list(oracle_mo
     assert rel_l2(means2D.grad.cpu().numpy()[:, :2], np.asarray(og["means2D"])[:, :2]) < GRAD_TOL
 
 
+def _flavour(name):
+    from log_amd import rasterizer as R
+    return {"wodilate": R.WODILATE, "upstream": R.UPSTREAM}[name]
+
+
 @pytest.mark.parametrize("name", CASES)
-def test_backward_vs_oracle(oracle_mod, name):
+@pytest.mark.parametrize("flavour_name", ["wodilate", "upstream"])
+@pytest.mark.parametrize("path", ["plain", "training"])
+def test_backward_vs_oracle(oracle_mod, name, flavour_name, path):
+    """Both packages' backward (round-5 verdict, next #2a: the upstream flavour -- `use_origin_render: True`,
+    LoG/render/renderer.py:99-107, cov + 0.3 with a transparent gradient, LoG/model/geometry.py:87-88 -- had no backward case
+    through scales / rotations), each as a plain backend call and as the TRAINING forward the autograd path makes
+    (accumulator rows prepared by the forward, the forward's hit masks handed to the reverse walk)."""
     import gpu_util as G
     cam, sc = _case(name)
     bg = (0.3, 0.6, 0.9)
-    hf = G.hip_forward(cam, sc, bg)
-    v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    fl = _flavour(flavour_name)
+    hf = G.hip_forward(cam, sc, bg, flavour=fl, scratch_floats=16 if path == "training" else 0)
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg, flavour=fl)
     dL = np.random.default_rng(1).random(of["image"].shape, dtype=np.float32)
-    hg = G.hip_backward(hf, dL)
+    hg = G.hip_backward(hf, dL, bwd_form=hf["fwd_form"] if path == "training" else None)
+    assert hg["bwd_masks"] == (path == "training")
     og = oracle_mod.backward(v, of, dL)
     # A6, every row: outputs of the reverse walk
     for k in ("means2D", "conic", "opacities", "colors"):
@@ -241,18 +258,95 @@ def test_backward_vs_oracle(oracle_mod, name):
     # rows the chain rule conditions to better than 500x, and on EVERY row HIP no further from float64 than twice the
     # fp32 oracle; the small scenes hold more pancake-flat Gaussians than the bench scenes: up to 10 % above the bound)
     g64 = oracle_mod.backward_f64(v, of, dL)
-    G.assert_gradients_anchored(G.gradient_anchor_stats(hg, og, g64), tol=GRAD_TOL, max_excluded=0.10, name="case_" + name)
+    G.assert_gradients_anchored(G.gradient_anchor_stats(hg, og, g64), tol=GRAD_TOL, max_excluded=0.10,
+                                name="case_%s_%s_%s" % (name, flavour_name, path),
+                                # the +0.3 low-pass keeps every 2-D covariance >= 0.3 I: no near-singular conics, so the plain
+                                # all-rows criterion of north_star holds on these scenes too (measured: see profiles/)
+                                all_rows_tol=None)
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_project_backward_isolated(oracle_mod, name):
-    """A6b alone on identical inputs (the oracle's dL/dmean2D, dL/dconic): same op sequence, so the
-    kernel must agree with the oracle to fp32 rounding on EVERY row, ill-conditioned ones included."""
+@pytest.mark.parametrize("form", ["quadrant", "rows"])
+@pytest.mark.parametrize("name", ["ragged", "c1", "big_splats", "dense_tile", "huge_tiles"])
+def test_hit_masks_hand_over(oracle_mod, name, form):
+    """Round 6: a training forward leaves the ballots of its per-chunk support tests in lograst_view.hit_masks and the
+    reverse walk of the SAME form takes its visits from them (no support test, only the visited records gathered).  Checked:
+    the masked walk's gradients are the oracle's; they are what a forward without the buffer gives (same addends, atomics
+    reorder the sums); a reverse walk of the OTHER form ignores the buffer (and is the oracle's too); and the masks really
+    are what drives the visits -- with the buffer zeroed the masked walk visits nothing."""
     import gpu_util as G
     cam, sc = _case(name)
     bg = (0.3, 0.6, 0.9)
-    hf = G.hip_forward(cam, sc, bg)
+    other = "rows" if form == "quadrant" else "quadrant"
     v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
+    dL = np.random.default_rng(4).standard_normal(of["image"].shape).astype(np.float32)
+    og = oracle_mod.backward(v, of, dL)
+    hf = G.hip_forward(cam, sc, bg, scratch_floats=16, fwd_form=form)
+    saved = hf["_torch"][-1]
+    assert saved["hit_masks"] is not None and saved["hit_mask_form"] == {"rows": 1, "quadrant": 2}[form]
+    g = G.hip_backward(hf, dL, bwd_form=form)
+    assert g["bwd_masks"]
+    g_other = G.hip_backward(hf, dL, bwd_form=other)
+    assert not g_other["bwd_masks"]
+    hf0 = G.hip_forward(cam, sc, bg, scratch_floats=16, fwd_form=form, hit_masks=False)
+    assert hf0["_torch"][-1]["hit_masks"] is None
+    for k in ("image", "final_T", "point_weight"):
+        assert (hf0[k].view(np.uint32) == hf[k].view(np.uint32)).all(), k
+    assert (hf0["n_contrib"] == hf["n_contrib"]).all() and (hf0["point_list"] == hf["point_list"]).all()
+    g0 = G.hip_backward(hf0, dL, bwd_form=form)
+    assert not g0["bwd_masks"]
+    for k in ("means2D", "conic", "opacities", "colors"):
+        assert rel_l2(g[k], og[k]) < GRAD_TOL, (k, rel_l2(g[k], og[k]))
+        assert rel_l2(g_other[k], og[k]) < GRAD_TOL, (k, rel_l2(g_other[k], og[k]))
+        assert rel_l2(g[k], g0[k]) < 1e-5, (k, rel_l2(g[k], g0[k]))
+    for k in ("means3D", "scales", "rotations"):
+        assert rel_l2(g[k], g0[k]) < 1e-4, (k, rel_l2(g[k], g0[k]))
+    saved["hit_masks"].zero_()
+    gz = G.hip_backward(hf, dL, bwd_form=form)
+    assert gz["bwd_masks"] and not gz["colors"].any() and not gz["conic"].any() and not gz["opacities"].any()
+    assert G.hip_backward(hf, dL, bwd_form=other)["colors"].any()      # the other form never looked at the buffer
+
+
+@pytest.mark.parametrize("flavour_name", ["wodilate", "upstream"])
+def test_backward_with_scale_modifier(oracle_mod, flavour_name):
+    """`scale_modifier` != 1 through the backward (round-5 verdict, next #2c: the forward-only case below was the only one):
+    the chain rule to dL/dscales carries the factor, dL/drotations sees the scaled covariance."""
+    import gpu_util as G
+    cam, sc = _case("ragged")
+    bg = (0.3, 0.6, 0.9)
+    fl = _flavour(flavour_name)
+    hf = G.hip_forward(cam, sc, bg, flavour=fl, scale_modifier=1.7, scratch_floats=16)
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg, flavour=fl, scale_modifier=1.7)
+    st = G.compare_forward(hf, of)
+    for k in ("radii_mismatch", "rec_bits_mismatch", "image_bits_mismatch", "n_contrib_mismatch"):
+        assert st[k] == 0, (k, st)
+    dL = np.random.default_rng(7).random(of["image"].shape, dtype=np.float32)
+    hg = G.hip_backward(hf, dL)
+    og = oracle_mod.backward(v, of, dL)
+    for k in ("means2D", "conic", "opacities", "colors"):
+        assert rel_l2(hg[k], og[k]) < GRAD_TOL, (k, rel_l2(hg[k], og[k]))
+    hp = G.hip_project_backward(hf, og["means2D"], og["conic"])
+    for k in ("means3D", "scales", "rotations"):
+        assert rel_l2(hp[k], og[k]) < 1e-6, (k, rel_l2(hp[k], og[k]))
+    g64 = oracle_mod.backward_f64(v, of, dL)
+    G.assert_gradients_anchored(G.gradient_anchor_stats(hg, og, g64), tol=GRAD_TOL, max_excluded=0.10,
+                                name="scale_modifier_" + flavour_name)
+    # and the factor is really in there: against the same scene at scale_modifier = 1 the scale gradients differ
+    hf1 = G.hip_forward(cam, sc, bg, flavour=fl, scale_modifier=1.0, scratch_floats=16)
+    assert rel_l2(G.hip_backward(hf1, dL)["scales"], hg["scales"]) > 1e-2
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("flavour_name", ["wodilate", "upstream"])
+def test_project_backward_isolated(oracle_mod, name, flavour_name):
+    """A6b alone on identical inputs (the oracle's dL/dmean2D, dL/dconic): same op sequence, so the
+    kernel must agree with the oracle to fp32 rounding on EVERY row, ill-conditioned ones included.  Both low-pass
+    flavours: the fork's clamp (masked sub-gradient) and the upstream +0.3 (transparent)."""
+    import gpu_util as G
+    cam, sc = _case(name)
+    bg = (0.3, 0.6, 0.9)
+    fl = _flavour(flavour_name)
+    hf = G.hip_forward(cam, sc, bg, flavour=fl)
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg, flavour=fl)
     dL = np.random.default_rng(1).random(of["image"].shape, dtype=np.float32)
     og = oracle_mod.backward(v, of, dL)
     hg = G.hip_project_backward(hf, og["means2D"], og["conic"])

@@ -67,22 +67,23 @@ def test_c2_full_size_vs_oracle(oracle_mod):
 
 
 def _assert_forward(hf, of, check_lists, form):
+    """(the upstream package's flavour has no fork maps: those keys are simply absent on both sides)"""
     import gpu_util as G
     st = G.compare_forward(hf, of) if check_lists else None
     if st is not None:
         for k in ("radii_mismatch", "rec_bits_mismatch", "offsets_mismatch", "list_mismatch", "n_contrib_mismatch",
                   "image_bits_mismatch", "final_T_bits_mismatch", "pid_mismatch"):
-            assert st[k] == 0, (form, k, st)
-        assert st["pwp_max_abs"] == 0.0 and st["pw_max_abs"] == 0.0, form
+            assert st.get(k, 0) == 0, (form, k, st)
+        assert st.get("pwp_max_abs", 0.0) == 0.0 and st.get("pw_max_abs", 0.0) == 0.0, form
     else:
         for k in ("radii", "point_id_pixel"):
-            assert (hf[k] == of[k]).all(), (form, k)
+            assert k not in hf or (hf[k] == of[k]).all(), (form, k)
         for k in ("image", "final_T", "point_weight_pixel", "point_weight"):
-            assert (hf[k].view(np.uint32) == of[k].view(np.uint32)).all(), (form, k)
+            assert k not in hf or (hf[k].view(np.uint32) == of[k].view(np.uint32)).all(), (form, k)
 
 
 def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_name=None,
-                 fwd_forms=("rows", "quadrant"), all_rows_tol=None):
+                 fwd_forms=("rows", "quadrant"), all_rows_tol=None, flavour=None):
     """Forward bit-exact (lists: exact, or the oracle's lists minus provably invisible entries), backward <= 1e-4 rel-L2
     on every output of the reverse walk, chain rule <= 1e-6 on identical inputs.  The forward prepares the backward's
     accumulators as the autograd path does (touched-only dL/dconic on large inputs).
@@ -90,18 +91,26 @@ def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_nam
     row-split form -- what bench.py's headline runs -- was only ever compared with the quadrant form); the last one's
     forward feeds the backward."""
     import gpu_util as G
-    v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
-    hf = None
+    from log_amd import rasterizer as R
+    flavour = flavour or R.WODILATE
+    v, of = G.oracle_forward(oracle_mod, cam, sc, bg, flavour=flavour)
+    dL = np.random.default_rng(dL_seed).random(of["image"].shape, dtype=np.float32)
+    og = oracle_mod.backward(v, of, dL)
+    hf, hg = None, None
     for form in fwd_forms:
         del hf
-        hf = G.hip_forward(cam, sc, bg, scratch_floats=16, fwd_form=form)
+        hf = G.hip_forward(cam, sc, bg, flavour=flavour, scratch_floats=16, fwd_form=form)
         assert hf["fwd_form"] == form
         _assert_forward(hf, of, check_lists, form)
-    dL = np.random.default_rng(dL_seed).random(of["image"].shape, dtype=np.float32)
-    hg = G.hip_backward(hf, dL)
-    og = oracle_mod.backward(v, of, dL)
+        # the reverse walk of the SAME form: its visits come from this forward's hit masks (round 6) -- every row of its four
+        # outputs against the oracle, for both forms
+        hg = G.hip_backward(hf, dL, bwd_form=form)
+        assert hg["bwd_masks"], form
+        for k in ("means2D", "conic", "opacities", "colors"):
+            assert rel_l2(hg[k], og[k]) < 1e-4, (form, k, rel_l2(hg[k], og[k]))
+    hn = G.hip_backward(hf, dL)                                     # ... and in the form the package picks by itself
     for k in ("means2D", "conic", "opacities", "colors"):          # the reverse walk: every row
-        assert rel_l2(hg[k], og[k]) < 1e-4, (k, rel_l2(hg[k], og[k]))
+        assert rel_l2(hn[k], og[k]) < 1e-4, (k, hn["bwd_form"], rel_l2(hn[k], og[k]))
     hp = G.hip_project_backward(hf, og["means2D"], og["conic"])    # the chain rule on identical inputs: every row
     for k in ("means3D", "scales", "rotations"):
         assert rel_l2(hp[k], og[k]) < 1e-6, k
@@ -117,14 +126,23 @@ def _full_parity(oracle_mod, cam, sc, bg, dL_seed=1, check_lists=True, stats_nam
 
 
 @pytest.mark.parametrize("opacity", [0.999, None], ids=["opaque", "opacity_rand"])
-def test_c2_every_view_vs_oracle(oracle_mod, opacity):
-    """C2 as SURVEY 8d defines it: all 8 orbit views, with opacity 0.999 and with random opacities."""
-    from log_amd import scenes
+@pytest.mark.parametrize("flavour_name", ["wodilate", "upstream"])
+def test_c2_every_view_vs_oracle(oracle_mod, opacity, flavour_name):
+    """C2 as SURVEY 8d defines it: all 8 orbit views, with opacity 0.999 and with random opacities.
+    `upstream` (round-5 verdict, next #2b): the SAME views through the other package's low-pass -- cov + 0.3 instead of the
+    fork's max(cov, 0.3) (LoG/model/geometry.py:87-88 against LoG/cuda/compute_radius_kernel.cu:100-104), which keeps every
+    2-D covariance >= 0.3 I and its conic well conditioned -- with north_star's PLAIN criterion asserted: rel-L2 <= 1e-4 over
+    ALL rows of all seven gradient tensors, HIP against float64 and against the fp32 oracle.  It holds there; what the fork's
+    flavour misses on these uniform draws (profiles/r05_gradient_anchor_stats.md, rows c2_*) is therefore the clamp's
+    conditioning (needle splats whose clamped covariance is nearly singular), not the kernels."""
+    from log_amd import rasterizer as R, scenes
     cams = scenes.orbit_cameras(8, W=1920, H=1080, focal=2139.0)
     sc = scenes.random_scene(1_000_000, seed=0, opacity=opacity)
+    up = flavour_name == "upstream"
     for v, cam in enumerate(cams):
         of = _full_parity(oracle_mod, cam, sc, (1.0, 1.0, 1.0), dL_seed=1 + v, check_lists=(v in (0, 5)),
-                          stats_name="c2_%s_view%d" % ("opaque" if opacity else "rand", v))
+                          stats_name="c2_%s%s_view%d" % ("upstream_" if up else "", "opaque" if opacity else "rand", v),
+                          flavour=R.UPSTREAM if up else R.WODILATE, all_rows_tol=1e-4 if up else None)
         assert of["I"] > 2_000_000
 
 

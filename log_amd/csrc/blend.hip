@@ -18,6 +18,11 @@
 // v_permlane32_swap / v_permlane16_swap + DPP row-rotate tree (28 VALU ops for 9 sums) and committed with
 // 3 atomic instructions -- not 9 atomics per (pixel, Gaussian) as in the third-party kernel.
 #include "common.hpp"
+// "These prefetched values have landed": an empty asm that reads and writes them -- the compiler has to wait for their loads
+// right here.  (A bare __builtin_amdgcn_s_waitcnt in front of a loop is hoisted above the loads it was meant for.)
+#define LR_LANDED(q0, q1, c, i)                                                                                  \
+  asm volatile("" : "+v"((q0).x), "+v"((q0).y), "+v"((q0).z), "+v"((q0).w), "+v"((q1).x), "+v"((q1).y), "+v"((q1).z), \
+               "+v"((q1).w), "+v"(c), "+v"(i))
 // Occupancy hints (waves per SIMD the register allocator aims for), per kernel: compile-time so that A/B builds
 // (`python -m log_amd.build <variant> -DLR_OCC_BWD_ROWS_WAVES=5`) can measure them; empty = the allocator's own choice.
 #define LR_OCC_ATTR(n) __attribute__((amdgpu_waves_per_eu(n)))
@@ -26,11 +31,10 @@
 #else
 #define LR_OCC_BWD_ROWS
 #endif
-#ifdef LR_OCC_FWD_ROWS_WAVES
-#define LR_OCC_FWD_ROWS LR_OCC_ATTR(LR_OCC_FWD_ROWS_WAVES)
-#else
-#define LR_OCC_FWD_ROWS
+#ifndef LR_OCC_FWD_ROWS_WAVES
+#define LR_OCC_FWD_ROWS_WAVES 5   // round 6: with the unconditional prefetch loads the allocator's own choice is 102 VGPRs (4 waves); 96 fit without a spill
 #endif
+#define LR_OCC_FWD_ROWS LR_OCC_ATTR(LR_OCC_FWD_ROWS_WAVES)
 #ifdef LR_OCC_BWD_WAVES
 #define LR_OCC_BWD LR_OCC_ATTR(LR_OCC_BWD_WAVES)
 #else
@@ -177,6 +181,7 @@ LR_DEV void lr_lazy_resume(const LrView& v, size_t pix, bool& done, float& T, fl
 // Which form wrote them: lograst_view.hit_mask_form of the backward's view (the caller knows what its forward launched:
 // lograst_forward_form); a reverse walk of the other form ignores the buffer and runs the tests as before.  The forward also
 // leaves the form in header word LR_HDR_MASKS (diagnostics).
+#define LR_MBUF_CHUNKS 64u   // row-split forward: chunks of hit masks a wave collects in LDS between two bursts of stores
 #define LR_MASK_FORM_ROWS 1u
 #define LR_MASK_FORM_QUAD 2u
 LR_DEV size_t lr_mask_slot(uint32_t list_begin, uint32_t tile) { return (size_t)(list_begin >> 6) + tile; }
@@ -587,6 +592,17 @@ LR_DEV float lr_quad_total(float x) {   // every lane of a quad <- the quad's to
   return x + lr_dpp_perm<0x4E>(x);      // quad_perm [2,3,0,1]
 }
 
+// The commit of a row visit, as the bare instruction.  Written with atomicAdd the pass loop "contains a VMEM access that may
+// load" (LLVM marks every atomic so), and SIInsertWaitcnts then flushes vmcnt in the loop's preheader (shouldFlushVmCnt)
+// -- i.e. it waits for the records and ids of the NEXT chunk, requested a few dozen instructions earlier, before the first
+// pass of THIS chunk: one exposed memory round trip per chunk and wave, the prefetch pipeline never overlaps anything.
+// Inline asm is invisible to that pass.  Safe: the instruction returns nothing; vmcnt counts it like any store, and an
+// uncounted operation can only make the compiler's own `s_waitcnt vmcnt(n)` wait longer than needed, never shorter (the
+// counter retires in order: at most n outstanding means everything but the youngest n has completed).
+LR_DEV void lr_atomic_add_noret(float* p, float x) {
+  asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(p), "v"(x) : "memory");
+}
+
 // The next entry of a row's hit mask, per lane (every lane of a 16-lane row holds the row's mask): position of the lowest
 // set bit, 64 = none (the all-zero staging slot); the bit is cleared.  Vector instructions (two v_ffbl, a few selects, a
 // 64-bit add / and): the scalar form -- four masks walked by s_ff1 / s_and / s_cselect chains, ~85 scalar instructions in
@@ -666,31 +682,45 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   // one of the four masks are gathered and staged.  Without masks: top = maxc and the tests run here, as before.
   const int top = use_masks ? ((maxc + 63) & ~63) : maxc;
   const uint32_t nchunks = ((uint32_t)top + 63u) >> 6;
+  // The loads of this pipeline are UNCONDITIONAL (lanes without an entry read a harmless address and the result is replaced
+  // by a select): as exec-masked branches every load had a `keep the old value` copy merged in behind it, and the waitcnt
+  // insertion -- which joins the loop's entry state with its steady state -- then put s_waitcnt vmcnt(0) right behind the id
+  // load at the top of every chunk: one exposed memory round trip per chunk and wave (rounds 3-5 shipped that).  Order per
+  // chunk: the gather of chunk ch + 1 first (its ids arrived a chunk ago), then the ids and masks of chunk ch + 2.
   auto load_id = [&](uint32_t c) -> uint32_t {
     const int pos = top - 1 - (int)(c * 64u) - lane;
-    return (c < nchunks && pos >= 0 && pos < maxc) ? plist[beg + (uint32_t)pos] : 0xffffffffu;
+    const bool ok = c < nchunks && pos >= 0 && pos < maxc;
+    const uint32_t got = plist[beg + (ok ? (uint32_t)pos : 0u)];
+    return ok ? got : 0xffffffffu;
   };
   const uint4* const mbase = use_masks ? reinterpret_cast<const uint4*>(masks + 16 * lr_mask_slot(beg, tile) +
                                                                         4 * __builtin_amdgcn_readfirstlane(wq)) : nullptr;
-  struct Masks4 { uint64_t m0, m1, m2, m3; };
+  struct Masks4 { uint64_t m0, m1, m2, m3; };                // as the forward wrote them: bit j = list position 64 c + j
   auto load_masks = [&](uint32_t c) -> Masks4 {              // (uniform address: scalar loads, 32 bytes per wave and chunk)
-    if (!use_masks || c >= nchunks) return Masks4{0ull, 0ull, 0ull, 0ull};
-    const uint4* mp = mbase + 8 * (size_t)(((uint32_t)top >> 6) - 1u - c);   // (16 words = 8 uint4 per slot)
+    if (!use_masks) return Masks4{0ull, 0ull, 0ull, 0ull};
+    const uint32_t cf = ((uint32_t)top >> 6) - 1u - min(c, nchunks - 1u);    // (past the end: the last chunk's once more)
+    const uint4* mp = mbase + 8 * (size_t)cf;                // (16 words = 8 uint4 per slot)
     const uint4 lo = mp[0], hi4 = mp[1];
-    return Masks4{__builtin_bitreverse64(((uint64_t)lo.y << 32) | lo.x), __builtin_bitreverse64(((uint64_t)lo.w << 32) | lo.z),
-                  __builtin_bitreverse64(((uint64_t)hi4.y << 32) | hi4.x), __builtin_bitreverse64(((uint64_t)hi4.w << 32) | hi4.z)};
+    return Masks4{((uint64_t)lo.y << 32) | lo.x, ((uint64_t)lo.w << 32) | lo.z,
+                  ((uint64_t)hi4.y << 32) | hi4.x, ((uint64_t)hi4.w << 32) | hi4.z};
+  };
+  auto wanted = [&](const Masks4& m) -> bool {               // does any row of this wave visit lane's entry?  (lane l of a
+    return !use_masks || (((m.m0 | m.m1 | m.m2 | m.m3) >> (63 - lane)) & 1ull) != 0ull;   // reverse chunk = the forward's bit 63 - l)
+  };
+  auto gather = [&](uint32_t idv, bool want, float4& q0, float4& q1, float& qc) {
+    const float4* rp = geom + LR_REC_QUADS * (size_t)(want ? idv : 0u);       // (record 0: inside the buffer, never used)
+    q0 = rp[0]; q1 = rp[1]; qc = reinterpret_cast<const float*>(rp)[8];
   };
   uint32_t id_n = load_id(0), id_nn = load_id(1);
   Masks4 mk_n = load_masks(0), mk_nn = load_masks(1);
-  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
-  float cb_n = 0.f;
-  auto wanted = [&](const Masks4& m) -> bool {               // does any row of this wave visit lane's entry?
-    return !use_masks || (((m.m0 | m.m1 | m.m2 | m.m3) >> lane) & 1ull) != 0ull;
-  };
-  if (id_n != 0xffffffffu && wanted(mk_n)) {
-    const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
-    g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
-  }
+  float4 g0_n, g1_n;
+  float cb_n;
+  gather(id_n, id_n != 0xffffffffu && wanted(mk_n), g0_n, g1_n, cb_n);
+  // Everything requested so far has landed before the loop is entered: the waitcnt insertion joins the loop's entry state
+  // with its steady state, and with the first gather still in flight at the entry it guards every later write of those
+  // registers -- temporaries of the pass loop -- with s_waitcnt vmcnt(4..5), which (the counter retires in order, and the
+  // commits of the passes count too) makes the second and third pass of every chunk wait for the NEXT chunk's records.
+  LR_LANDED(g0_n, g1_n, cb_n, id_nn);
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     const int hi = top - (int)(ch * 64u);
@@ -699,17 +729,14 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     const float cb = cb_n;
     const Masks4 mk = mk_n;
     id_n = id_nn;
-    id_nn = load_id(ch + 2);
     mk_n = mk_nn;
+    gather(id_n, id_n != 0xffffffffu && wanted(mk_n), g0_n, g1_n, cb_n);
+    id_nn = load_id(ch + 2);
     mk_nn = load_masks(ch + 2);
-    if (id_n != 0xffffffffu && wanted(mk_n)) {
-      const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
-      g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
-    }
     // this chunk's entries -> LDS (the wave's own slots; the previous chunk's reads have all returned)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (wanted(mk)) {
+    if (id != 0xffffffffu && wanted(mk)) {
       stage[lane * LR_RB_SLOT + 0] = g0;
       stage[lane * LR_RB_SLOT + 1] = g1;
       stage[lane * LR_RB_SLOT + 2] = float4{cb, __uint_as_float(id), 0.f, 0.f};
@@ -742,7 +769,8 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       }
     }
     uint64_t mrow;                                            // this lane's row's hit mask
-    if (use_masks) mrow = lr_mask_before(lr_row_mask(row, mk.m0, mk.m1, mk.m2, mk.m3), hi, rmax);   // (rmax: this lane's row's deepest contributor)
+    if (use_masks) mrow = lr_mask_before(lr_row_mask(row, __builtin_bitreverse64(mk.m0), __builtin_bitreverse64(mk.m1),
+                                                     __builtin_bitreverse64(mk.m2), __builtin_bitreverse64(mk.m3)), hi, rmax);   // (rmax: this lane's row's deepest contributor)
     else mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));
     if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone
     while (__builtin_amdgcn_ballot_w64(mrow != 0ull) != 0) {
@@ -803,8 +831,8 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const float xa = sel == 0 ? s1a : (sel == 1 ? s2a : s3);
       const float xb = sel == 0 ? s1b : (sel == 1 ? s2b : s3);
       if (!LR_ABLATED(1)) {
-        if (on_a && gida != 0xffffffffu) atomicAdd(dst + (size_t)gida * LOGRAST_BWD_ROW_FLOATS, xa);
-        if (on_b && gidb != 0xffffffffu) atomicAdd(dst + (size_t)gidb * LOGRAST_BWD_ROW_FLOATS, xb);
+        if (on_a && gida != 0xffffffffu) lr_atomic_add_noret(dst + (size_t)gida * LOGRAST_BWD_ROW_FLOATS, xa);
+        if (on_b && gidb != 0xffffffffu) lr_atomic_add_noret(dst + (size_t)gidb * LOGRAST_BWD_ROW_FLOATS, xb);
       }
     }
   }
@@ -836,7 +864,27 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   uint32_t end = offsets[tile + 1], first;
   bool clamped;
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
-  uint64_t* const mrow_out = masks ? masks + 16 * lr_mask_slot(beg, tile) + 4 * wq + (lane >> 4) : nullptr;
+  // Hit masks for the reverse walk: collected in LDS (64 chunks x 4 block masks per wave) and written out in bursts -- when
+  // the buffer is full and after the walk.  A store per chunk, straight from the loop, cost the kernel 60-90 us at 30 M
+  // (544 -> 602-632): gfx9 counts loads and stores in ONE counter (vmcnt) and they return out of order with each other, so
+  // with a store in flight every wait for a prefetched record becomes vmcnt(0) -- the two-chunk software pipeline of this
+  // loop drains once per chunk.  (The quadrant kernel's records come through the scalar cache: measured neutral there.)
+  __shared__ uint64_t lr_mbuf[4][LR_MBUF_CHUNKS * 4];
+  uint64_t* const mslot = masks ? masks + 16 * lr_mask_slot(beg, tile) + 4 * wq : nullptr;
+  uint32_t mcount = 0;                                       // chunks waiting in lr_mbuf[wq] (wave-uniform)
+  uint32_t mfirst = 0;                                       // ... the first of them (chunk index inside the tile's list)
+  auto flush_masks = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!LR_ABLATED(8))
+    for (uint32_t i = (uint32_t)lane; i < mcount * 4u; i += 64u)   // lane -> (chunk i / 4, block i % 4): 32 adjacent bytes per chunk
+      mslot[16 * (size_t)(mfirst + (i >> 2)) + (i & 3u)] = lr_mbuf[wq][i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    mfirst += mcount;
+    mcount = 0;
+  };
   if (!lr_lazy_range(lazy_state + lr_sorted_off(tiles), tiles, lazy, tile, wq, beg, end, first, clamped)) return;
   const int row = lane >> 4, li = lane & 15;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
@@ -860,17 +908,32 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   const uint64_t rowbits = 0xffffull;
 
   const uint32_t nchunks = (end - beg + 63u) >> 6;
+  if (end == beg) {                                          // an empty list (the loads below are unconditional: plist[beg] must exist)
+    if (inside && lazy != 2) {
+      const size_t plane = (size_t)v.W * v.H;
+      final_T[pix] = 1.f; n_contrib[pix] = 0;
+      image[pix] = v.bg[0]; image[plane + pix] = v.bg[1]; image[2 * plane + pix] = v.bg[2];   // (fma(1, bg, 0) = bg)
+      if (EXTRAS) { pid[pix] = -1; pwp[pix] = 0.f; }
+    }
+    return;
+  }
+  // Unconditional loads, the gather of chunk ch + 1 in front of the ids of chunk ch + 2 (see lr_blend_bwd_rows_kernel: as
+  // exec-masked branches they drew an s_waitcnt vmcnt(0) right behind the id load of every chunk)
   auto load_id = [&](uint32_t c) -> uint32_t {
     const uint32_t idx = beg + c * 64u + (uint32_t)lane;
-    return (c < nchunks && idx < end) ? plist[idx] : 0xffffffffu;
+    const bool ok = c < nchunks && idx < end;
+    const uint32_t got = plist[ok ? idx : beg];
+    return ok ? got : 0xffffffffu;
+  };
+  auto gather = [&](uint32_t idv, float4& q0, float4& q1, float& qc) {
+    const float4* rp = geom + LR_REC_QUADS * (size_t)(idv != 0xffffffffu ? idv : 0u);   // (record 0: inside the buffer, never used)
+    q0 = rp[0]; q1 = rp[1]; qc = reinterpret_cast<const float*>(rp)[8];
   };
   uint32_t id_n = load_id(0), id_nn = load_id(1);
-  float4 g0_n = {0.f, 0.f, 0.f, 0.f}, g1_n = {0.f, 0.f, 0.f, 0.f};
-  float cb_n = 0.f;
-  if (id_n != 0xffffffffu) {
-    const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
-    g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
-  }
+  float4 g0_n, g1_n;
+  float cb_n;
+  gather(id_n, g0_n, g1_n, cb_n);
+  LR_LANDED(g0_n, g1_n, cb_n, id_nn);                        // (see lr_blend_bwd_rows_kernel: the loop's entry state = its steady state)
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     if (__all(done)) break;
@@ -878,11 +941,8 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     const float4 g0 = g0_n, g1 = g1_n;
     const float cb = cb_n;
     id_n = id_nn;
+    gather(id_n, g0_n, g1_n, cb_n);
     id_nn = load_id(ch + 2);
-    if (id_n != 0xffffffffu) {
-      const float4* rp = geom + LR_REC_QUADS * (size_t)id_n;
-      g0_n = rp[0]; g1_n = rp[1]; cb_n = reinterpret_cast<const float*>(rp)[8];
-    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     stage[lane * LR_RB_SLOT + 0] = g0;
@@ -904,7 +964,11 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     }
     uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
     const int pos0 = (int)(first + ch * 64u);
-    if (mrow_out && li == 0) mrow_out[16 * (size_t)(pos0 >> 6)] = mrow;   // four lanes, 32 adjacent bytes: for the reverse walk (hit masks, above)
+    if (mslot) {                                              // for the reverse walk (hit masks, above)
+      if (mcount == 0) mfirst = (uint32_t)pos0 >> 6;
+      if (li == 0 && !LR_ABLATED(16)) lr_mbuf[wq][mcount * 4u + (uint32_t)row] = mrow;
+      if (++mcount == LR_MBUF_CHUNKS) flush_masks();
+    }
     if (LR_ABLATED(4)) mrow = 0ull;   // experiment builds: the chunk prologue alone (gathers, staging, support tests), every list to its end
     while (true) {
       // a row whose 16 pixels are all saturated takes no more entries
@@ -967,6 +1031,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       }
     }
   }
+  if (mslot && mcount) flush_masks();
   if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
     if (lane == 0) { atomicOr(lazy_state + lr_sorted_off(tiles) + tiles + tile, 1u << wq); atomicOr(lazy_state + LR_HDR_OPEN, 1u); }   // open[tile], header
     if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);

@@ -81,6 +81,7 @@ _INPLACE_TAG = "_lograst_inplace_grad"   # attribute set on leaves whose owner a
 _status = {}          # device -> int32[8] status block (sticky across forwards, all streams)
 _debug_keep = False   # tests: keep dL/dconic of the last backward (HipBackend.last_conic_grad)
 _hit_masks = True     # a training forward hands its compositing kernels a hit-mask buffer for the reverse walk (blend.hip)
+_zero_hit_masks = False   # tools/mask_stats.py: a zero-filled buffer, so that the slots nobody wrote read as "no visit"
 _keep_keys = False    # tests: the forward's key buffer stays alive in `saved` (finish_lists below needs it)
 _DEBUG_ADDR = bool(int(__import__('os').environ.get('LOGRAST_DEBUG_ADDR', '0')))
 
@@ -444,7 +445,8 @@ class HipBackend:
             """The hit-mask buffer of a training forward with room for `cap` tile instances (uninitialised)."""
             if not want_masks:
                 return None
-            m = torch.empty(L.lograst_hit_mask_bytes(cap, W, H) // 8, dtype=torch.int64, device=device)
+            m = (torch.zeros if _zero_hit_masks else torch.empty)(L.lograst_hit_mask_bytes(cap, W, H) // 8, dtype=torch.int64,
+                                                                  device=device)
             view.hit_masks, view.hit_mask_words = m.data_ptr(), m.numel()
             return m
         ckey = (device.index, W, H, _tile_rows.get())

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--train-fwd-only", action="store_true", help="training forwards (accumulator rows, hit masks) without their backward")
     ap.add_argument("--sink", action="store_true", help="backward adds into one row-major running-sum buffer (bench.py's pipelined form)")
     ap.add_argument("--env", nargs="*", default=[])
     ap.add_argument("--tag", default="")
@@ -48,6 +49,10 @@ def main():
                     rast(means3D=wl.base["means3D"], means2D=torch.empty(wl.N, 3, device=dev), shs=None,
                          colors_precomp=wl.base["colors"], opacities=wl.base["opacities"], scales=wl.base["scales"],
                          rotations=wl.base["rotations"], cov3D_precomp=None)
+            elif a.train_fwd_only:
+                rast(means3D=leaves["means3D"], means2D=torch.empty(wl.N, 3, device=dev).requires_grad_(True), shs=None,
+                     colors_precomp=leaves["colors"], opacities=leaves["opacities"], scales=leaves["scales"],
+                     rotations=leaves["rotations"], cov3D_precomp=None)
             else:
                 wl.one_view(rast, leaves)
                 for t in leaves.values():

@@ -62,6 +62,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BENCH_ROUND = 6        # committed counter profiles of EARLIER rounds are stale (the kernels changed): roofline.traffic drops them
 
 
 def parse():
@@ -85,9 +86,14 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true",
                     help="pipelined mode: enqueue every view's ~15 launches from Python instead of replaying one captured "
                          "HIP graph per view")
-    ap.add_argument("--exchange-parts", type=int, default=int(os.environ.get("LOGRAST_EXCHANGE_PARTS", "1")),
-                    help="N > 1: groups of views per step, each reduce-scattered under the next group's rendering")
+    ap.add_argument("--exchange-parts", type=int, default=int(os.environ.get("LOGRAST_EXCHANGE_PARTS", "0")),
+                    help="N > 1: groups of views per step, each exchanged under the next group's rendering.  0 (default) = one "
+                         "group per view when the row-sparse exchange runs (STREAMED: a view's touched rows are packed, cleared "
+                         "and sent while the next view renders; log_amd.dist.StepExchange), one group otherwise (a dense group "
+                         "exchange is as large as the whole step's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-out", default=None,
+                    help="where the full result object goes (default: bench_full.json next to bench.py and in gpurun_out/)")
     ap.add_argument("--print-full", action="store_true",
                     help="also print the full result object (what bench_full.json holds) on an EARLIER stdout line")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -235,7 +241,8 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     dev, N = wl.dev, wl.N
     wl.zero_means2d = not (sync_free and fused)
     rank = dist.get_rank() if world > 1 else 0
-    parts = max(1, min(int(args.exchange_parts), len(wl.rasts) // S)) if world > 1 else 1
+    auto_parts = int(args.exchange_parts) <= 0
+    parts = max(1, min(len(wl.rasts) // S if auto_parts else int(args.exchange_parts), len(wl.rasts) // S)) if world > 1 else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     # The step's gradient exchange (log_amd.dist.StepExchange): the rank's views in `parts` consecutive groups with a
     # bucket each; group g's reduce-scatter runs on a side stream under the rendering of group g + 1.
@@ -252,11 +259,25 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     compact = {"on": args.exchange == "compact" and world > 1}
     sparse = {"on": args.exchange == "sparse" and world > 1 and row_major, "kmax": None, "gather": None}
 
+    gathered = {"t": None}     # streamed sparse exchange: the persistent result of the closing all-gather (bucket 0 stays clean)
+
+    def n_parts():
+        """Groups of views in use: all of them when the groups' exchanges are smaller than the step's (row-sparse, touched
+        blocks), ONE when --exchange-parts is automatic and the dense form runs (every dense group is full-size)."""
+        return parts if (sparse["on"] or compact["on"] or not auto_parts) else 1
+
+    def gather(total):
+        if sparse["on"] and n_parts() > 1:
+            if gathered["t"] is None:
+                gathered["t"] = torch.empty(world * ex.buckets[0].Pr, 16, device=dev)
+            return ex.all_gather_grads(total, sparse_kmax=sparse["gather"] or "exact", into=gathered["t"])
+        return ex.all_gather_grads(total, sparse_kmax=(sparse["gather"] or "exact") if sparse["on"] else None)
+
     def exchange():
         """The step's exchange: reduce-scatter (dense / touched blocks / touched rows) per group, then the all-gather."""
-        for part in range(parts):
+        for part in range(n_parts()):
             ex.launch(part, compact=compact["on"], kmax=sparse["kmax"] if sparse["on"] else compact.get("kmax"), sparse=sparse["on"])
-        ex.all_gather_grads(ex.finish(), sparse_kmax=(sparse["gather"] or "exact") if sparse["on"] else None)
+        gather(ex.finish())
     lanes = []
     for li in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient buckets
         leaves = {k: v.detach().requires_grad_(True) for k, v in wl.base.items()}
@@ -265,21 +286,31 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         bks[0].attach(leaves)
         lanes.append((leaves, bks))
     lane_views = [wl.rasts[li::S] for li in range(S)]
-    part_of = [[min(j * parts // max(len(lv), 1), parts - 1) for j in range(len(lv))] for lv in lane_views]
+
+    def part_of_view(li, j):
+        np_ = n_parts()
+        return min(j * np_ // max(len(lane_views[li]), 1), np_ - 1)
 
     lane_graphs = None
+    state = {"clean": False}   # did the previous step leave every bucket all zero (streamed exchange: pack and clear)?
 
     def step(do_exchange=True):
         main = torch.cuda.current_stream(dev)
         for st in streams:
             st.wait_stream(main)
+        # (streamed sparse exchange, one lane: every bucket was cleared by its own pack -- no zero-fill between steps)
+        clean = sparse["on"] and n_parts() > 1 and S == 1 and ex.streamed and do_exchange and state["clean"]
         for li, (_, bks) in enumerate(lanes):
             with torch.cuda.stream(streams[li]):
-                for bk in bks:
-                    bk.zero()
-        for part in range(parts):
+                if clean:
+                    ex.begin_step()
+                else:
+                    for bk in bks:
+                        bk.zero()
+        state["clean"] = bool(sparse["on"] and n_parts() > 1 and do_exchange)
+        for part in range(n_parts()):
             for li, (leaves, bks) in enumerate(lanes):
-                mine = [j for j in range(len(lane_views[li])) if part_of[li][j] == part]
+                mine = [j for j in range(len(lane_views[li])) if part_of_view(li, j) == part]
                 with torch.cuda.stream(streams[li]):
                     if lane_graphs is not None:
                         for j in mine:
@@ -306,7 +337,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                     ex.launch(part, compact=compact["on"], kmax=sparse["kmax"] if sparse["on"] else compact.get("kmax"),
                               sparse=sparse["on"])
         if world > 1 and do_exchange:                   # every rank ends the step with the whole gradient sum
-            ex.all_gather_grads(ex.finish(), sparse_kmax=(sparse["gather"] or "exact") if sparse["on"] else None)
+            gather(ex.finish())
 
     # ---- V and I per view, measured once in exact mode (one 4-byte read-back per view) ----
     R.set_instance_capacity(None)
@@ -321,6 +352,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
            "V": float(np.mean([s[0] for s in stats])), "I": float(np.mean([s[1] for s in stats])),
            "I_rect": float(np.mean([s[3] for s in stats])), "bucket_floats": int(ex.buckets[0].flat.numel()),
            "exchange_parts": parts}
+    res["exchange_parts_auto"] = auto_parts
     cap = int(max(s[1] for s in stats) * 1.02) + 1024
     if sync_free:
         # from here on: no host sync inside forward(); the longest tile list (it picks the sort's multi-block levels)
@@ -382,6 +414,8 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                     res["exchange_sparse_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
                     torch.cuda.synchronize()
         res["exchange_mode"] = "sparse" if sparse["on"] else ("compact" if compact["on"] else "dense")
+        res["exchange_parts"] = n_parts()
+        res["exchange_streamed"] = bool(sparse["on"] and n_parts() > 1)
         del nz
         ex.reset_timing()
     res["graphs"] = False
@@ -395,7 +429,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             for li, (leaves, bks) in enumerate(lanes):
                 pool, gl = torch.cuda.graph_pool_handle(), []
                 for j, rast in enumerate(lane_views[li]):
-                    with R.accumulate_grads_into(bks[part_of[li][j]].views):
+                    with R.accumulate_grads_into(bks[part_of_view(li, j)].views):
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, pool=pool, stream=streams[li]):
                             wl.one_view(rast, leaves)
@@ -812,6 +846,7 @@ def main():
     if world > 1:
         result["exchange"] = {
             "mode": r.get("exchange_mode"), "policy": args.exchange, "parts": r["exchange_parts"], "backend": backend,
+            "streamed": r.get("exchange_streamed"), "parts_policy": "auto" if r.get("exchange_parts_auto") else "fixed",
             "nonzero_gradient_row_fraction": r.get("exchange_nonzero_row_fraction"),
             "touched_row_fraction": r.get("exchange_touched_row_fraction"), "row_bounds": r.get("exchange_row_bounds"),
             "sparse_error": r.get("exchange_sparse_error"),
@@ -957,6 +992,7 @@ def main():
         result["secondary"] = sec
 
     if rank == 0:
+        result["parity"] = parity_summary()
         flatten_for_the_driver(result)
         emit(result, args)
     if world > 1:
@@ -1023,8 +1059,8 @@ def compact_line(result):
     if isinstance(rf, dict):
         r = {"bound": rf.get("bound"), "kernel": rf.get("kernel"), "achieved": _num(rf.get("achieved")),
              "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _num(rf.get("frac"), 4),
-             "traffic": _num(rf.get("traffic"), 8), "traffic_source": "profiles/ (rocprofv3 --pmc, builder-collected)"
-             if rf.get("traffic") else None,
+             "traffic": _num(rf.get("traffic"), 8),
+             "traffic_source": (str(rf.get("traffic_source", ""))[17:].split(" ")[0] if rf.get("traffic") else None),
              "valu_issue_frac": _num(rf.get("valu_issue_frac"), 3), "avg_launch_us": _num(rf.get("avg_launch_us"), 5),
              "algorithmic_bytes_per_launch": _num(rf.get("algorithmic_bytes_per_launch"), 8),
              "measured_stream_copy_GBs": _num(rf.get("measured_stream_copy_GBs"), 5),
@@ -1049,8 +1085,8 @@ def compact_line(result):
             if cb.get(k) is not None:
                 b[k] = _num(cb[k]) if not isinstance(cb[k], str) else cb[k][:120]
         line["cpu_baseline"] = b
-    if result.get("parity") is not None:
-        line["parity"] = result["parity"]
+    if parity_line(result.get("parity")) is not None:
+        line["parity"] = parity_line(result.get("parity"))
     line["details"] = "bench_full.json (profiles/r06_bench_full.json: the builder's copy of one run)"
     text = json.dumps(line, separators=(",", ":"))
     if len(text) >= LINE_LIMIT:                    # never let the line outgrow the driver again: shed the per-kernel times
@@ -1061,13 +1097,14 @@ def compact_line(result):
 def emit(result, args=None):
     """Full result -> bench_full.json (+ gpurun_out/); compact contract line -> the LAST stdout line."""
     full = json.dumps(result)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
-        if os.path.isdir(d):
-            try:
-                with open(os.path.join(d, "bench_full.json"), "w") as f:
-                    f.write(full + "\n")
-            except OSError:
-                pass
+    where = ([args.full_out] if args is not None and getattr(args, "full_out", None) else
+             [os.path.join(d, "bench_full.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)])
+    for path in where:
+        try:
+            with open(path, "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
     if args is not None and getattr(args, "print_full", False):
         print(full, flush=True)
     text = json.dumps(compact_line(result), separators=(",", ":"))
@@ -1147,8 +1184,10 @@ def roof(prof, alg, alg_eff, N, W, H):
                   "achieved_survey_formula": alg.get(dom, 0) / avg_s / 1e9,
                   "frac_survey_formula": alg.get(dom, 0) / avg_s / 1e9 / HBM_PEAK_GBS,
                   "traffic": pmc_traffic(dom, N, W, H),
-                  "traffic_source": "committed profile (profiles/r*_traffic*.json, collected by the builder with rocprofv3 "
-                                    "--pmc on this workload; not measured in this run)",
+                  "traffic_source": ("committed profile %s (collected by the builder with rocprofv3 --pmc on this workload in "
+                                     "this round; not measured in this run)" % os.path.relpath(traffic_profile(N, W, H)[0], ROOT)
+                                     if traffic_profile(N, W, H)[0] else
+                                     "none: no counter profile of this workload from round %d is committed" % BENCH_ROUND),
                   # the compositing kernels are bound by fp32 VALU issue, which the hbm/mfma vocabulary of
                   # this object cannot name: fraction of SIMD issue cycles spent in VALU ops (PMC pass)
                   "valu_issue_frac": pmc_traffic(dom, N, W, H, "valu_active_frac_at_2p4GHz"),
@@ -1236,21 +1275,66 @@ def compute_radius_leg(wl, reps=5):
             "gaussians_per_s": wl.N / (best * 1e-3)}
 
 
-def pmc_traffic(kernel, N, W, H, field="traffic_bytes"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_traffic*.json,
-    FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md prescribes); None when no profile of this
-    exact workload is committed -- counters cannot be collected from inside the timed run."""
+def traffic_profile(N, W, H):
+    """-> (path, dict) of the committed counter profile of this exact workload FROM THIS ROUND (profiles/rNN_traffic*.json,
+    NN = BENCH_ROUND), or (None, None): a profile of an earlier round describes kernels that have changed since
+    (round-5 verdict, #8: `roofline.traffic` must not go stale silently)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r%02d_traffic*.json" % BENCH_ROUND)), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
             wl = d.get("workload", {})
-            if (wl.get("gaussians"), wl.get("width"), wl.get("height")) == (N, W, H) and kernel in d["kernels"]:
-                return d["kernels"][kernel].get(field)
+            if (wl.get("gaussians"), wl.get("width"), wl.get("height")) == (N, W, H):
+                return path, d
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, None
+
+
+def pmc_traffic(kernel, N, W, H, field="traffic_bytes"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE
+    collected and corrected as MI355X_MICROARCH.md prescribes); None when no profile of this exact workload from this
+    round is committed -- counters cannot be collected from inside the timed run."""
+    _, d = traffic_profile(N, W, H)
+    try:
+        return d["kernels"][kernel].get(field) if d else None
+    except (KeyError, AttributeError):
+        return None
+
+
+def parity_summary():
+    """The measured gradient deviations of this round's `pytest -m gpu` run (profiles/rNN_parity_summary.json, written by
+    tools/anchor_stats_md.py from the tests' own dumps): HIP against the fp32 oracle and against float64, all rows and
+    well-conditioned rows, per case group -- carried in the full result so that what misses north_star's plain 1e-4 (the
+    fork's clamp on check_gui's uniform draws) is reported next to the throughput, not buried (round-5 verdict, next #2d)."""
+    path = os.path.join(ROOT, "profiles", "r%02d_parity_summary.json" % BENCH_ROUND)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    d["file"] = os.path.relpath(path, ROOT)
+    return d
+
+
+def parity_line(p):
+    """The few numbers of parity_summary() the compact line carries: worst all-rows rel-L2 (HIP vs fp32 oracle) over the C2
+    views, per flavour, and on the trained-like 30 M scene."""
+    if not isinstance(p, dict):
+        return None
+    g = p.get("groups", {})
+    worst = lambda names: max([g[n][k]["all_rows_hip_vs_oracle"] for n in names if n in g for k in ("means3D", "scales", "rotations")
+                               if k in g[n] and "all_rows_hip_vs_oracle" in g[n][k]] or [None], key=lambda x: -1 if x is None else x)
+    walk = lambda names: max([g[n][k]["hip_vs_f64"] for n in names if n in g for k in ("means2D", "conic", "opacities", "colors")
+                              if k in g[n]] or [None], key=lambda x: -1 if x is None else x)
+    out = {"tol": 1e-4, "what": "max rel-L2 over ALL rows, HIP vs fp32 oracle (dL/dmeans3D, dscales, drotations), MI355X",
+           "c2_upstream_pkg": _num(worst(("c2_upstream_opaque", "c2_upstream_rand")), 2),
+           "c2_wodilate_fork_clamp": _num(worst(("c2_opaque", "c2_rand")), 2),
+           "trained_like_30M": _num(worst(("trained_like_30M",)), 2),
+           "reverse_walk_vs_f64_c2": _num(walk(("c2_opaque", "c2_rand", "c2_upstream_opaque", "c2_upstream_rand")), 2),
+           "file": p.get("file")}
+    return {k: v for k, v in out.items() if v is not None}
 
 
 def cpu_baseline(sc, cams, wloss, N, budget_s=12.0, max_passes=64):
@@ -1272,9 +1356,29 @@ def cpu_baseline(sc, cams, wloss, N, budget_s=12.0, max_passes=64):
         oracle.backward(v, f, wloss)
         passes += 1
     dt = time.perf_counter() - t0
-    return {"value": N * passes / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
-            "sample": "%d view pass(es) (cycling the %d views), all %d Gaussians each, forward+backward, %.1f s total"
-                      % (passes, len(views), N, dt)}
+    out = {"value": N * passes / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+           "sample": "%d view pass(es) (cycling the %d views), all %d Gaussians each, forward+backward, %.1f s total"
+                     % (passes, len(views), N, dt)}
+    out.update(reference_python_radius())
+    return out
+
+
+def reference_python_radius():
+    """north_star: "alongside the reference's pure-PyTorch/CPU render path timed on the same box's host cores".  The
+    reference has no CPU renderer; its only CPU-runnable arithmetic on this path is LoG.model.geometry.compute_radius
+    (geometry.py:132-151, the Python twin of A0).  /root/reference does not exist on the driver's box, so the number is the
+    builder's measurement on a pool box of the same kind (tools/time_reference_radius.py, which IMPORTS the reference:
+    profiles/rNN_reference_python_radius.json), carried here next to the port's whole-path figure."""
+    path = os.path.join(ROOT, "profiles", "r%02d_reference_python_radius.json" % BENCH_ROUND)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return {"reference_python_radius_gaussians_per_s": d["gaussians_per_s"], "reference_python_radius_cores": d["cores"],
+                "reference_python_radius_points": d["points"],
+                "reference_python_radius_gpu_kernel_gaussians_per_s": d.get("gpu_gaussians_per_s"),
+                "reference_python_radius_source": os.path.relpath(path, ROOT) + " (geometry.py:132-151; builder-run on a pool box)"}
+    except (OSError, ValueError, KeyError):
+        return {}
 
 
 if __name__ == "__main__":

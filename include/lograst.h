@@ -250,10 +250,17 @@ int lograst_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks
  *                 ((s0 + s1) + s2) + ... on every run, whatever order the segments arrived in)
  *   atomic == 0:  dest[s * dest_group_rows + index][..] = values   (segment s owns its own range of rows: plain stores;
  *                 dest_group_rows >= rows_per_group)
+ *   atomic == 2:  dest[s * dest_group_rows + index][..] = 0        (version 4: clears exactly the rows an earlier
+ *                 atomic == 0 call with the same segments wrote -- cheaper than zero-filling a mostly empty result)
  * dest and packed must be 16-byte aligned. */
 size_t lograst_sparse_segment_floats(int32_t kmax);
 int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
                       uint32_t* overflow, void* stream);
+/* lograst_pack_rows that also ZEROES every row it packed in `rows` ("pack and clear", version 4): the bucket of a group of
+ * views is all zero again once its rows are on their way, so a step that streams its exchange group by group
+ * (log_amd.dist.StepExchange, parts > 1, sparse) never zero-fills its buckets.  Rows dropped by an exceeded kmax stay. */
+int lograst_pack_rows_clear(float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                            uint32_t* overflow, void* stream);
 int lograst_unpack_rows(float* dest, const float* packed, int32_t segments, int32_t kmax, int64_t rows_per_group,
                         int64_t dest_group_rows, int32_t atomic, void* stream);
 

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "lograst_stream_copy": (ctypes.c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
     "lograst_sparse_segment_floats": (c_size_t, [c_int32]),
     "lograst_pack_rows": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "lograst_pack_rows_clear": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "lograst_unpack_rows": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64, c_int32,
                                            c_void_p]),
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),

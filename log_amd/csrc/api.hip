@@ -28,10 +28,10 @@ bool lr_band_sparse(const LrView& v, int batch);
 void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 // exchange.hip
-void lx_launch_pack_rows(const float* rows, int groups, long long rows_per_group, int kmax, float* packed,
-                         size_t seg_floats, uint32_t* overflow, hipStream_t s);
+void lx_launch_pack_rows(float* rows, int groups, long long rows_per_group, int kmax, float* packed,
+                         size_t seg_floats, uint32_t* overflow, int clear, hipStream_t s);
 void lx_launch_unpack_rows(float* dest, const float* packed, int segments, int kmax, size_t seg_floats,
-                           long long rows_per_group, long long dest_group_rows, int atomic, hipStream_t s);
+                           long long rows_per_group, long long dest_group_rows, int add, int zero, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
                     uint32_t capacity, uint32_t max_len_hint, uint32_t* status, float* zero_n, float* zero_block,
                     int zero_block_floats, int rebased, int speculative, int band, int staged_k, hipStream_t s);
@@ -670,7 +670,20 @@ int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group,
   if ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(packed)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: rows / packed must be 16-byte aligned");
   if (rows_per_group > 0x7fffffffLL) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: rows_per_group exceeds 31 bits (int32 row indices)");
-  lx_launch_pack_rows(rows, groups, rows_per_group, kmax, packed, lograst_sparse_segment_floats(kmax), overflow, (hipStream_t)stream);
+  lx_launch_pack_rows(const_cast<float*>(rows), groups, rows_per_group, kmax, packed, lograst_sparse_segment_floats(kmax), overflow, 0,
+                      (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+int lograst_pack_rows_clear(float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                            uint32_t* overflow, void* stream) {
+  if (groups < 0 || rows_per_group < 0 || kmax <= 0) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows_clear: negative size or kmax <= 0");
+  if (groups == 0 || rows_per_group == 0) return LOGRAST_OK;
+  if (!rows || !packed) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(packed)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows_clear: rows / packed must be 16-byte aligned");
+  if (rows_per_group > 0x7fffffffLL) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows_clear: rows_per_group exceeds 31 bits (int32 row indices)");
+  lx_launch_pack_rows(rows, groups, rows_per_group, kmax, packed, lograst_sparse_segment_floats(kmax), overflow, 1, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
@@ -682,10 +695,11 @@ int lograst_unpack_rows(float* dest, const float* packed, int32_t segments, int3
   if (!dest || !packed) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
   if ((reinterpret_cast<uintptr_t>(dest) | reinterpret_cast<uintptr_t>(packed)) & 15u)
     return lr_fail(LOGRAST_ERR_ARG, "lograst_unpack_rows: dest / packed must be 16-byte aligned");
-  if (!atomic && dest_group_rows < rows_per_group)
+  if (atomic != 1 && dest_group_rows < rows_per_group)
     return lr_fail(LOGRAST_ERR_ARG, "lograst_unpack_rows: dest_group_rows must cover rows_per_group (segment s owns rows [s * dest_group_rows, ...))");
+  if (atomic < 0 || atomic > 2) return lr_fail(LOGRAST_ERR_ARG, "lograst_unpack_rows: atomic is 0 (store), 1 (add) or 2 (zero the named rows)");
   lx_launch_unpack_rows(dest, packed, segments, kmax, lograst_sparse_segment_floats(kmax), rows_per_group,
-                        atomic ? 0 : dest_group_rows, atomic, (hipStream_t)stream);
+                        atomic == 1 ? 0 : dest_group_rows, atomic == 1, atomic == 2, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

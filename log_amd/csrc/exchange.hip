@@ -23,8 +23,12 @@ lx_clear_headers_kernel(float* __restrict__ packed, int groups, size_t seg_float
 // One workgroup: LX_ROWS_PER_BLOCK consecutive rows of ONE group (four rows per thread, their 16 loads in flight
 // together); non-zero rows are counted per wave (ballot), ranked across the workgroup in LDS, and ONE atomic per workgroup
 // reserves the slots in the group's segment (a counter per group is one address: per-wave atomics on it would serialise).
+// CLEAR: a packed row is zeroed in the bucket behind the copy ("pack and clear": the bucket of a group of views is all zero
+// again once its rows are on their way, so a step that streams its exchange group by group never zero-fills a 1.9 GB
+// bucket; rows dropped by an exceeded kmax stay -- the caller repeats that step from zeroed buckets anyway).
+template <bool CLEAR>
 __global__ void __launch_bounds__(256)
-lx_pack_rows_kernel(const float4* __restrict__ rows, int groups, long long rows_per_group, int kmax,
+lx_pack_rows_kernel(float4* __restrict__ rows, int groups, long long rows_per_group, int kmax,
                     float* __restrict__ packed, size_t seg_floats, uint32_t* __restrict__ overflow, int blocks_per_group) {
   __shared__ uint32_t wave_cnt[4][4];
   __shared__ uint32_t base_s;
@@ -39,7 +43,7 @@ lx_pack_rows_kernel(const float4* __restrict__ rows, int groups, long long rows_
     const long long r = r0 + u * 256 + tid;
     nz[u] = false;
     if (r < rows_per_group) {
-      const float4* p = rows + 4 * ((size_t)g * (size_t)rows_per_group + (size_t)r);
+      const float4* p = rows + 4 * ((size_t)g * (size_t)rows_per_group + (size_t)r);   // (read before any store of this thread: CLEAR touches its own rows only)
 #pragma unroll
       for (int q = 0; q < 4; q++) v[u][q] = p[q];
     }
@@ -82,6 +86,11 @@ lx_pack_rows_kernel(const float4* __restrict__ rows, int groups, long long rows_
 #pragma unroll
       for (int q = 0; q < 4; q++) vals[4 * (size_t)pos + q] = v[u][q];
       idx[pos] = (int32_t)(r0 + u * 256 + tid);
+      if (CLEAR) {
+        float4* p = rows + 4 * ((size_t)g * (size_t)rows_per_group + (size_t)(r0 + u * 256 + tid));
+#pragma unroll
+        for (int q = 0; q < 4; q++) p[q] = float4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
 }
@@ -92,7 +101,10 @@ lx_pack_rows_kernel(const float4* __restrict__ rows, int groups, long long rows_
 // rank) order, on one stream: the sum of a row is ((s0 + s1) + s2) + ... whatever the arrival order, run to run (round-4
 // verdict, weak #8: float atomics over all segments in one launch made the result order-dependent from three ranks on).
 // Else (STORE) segment s owns rows [s * dest_group_rows, ...) and all segments go in one launch.
-template <bool ADD>
+// MODE 0: store, 1: add, 2: store ZEROS into the rows segment s names (the owner-major layout of MODE 0): clears exactly
+// the rows an earlier MODE 0 call wrote -- a gathered result of 29 % non-zero rows is cleared with a third of the writes of a
+// zero-fill.
+template <int MODE>
 __global__ void __launch_bounds__(256)
 lx_unpack_rows_kernel(float* __restrict__ dest, const float* __restrict__ packed, int first_segment, int kmax,
                       size_t seg_floats, long long rows_per_group, long long dest_group_rows) {
@@ -105,30 +117,38 @@ lx_unpack_rows_kernel(float* __restrict__ dest, const float* __restrict__ packed
   if (r < 0 || (long long)r >= rows_per_group) return;        // (a corrupt index never leaves the destination's rows)
   const float val = seg[16 + 16 * (size_t)j + c];
   float* d = dest + 16 * ((size_t)s * (size_t)dest_group_rows + (size_t)r) + c;
-  if (ADD) *d = *d + val; else *d = val;
+  if (MODE == 1) *d = *d + val; else if (MODE == 2) *d = 0.f; else *d = val;
 }
 
-void lx_launch_pack_rows(const float* rows, int groups, long long rows_per_group, int kmax, float* packed,
-                         size_t seg_floats, uint32_t* overflow, hipStream_t s) {
+void lx_launch_pack_rows(float* rows, int groups, long long rows_per_group, int kmax, float* packed,
+                         size_t seg_floats, uint32_t* overflow, int clear, hipStream_t s) {
   if (groups <= 0 || rows_per_group <= 0) return;
   const int bpg = (int)((rows_per_group + LX_ROWS_PER_BLOCK - 1) / LX_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(lx_clear_headers_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, packed, groups, seg_floats);
-  hipLaunchKernelGGL(lx_pack_rows_kernel, dim3((uint32_t)groups * (uint32_t)bpg), dim3(256), 0, s,
-                     reinterpret_cast<const float4*>(rows), groups, rows_per_group, kmax, packed, seg_floats, overflow, bpg);
+  if (clear)
+    hipLaunchKernelGGL(lx_pack_rows_kernel<true>, dim3((uint32_t)groups * (uint32_t)bpg), dim3(256), 0, s,
+                       reinterpret_cast<float4*>(rows), groups, rows_per_group, kmax, packed, seg_floats, overflow, bpg);
+  else
+    hipLaunchKernelGGL(lx_pack_rows_kernel<false>, dim3((uint32_t)groups * (uint32_t)bpg), dim3(256), 0, s,
+                       reinterpret_cast<float4*>(rows), groups, rows_per_group, kmax, packed, seg_floats, overflow, bpg);
 }
 
 void lx_launch_unpack_rows(float* dest, const float* packed, int segments, int kmax, size_t seg_floats,
-                           long long rows_per_group, long long dest_group_rows, int add, hipStream_t s) {
+                           long long rows_per_group, long long dest_group_rows, int add, int zero, hipStream_t s) {
   if (segments <= 0 || kmax <= 0) return;
   if (add) {
     // one launch per segment, in segment order (kernels of one stream run one after the other: deterministic sums)
     const dim3 grid((uint32_t)((kmax + 15) / 16), 1u);
     for (int seg = 0; seg < segments; seg++)
-      hipLaunchKernelGGL(lx_unpack_rows_kernel<true>, grid, dim3(256), 0, s, dest, packed, seg, kmax, seg_floats,
+      hipLaunchKernelGGL(lx_unpack_rows_kernel<1>, grid, dim3(256), 0, s, dest, packed, seg, kmax, seg_floats,
                          rows_per_group, 0LL);
   } else {
     const dim3 grid((uint32_t)((kmax + 15) / 16), (uint32_t)segments);
-    hipLaunchKernelGGL(lx_unpack_rows_kernel<false>, grid, dim3(256), 0, s, dest, packed, 0, kmax, seg_floats,
-                       rows_per_group, dest_group_rows);
+    if (zero)
+      hipLaunchKernelGGL(lx_unpack_rows_kernel<2>, grid, dim3(256), 0, s, dest, packed, 0, kmax, seg_floats,
+                         rows_per_group, dest_group_rows);
+    else
+      hipLaunchKernelGGL(lx_unpack_rows_kernel<0>, grid, dim3(256), 0, s, dest, packed, 0, kmax, seg_floats,
+                         rows_per_group, dest_group_rows);
   }
 }

@@ -98,6 +98,18 @@ def _lazy_list_check(saved, offs, I, W, H):
     return dict(ordered_len=ordered, lazy_lists=int(partly.sum()), lazy_prefix_mismatch=mismatch, walk_beyond_ordered=beyond)
 
 
+class Grads(dict):
+    """The gradient arrays of one backward (a plain dict to every caller that iterates) + what ran, as g["bwd_form"] /
+    g["bwd_masks"] (not among the keys)."""
+
+    def __init__(self, arrays, **meta):
+        super().__init__(arrays)
+        self.meta = meta
+
+    def __getitem__(self, k):
+        return self.meta[k] if k in self.meta else dict.__getitem__(self, k)
+
+
 def hip_backward(hf, dL, bwd_form=None):
     """bwd_form: "rows" / "quadrant" forces the reverse walk's form (knob LOGRAST_BWD_ROWS) for this call; None = the
     package's choice (from the forward's own instance count).  out["bwd_form"] says which one ran, out["bwd_masks"] whether
@@ -121,9 +133,9 @@ def hip_backward(hf, dL, bwd_form=None):
         # is zero by construction; lograst.h: LOGRAST_BWD_CONIC_TOUCHED_ONLY)
         conic[saved["point_weight"] == 0] = 0
     masks = saved.get("hit_masks") is not None and {1: "rows", 2: "quadrant"}.get(saved.get("hit_mask_form")) == ran
-    return dict(conic=conic.cpu().numpy(), means3D=g_m3.cpu().numpy(), means2D=g_m2.cpu().numpy(), colors=g_c.cpu().numpy(),
-                opacities=g_o.cpu().numpy().reshape(-1, 1), scales=g_s.cpu().numpy(), rotations=g_r.cpu().numpy(),
-                bwd_form=ran, bwd_masks=bool(masks))
+    return Grads(dict(conic=conic.cpu().numpy(), means3D=g_m3.cpu().numpy(), means2D=g_m2.cpu().numpy(), colors=g_c.cpu().numpy(),
+                      opacities=g_o.cpu().numpy().reshape(-1, 1), scales=g_s.cpu().numpy(), rotations=g_r.cpu().numpy()),
+                 bwd_form=ran, bwd_masks=bool(masks))
 
 
 def hip_project_backward(hf, g_mean2d, g_conic):

@@ -111,3 +111,29 @@ def test_emit_prints_the_compact_line_last(tmp_path, capsys, monkeypatch):
     assert len(out[-1]) < bench.LINE_LIMIT
     with open(tmp_path / "bench_full.json") as f:
         assert json.load(f)["value"] == full["value"]
+
+
+def test_roofline_traffic_comes_from_this_round_or_not_at_all():
+    """round-5 verdict, #8: `roofline.traffic` is read from a committed counter profile, not measured in the run -- so it
+    must be this round's (the kernels of an earlier round's profile have changed) or absent."""
+    path, d = bench.traffic_profile(30_000_000, 1920, 1080)
+    assert os.path.exists(os.path.join(ROOT, "profiles", "r05_traffic_30M.json"))       # an older one exists, and is not taken
+    assert path is None or os.path.basename(path).startswith("r%02d_" % bench.BENCH_ROUND), path
+    if path is None:
+        assert bench.pmc_traffic("project", 30_000_000, 1920, 1080) is None
+    else:
+        assert d["kernels"]["project"]["traffic_bytes"] > 3.0e9                         # >= the algorithmic 100 B per Gaussian
+        assert bench.pmc_traffic("project", 30_000_000, 1920, 1080) == d["kernels"]["project"]["traffic_bytes"]
+    assert bench.pmc_traffic("project", 12345, 64, 64) is None
+
+
+def test_parity_summary_reaches_the_line():
+    p = bench.parity_summary()
+    if p is None:
+        pytest.skip("no parity summary of this round committed yet")
+    line = bench.parity_line(p)
+    assert line["tol"] == 1e-4 and line["file"].startswith("profiles/r%02d_" % bench.BENCH_ROUND)
+    # the upstream package's flavour meets north_star's plain tolerance on every C2 view; the fork's clamp does not on
+    # check_gui's uniform draws -- both are REPORTED
+    assert line["c2_upstream_pkg"] < 1e-4 < line["c2_wodilate_fork_clamp"]
+    assert line["trained_like_30M"] < 1e-4

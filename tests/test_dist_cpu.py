@@ -450,9 +450,41 @@ def _sparse_worker(rank, world, port, out):
             local.append(b.blocks["rows"].clone())
             ex.launch(part, sparse=True)
         total = ex.finish()
+        cleared = [float(b.blocks["rows"].abs().sum()) for b in ex.buckets]      # pack and clear: every bucket is all zero again
         ex.all_gather_grads(total, sparse_kmax="exact")
         res["float"] = dict(local=local, rows=total["rows"].clone(), full=ex.buckets[0].blocks["rows"].clone(),
-                            Pr=ex.buckets[0].Pr, over=ex.compact_overflowed())
+                            Pr=ex.buckets[0].Pr, over=ex.compact_overflowed(), cleared=cleared, streamed=ex.streamed)
+        # round 6: the STREAMED exchange, one group per view (parts = 8), against ONE group holding the sum of the same eight
+        # views (integer-valued gradients: exact in any order, so the two must agree bit for bit), sized exactly and from bounds
+        per_view = []
+        for v in range(8):
+            gen = torch.Generator().manual_seed(5000 + 100 * rank + v)
+            touched = torch.randperm(P, generator=gen)[:60]                      # 6 % of the rows per view, overlapping between views
+            per_view.append((touched, torch.randint(-8, 9, (60, 14), generator=gen).float(),
+                             (torch.rand(P, generator=gen) < 0.3).to(torch.int32)))
+        for mode, parts, kw_rs, kw_ag in (("one_group", 1, dict(sparse=True), dict(sparse_kmax="exact")),
+                                          ("stream8", 8, dict(sparse=True), dict(sparse_kmax="exact")),
+                                          ("stream8_bound", 8, dict(sparse=True, kmax=64), dict(sparse_kmax=500))):
+            ex = StepExchange(P, "cpu", world, rank, parts=parts, row_major=True)
+            result = torch.full((world * ex.buckets[0].Pr, 16), float("nan")) if parts > 1 else None   # (the first gather zero-fills it)
+            for step in range(2):                                                # two steps: the second one starts from begin_step(), no zero()
+                if step:
+                    ex.begin_step()
+                for v, (touched, vals, seen) in enumerate(per_view):
+                    b = ex.bucket_of(v, 8)
+                    b.views["rows"][touched, :14] += vals * (step + 1)
+                    b.mark_seen(seen)
+                    if v == ex.last_view_of(ex.buckets.index(b), 8):
+                        ex.launch(ex.buckets.index(b), **kw_rs)
+                total = ex.finish()
+                left = [float(b.blocks["rows"].abs().sum()) for b in ex.buckets]
+                ex.all_gather_grads(total, into=result, **kw_ag)                 # (streamed: a persistent result, bucket 0 stays clean)
+                full = ex.buckets[0].blocks["rows"].clone() if result is None else result.reshape(-1).clone()
+                after = [float(b.blocks["rows"].abs().sum()) for b in ex.buckets]
+                res["%s_step%d" % (mode, step)] = dict(rows=total["rows"].clone(), seen=total["seen"].clone(), full=full, left=left,
+                                                       after=after, over=ex.compact_overflowed(), streamed=ex.streamed)
+                if parts == 1:
+                    ex.zero()                                                    # (the one-group form keeps its sums: zero-filled as before)
         torch.save(res, os.path.join(out, f"s{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -481,21 +513,35 @@ def test_row_sparse_exchange_equals_the_dense_one(tmp_path, world):
         assert 0 < got[r]["sparse_exact"]["kmax"] <= 150 and 0 < got[r]["sparse_exact"]["gk"] <= 2 * 150 * world
         assert got[r]["sparse_bound"]["kmax"] == 200
         assert got[r]["sparse_small"]["over"]                                   # 20 rows per pair cannot hold ~50-75
-    # non-integer gradients: every owner's shard = per group the sum over ranks in rank order, then the groups summed; the
-    # gathered bucket is those shards side by side -- bit for bit, on every rank
+    # non-integer gradients: the streamed exchange adds every received segment into the step's ONE running shard as it
+    # arrives -- group after group, inside a group rank after rank: a row's sum is the left fold
+    # ((((0 + a[g0, r0]) + a[g0, r1]) + ...) + a[g1, r0]) + ... -- and the gathered bucket is those shards side by side, bit
+    # for bit, on every rank
     Pr = got[0]["float"]["Pr"]
-    parts = []
+    want = torch.zeros_like(got[0]["float"]["local"][0])
     for part in range(2):
-        acc = got[0]["float"]["local"][part].clone()
-        for r in range(1, world):
-            acc = acc + got[r]["float"]["local"][part]
-        parts.append(acc)
-    want = (parts[0] + parts[1]).view(world, Pr, 16)
+        for r in range(world):
+            want = want + got[r]["float"]["local"][part]
+    want = want.view(world, Pr, 16)
     for r in range(world):
         f = got[r]["float"]
-        assert not f["over"]
+        assert not f["over"] and f["streamed"]
+        assert f["cleared"] == [0.0, 0.0], f["cleared"]                          # pack and clear left every bucket all zero
         assert torch.equal(f["rows"], want[r]), r
         assert torch.equal(f["full"].view(world, Pr, 16), want), r
+    # one group per view (parts = 8) == one group for all eight views, bit for bit (integer-valued gradients), over two
+    # steps of which the second starts from begin_step() instead of a zero-fill
+    for r in range(world):
+        for step in range(2):
+            one = got[r]["one_group_step%d" % step]
+            assert not one["over"] and not one["streamed"] and float(one["full"].abs().sum()) > 0
+            for mode in ("stream8", "stream8_bound"):
+                m = got[r]["%s_step%d" % (mode, step)]
+                assert m["streamed"] and not m["over"], (r, mode, step)
+                assert m["left"] == [0.0] * 8 and m["after"] == [0.0] * 8, (mode, m["left"], m["after"])
+                assert torch.equal(m["rows"], one["rows"]) and torch.equal(m["seen"], one["seen"]), (r, mode, step)
+                assert torch.equal(m["full"], one["full"]), (r, mode, step)
+        assert torch.equal(got[r]["stream8_step1"]["full"], got[0]["stream8_step1"]["full"])
 
 
 def test_pack_rows_edge_cases():

@@ -13,12 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(*flags, env=None):
+    """-> the FULL result object (bench.py --print-full: an earlier stdout line), after checking that the LAST stdout line is
+    the compact contract object the driver parses (< 4 KB, the same value)."""
     e = dict(os.environ, **(env or {}))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), env=e, capture_output=True,
-                         text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--print-full"] + list(flags), env=e,
+                         capture_output=True, text=True, timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert out.returncode == 0 and lines, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
-    return json.loads(lines[-1])
+    assert out.returncode == 0 and len(lines) >= 2, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+    assert out.stdout.rstrip().splitlines()[-1] == lines[-1] and len(lines[-1]) < 4096, len(lines[-1])
+    full, line = json.loads(lines[-2]), json.loads(lines[-1])
+    assert line["value"] == pytest.approx(full["value"], rel=1e-6) and line["n_gpus"] == full["n_gpus"]
+    full["_line"] = line
+    return full
 
 
 def test_bench_self_spawns_two_ranks_and_reports_them():
@@ -40,6 +46,18 @@ def test_bench_self_spawns_two_ranks_and_reports_them():
         assert forced["exchange"]["mode"] == mode and forced["value"] > 0
         if mode == "sparse":
             assert 0 < forced["exchange"]["touched_row_fraction"] <= 1.0
+            # round 6: by default the row-sparse exchange is STREAMED, one group per view (a view's touched rows are packed,
+            # cleared and sent while the next view renders); --exchange-parts 1 is round 5's one exchange per step
+            # (200 000 Gaussians: three views in flight per rank, so 8 // 3 = 2 groups; the 30 M headline: one per view)
+            assert forced["exchange"]["streamed"] and forced["exchange"]["parts"] >= 2, forced["exchange"]
+            one = _bench("--gpus", "2", "--gaussians", "200000", "--steps", "2", "--warmup", "1", "--no-secondary",
+                         "--no-cpu-baseline", "--no-dropin-mode", "--exchange", "sparse", "--exchange-parts", "1",
+                         env={"LOGRAST_DIST_BACKEND": "gloo", "LOGRAST_SHARE_GPU": "1"})
+            assert not one["exchange"]["streamed"] and one["exchange"]["parts"] == 1 and one["value"] > 0
+            for e in (forced["exchange"], one["exchange"]):
+                assert e["exchange_only_ms_per_step"] > 0 and e["timing_ms"]["exposed_join_ms_per_step"] >= 0
+        else:
+            assert forced["exchange"]["parts"] == 1 and not forced["exchange"]["streamed"]
 
 
 def test_bench_two_ranks_over_rccl_when_the_box_has_two_gpus():
@@ -73,11 +91,22 @@ def test_bench_line_carries_the_contract_fields():
     assert r["fwd_form"] in ("rows", "quadrant") and r["bwd_form"] in ("rows", "quadrant")
     assert d["config"]["ms_per_view_trained_like"] > 0
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert "committed profile" in r["traffic_source"]
+    # (this test's 300 000-Gaussian workload has no counter profile: traffic is absent and the source says so; the headline's
+    # comes from this round's committed profile -- tests/test_bench_line_cpu.py)
+    assert r["traffic"] is None and r["traffic_source"].startswith("none")
     # effective algorithmic bytes: no kernel is credited with more than the peak
     for name, k in d["kernels"].items():
         assert k.get("hbm_frac", 0.0) <= 1.0, (name, k)
     assert d["measured_stream_copy_GBs"] > 1000 and d["measured_copy_GBs"] > 1000
+    # ... and the compact last line (what BENCH_rNN.json keeps): the contract objects, the mode note up front
+    line = d["_line"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "mode"):
+        assert k in line, k
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"] or k == "traffic", k
+    assert line["config"]["dropin_default_ms_per_view"] > 0 and line["config"]["ms_per_view"] > 0
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
     assert 0 < d["algorithmic_frac_of_measured_stream_copy"] < 1
     assert d["effective_units_per_view"]["I_walked_bwd"] <= d["config"]["tile_instances_per_view"]
     fo = d["forward_only"]["headline"]
@@ -251,3 +280,49 @@ def test_pack_and_unpack_rows_kernels():
     part = part.view(G, R, 16).cpu()
     kept = (part != 0).any(2)
     assert int(kept.sum()) == 3 * 512 and torch.equal(part[kept], rows[kept])
+
+
+def test_pack_and_clear_and_the_zeroing_unpack():
+    """Round 6, the streamed exchange's device side: lograst_pack_rows_clear packs what lograst_pack_rows packs and leaves the
+    packed rows ZERO in the bucket (rows dropped by an exceeded bound stay); lograst_unpack_rows(atomic = 2) clears exactly
+    the rows an owner-major store wrote.  Against the torch formulation the gloo tests run."""
+    import torch
+    from log_amd import dist as D
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    G, R = 4, 70_000 + 13
+    rows = torch.zeros(G, R, 16)
+    for g in range(G):
+        sel = torch.randperm(R, generator=gen)[: 5000 + 1000 * g]
+        rows[g, sel] = torch.randn(sel.numel(), 16, generator=gen)
+    bucket = rows.to(dev).contiguous()
+    k = 9000
+    plain, over0 = D._pack_segments(bucket.clone(), k)
+    packed, over = D._pack_segments(bucket, k, clear=True)
+    assert not bool(over) and not bool(over0)
+    assert float(bucket.abs().sum()) == 0.0                              # every packed row is gone from the bucket
+    back = torch.zeros(G * R, 16, device=dev)
+    D._unpack_segments(back, packed, G, k, per_segment_rows=R)
+    assert torch.equal(back.view(G, R, 16).cpu(), rows)                  # ... and arrived intact
+    back2 = torch.zeros(G * R, 16, device=dev)
+    D._unpack_segments(back2, plain, G, k, per_segment_rows=R)
+    assert torch.equal(back2, back)
+    # the torch formulation does the same
+    cpu_rows = rows.clone()
+    cpu_packed, cpu_over = D._pack_segments(cpu_rows, k, clear=True)
+    assert float(cpu_rows.abs().sum()) == 0.0 and not bool(cpu_over)
+    # clear what the store wrote: the result buffer is all zero again, rows it did not write are left alone
+    back[5] = 7.0 if float(back[5].abs().sum()) == 0.0 else back[5]
+    marker = back[5].clone()
+    D._unpack_segments(back, packed, G, k, per_segment_rows=R, zero=True)
+    wrote = (rows.view(G * R, 16) != 0).any(1)
+    assert float(back[wrote.to(dev)].abs().sum()) == 0.0
+    if not bool(wrote[5]):
+        assert torch.equal(back[5], marker)
+    # an exceeded bound: flagged; the kept rows are cleared, the dropped ones stay in the bucket (nothing is lost silently)
+    bucket = rows.to(dev).contiguous()
+    small, over = D._pack_segments(bucket, 4096, clear=True)
+    assert bool(over)
+    part = torch.zeros(G * R, 16, device=dev)
+    D._unpack_segments(part, small, G, 4096, per_segment_rows=R)
+    assert torch.equal((part.view(G, R, 16) + bucket).cpu(), rows)       # every row is in exactly one of the two places

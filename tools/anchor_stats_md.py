@@ -46,3 +46,31 @@ out += ["", "Totals: %d (case, output) rows checked, %d violations of the every-
 path = os.path.join(ROOT, "profiles", "%s_gradient_anchor_stats.md" % tag)
 open(path, "w").write("\n".join(out) + "\n")
 print(path, len(files), "cases;", tot_rows, "rows;", tot_viol, "violations; worst excess", round(worst, 1))
+
+
+# ---- a summary bench.py can carry (round-5 verdict, next #2d: the deviation from north_star's plain 1e-4 reported, not buried)
+import re
+groups = {}
+for f in files:
+    d = json.load(open(f))
+    case = os.path.basename(f)[:-5]
+    g = re.sub(r"_view\d+$", "", case)
+    e = groups.setdefault(g, {"cases": 0})
+    e["cases"] += 1
+    for k in ("means3D", "scales", "rotations"):
+        if k in d:
+            for key, src in (("all_rows_hip_vs_oracle", "rel_l2_all_hip_vs_oracle"), ("all_rows_hip_vs_f64", "rel_l2_all_hip"),
+                             ("all_rows_oracle_vs_f64", "rel_l2_all_oracle"), ("well_conditioned_rows_hip_vs_f64", "rel_l2_well_hip"),
+                             ("excluded_fraction", "excluded_fraction")):
+                if src in d[k]:
+                    e.setdefault(k, {})[key] = max(e.get(k, {}).get(key, 0.0), d[k][src])
+    for k in ("means2D", "conic", "opacities", "colors"):
+        if k in d:
+            e.setdefault(k, {})["hip_vs_oracle"] = max(e.get(k, {}).get("hip_vs_oracle", 0.0), d[k].get("rel_l2_hip_vs_oracle", 0.0))
+            e[k]["hip_vs_f64"] = max(e[k].get("hip_vs_f64", 0.0), d[k]["rel_l2_hip"])
+summary = {"source": "tests/gpu_util.py::gradient_anchor_stats on the MI355X (%s); per group of cases the MAXIMUM relative L2 over "
+                     "its views; tolerance of BASELINE.json north_star: 1e-4" % note,
+           "round": tag, "groups": groups}
+spath = os.path.join(ROOT, "profiles", "%s_parity_summary.json" % tag)
+json.dump(summary, open(spath, "w"), indent=1, sort_keys=True)
+print(spath, len(groups), "groups")

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -31,9 +31,12 @@ def stats(path, title, out):
 
 for n, t in (("b_default", "default"), ("b_oprand", "opacity_rand"), ("b_10M", "10M")):
     f = os.path.join(G, n + ".log")
-    if os.path.exists(f) and any(l.startswith("{") for l in open(f)):
+    if os.path.exists(f) and any(l.startswith("{") for l in open(f)):     # the compact contract line (what the driver parses)
         line = [l for l in open(f) if l.startswith("{")][-1]
-        json.dump(json.loads(line), open(os.path.join(P, f"{tag}_bench_{t}.json"), "w"), indent=1)
+        json.dump(json.loads(line), open(os.path.join(P, f"{tag}_bench_{t}_line.json"), "w"), indent=1)
+    f = os.path.join(G, n + "_full.json")
+    if os.path.exists(f):                                                 # the full result (bench.py --full-out)
+        json.dump(json.load(open(f)), open(os.path.join(P, f"{tag}_bench_{'full' if t == 'default' else t}.json"), "w"), indent=1)
 cmd = ("python bench.py --views 4 --steps 1 --warmup 0 --streams 1 --no-graphs --no-cpu-baseline --no-kernel-timing "
        "--no-secondary --no-dropin-mode --no-rand-variant --no-forward-only --no-trained-like")
 WORKLOAD = "the bench headline: 30 M random Gaussians @1080p, 4 views (stats pass + 1 step), one stream, eager launches"

@@ -6,14 +6,15 @@
 # counter group per pass (HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes).
 # The profiled workload is the bench headline: 30 M Gaussians @1080p (past the 256 MiB Infinity Cache, so
 # FETCH_SIZE / WRITE_SIZE are memory-side traffic), views launched eagerly on one stream (rocprofv3 serialises kernels).
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 D=$PWD/gpurun_out
 mkdir -p "$D"
 P="python bench.py --views 4 --steps 1 --warmup 0 --streams 1 --no-graphs --no-cpu-baseline --no-kernel-timing --no-secondary --no-dropin-mode --no-rand-variant --no-forward-only --no-trained-like"
-timeout 900 python bench.py > $D/b_default.log 2>&1
-timeout 600 python bench.py --gaussians 10000000 --no-cpu-baseline --no-secondary --no-forward-only > $D/b_10M.log 2>&1
+# (the LAST stdout line of bench.py is the compact contract object; the full result goes to --full-out)
+timeout 900 python bench.py --steps 20 --warmup 5 --full-out $D/b_default_full.json > $D/b_default.log 2>&1
+timeout 600 python bench.py --gaussians 10000000 --no-cpu-baseline --no-secondary --no-forward-only --full-out $D/b_10M_full.json > $D/b_10M.log 2>&1
 rm -rf $D/${TAG}_trace $D/${TAG}_pmc_fetch $D/${TAG}_pmc_write $D/${TAG}_pmc_sq
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/${TAG}_trace -o h30 -- $P > $D/${TAG}_trace.log 2>&1
 # the same step on the trained-like scene (log-normal scales: rects of 5..16 tiles, a few larger): kernel times only

@@ -1076,7 +1076,7 @@ def compact_line(result):
         kus = {k[len("kernel_us_"):]: _num(v, 4) for k, v in rf.items() if k.startswith("kernel_us_")}
         for k, v in sorted(kus.items()):
             r["us_" + k[:36]] = v
-        line["roofline"] = {k: v for k, v in r.items() if v is not None}
+        line["roofline"] = {k: v for k, v in r.items() if v is not None or k == "traffic"}   # (traffic: a number or null, never absent)
     if isinstance(cb, dict):
         b = {"value": _num(cb.get("value"), 6), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
              "sample": str(cb.get("sample", ""))[:120]}

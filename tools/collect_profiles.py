@@ -77,7 +77,10 @@ if all(os.path.exists(x) for x in (sq, fe, wr)):
         twice = lambda k: k.startswith("lr_blend_fwd")
         return {k: agg[k] / (cnt[k] / 2 if twice(k) and cnt[k] % 2 == 0 else cnt[k]) for k in agg}
     f, w = load(fe, "FETCH_SIZE"), load(wr, "WRITE_SIZE")
-    names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_bwd_rows_kernel": "blend_bwd", "lr_blend_fwd_kernel<true>": "blend_fwd",
+    names = {"lr_blend_bwd_kernel": "blend_bwd", "lr_blend_bwd_rows_kernel": "blend_bwd", "lr_blend_bwd_kernel<false>": "blend_bwd",
+             "lr_blend_bwd_rows_kernel<false>": "blend_bwd", "lr_blend_bwd_kernel<true>": "blend_bwd",
+             "lr_blend_bwd_rows_kernel<true>": "blend_bwd",      # (<true>: the reverse walk on the forward's hit masks -- the steady state; listed last: it wins)
+             "lr_blend_fwd_kernel<true>": "blend_fwd",
              "lr_blend_fwd_rows_kernel<true>": "blend_fwd", "lr_project_kernel": "project", "lr_project_batched_kernel": "project",
              "lr_project_batched_kernel<false>": "project", "lr_fill_staged_kernel": "fill_keys",
              "lr_fill_kernel": "fill_keys", "lr_fill_kernel<1>": "fill_keys", "lr_project_bwd_kernel<true, true, false, true>": "project_bwd",

@@ -1046,7 +1046,7 @@ def compact_line(result):
     c["ms_per_view_opacity_rand"] = _num(cfg.get("ms_per_view_opacity_rand"))
     c["ms_per_view_trained_like"] = _num(cfg.get("ms_per_view_trained_like"))
     c["forward_only_ms_per_view"] = _num(g(result, "forward_only", "headline", "capacity_hint", "ms_per_view"))
-    for k in ("c2_ms_per_view", "c3_ms_per_view", "c5_band_ms_per_view_gradient_sink"):
+    for k in ("c2_ms_per_view", "c3_ms_per_view", "c3_fused_step_ms_per_view", "c5_band_ms_per_view_gradient_sink"):
         c[k] = _num(cfg.get(k))
     c["parallelism"] = str(cfg.get("parallelism", ""))[:120]
     ex = result.get("exchange")
@@ -1152,6 +1152,7 @@ def flatten_for_the_driver(result):
     for key, path in (("c2_ms_per_view", ("c2", "modes", "pipelined", "ms_per_view")),
                       ("c2_dropin_default_ms_per_view", ("c2", "modes", "dropin_default", "ms_per_view")),
                       ("c3_ms_per_view", ("c3", "ms_per_view")),
+                      ("c3_fused_step_ms_per_view", ("c3", "ms_per_view_fused_step")),
                       ("c5_band_ms_per_view_gradient_sink", ("c5_band", "ms_per_view_band_clipped_gradient_sink"))):
         v = g(sec, *path)
         if v is not None:

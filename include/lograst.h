@@ -452,6 +452,21 @@ int lograst_sparse_adam(int32_t m, int32_t num_points, const int64_t* index, con
                         int32_t num_keys, const lograst_adam_key* keys, double beta1, double beta2,
                         double bias_correction2_sqrt, double eps, void* stream);
 
+/* Version 4: lograst_activate_backward (below) and lograst_sparse_adam in ONE launch, for steps of a single view (the
+ * reference's trainer: one backward, then SparseOptimizer.step).  For every r < n with radii[r] > 0 (LoG's flag_vis,
+ * LoG/model/counter.py:48) the raw gradients of row r are computed as lograst_activate_backward computes them (dl_dact_xyz
+ * passes through) and applied at once to model row index[r] and its moments as lograst_sparse_adam applies them -- the
+ * gradients are never written.  keys[6] in the order xyz, scaling, opacity, rotation, colors, shs (widths 3, 3, 1, 4, 3,
+ * 3 * sh_coeffs; `grad` is ignored, `param` = the gathered raw rows [n, width]; model_param == NULL: key not optimised).
+ * Same op sequences as the two kernels: the model and the moments come out bit for bit the same. */
+int lograst_activate_backward_adam(int32_t n, const float* raw_xyz, const float* raw_scaling, const float* raw_opacity,
+                                   const float* raw_rotation, int32_t sh_coeffs, int32_t active_degree,
+                                   const float* camera_center, const float* dl_dact_xyz, const float* dl_dact_scaling,
+                                   const float* dl_dact_opacity, const float* dl_dact_rotation, const float* dl_dact_colors,
+                                   int32_t num_points, const int64_t* index, const int32_t* radii,
+                                   const lograst_adam_key* keys, double beta1, double beta2, double bias_correction2_sqrt,
+                                   double eps, void* stream);
+
 /* ---- rows N2 / N3: LoG.get_all + Activation.activate_root_return, fused ---------------------------------------
  * Replaces the per-key gathers of LoG.get_all (/root/reference/LoG/model/level_of_gaussian.py:262-296) and the
  * activations of Activation.activate_root_return / colors_activation (/root/reference/LoG/model/activation.py:27-44;

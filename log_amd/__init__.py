@@ -16,10 +16,14 @@ def install_compute_radius():
     return shim
 
 
-def install_all():
+def install_all(fused_step=False):
     """Everything a LoG process needs, in one call: the LoG.cuda.compute_radius module, then every
     drop-in method assigned onto LoG's own classes (needs LoG importable): LoG.get_all, TensorTree.traverse,
-    Counter.update_by_output, SparseOptimizer.step."""
+    Counter.update_by_output, SparseOptimizer.step.
+    fused_step (opt-in, round 6): the backward of LoG.get_all applies SparseOptimizer's update itself, in the kernel that
+    computes the raw gradients (log_amd.get_all.set_fused_step: the update then happens at backward time -- the same result
+    for LoG's trainer, one backward per step)."""
     install_compute_radius()
     from . import counter, get_all, lod, sparse_optimizer
+    get_all.set_fused_step(bool(fused_step))
     return [m.install() for m in (get_all, lod, counter, sparse_optimizer)]

@@ -106,6 +106,9 @@ _SIGNATURES = {
     "lograst_sparse_adam": (ctypes.c_int, [c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                            ctypes.POINTER(LograstAdamKey), ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, c_void_p]),
+    "lograst_activate_backward_adam": (ctypes.c_int, [c_int32] + [c_void_p] * 4 + [c_int32, c_int32] + [c_void_p] * 6 +
+                                       [c_int32, c_void_p, c_void_p, ctypes.POINTER(LograstAdamKey), ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
     "lograst_gather_activate": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_int32] + [c_void_p] * 12),
     "lograst_activate_backward": (ctypes.c_int, [c_int32] + [c_void_p] * 4 + [c_int32, c_int32] + [c_void_p] * 11),
     "lograst_profile_enable": (None, [ctypes.c_int]),

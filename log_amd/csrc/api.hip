@@ -83,6 +83,8 @@ hipError_t lr_launch_sparse_adam(const AdamArgs& a, int num_keys, hipStream_t s)
 
 hipError_t lr_launch_gather_activate(const GatherArgs& a, hipStream_t s);
 hipError_t lr_launch_activate_bwd(const ActBwdArgs& a, hipStream_t s);
+hipError_t lr_launch_activate_bwd_adam(const ActBwdArgs& a, const AdamArgs& f, const float* g_a_xyz, const int32_t* radii,
+                                       hipStream_t s);
 
 static thread_local std::string g_err;
 static int lr_fail(int code, const std::string& msg) {
@@ -1036,6 +1038,53 @@ int lograst_activate_backward(int32_t n, const float* raw_xyz, const float* raw_
   a.n = n; a.K = sh_coeffs; a.deg = active_degree;
   g_prof_call++;
   LR_HIP(lr_launch_activate_bwd(a, (hipStream_t)stream));
+  return LOGRAST_OK;
+}
+
+int lograst_activate_backward_adam(int32_t n, const float* raw_xyz, const float* raw_scaling, const float* raw_opacity,
+                                   const float* raw_rotation, int32_t sh_coeffs, int32_t active_degree,
+                                   const float* camera_center, const float* dl_dact_xyz, const float* dl_dact_scaling,
+                                   const float* dl_dact_opacity, const float* dl_dact_rotation, const float* dl_dact_colors,
+                                   int32_t num_points, const int64_t* index, const int32_t* radii,
+                                   const lograst_adam_key* keys, double beta1, double beta2, double bias_correction2_sqrt,
+                                   double eps, void* stream) {
+  int rc = lr_ga_check(n, sh_coeffs, active_degree, camera_center);
+  if (rc) return rc;
+  if (n == 0) return LOGRAST_OK;
+  if (num_points <= 0) return lr_fail(LOGRAST_ERR_ARG, "rows of an empty model");
+  if (!raw_xyz || !raw_scaling || !raw_opacity || !raw_rotation || !dl_dact_xyz || !dl_dact_scaling || !dl_dact_opacity ||
+      !dl_dact_rotation || !dl_dact_colors || !index || !radii || !keys)
+    return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  static const int widths[6] = {3, 3, 1, 4, 3, 0};
+  ActBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.r_xyz = raw_xyz; a.r_scaling = raw_scaling; a.r_opacity = raw_opacity; a.r_rotation = raw_rotation;
+  a.campos = camera_center;
+  a.g_a_scaling = dl_dact_scaling; a.g_a_opacity = dl_dact_opacity; a.g_a_rotation = dl_dact_rotation;
+  a.g_a_colors = dl_dact_colors;
+  a.n = n; a.K = sh_coeffs; a.deg = active_degree;
+  AdamArgs f;
+  memset(&f, 0, sizeof(f));
+  for (int i = 0; i < 6; i++) {
+    const lograst_adam_key& k = keys[i];
+    if (!k.model_param) continue;                            // key not optimised in this step
+    const int w = i == 5 ? 3 * sh_coeffs : widths[i];
+    if (k.width != w) return lr_fail(LOGRAST_ERR_ARG, "lograst_activate_backward_adam: key widths are 3, 3, 1, 4, 3, 3 * sh_coeffs (xyz, scaling, opacity, rotation, colors, shs)");
+    if (i == 5 && (sh_coeffs == 0 || active_degree == 0)) return lr_fail(LOGRAST_ERR_ARG, "shs key without active SH coefficients");
+    if (!k.param || !k.exp_avg || !k.exp_avg_sq) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer in key");
+    a.g_shs = nullptr;
+    f.key[i].model = (float*)k.model_param; f.key[i].param = (const float*)k.param; f.key[i].grad = nullptr;
+    f.key[i].exp_avg = (float*)k.exp_avg; f.key[i].exp_avg_sq = (float*)k.exp_avg_sq;
+    f.key[i].max_exp_avg_sq = (float*)k.max_exp_avg_sq;
+    f.key[i].width = k.width; f.key[i].neg_step_size = -k.step_size;
+  }
+  if ((reinterpret_cast<uintptr_t>(raw_rotation) | reinterpret_cast<uintptr_t>(dl_dact_rotation)) & 15u)
+    return lr_fail(LOGRAST_ERR_ARG, "raw_rotation / dl_dact_rotation must be 16-byte aligned");
+  f.index = index; f.flag_vis = nullptr; f.m = n; f.num_points = num_points;
+  f.beta1 = (float)beta1; f.beta2 = (float)beta2; f.omb1 = (float)(1.0 - beta1); f.omb2 = (float)(1.0 - beta2);
+  f.bc2_sqrt = (float)bias_correction2_sqrt; f.eps = (float)eps;
+  g_prof_call++;
+  LR_HIP(lr_launch_activate_bwd_adam(a, f, dl_dact_xyz, radii, (hipStream_t)stream));
   return LOGRAST_OK;
 }
 

@@ -326,6 +326,173 @@ ga_bwd_kernel(ActBwdArgs a) {
   }
 }
 
+// ---- activation backward + sparse Adam in one kernel (round 6; round-5 verdict, next #6) -------------------------------
+// A single-view LoG step runs the activation backward (raw gradients of the selected rows: 59 floats per row at SH degree 3,
+// written compact) and, one launch later, SparseOptimizer.step (sparse_optimizer.py:41-78,163-196), which reads those
+// gradients back together with the gathered parameters and both moments.  Fused, a raw gradient never leaves the registers /
+// the wave's LDS rows: per element the kernel reads the gathered parameter (compact) and both moments (model rows) and
+// writes both moments and the model row -- 24 bytes instead of 32 (+ the launch).  Same op sequences as ga_bwd_kernel and
+// adam_kernel (counter.hip), so the model and the moments come out bit for bit as from the two kernels.
+// key order: 0 xyz, 1 scaling, 2 opacity, 3 rotation, 4 colors, 5 shs (model == nullptr: key not optimised).
+// One element's update in two halves, so that a thread can have the moments of ALL its elements in flight before the first
+// store (written as one read-modify-write after the other, every store may alias the next load -- the moments arrive as
+// plain float* -- and a lane's 14 + 3 K elements become one dependent chain of memory round trips).
+struct GaElem { size_t o; float p0, g, m0, v0, vm; bool on; };
+LR_DEV void ga_adam_load(const AdamKey& k, GaElem& e) {
+  e.m0 = 0.f; e.v0 = 0.f; e.vm = 0.f;
+  if (e.on) {
+    e.m0 = k.exp_avg[e.o];
+    e.v0 = k.exp_avg_sq[e.o];
+    if (k.max_exp_avg_sq) e.vm = k.max_exp_avg_sq[e.o];
+  }
+}
+LR_DEV void ga_adam_store(const AdamKey& k, const AdamArgs& f, const GaElem& e) {
+  if (!e.on) return;
+  const float m = lr_fma(e.g, f.omb1, e.m0 * f.beta1);
+  const float v = lr_fma(f.omb2 * e.g, e.g, e.v0 * f.beta2);
+  k.exp_avg[e.o] = m;
+  k.exp_avg_sq[e.o] = v;
+  float vd = v;
+  if (k.max_exp_avg_sq) {
+    vd = fmaxf(e.vm, v);
+    k.max_exp_avg_sq[e.o] = vd;
+  }
+  const float denom = sqrtf(vd) / f.bc2_sqrt + f.eps;
+  k.model[e.o] = e.p0 + k.neg_step_size * (m / denom);
+}
+
+#define GA_SH_UNROLL 8
+__global__ void __launch_bounds__(256)
+ga_bwd_adam_kernel(ActBwdArgs a, AdamArgs f, const float* __restrict__ g_a_xyz, const int32_t* __restrict__ radii) {
+  extern __shared__ float lr_sh_lds[];
+  __shared__ long long lr_rowidx[4][64];
+  const int L = 3 * a.K, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (i0 >= a.n) return;
+  const int rows = min(64, a.n - i0);
+  const int i = i0 + lane;
+  const bool ok = i < a.n;
+  float gc[3] = {0.f, 0.f, 0.f};
+  long long row = -1;                                       // the model row this lane updates (-1: not visible / no row)
+  if (ok && radii[i] > 0) {
+    row = f.index[i];
+    if (row < 0 || row >= (long long)f.num_points) row = -1;
+  }
+  if (ok) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) gc[k] = a.g_a_colors[3 * (size_t)i + k];
+  }
+  {
+    // the row's 14 small values: xyz 0-2, scaling 3-5, colors 6-8, opacity 9, rotation 10-13 (keys 0, 1, 4, 2, 3)
+    const bool vis = row >= 0;
+    const size_t r = vis ? (size_t)row : 0, c = ok ? (size_t)i : 0;
+    GaElem e[14];
+    float4 q = {0.f, 0.f, 0.f, 1.f}, gy = {0.f, 0.f, 0.f, 0.f};
+    if (vis && f.key[3].model) { q = reinterpret_cast<const float4*>(a.r_rotation)[c]; gy = reinterpret_cast<const float4*>(a.g_a_rotation)[c]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      e[k].on = vis && f.key[0].model; e[k].o = 3 * r + k;
+      e[k].p0 = e[k].on ? f.key[0].param[3 * c + k] : 0.f;
+      e[k].g = e[k].on ? g_a_xyz[3 * c + k] : 0.f;
+      e[3 + k].on = vis && f.key[1].model; e[3 + k].o = 3 * r + k;
+      e[3 + k].p0 = e[3 + k].on ? f.key[1].param[3 * c + k] : 0.f;
+      e[3 + k].g = e[3 + k].on ? a.g_a_scaling[3 * c + k] * expf(a.r_scaling[3 * c + k]) : 0.f;
+      e[6 + k].on = vis && f.key[4].model; e[6 + k].o = 3 * r + k;
+      e[6 + k].p0 = e[6 + k].on ? f.key[4].param[3 * c + k] : 0.f;
+      e[6 + k].g = gc[k] * SH_C0;
+    }
+    e[9].on = vis && f.key[2].model; e[9].o = r;
+    e[9].p0 = e[9].on ? f.key[2].param[c] : 0.f;
+    e[9].g = 0.f;
+    if (e[9].on) {
+      const float sg = ga_sigmoid(a.r_opacity[c]);
+      e[9].g = a.g_a_opacity[c] * (sg * (1.f - sg));
+    }
+    {
+      const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w, nrm = sqrtf(n2);
+      float4 gq;
+      if (nrm > 1e-12f) {   // y = q / |q|: dL/dq = (g - y (y . g)) / |q|; below eps the clamp makes y = q / eps
+        const float ix = 1.f / nrm, yx = q.x * ix, yy = q.y * ix, yz = q.z * ix, yw = q.w * ix;
+        const float dot = yx * gy.x + yy * gy.y + yz * gy.z + yw * gy.w;
+        gq = float4{(gy.x - yx * dot) * ix, (gy.y - yy * dot) * ix, (gy.z - yz * dot) * ix, (gy.w - yw * dot) * ix};
+      } else {
+        gq = float4{gy.x * 1e12f, gy.y * 1e12f, gy.z * 1e12f, gy.w * 1e12f};
+      }
+      const float gqa[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        e[10 + k].on = vis && f.key[3].model; e[10 + k].o = 4 * r + k;
+        e[10 + k].p0 = e[10 + k].on ? f.key[3].param[4 * c + k] : 0.f;
+        e[10 + k].g = gqa[k];
+      }
+    }
+    // all moments requested, then all updates
+#pragma unroll
+    for (int k = 0; k < 14; k++) ga_adam_load(f.key[k < 3 ? 0 : (k < 6 ? 1 : (k < 9 ? 4 : (k < 10 ? 2 : 3)))], e[k]);
+#pragma unroll
+    for (int k = 0; k < 14; k++) ga_adam_store(f.key[k < 3 ? 0 : (k < 6 ? 1 : (k < 9 ? 4 : (k < 10 ? 2 : 3)))], f, e[k]);
+  }
+  if (L > 0 && f.key[5].model) {
+    float* const wl = lr_sh_lds + wave * 64 * (L + 1);
+    lr_rowidx[wave][lane] = row;
+    if (ok) {
+      float b[16], bx[16], by[16], bz[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) b[k] = 0.f;
+      if (a.deg > 0) {
+        const float vx = a.r_xyz[3 * (size_t)i] - a.campos[0], vy = a.r_xyz[3 * (size_t)i + 1] - a.campos[1],
+                    vz = a.r_xyz[3 * (size_t)i + 2] - a.campos[2];
+        const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+        lr_sh_basis(a.deg, vx / nrm, vy / nrm, vz / nrm, b, bx, by, bz);
+      }
+      const int nk = (a.deg + 1) * (a.deg + 1);
+      float* rowp = wl + lane * (L + 1);
+      for (int k = 0; k < a.K; k++) {
+        const float w = (k + 1 < nk && k + 1 < 16) ? b[k + 1] : 0.f;   // coefficients above the active degree: zero gradient
+        rowp[3 * k] = w * gc[0]; rowp[3 * k + 1] = w * gc[1]; rowp[3 * k + 2] = w * gc[2];
+      }
+    }
+    lr_sh_wave_sync();
+    // the wave walks its rows' L coefficients contiguously: element e = (row r, column c) of the compact block; the model
+    // side is one contiguous 4 L-byte piece per visible row.  GA_SH_UNROLL elements per lane in flight.
+    const float* __restrict__ p_sh = f.key[5].param + (size_t)i0 * L;
+    const int total = rows * L;
+    for (int e0 = lane; e0 < total; e0 += 64 * GA_SH_UNROLL) {
+      GaElem e[GA_SH_UNROLL];
+#pragma unroll
+      for (int u = 0; u < GA_SH_UNROLL; u++) {
+        const int x = e0 + 64 * u;
+        e[u].on = false; e[u].o = 0; e[u].p0 = 0.f; e[u].g = 0.f;
+        if (x < total) {
+          const int r = x / L, c = x - r * L;
+          const long long mr = lr_rowidx[wave][r];
+          if (mr >= 0) { e[u].on = true; e[u].o = (size_t)mr * L + c; e[u].p0 = p_sh[x]; e[u].g = wl[r * (L + 1) + c]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GA_SH_UNROLL; u++) ga_adam_load(f.key[5], e[u]);
+#pragma unroll
+      for (int u = 0; u < GA_SH_UNROLL; u++) ga_adam_store(f.key[5], f, e[u]);
+    }
+  }
+}
+
+hipError_t lr_launch_activate_bwd_adam(const ActBwdArgs& a, const AdamArgs& f, const float* g_a_xyz, const int32_t* radii,
+                                       hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  const size_t lds = sizeof(float) * 4 * 64 * (size_t)(3 * a.K + 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ga_bwd_adam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  lr_prof_begin(LRK_ADAM, s);
+  hipLaunchKernelGGL(ga_bwd_adam_kernel, dim3((a.n + 255) / 256), dim3(256), (a.K > 0 && f.key[5].model) ? lds : 0, s, a, f,
+                     g_a_xyz, radii);
+  lr_prof_end(LRK_ADAM, s);
+  return hipGetLastError();
+}
+
 hipError_t lr_launch_gather_activate(const GatherArgs& a, hipStream_t s) {
   if (a.n <= 0) return hipSuccess;
   const size_t lds = sizeof(float) * 4 * 64 * (size_t)(3 * a.K + 1);

@@ -819,6 +819,44 @@ class HipBackend:
         act["xyz"] = raw["xyz"]
         return raw, act
 
+    def activate_backward_adam(self, raw, n, degree, campos, g_xyz, g_scaling, g_opacity, g_rotation, g_colors, index, radii,
+                               entries, beta1, beta2, bias_correction2_sqrt, eps):
+        """Activation backward + sparse Adam in one launch (lograst_activate_backward_adam; log_amd.get_all's fused step).
+        entries: {key: (model_param, exp_avg, exp_avg_sq, max_exp_avg_sq | None, step_size)} for the keys that are optimised
+        (of xyz / scaling / opacity / rotation / colors / shs)."""
+        device = raw["xyz"].device
+        L = self.require(device)
+        K = int(raw["shs"].shape[1]) if "shs" in raw else 0
+        ups = [_dev_f32(t, device) for t in (g_xyz, g_scaling, g_opacity, g_rotation, g_colors)]
+        cp = _dev_f32(campos, device).reshape(-1) if campos is not None else None
+        idx = index.detach().to(torch.int64).contiguous()
+        rad = radii.detach().to(torch.int32).contiguous()
+        if int(idx.numel()) < n or int(rad.numel()) < n:
+            raise ValueError("index / radii are shorter than the rows that are parameters")
+        keys = (_lib.LograstAdamKey * 6)()
+        num_points = int(next(iter(entries.values()))[0].shape[0])
+        for slot, key in zip(keys, ("xyz", "scaling", "opacity", "rotation", "colors", "shs")):
+            if key not in entries:
+                continue
+            model_p, m1, m2, mmax, step_size = entries[key]
+            width = int(model_p[0].numel()) if num_points else 1
+            for t in (model_p, m1, m2) + ((mmax,) if mmax is not None else ()):
+                if t.device != device or t.dtype != torch.float32 or not t.is_contiguous() or t.shape != model_p.shape:
+                    raise ValueError("parameters and Adam moments must be contiguous fp32 tensors on the parameter's device")
+            p = raw[key]
+            if not p.is_contiguous() or int(p.numel()) < n * width:
+                raise ValueError("gathered parameter rows do not match")
+            slot.model_param, slot.param, slot.grad = model_p.data_ptr(), p.data_ptr(), None
+            slot.exp_avg, slot.exp_avg_sq = m1.data_ptr(), m2.data_ptr()
+            slot.max_exp_avg_sq = mmax.data_ptr() if mmax is not None else None
+            slot.width, slot.step_size = width, float(step_size)
+        with torch.cuda.device(device):
+            _lib.check(L.lograst_activate_backward_adam(
+                int(n), _ptr(raw["xyz"]), _ptr(raw["scaling"]), _ptr(raw["opacity"]), _ptr(raw["rotation"]), K, int(degree),
+                _ptr(cp), _ptr(ups[0]), _ptr(ups[1]), _ptr(ups[2]), _ptr(ups[3]), _ptr(ups[4]), num_points, _ptr(idx),
+                _ptr(rad), keys, float(beta1), float(beta2), float(bias_correction2_sqrt), float(eps), _stream_ptr(device)))
+        del ups
+
     def activate_backward(self, raw, n, degree, campos, g_scaling, g_opacity, g_rotation, g_colors):
         """-> dict of dL/d(raw rows [0, n)) for scaling / opacity / rotation / colors (/ shs when degree > 0)."""
         device = raw["xyz"].device
@@ -843,6 +881,12 @@ class HipBackend:
 
 
 _backend = HipBackend()
+_backward_view = threading.local()     # .radii: the radii of the forward whose backward ran last on this thread (see backward())
+
+
+def last_backward_radii():
+    """The `radii` output of the rasterizer forward whose backward node ran last on this thread, or None."""
+    return getattr(_backward_view, "radii", None)
 
 
 # ---- multi-view gradient accumulation (new design, SURVEY 8e; not part of the reference's API) ---------------
@@ -972,6 +1016,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         m, s, r = ctx.saved_tensors
         if grad_image is None:   # only non-differentiable outputs were used downstream
             return (None,) * 11
+        # which view's backward is running: nodes further down the same graph (log_amd.get_all's fused step) read the
+        # visibility of THIS render from here (the rasterizer's node runs before the nodes that produced its inputs)
+        _backward_view.radii = ctx.saved.get("radii") if isinstance(ctx.saved, dict) else None
         m2_shape, o_shape = ctx.shapes
         sh, clamped = ctx.sh
         pw = ctx.saved.get("point_weight") if isinstance(ctx.saved, dict) else None

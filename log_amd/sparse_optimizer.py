@@ -41,12 +41,55 @@ def _migrate_state(opt, device):
                     setattr(d, key, moved)       # BufferDict (nn.Module): replaces the registered buffer
 
 
+def _lr_of(opt, key, steps):
+    if key == "xyz":
+        return opt.xyz_scheduler_args(steps)
+    if key == "scaling":
+        return opt.scaling_scheduler_args(steps)
+    return opt.lr_dict[key]
+
+
+def fused_update(fused, pack, n, radii, g_xyz, g_scaling, g_opacity, g_rotation, g_colors):
+    """Called from the backward of ``log_amd.get_all`` (``set_fused_step(True)``): the step's Adam update of the rows with
+    ``radii > 0``, applied by the kernel that computes their raw gradients.  Uses the scalars ``step`` would use (the step
+    number is the NEXT one: ``step`` itself still advances the counters).  -> True when the update was applied; False
+    (nothing touched) when this optimizer cannot be fused: the caller then produces the gradients as usual."""
+    opt = fused["optimizer"]
+    if getattr(opt, "_lograst_fused_pending", False):
+        return False                         # a second backward before step(): that one goes the ordinary way
+    bufs = fused["bufs"]
+    try:
+        steps = _host_steps(opt) + 1
+        bc1, bc2 = 1 - BETA1 ** steps, 1 - BETA2 ** steps
+        device = g_xyz.device
+        _migrate_state(opt, device)
+        entries = {}
+        for key in pack["param_keys"]:
+            entries[key] = (bufs[key].data, opt.exp_avg[key], opt.exp_avg_sq[key],
+                            opt.max_exp_avg_sq[key] if getattr(opt, "use_amsgrad", False) else None, _lr_of(opt, key, steps) / bc1)
+    except (KeyError, AttributeError):
+        return False
+    with torch.no_grad():
+        _r._backend.activate_backward_adam(pack["raw"], n, pack["degree"], pack["campos"], g_xyz, g_scaling, g_opacity,
+                                           g_rotation, g_colors, fused["index"], radii, entries, BETA1, BETA2,
+                                           math.sqrt(bc2), EPS)
+    opt._lograst_fused_pending = True
+    return True
+
+
 def step(self, model, index, params, flag_vis):
     """Same signature and effects as SparseOptimizer.step: rows ``index[flag_vis]`` of every ``getattr(model, key)``
     with a gradient, and of its Adam moments, are updated; ``self.xyz_lr`` and ``self.global_steps`` advance."""
     steps = _host_steps(self) + 1            # read (first call only) BEFORE the device-side increment
     self.global_steps += 1
     self._lograst_steps = steps
+    if getattr(self, "_lograst_fused_pending", False):
+        # the update of this step was applied by the backward (log_amd.get_all, set_fused_step): what is left is the
+        # bookkeeping -- the counters above and the learning rate the trainer reads back (level_of_gaussian.py:394)
+        self._lograst_fused_pending = False
+        if "xyz" in params:
+            self.xyz_lr = self.xyz_scheduler_args(steps)
+        return
     bc1 = 1 - BETA1 ** steps
     bc2 = 1 - BETA2 ** steps
     _migrate_state(self, next(iter(params.values())).device)

@@ -213,3 +213,105 @@ def test_owner_computes_step_on_device_matches_reference_golden():
         np.testing.assert_allclose(params.views[n].cpu().numpy().reshape(g["final_" + n].shape), g["final_" + n], rtol=2e-6, atol=1e-9)
         np.testing.assert_allclose(opt.exp_avg[n].cpu().numpy()[:P].reshape(g["final_exp_avg_" + n].shape),
                                    g["final_exp_avg_" + n], rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("degree,amsgrad", [(3, False), (1, True), (0, False)])
+def test_fused_step_kernel_equals_activation_backward_plus_sparse_adam(degree, amsgrad):
+    """Round 6 (round-5 verdict, next #6): lograst_activate_backward_adam -- the activation backward applying the reference's
+    sparse Adam itself, the compact raw gradients never written -- against the two kernels it replaces, on IDENTICAL inputs
+    (the same gathered rows, the same dL/d(activated), the same visibility): same op sequences, so the model, both moments
+    and the amsgrad maximum come out BIT FOR BIT the same.  The unfused pair is pinned to goldens produced by the reference's
+    own SparseOptimizer / Activation (adam_*.npz, getall_*.npz), so the pin carries over."""
+    import math
+    import torch
+    from log_amd import rasterizer as R
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(7 + degree)
+    P, n_all, n = 50_000, 20_011, 17_003                      # model rows, gathered rows, rows that are parameters
+    K = max((degree + 1) ** 2 - 1, 3)
+    rnd = lambda *sh: torch.randn(*sh, device=dev, generator=gen)
+    bufs = {"xyz": rnd(P, 3), "scaling": rnd(P, 3) * 0.3 - 3.0, "opacity": rnd(P, 1), "rotation": rnd(P, 4),
+            "colors": rnd(P, 3), "shs": rnd(P, K, 3) * 0.2}
+    index = torch.randperm(P, device=dev, generator=gen)[:n_all]
+    campos = torch.tensor([0.3, -2.0, 1.0], device=dev)
+    raw, act = R._backend.gather_activate(index, bufs, degree, campos if degree > 0 else None)
+    ups = {"xyz": rnd(n_all, 3), "scaling": rnd(n_all, 3), "opacity": rnd(n_all, 1), "rotation": rnd(n_all, 4),
+           "colors": rnd(n_all, 3)}
+    radii = (torch.rand(n_all, device=dev, generator=gen) < 0.6).to(torch.int32) * 7
+    keys = [k for k in bufs if k != "shs" or degree > 0]
+    lr = {"xyz": 1.6e-4, "scaling": 5e-3, "opacity": 0.05, "rotation": 1e-3, "colors": 2.5e-3, "shs": 1.25e-4}
+    m1_0 = {k: rnd(*v.shape) * 1e-3 for k, v in bufs.items()}
+    m2_0 = {k: (rnd(*v.shape) * 1e-3) ** 2 for k, v in bufs.items()}
+    mx_0 = {k: (rnd(*v.shape) * 1e-3) ** 2 for k, v in bufs.items()}
+    results = []
+    for fused in (False, True):
+        model = {k: v.clone() for k, v in bufs.items()}
+        m1, m2 = {k: v.clone() for k, v in m1_0.items()}, {k: v.clone() for k, v in m2_0.items()}
+        mx = {k: v.clone() for k, v in mx_0.items()} if amsgrad else None
+        steps = 5
+        bc1, bc2 = 1 - 0.9 ** steps, 1 - 0.999 ** steps
+        if fused:
+            entries = {k: (model[k], m1[k], m2[k], mx[k] if amsgrad else None, lr[k] / bc1) for k in keys}
+            R._backend.activate_backward_adam(raw, n, degree, campos if degree > 0 else None, ups["xyz"], ups["scaling"],
+                                              ups["opacity"], ups["rotation"], ups["colors"], index[:n], radii, entries,
+                                              0.9, 0.999, math.sqrt(bc2), 1e-15)
+        else:
+            g = R._backend.activate_backward(raw, n, degree, campos if degree > 0 else None, ups["scaling"], ups["opacity"],
+                                             ups["rotation"], ups["colors"])
+            g["xyz"] = ups["xyz"][:n]
+            entries = [(model[k], raw[k][:n], g[k], m1[k], m2[k], mx[k] if amsgrad else None, lr[k] / bc1) for k in keys]
+            R._backend.sparse_adam(index[:n], radii[:n] > 0, entries, 0.9, 0.999, math.sqrt(bc2), 1e-15)
+        torch.cuda.synchronize()
+        results.append((model, m1, m2, mx))
+    (ma, a1, a2, ax), (mb, b1, b2, bx) = results
+    touched = 0
+    for k in bufs:
+        assert torch.equal(ma[k], mb[k]) and torch.equal(a1[k], b1[k]) and torch.equal(a2[k], b2[k]), k
+        if amsgrad:
+            assert torch.equal(ax[k], bx[k]), k
+        touched += int((mb[k] != bufs[k]).sum())
+    assert touched > 100_000
+    if degree == 0:
+        assert torch.equal(mb["shs"], bufs["shs"])            # unused coefficients: no gradient, no update
+    vis_rows = index[:n][radii[:n] > 0]
+    hidden = torch.ones(P, dtype=torch.bool, device=dev)
+    hidden[vis_rows] = False
+    assert torch.equal(mb["xyz"][hidden], bufs["xyz"][hidden])  # rows that are not visible parameters never move
+
+
+def test_fused_step_through_the_drop_ins():
+    """``log_amd.get_all.set_fused_step(True)`` in the flow of a LoG training view (select -> gather / activate -> rasterize
+    fwd + bwd -> counter -> step): the update is applied by the backward, nothing is left on ``params[key].grad``, ``step``
+    is reduced to its bookkeeping (step counter, the learning rate the trainer reads back), and the model agrees with the
+    unfused drop-ins' to the run-to-run noise of the rasterizer's own gradients (its reverse walk sums with atomics)."""
+    import os
+    import sys
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_log_step as B
+    from log_amd import get_all
+    wl = B.Workload(roots=3000, levels=4, sh_degree=3, views=3, root_scale=0.05)
+    packs = [wl.rasterizer_for(c) for c in wl.cams]
+    states = []
+    for fused in (False, True):
+        st = B.State(wl)
+        prev = get_all.set_fused_step(fused)
+        try:
+            for p in packs + packs[:1]:
+                B.view(wl, st, p, True, lambda name: None)
+                params = st.gaussian.visibility_flag["params"]
+                if fused:
+                    assert all(p_.grad is None for p_ in params.values())          # nothing was written for the optimizer to read
+                else:
+                    assert params["xyz"].grad is not None
+                assert not getattr(st.opt, "_lograst_fused_pending", False)        # step() consumed it
+        finally:
+            get_all.set_fused_step(prev)
+        states.append(st)
+    a, b = states
+    assert float(a.opt.global_steps) == float(b.opt.global_steps) == 4.0 and a.opt.xyz_lr == b.opt.xyz_lr
+    for k in wl.keys:
+        da = (a.bufs[k] - wl.bufs[k]).double()
+        assert float((b.bufs[k] - a.bufs[k]).double().norm()) <= 1e-4 * float(da.norm()), k
+        assert float(da.norm()) > 0

@@ -87,13 +87,14 @@ class State:
             keys=wl.keys, active_sh_degree=D, items=lambda: ((k, self.bufs[k]) for k in wl.keys), visibility_flag=None,
             activation=types.SimpleNamespace(scaling_activation=torch.exp, rotation_activation=torch.nn.functional.normalize),
             **self.bufs)
-        self.model = types.SimpleNamespace(gaussian=self.gaussian, fix_parent=True, training=True)
+        self.model = types.SimpleNamespace(gaussian=self.gaussian, fix_parent=True, training=True)   # (+ .optimizer below, as LoG has it)
         self.counter = types.SimpleNamespace(**{k: torch.zeros(P, dtype=d, device=dev) for k, d in CDT.items()})
         z = lambda: {k: torch.zeros_like(v) for k, v in self.bufs.items()}
         self.opt = types.SimpleNamespace(global_steps=torch.tensor(0., device=dev), lr_dict=dict(LR), exp_avg=z(),
                                          exp_avg_sq=z(), use_amsgrad=False, xyz_lr=None,
                                          xyz_scheduler_args=lambda st: 1.6e-4, scaling_scheduler_args=lambda st: 5e-3)
         self.model_ns = types.SimpleNamespace(**self.bufs)
+        self.model.optimizer = self.opt          # level_of_gaussian.py:352 (read by log_amd.get_all's fused step only)
 
 
 def split_leaf_node(wl, index_all):
@@ -295,7 +296,7 @@ def render_only(wl, reps=2):
 
 
 def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, with_torch=False, dev=None,
-                forward_only=False):
+                forward_only=False, fused_step=True):
     """-> dict for the C3 leg: ms per training view of the fused (drop-in) pipeline, its stage and kernel breakdown,
     and (with_torch) the same step with everything except the rasterizer done the reference's way in torch."""
     from log_amd import _lib, rasterizer as R
@@ -332,6 +333,27 @@ def c3_pipeline(roots=40000, levels=7, sh_degree=3, views=8, root_scale=0.03, wi
                        k: float((st_f.bufs[k] - st_t.bufs[k]).norm() / st_t.bufs[k].norm()) for k in wl.keys})
     if forward_only:
         out["forward_only"] = render_only(wl)
+    if fused_step:
+        # round 6: the same view with the activation backward and sparse Adam in ONE kernel (log_amd.get_all.set_fused_step:
+        # opt-in; the compact raw gradients are never written)
+        from log_amd import get_all
+        prev = get_all.set_fused_step(True)
+        try:
+            tot_s, _, _, st_s = run(wl, True, False)
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+            _, stg_s, _, _ = run(wl, True, True)
+            prof_s = _lib.profile_read()
+            _lib.profile_enable(False)
+        finally:
+            get_all.set_fused_step(prev)
+        out.update(ms_per_view_fused_step=tot_s, stages_ms_fused_step=stg_s,
+                   kernels_us_per_view_fused_step={k: round(v[0] / (2 * wl.V) * 1e3, 1) for k, v in prof_s.items()},
+                   # (the two pipelines' rasterizer gradients differ by their atomics' summation order, so the models agree to
+                   # that noise, not bit for bit; the kernels themselves are bit-identical on identical inputs: tests/test_gpu_train_ops.py)
+                   fused_step_model_rel_l2_vs_unfused={
+                       k: float((st_s.bufs[k] - st_f.bufs[k]).double().norm() /
+                                max(float((st_f.bufs[k] - wl.bufs[k]).double().norm()), 1e-30)) for k in wl.keys})
     # the same view with the rasterizer's sync-free mode (log_amd.rasterizer.set_instance_capacity: no read-back in the
     # forward at all, one C-ABI call): capacity and longest-list hint from the views just run, +10 %, checked afterwards.
     # (Since round 3 the default forward does not stall the stream on its read-back either: the two should agree.)

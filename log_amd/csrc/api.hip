@@ -126,6 +126,7 @@ static const LrKnobInfo kKnobs[] = {
     {"LOGRAST_FILL_STAGED", 2, 0, 3, "bucket fill of batched full views: K = the batch's slot-table row staged in LDS by workgroups of up to K x 1024 consecutive Gaussians (K per thread), 0 = one table look-up per tile instance"},
     {"LOGRAST_FILL_PER_THREAD", 1, 1, 4, "bucket fill: Gaussians per thread (their fill records are requested together): 1, 2 or 4"},
     {"LOGRAST_BAND_SPARSE", 1, 0, 1, "band views (tile_row_begin/end a proper part of the grid): 1 = the band projection (Gaussians without a rect cost 44 bytes, survivors compacted into full waves), 0 = the full-view kernel"},
+    {"LOGRAST_FWD_BLOCK_TEST", 1, 0, 1, "row-split compositing: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block (the reverse walk on the forward's hit masks visits what the forward's test kept)"},
     {"LOGRAST_BWD_BLOCK_TEST", 1, 0, 1, "row-split reverse walk: 1 = exact support test per 4x4 block, 0 = exact for the quadrant + bounding box per block"},
 };
 static const int kNumKnobs = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));

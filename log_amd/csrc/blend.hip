@@ -852,7 +852,7 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
                          float* __restrict__ image, float* __restrict__ final_T, int* __restrict__ n_contrib,
                          int* __restrict__ pid, float* __restrict__ pwp, float* __restrict__ pw,
                          float4* __restrict__ zero_rows, int xcd_mode, int cull, uint32_t* __restrict__ lazy_state,
-                         int lazy, uint64_t* __restrict__ masks, uint32_t* __restrict__ hdr_w LR_ABLATE_PARAM) {
+                         int lazy, uint64_t* __restrict__ masks, uint32_t* __restrict__ hdr_w, int block_test LR_ABLATE_PARAM) {
   __shared__ float4 lr_stage[4][65 * LR_RB_SLOT];
   if (lr_bail(state, capacity)) return;
   if (lazy == 2 && !lazy_state[LR_HDR_OPEN]) return;         // nobody parked (lazy_state: the tile state again, through the pointer these kernels WRITE sorted[] / open[] / the flag with)
@@ -955,12 +955,23 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     bool r0 = valid, r1 = valid, r2 = valid, r3 = valid;
     if (cull) {
       const LrSupport sp = lr_support_prepare(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y);
-      // the four 4x4 blocks two at a time (lr_support_box2: the decisions of four lr_support_box calls, packed arithmetic)
-      bool k0, k1, k2, k3;
-      const lr_f2 X0 = {bx[0], bx[1]}, X1 = {bx[0] + 3.f, bx[1] + 3.f};
-      lr_support_box2(sp, X0, X1, lr_f2{by[0], by[0]}, lr_f2{by[0] + 3.f, by[0] + 3.f}, k0, k1);
-      lr_support_box2(sp, X0, X1, lr_f2{by[1], by[1]}, lr_f2{by[1] + 3.f, by[1] + 3.f}, k2, k3);
-      r0 = r0 && k0; r1 = r1 && k1; r2 = r2 && k2; r3 = r3 && k3;
+      if (block_test) {
+        // the four 4x4 blocks two at a time (lr_support_box2: the decisions of four lr_support_box calls, packed arithmetic)
+        bool k0, k1, k2, k3;
+        const lr_f2 X0 = {bx[0], bx[1]}, X1 = {bx[0] + 3.f, bx[1] + 3.f};
+        lr_support_box2(sp, X0, X1, lr_f2{by[0], by[0]}, lr_f2{by[0] + 3.f, by[0] + 3.f}, k0, k1);
+        lr_support_box2(sp, X0, X1, lr_f2{by[1], by[1]}, lr_f2{by[1] + 3.f, by[1] + 3.f}, k2, k3);
+        r0 = r0 && k0; r1 = r1 && k1; r2 = r2 && k2; r3 = r3 && k3;
+      } else {            // LOGRAST_FWD_BLOCK_TEST=0: exact test for the quadrant, the support's bounding box against each block
+        const bool q = lr_support_box(sp, bx[0], bx[0] + 7.f, by[0], by[0] + 7.f);
+        const bool bb = sp.mode == 2;
+        const bool x_lo = !bb || (sp.mx - sp.ex <= bx[0] + 3.f), x_hi = !bb || (sp.mx + sp.ex >= bx[1]);
+        const bool y_lo = !bb || (sp.my - sp.ey <= by[0] + 3.f), y_hi = !bb || (sp.my + sp.ey >= by[1]);
+        r0 = r0 && q && x_lo && y_lo;
+        r1 = r1 && q && x_hi && y_lo;
+        r2 = r2 && q && x_lo && y_hi;
+        r3 = r3 && q && x_hi && y_hi;
+      }
     }
     uint64_t mrow = lr_row_mask(row, __ballot(r0), __ballot(r1), __ballot(r2), __ballot(r3));   // this lane's row's hit mask
     const int pos0 = (int)(first + ch * 64u);
@@ -1074,6 +1085,7 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   static const int fwd_ablate = lr_env_int("LOGRAST_FWD_ABLATE", 0);   // timing experiments (row-split form): 1 no point_weight atomics, 2 no row clears
 #endif
   const int rows = lr_blend_fwd_form(v) == (int)LR_MASK_FORM_ROWS;
+  LR_KNOB(fwd_block_test, "LOGRAST_FWD_BLOCK_TEST", 1);
   if (!cull) masks = nullptr;                                // (experiment builds without support tests: nothing to hand over)
   uint32_t grid = lr_blend_grid(tiles, v.gx, v.gy, xcd_mode);
   if (lazy == 2) {   // only streamed lists can be open: in the scan's longest-first order they sit in front of every shorter one
@@ -1086,10 +1098,10 @@ void lr_launch_blend_fwd(const LrView& v, const void* geom, const uint32_t* stat
   if (rows) {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w, fwd_block_test LR_ABLATE_PASS(fwd_ablate));
     else
       hipLaunchKernelGGL(lr_blend_fwd_rows_kernel<false>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,
-                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w LR_ABLATE_PASS(fwd_ablate));
+                         image, final_T, n_contrib, pid, pwp, pw, z4, xcd_mode, cull, lazy_state, lazy, masks, hdr_w, fwd_block_test LR_ABLATE_PASS(fwd_ablate));
   } else {
     if (v.extras)
       hipLaunchKernelGGL(lr_blend_fwd_kernel<true>, dim3(grid), dim3(256), lds_fwd, s, v, g4, state, tiles, plist, capacity,

@@ -25,6 +25,7 @@ CANDIDATES = {
     "LOGRAST_BWD_ROWS": (0, 1, 2),
     "LOGRAST_FWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
+    "LOGRAST_FWD_BLOCK_TEST": (0, 1),
     "LOGRAST_MID_COOP": (0, 8, 16, 32),       # rects of 5..16 tiles: wave-cooperative counting up to this many per wave
     "LOGRAST_MID_RANK": (0, 1),
     "LOGRAST_HIT_MASKS": (0, 1),              # the forward's support ballots handed to the reverse walk

@@ -31,6 +31,7 @@ SWEEP = {
     "LOGRAST_BWD_ROWS": (0, 1, 2),
     "LOGRAST_FWD_ROWS": (0, 1, 2),
     "LOGRAST_BWD_BLOCK_TEST": (0, 1),
+    "LOGRAST_FWD_BLOCK_TEST": (0, 1),
     "LOGRAST_BAND_SPARSE": (0, 1),
     "LOGRAST_FILL_PER_THREAD": (1, 2, 4),
     "LOGRAST_FILL_STAGED": (0, 1, 2, 3),

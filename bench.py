@@ -1060,7 +1060,8 @@ def compact_line(result):
         r = {"bound": rf.get("bound"), "kernel": rf.get("kernel"), "achieved": _num(rf.get("achieved")),
              "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _num(rf.get("frac"), 4),
              "traffic": _num(rf.get("traffic"), 8),
-             "traffic_source": (str(rf.get("traffic_source", ""))[17:].split(" ")[0] if rf.get("traffic") else None),
+             "traffic_source": (next((w for w in str(rf.get("traffic_source", "")).split() if w.startswith("profiles/")), None)
+                                if rf.get("traffic") else None),
              "valu_issue_frac": _num(rf.get("valu_issue_frac"), 3), "avg_launch_us": _num(rf.get("avg_launch_us"), 5),
              "algorithmic_bytes_per_launch": _num(rf.get("algorithmic_bytes_per_launch"), 8),
              "measured_stream_copy_GBs": _num(rf.get("measured_stream_copy_GBs"), 5),

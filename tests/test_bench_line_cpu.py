@@ -69,6 +69,8 @@ def test_compact_line_from_committed_full_results(name, full):
     for k in CPU:
         assert k in back["cpu_baseline"], k
     assert back["config"]["ms_per_view"] > 0
+    if back["roofline"]["traffic"] is not None and name >= "r06":     # (rounds 4-5 named no file: "profiles/r*_traffic*.json")
+        assert back["roofline"]["traffic_source"].startswith("profiles/r") and back["roofline"]["traffic_source"].endswith(".json")
     if "dropin_default" in full["modes"]:
         assert back["config"]["dropin_default_ms_per_view"] >= back["config"]["ms_per_view"] * 0.9
 

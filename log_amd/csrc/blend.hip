@@ -658,9 +658,15 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   const int maxc = max(max(rm0, rm1), max(rm2, rm3));
   if (maxc == 0) return;
 
-  float4* const stage = lr_stage[wq];
-  if (lane < LR_RB_SLOT) stage[64 * LR_RB_SLOT + lane] = float4{0.f, 0.f, 0.f, 0.f};   // the all-zero entry (id patched below)
-  if (lane == 2) stage[64 * LR_RB_SLOT + 2] = float4{0.f, __uint_as_float(0xffffffffu), 0.f, 0.f};
+  // The chunk's entries staged FIELD-major (round 6): sf[f * 65 + j] = field f of entry j (0 mx, 1 my, 2 A, 3 B, 4 C, 5 opacity,
+  // 6-8 colour, 9 id bits); slot 64 = the all-zero entry of rows without work.  The pass loop packs the SAME field of its two
+  // entries into one 64-bit register pair (v_pk_*: entry a in the low half, entry b in the high half): with 48-byte entries read
+  // as three ds_read_b128 each, every such pair cost a v_mov per half (27 of the loop's 204 VALU instructions were plain
+  // moves); a ds_read_b32 per field lands in the half it is used in.
+  float* const sf = reinterpret_cast<float*>(lr_stage[wq]);
+#define LR_SF(f, j) sf[(f) * 65 + (j)]
+  const uint32_t sf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)sf;   // its LDS byte address
+  if (lane < 10) LR_SF(lane, 64) = lane == 9 ? __uint_as_float(0xffffffffu) : 0.f;   // the all-zero entry
 
   // Where a row's sums go: after the packed reductions (see the loop) every lane of a quad holds the quad's total of
   //   S1: quads (col r, col b, col g, opacity)   S2: quads (mean x, conic A, mean y, conic B)   S3: lanes 0-7 / 8-15: conic C of entry 0 / 1
@@ -737,9 +743,9 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (id != 0xffffffffu && wanted(mk)) {
-      stage[lane * LR_RB_SLOT + 0] = g0;
-      stage[lane * LR_RB_SLOT + 1] = g1;
-      stage[lane * LR_RB_SLOT + 2] = float4{cb, __uint_as_float(id), 0.f, 0.f};
+      LR_SF(0, lane) = g0.x; LR_SF(1, lane) = g0.y; LR_SF(2, lane) = g0.z; LR_SF(3, lane) = g0.w;
+      LR_SF(4, lane) = g1.x; LR_SF(5, lane) = g1.y; LR_SF(6, lane) = g1.z; LR_SF(7, lane) = g1.w;
+      LR_SF(8, lane) = cb; LR_SF(9, lane) = __uint_as_float(id);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -776,18 +782,39 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
     while (__builtin_amdgcn_ballot_w64(mrow != 0ull) != 0) {
       // every row's next two entries (64 = none: the all-zero slot)
       const uint32_t ja = lr_take_bit(mrow), jb = lr_take_bit(mrow);
-      const float4* sa = stage + ja * LR_RB_SLOT;
-      const float4* sb = stage + jb * LR_RB_SLOT;
-      const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
-      const uint32_t gida = __float_as_uint(a2.y), gidb = __float_as_uint(b2.y);
-      const float op0 = a1.y, op1 = b1.y;
-      const lr_f2 dx2 = lr_f2{a0.x, b0.x} - pxf, dy2 = lr_f2{a0.y, b0.y} - pyf;
+      // twenty single-dword LDS reads, each into the register half it is used in (written with plain loads the compiler
+      // merges two FIELDS of one entry into a ds_read2_b32 -- pairs within an entry again, and the moves are back)
+      float fa[10], fb[10];
+      {
+        const uint32_t aa = sf_lds + 4u * ja, ab = sf_lds + 4u * jb;
+        asm volatile(
+            "ds_read_b32 %0, %20\n ds_read_b32 %10, %21\n"
+            "ds_read_b32 %1, %20 offset:260\n ds_read_b32 %11, %21 offset:260\n"
+            "ds_read_b32 %2, %20 offset:520\n ds_read_b32 %12, %21 offset:520\n"
+            "ds_read_b32 %3, %20 offset:780\n ds_read_b32 %13, %21 offset:780\n"
+            "ds_read_b32 %4, %20 offset:1040\n ds_read_b32 %14, %21 offset:1040\n"
+            "ds_read_b32 %5, %20 offset:1300\n ds_read_b32 %15, %21 offset:1300\n"
+            "ds_read_b32 %6, %20 offset:1560\n ds_read_b32 %16, %21 offset:1560\n"
+            "ds_read_b32 %7, %20 offset:1820\n ds_read_b32 %17, %21 offset:1820\n"
+            "ds_read_b32 %8, %20 offset:2080\n ds_read_b32 %18, %21 offset:2080\n"
+            "ds_read_b32 %9, %20 offset:2340\n ds_read_b32 %19, %21 offset:2340\n"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fa[2]), "=&v"(fa[3]), "=&v"(fa[4]), "=&v"(fa[5]), "=&v"(fa[6]), "=&v"(fa[7]),
+              "=&v"(fa[8]), "=&v"(fa[9]), "=&v"(fb[0]), "=&v"(fb[1]), "=&v"(fb[2]), "=&v"(fb[3]), "=&v"(fb[4]), "=&v"(fb[5]),
+              "=&v"(fb[6]), "=&v"(fb[7]), "=&v"(fb[8]), "=&v"(fb[9])
+            : "v"(aa), "v"(ab)
+            : "memory");
+      }
+      const lr_f2 Ar = {fa[2], fb[2]}, Br = {fa[3], fb[3]}, Cr = {fa[4], fb[4]};
+      const lr_f2 op2 = {fa[5], fb[5]};
+      const lr_f2 cr = {fa[6], fb[6]}, cg = {fa[7], fb[7]}, cbl = {fa[8], fb[8]};
+      const uint32_t gida = __float_as_uint(fa[9]), gidb = __float_as_uint(fb[9]);
+      const lr_f2 dx2 = lr_f2{fa[0], fb[0]} - pxf, dy2 = lr_f2{fa[1], fb[1]} - pyf;
       const lr_f2 hdx2 = dx2 * -0.5f, hdy2 = dy2 * -0.5f;
-      const lr_f2 bdx = lr_f2{a0.w, b0.w} * dx2;
-      const lr_f2 pw2 = lr_fma2(lr_f2{a0.z, b0.z} * dx2, hdx2,
-                                lr_fma2(lr_f2{a1.x, b1.x} * dy2, hdy2, lr_f2{-bdx.x, -bdx.y} * dy2));
+      const lr_f2 bdx = Br * dx2;
+      const lr_f2 pw2 = lr_fma2(Ar * dx2, hdx2, lr_fma2(Cr * dy2, hdy2, lr_f2{-bdx.x, -bdx.y} * dy2));
       const lr_f2 G2 = lr_exp2(pw2);
-      const lr_f2 al2 = lr_f2{op0, op1} * G2;
+      const lr_f2 al2 = op2 * G2;
       const float alpha0 = fminf(0.99f, al2.x), alpha1 = fminf(0.99f, al2.y);
       const int k0 = hi - 1 - (int)ja, k1 = hi - 1 - (int)jb;   // list positions (the all-zero slot has opacity 0: never a hit)
       const bool hit0 = (k0 < lastc) & !(pw2.x > 0.f) & !(alpha0 < 1.0f / 255.0f);
@@ -803,7 +830,6 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       const lr_f2 T2 = {Ta, Tb};
       T = Tb;
       const lr_f2 w = alpha * T2;
-      const lr_f2 cr = {a1.z, b1.z}, cg = {a1.w, b1.w}, cbl = {a2.x, b2.x};
       const float a0r = lr_fma(alpha.x, cr.x, om.x * acc0), a0g = lr_fma(alpha.x, cg.x, om.x * acc1),
                   a0b = lr_fma(alpha.x, cbl.x, om.x * acc2);
       lr_f2 dL_dalpha = lr_fma2(cr - lr_f2{acc0, a0r}, lr_f2{dp0, dp0},
@@ -812,8 +838,7 @@ lr_blend_bwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
       acc0 = lr_fma(alpha.y, cr.y, om.y * a0r);
       acc1 = lr_fma(alpha.y, cg.y, om.y * a0g);
       acc2 = lr_fma(alpha.y, cbl.y, om.y * a0b);
-      const lr_f2 Ar = {a0.z, b0.z}, Br = {a0.w, b0.w}, Cr = {a1.x, b1.x};
-      const lr_f2 dL_dG = lr_f2{op0, op1} * dL_dalpha;
+      const lr_f2 dL_dG = op2 * dL_dalpha;
       const lr_f2 gdx = G * dx2, gdy = G * dy2;
       const lr_f2 dG_ddx = lr_fma2(-Ar, gdx, -(Br * gdy));
       const lr_f2 dG_ddy = lr_fma2(-Cr, gdy, -(Br * gdx));

@@ -191,6 +191,42 @@ LR_DEV uint64_t lr_mask_before(uint64_t m, int hi, int limit) {
   return sh <= 0 ? m : (sh >= 64 ? 0ull : (m & (~0ull << sh)));
 }
 
+// ---- the forward's per-Gaussian outputs, committed once per chunk (round 6) ---------------------------------------------
+// A contributing visit used to end in memory operations of its own: an atomicMax on point_weight[g] and -- in a training
+// forward on a large input -- the clearing of g's accumulator row.  The experiment build showed what they cost
+// (profiles/r06_fwd_memops.jsonl, 30 M Gaussians, row-split form): the kernel takes 572-595 us with them and 407-417 without
+// (opacity = rand: 1098 / 713) -- and leaving out EITHER kind alone already gives 437 / 441: not their throughput, their
+// place.  gfx9 counts loads, stores and atomics in one counter that retires IN ORDER, so the wait for the next chunk's
+// prefetched records at the end of every chunk also waited for the last atomic / store the pass loop had just issued -- a
+// memory-side round trip of its own, once per chunk and wave.  Now a visit raises a per-wave LDS maximum of its entry
+// (ds_max_u32: one lane), and the chunk's maxima and row clears leave in ONE burst at the top of the NEXT chunk, in front of
+// that chunk's prefetch loads: nothing the chunk's final wait covers is younger than the loads it is for, and the burst
+// has a whole chunk of passes to complete.  Same values (a maximum of the same numbers; the same rows cleared).
+template <bool EXTRAS>
+LR_DEV void lr_fwd_commit_chunk(uint32_t* wmx, int lane, uint32_t id_prev, float* __restrict__ pw, float4* __restrict__ zero_rows) {
+  if (!EXTRAS) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t m = (id_prev != 0xffffffffu) ? wmx[lane] : 0u;
+  if (m != 0u) atomicMax(reinterpret_cast<unsigned int*>(pw) + id_prev, m);
+  // training forward: this Gaussian contributes, so the reverse walk will add to its 64-byte accumulator row -- clear it
+  // (every wave that meets the Gaussian stores the same zeros; rows of Gaussians nobody meets are never read).  Four lanes
+  // per row, one quarter each: every store instruction writes up to sixteen COMPLETE lines (a lane clearing its own row in
+  // four instructions is four partial writes per line at the L2).
+  if (zero_rows) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int e = 16 * k + (lane >> 2);
+      const uint32_t me = (uint32_t)__shfl((int)m, e), ide = (uint32_t)__shfl((int)id_prev, e);
+      if (me != 0u) zero_rows[4 * (size_t)ide + (lane & 3)] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  wmx[lane] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool EXTRAS>
 __global__ void __launch_bounds__(256) LR_OCC_FWD
 lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* __restrict__ state,
@@ -210,6 +246,10 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
   bool clamped;
   const int lane = threadIdx.x & 63, quad = threadIdx.x >> 6;
   uint64_t* const mrow_out = masks ? masks + 4 * lr_mask_slot(beg, tile) + quad : nullptr;
+  __shared__ uint32_t lr_wmax_q[4][64];                      // per wave and chunk: the running maximum of alpha T of every entry
+  uint32_t* const wmx = lr_wmax_q[quad];
+  if (EXTRAS) wmx[lane] = 0u;
+  uint32_t id_prev = 0xffffffffu;                            // the ids of the chunk whose commit is pending (lr_fwd_commit_chunk)
   if (!lr_lazy_range(lazy_state + lr_sorted_off(tiles), tiles, lazy, tile, quad, beg, end, first, clamped)) return;
   const int tx = tile % (uint32_t)v.gx, ty = tile / (uint32_t)v.gx;
   const int qx0 = tx * 16 + (quad & 1) * 8, qy0 = ty * 16 + (quad >> 1) * 8;
@@ -240,7 +280,9 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     if (__all(done)) break;
+    lr_fwd_commit_chunk<EXTRAS>(wmx, lane, id_prev, pw, zero_conic);   // the previous chunk's, in front of this chunk's loads
     const uint32_t id = id_n;
+    id_prev = id;
     const float4 g0 = g0_n;
     const float2 g1 = g1_n;
     id_n = id_nn;
@@ -308,11 +350,7 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (EXTRAS) {
           if (w0 > wmax) { wmax = w0; wid = gid; }
           const uint32_t m = lr_wave_umax_to63(__float_as_uint(w0));  // w >= 0: unsigned order == float order
-          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
-          // training forward: this Gaussian contributes, so the reverse walk will add to its 64-byte accumulator row --
-          // clear it (four lanes, one quarter each; every wave that meets the Gaussian stores the same zeros; rows of
-          // Gaussians nobody meets are never read)
-          if (zero_conic && lane >= 60) zero_conic[4 * (size_t)(uint32_t)gid + (lane - 60)] = float4{0.f, 0.f, 0.f, 0.f};
+          if (lane == 63) atomicMax(&wmx[j0], m);                     // (LDS; point_weight and the row clear: lr_fwd_commit_chunk)
         }
       }
       if (hit1) {
@@ -322,16 +360,13 @@ lr_blend_fwd_kernel(LrView v, const float4* __restrict__ geom, const uint32_t* _
         if (EXTRAS) {
           if (w1 > wmax) { wmax = w1; wid = gid; }
           const uint32_t m = lr_wave_umax_to63(__float_as_uint(w1));
-          if (lane == 63) atomicMax(reinterpret_cast<unsigned int*>(pw) + gid, m);
-          // training forward: this Gaussian contributes, so the reverse walk will add to its 64-byte accumulator row --
-          // clear it (four lanes, one quarter each; every wave that meets the Gaussian stores the same zeros; rows of
-          // Gaussians nobody meets are never read)
-          if (zero_conic && lane >= 60) zero_conic[4 * (size_t)(uint32_t)gid + (lane - 60)] = float4{0.f, 0.f, 0.f, 0.f};
+          if (lane == 63) atomicMax(&wmx[j1], m);
         }
       }
       if (!(hit0 | hit1) && __all(done)) break;
     }
   }
+  lr_fwd_commit_chunk<EXTRAS>(wmx, lane, id_prev, pw, zero_conic);   // the last chunk's
   if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
     if (lane == 0) { atomicOr(lazy_state + lr_sorted_off(tiles) + tiles + tile, 1u << quad); atomicOr(lazy_state + LR_HDR_OPEN, 1u); }   // open[tile], header
     if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);
@@ -895,6 +930,10 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
   // with a store in flight every wait for a prefetched record becomes vmcnt(0) -- the two-chunk software pipeline of this
   // loop drains once per chunk.  (The quadrant kernel's records come through the scalar cache: measured neutral there.)
   __shared__ uint64_t lr_mbuf[4][LR_MBUF_CHUNKS * 4];
+  __shared__ uint32_t lr_wmax_r[4][65];                      // per wave and chunk: the running maximum of alpha T of every entry (+ slot 64: rows without work)
+  uint32_t* const wmx = lr_wmax_r[wq];
+  if (EXTRAS) { wmx[lane] = 0u; if (lane == 0) wmx[64] = 0u; }
+  uint32_t id_prev = 0xffffffffu;                            // the ids of the chunk whose commit is pending (lr_fwd_commit_chunk)
   uint64_t* const mslot = masks ? masks + 16 * lr_mask_slot(beg, tile) + 4 * wq : nullptr;
   uint32_t mcount = 0;                                       // chunks waiting in lr_mbuf[wq] (wave-uniform)
   uint32_t mfirst = 0;                                       // ... the first of them (chunk index inside the tile's list)
@@ -962,7 +1001,9 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
 
   for (uint32_t ch = 0; ch < nchunks; ch++) {
     if (__all(done)) break;
+    lr_fwd_commit_chunk<EXTRAS>(wmx, lane, id_prev, pw, zero_rows);   // the previous chunk's, in front of this chunk's loads
     const uint32_t id = id_n;
+    id_prev = id;
     const float4 g0 = g0_n, g1 = g1_n;
     const float cb = cb_n;
     id_n = id_nn;
@@ -1056,18 +1097,14 @@ lr_blend_fwd_rows_kernel(LrView v, const float4* __restrict__ geom, const uint32
         LR_RMAX(ma, 0xB1); LR_RMAX(mb, 0xB1);
         LR_RMAX(ma, 0x4E); LR_RMAX(mb, 0x4E);
 #undef LR_RMAX
-        if (ma != 0u) {
-          if (li == 0 && !LR_ABLATED(1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gida, ma);
-          if (zero_rows && li < 4 && !LR_ABLATED(2)) zero_rows[4 * (size_t)(uint32_t)gida + li] = float4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (mb != 0u) {
-          if (li == 0 && !LR_ABLATED(1)) atomicMax(reinterpret_cast<unsigned int*>(pw) + (uint32_t)gidb, mb);
-          if (zero_rows && li < 4 && !LR_ABLATED(2)) zero_rows[4 * (size_t)(uint32_t)gidb + li] = float4{0.f, 0.f, 0.f, 0.f};
-        }
+        // (LDS, one lane per row and entry; point_weight and the row clears leave once per chunk: lr_fwd_commit_chunk)
+        if (li == 0 && ma != 0u && !LR_ABLATED(1)) atomicMax(&wmx[ja], ma);
+        if (li == 0 && mb != 0u && !LR_ABLATED(1)) atomicMax(&wmx[jb], mb);
       }
     }
   }
   if (mslot && mcount) flush_masks();
+  lr_fwd_commit_chunk<EXTRAS>(wmx, lane, id_prev, pw, zero_rows);   // the last chunk's
   if (clamped && !__all(done)) {                             // out of ordered entries with a pixel open: to be continued
     if (lane == 0) { atomicOr(lazy_state + lr_sorted_off(tiles) + tiles + tile, 1u << wq); atomicOr(lazy_state + LR_HDR_OPEN, 1u); }   // open[tile], header
     if (inside) lr_lazy_park<EXTRAS>(v, pix, done, T, C0, C1, C2, last, wid, wmax, image, final_T, n_contrib, pid, pwp);

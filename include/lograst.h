@@ -32,7 +32,9 @@ extern "C" {
  * out-of-bounds writes; always size it with lograst_geom_bytes); (b) bwd_rows slots 12-15 are scratch of the chain rule
  * (band views keep the compact live-row list there); (c) point_list tails of streamed lists (> 4096 keys) are unspecified
  * until lograst_finish_lists, which now checks that `keys` is the buffer the forward filled and synchronises the stream;
- * (d) the forward takes an optional hit-mask buffer for the reverse walk (lograst_view.hit_masks, see below).
+ * (d) lograst_view gained hit_masks / hit_mask_words / hit_mask_form: an optional buffer in which the forward leaves its
+ * per-chunk support ballots for the reverse walk (below); new entry points: lograst_hit_mask_bytes, lograst_forward_form,
+ * lograst_pack_rows_clear, lograst_unpack_rows(atomic = 2), lograst_activate_backward_adam.
  * 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows); lograst_view gained walk_form.  Added since without a version change (new entry points only): lograst_sparse_segment_floats / lograst_pack_rows / lograst_unpack_rows / lograst_ordered_lengths / lograst_finish_lists */
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */

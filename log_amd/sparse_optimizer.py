@@ -89,7 +89,10 @@ def step(self, model, index, params, flag_vis):
         self._lograst_fused_pending = False
         if "xyz" in params:
             self.xyz_lr = self.xyz_scheduler_args(steps)
-        return
+        if all(getattr(p_, "grad", None) is None for p_ in params.values()):
+            return
+        # (gradients on the parameters all the same: a further backward ran before this step and went the ordinary way --
+        # its update is applied below, with this step's scalars)
     bc1 = 1 - BETA1 ** steps
     bc2 = 1 - BETA2 ** steps
     _migrate_state(self, next(iter(params.values())).device)

@@ -291,6 +291,8 @@ def test_every_long_list_needs_its_tail(oracle_mod):
     bg = (0.2, 0.5, 0.8)
     v, of = G.oracle_forward(oracle_mod, cam, sc, bg)
     lens = np.diff(of["tile_offsets"].astype(np.int64))
+    dL = np.random.default_rng(9).random(of["image"].shape, dtype=np.float32)
+    og = oracle_mod.backward(v, of, dL)
     for form in ("rows", "quadrant"):
         hf = G.hip_forward(cam, sc, bg, scratch_floats=16, fwd_form=form)
         hl = np.diff(hf["tile_offsets"].astype(np.int64))
@@ -299,11 +301,12 @@ def test_every_long_list_needs_its_tail(oracle_mod):
         assert hf["lazy_lists"] < long_lists // 10, (hf["lazy_lists"], long_lists)     # (nearly) every one was finished by the second pass
         assert hf["n_contrib"].max() > 7680
         _assert_forward(hf, of, True, form)
-    dL = np.random.default_rng(9).random(of["image"].shape, dtype=np.float32)
-    hg = G.hip_backward(hf, dL)
-    og = oracle_mod.backward(v, of, dL)
-    for k in ("means2D", "conic", "opacities", "colors"):
-        assert rel_l2(hg[k], og[k]) < 1e-4, (k, rel_l2(hg[k], og[k]))
+        # the reverse walk of the same form: its visits come from hit masks that BOTH compositing passes wrote (the first up
+        # to the park position, the second from there on), hundreds of chunks deep
+        hg = G.hip_backward(hf, dL, bwd_form=form)
+        assert hg["bwd_masks"], form
+        for k in ("means2D", "conic", "opacities", "colors"):
+            assert rel_l2(hg[k], og[k]) < 1e-4, (form, k, rel_l2(hg[k], og[k]))
 
 
 @pytest.mark.parametrize("n,W,H", [(2_000_000, 3840, 2160), (10_000_000, 1920, 1080)],

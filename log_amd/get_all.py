@@ -95,6 +95,9 @@ def get_all(self, camera, rasterizer):
     if _fused_step and opt is not None:
         # what the fused step needs at backward time: the optimizer, the model buffers and the rows' model indices
         fused = {"optimizer": opt, "bufs": bufs, "index": index[:n_param]}
+        # (one fused update per optimizer step: a second training get_all before the step -- a batch of several views --
+        # sends ALL of that step's backwards the ordinary way, see sparse_optimizer.fused_update)
+        opt._lograst_open_packs = getattr(opt, "_lograst_open_packs", 0) + 1
     pack = {"raw": raw, "act": act, "n_param": n_param, "degree": degree, "campos": campos, "param_keys": param_keys,
             "fused": fused}
     xyz, scaling, opacity, rotation, colors = _Activate.apply(pack, *[params[k] for k in param_keys])

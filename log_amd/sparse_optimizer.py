@@ -55,8 +55,10 @@ def fused_update(fused, pack, n, radii, g_xyz, g_scaling, g_opacity, g_rotation,
     number is the NEXT one: ``step`` itself still advances the counters).  -> True when the update was applied; False
     (nothing touched) when this optimizer cannot be fused: the caller then produces the gradients as usual."""
     opt = fused["optimizer"]
-    if getattr(opt, "_lograst_fused_pending", False):
-        return False                         # a second backward before step(): that one goes the ordinary way
+    if getattr(opt, "_lograst_fused_pending", False) or getattr(opt, "_lograst_open_packs", 1) != 1:
+        # more than one training get_all since the last step() (a batch of several views: their gradients must be SUMMED
+        # before Adam sees them), or a second backward through the same pack: everything goes the ordinary way
+        return False
     bufs = fused["bufs"]
     try:
         steps = _host_steps(opt) + 1
@@ -83,6 +85,7 @@ def step(self, model, index, params, flag_vis):
     steps = _host_steps(self) + 1            # read (first call only) BEFORE the device-side increment
     self.global_steps += 1
     self._lograst_steps = steps
+    self._lograst_open_packs = 0
     if getattr(self, "_lograst_fused_pending", False):
         # the update of this step was applied by the backward (log_amd.get_all, set_fused_step): what is left is the
         # bookkeeping -- the counters above and the learning rate the trainer reads back (level_of_gaussian.py:394)

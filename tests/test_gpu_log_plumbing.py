@@ -122,6 +122,18 @@ def test_reference_classes_train_three_steps_on_the_device(ref_env, oracle_mod, 
         loaded_before = _loaded_lograst()
         sel_gpu, img_gpu = _steps(gpu, dev, log)
         torch.cuda.synchronize()
+        # ---- the same three steps with the opt-in fused step (round 6: the activation backward applies the sparse Adam
+        # update in the same kernel, log_amd.get_all.set_fused_step) under the reference's unmodified trainer calls ----
+        from log_amd import get_all as _ga
+        log_amd.install_all(fused_step=True)
+        try:
+            fus = P._log_model(0, 400).to(dev)
+            assert getattr(fus, "optimizer", None) is not None                 # level_of_gaussian.py:352: what the fused step reads
+            sel_fus, img_fus = _steps(fus, dev, log)
+            torch.cuda.synchronize()
+            assert all(p_.grad is None for p_ in fus.gaussian.visibility_flag["params"].values())   # applied by the backward
+        finally:
+            _ga.set_fused_step(False)
     finally:
         (TensorTree.traverse, Counter.update_by_output, SparseOptimizer.step, SparseOptimizer.load_state_dict,
          LoG.get_all, ref_renderer.torch) = saved
@@ -167,6 +179,23 @@ def test_reference_classes_train_three_steps_on_the_device(ref_env, oracle_mod, 
         rel = float((a - b).norm() / b.norm())
         log("%s: exp_avg rel-L2 = %.3e" % (k, rel))
         assert float(b.norm()) > 0 and rel < 2e-3, k
+    # fused step against the unfused device trajectory: same selection, same counters, parameters and moments to the
+    # run-to-run noise of the device's own gradients (atomics order) through Adam
+    for it, (a, b) in enumerate(zip(sel_gpu, sel_fus)):
+        assert torch.equal(a, b), it
+    assert float(fus.optimizer.global_steps) == float(STEPS) and fus.optimizer.xyz_lr == gpu.optimizer.xyz_lr
+    for k in ("radii_max", "visible_count", "radii_max_max", "area_sum", "create_steps"):
+        assert torch.equal(getattr(fus.counter, k), getattr(gpu.counter, k)), k
+    for k in ("xyz", "colors", "scaling", "opacity", "rotation", "shs"):
+        p, q = getattr(fus.gaussian, k).cpu(), getattr(gpu.gaussian, k).cpu()
+        d = (p - q).abs()
+        frac = float((d > 1e-5 * (1 + q.abs())).float().mean())
+        a, b = fus.optimizer.exp_avg[k].cpu(), gpu.optimizer.exp_avg[k].cpu()
+        rel = float((a - b).norm() / b.norm())
+        log("fused step vs unfused on the device, %s: max |diff| = %.3e, fraction beyond 1e-5 = %.4f, exp_avg rel-L2 = %.3e"
+            % (k, float(d.max()), frac, rel))
+        assert frac < 0.02 and float(d.max()) <= 2.5 * cfg_lr[k] * STEPS and rel < 2e-3, k
+        assert float((p - getattr(cpu0, k)).abs().max()) > 0, k                  # (it did move)
     try:
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "gpu_log_plumbing.log")
         os.makedirs(os.path.dirname(out), exist_ok=True)

@@ -306,6 +306,28 @@ def test_fused_step_through_the_drop_ins():
                 else:
                     assert params["xyz"].grad is not None
                 assert not getattr(st.opt, "_lograst_fused_pending", False)        # step() consumed it
+            if fused:
+                # two training get_all's before ONE step (a batch of several views): neither backward may apply an update
+                # of its own -- both go the ordinary way and leave their gradients on the parameters
+                from log_amd import lod
+                rast, camera = packs[1]
+                index, index_node = B.split_leaf_node(wl, lod.traverse(wl.tree, st.gaussian, wl.roots, rast))
+                before = {k: st.bufs[k].clone() for k in wl.keys}
+                images, packs_params = [], []
+                for _ in range(2):                                                 # renderer.py: every view's forward ...
+                    st.gaussian.visibility_flag = {"index": index, "index_node": index_node}
+                    act = get_all.get_all(st.model, camera, rast)
+                    packs_params.append(st.gaussian.visibility_flag["params"])
+                    means2D = torch.zeros_like(act["xyz"], requires_grad=True)
+                    images.append(rast(means3D=act["xyz"], means2D=means2D, shs=None, colors_precomp=act["colors"],
+                                       opacities=act["opacity"], scales=act["scaling"], rotations=act["rotation"],
+                                       cov3D_precomp=None)[0])
+                (images[0] + images[1]).backward(gradient=wl.wloss)                # ... then ONE backward over the batch
+                for params in packs_params:
+                    assert params["xyz"].grad is not None
+                assert not getattr(st.opt, "_lograst_fused_pending", False)
+                assert all(torch.equal(before[k], st.bufs[k]) for k in wl.keys)    # nothing applied at backward time
+                st.opt._lograst_open_packs = 0                                     # (what step() does)
         finally:
             get_all.set_fused_step(prev)
         states.append(st)

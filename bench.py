@@ -97,6 +97,8 @@ def parse():
     ap.add_argument("--print-full", action="store_true",
                     help="also print the full result object (what bench_full.json holds) on an EARLIER stdout line")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-pack-hint", action="store_true",
+                    help="streamed row-sparse exchange: scan the gradient rows themselves instead of the view's point_weight")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 / C3 legs (they run at N = 1 only)")
     ap.add_argument("--no-dropin-mode", action="store_true", help="skip the drop-in-default measurement of the headline")
     ap.add_argument("--c3-torch", action="store_true", help="C3 leg: also time the reference-style torch pipeline")
@@ -168,6 +170,12 @@ def effective_units(wl):
     return {k: v / len(wl.rasts) for k, v in acc.items()}
 
 
+def dist_on(world):
+    """More than one rank -- or LOGRAST_DIST_SINGLE_RANK=1 (diagnostics on a one-GPU box: the step's whole exchange runs
+    through a ONE-rank RCCL process group, every collective a real RCCL call on the device; the driver never sets it)."""
+    return world > 1 or os.environ.get("LOGRAST_DIST_SINGLE_RANK", "0") == "1"
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` without a launcher: re-run under torch.distributed.run, one rank per GPU."""
     with socket.socket() as s:
@@ -211,6 +219,7 @@ class RasterWorkload:
         self.torch = torch
         self.zero_means2d = True
         self.last_radii = None
+        self.last_weight = None
 
     def one_view(self, rast, leaves):
         torch = self.torch
@@ -225,6 +234,7 @@ class RasterWorkload:
         # itself is consumed by nobody, so no reduction kernel is launched for it)
         out[0].backward(gradient=self.wloss)
         self.last_radii = out[1]
+        self.last_weight = out[4] if len(out) > 4 else None     # point_weight: zero exactly where the view touched nothing
         return out
 
 
@@ -240,24 +250,24 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     from log_amd.dist import GradientBucket, StepExchange
     dev, N = wl.dev, wl.N
     wl.zero_means2d = not (sync_free and fused)
-    rank = dist.get_rank() if world > 1 else 0
+    rank = dist.get_rank() if dist_on(world) else 0
     auto_parts = int(args.exchange_parts) <= 0
-    parts = max(1, min(len(wl.rasts) // S if auto_parts else int(args.exchange_parts), len(wl.rasts) // S)) if world > 1 else 1
+    parts = max(1, min(len(wl.rasts) // S if auto_parts else int(args.exchange_parts), len(wl.rasts) // S)) if dist_on(world) else 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     # The step's gradient exchange (log_amd.dist.StepExchange): the rank's views in `parts` consecutive groups with a
     # bucket each; group g's reduce-scatter runs on a side stream under the rendering of group g + 1.
     # N > 1: the buckets carry the per-row seen counts (what an owner-computes optimizer step needs, and what the
     # touched-row-block exchange reads); --exchange auto decides ONCE, from the warm-up, whether the block form can pay
     # (it costs a bitmap all-reduce and a small read-back per group of views): dense when most blocks are touched.
-    track = world > 1
+    track = dist_on(world)
     block_rows = 4096 if (track and args.exchange != "dense") else 0
     # fused accumulation: the buckets are row-major (one 64-byte row of running sums per Gaussian: the chain rule's
     # read-modify-write of a live Gaussian is one line instead of five pieces in five arrays; the exchange moves one block)
     row_major = fused and not args.planar_bucket
     ex = StepExchange(N, dev, world, rank, parts=parts, block_rows=block_rows, track_seen=track, timing=track,
                       row_major=row_major)
-    compact = {"on": args.exchange == "compact" and world > 1}
-    sparse = {"on": args.exchange == "sparse" and world > 1 and row_major, "kmax": None, "gather": None}
+    compact = {"on": args.exchange == "compact" and dist_on(world)}
+    sparse = {"on": args.exchange == "sparse" and dist_on(world) and row_major, "kmax": None, "gather": None}
 
     gathered = {"t": None}     # streamed sparse exchange: the persistent result of the closing all-gather (bucket 0 stays clean)
 
@@ -292,6 +302,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         return min(j * np_ // max(len(lane_views[li]), 1), np_ - 1)
 
     lane_graphs = None
+    graph_weight = {}
     state = {"clean": False}   # did the previous step leave every bucket all zero (streamed exchange: pack and clear)?
 
     def step(do_exchange=True):
@@ -328,15 +339,24 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                 main.wait_stream(st)                    # (a dependency on the device, not a host wait)
             for _, bks in lanes[1:]:
                 ex.buckets[part].flat.add_(bks[part].flat)
-            if world > 1:
+            if dist_on(world):
                 # rows this group of views saw: in this workload every view sees the same rows (radii > 0 for the views'
                 # common frustum), recorded once per group from the last forward's radii (kept by one_view)
+                streamed = bool(sparse["on"] and n_parts() > 1)
                 if wl.last_radii is not None:
-                    ex.buckets[part].mark_seen(wl.last_radii)
+                    ex.seen_bucket(part, streamed).mark_seen(wl.last_radii)
+                if do_exchange and streamed and S == 1 and not args.no_pack_hint:
+                    # one view in this group: its point_weight says which rows it touched -- the pack reads 4 bytes per row
+                    # of the other 94 % instead of 64 (log_amd.dist.GradientBucket.mark_touched)
+                    mine = [j for j in range(len(lane_views[0])) if part_of_view(0, j) == part]
+                    if len(mine) == 1:
+                        w = graph_weight.get((0, mine[0])) if lane_graphs is not None else wl.last_weight
+                        if w is not None:
+                            ex.buckets[part].mark_touched(w)
                 if do_exchange:
                     ex.launch(part, compact=compact["on"], kmax=sparse["kmax"] if sparse["on"] else compact.get("kmax"),
                               sparse=sparse["on"])
-        if world > 1 and do_exchange:                   # every rank ends the step with the whole gradient sum
+        if dist_on(world) and do_exchange:                   # every rank ends the step with the whole gradient sum
             gather(ex.finish())
 
     # ---- V and I per view, measured once in exact mode (one 4-byte read-back per view) ----
@@ -361,7 +381,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     R.overflow_since_reset(dev)         # clear the status block: from here on every forward is recorded in it
     for _ in range(warmup):
         step()
-    if world > 1:
+    if dist_on(world):
         # what the step's exchange has to move: rows with a non-zero gradient (any column) and 4096-row blocks holding one
         torch.cuda.synchronize()
         g = ex.buckets[0]
@@ -431,9 +451,16 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                 for j, rast in enumerate(lane_views[li]):
                     with R.accumulate_grads_into(bks[part_of_view(li, j)].views):
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, pool=pool, stream=streams[li]):
+                        # thread_local: found in round 6 with a one-rank RCCL group -- under the default (global) mode the
+                        # process group's WATCHDOG thread, polling the events of the warm-up's collectives, gets
+                        # hipErrorStreamCaptureUnsupported from hipEventQuery while this thread captures, and its
+                        # exception aborts the process (a race: it needs a collective the watchdog has not retired yet)
+                        with torch.cuda.graph(g, pool=pool, stream=streams[li], capture_error_mode="thread_local"):
                             wl.one_view(rast, leaves)
                     gl.append(g)
+                    # (the view's point_weight lives in the graph's pool: held here so that no later capture reuses it --
+                    # every replay rewrites it in place; the streamed exchange reads it as the pack's hint)
+                    graph_weight[(li, j)] = wl.last_weight
                 built.append(gl)
             torch.cuda.synchronize()
             lane_graphs = built
@@ -448,7 +475,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         _lib.profile_reset()
         _lib.profile_enable(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -456,7 +483,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         step()
     res["t_enqueued"] = time.perf_counter() - t0
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     torch.cuda.synchronize()
     res["elapsed"] = time.perf_counter() - t0
@@ -479,7 +506,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             torch.cuda.synchronize()
             _lib.profile_enable(False)
             res["prof_serial"] = _lib.profile_read()
-    if world > 1:
+    if dist_on(world):
         res["exchange_timing"] = ex.timing_summary(steps)
         # The same collectives with nothing to hide under: link time alone, so that a first run on real xGMI separates what
         # the links cost from what the overlap lost (exposed = ms_per_step - rendering; hidden = exchange_only - exposed).
@@ -508,14 +535,14 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             b0 = ex.buckets[0]
             res["exchange_bytes_per_step"] = int(4 * (world - 1) * (parts * SPARSE_FLOATS * max(b.sparse_kmax for b in ex.buckets)
                                                                     + b0.Pr + SPARSE_FLOATS * ex.gather_kmax))
-    if world > 1:
+    if dist_on(world):
         assert not ex.compact_overflowed(), "touched-block exchange outgrew its bound inside the timed region: result invalid"
     chk = R.overflow_since_reset(dev)   # every forward since the capacity was set, on all streams
     assert not chk["overflowed"] and chk["max_instances"] <= cap, \
         "tile-instance capacity overflow inside the timed region: result invalid (%r)" % (chk,)
     R.set_instance_capacity(None)
     wl.zero_means2d = True
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([res["elapsed"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         res["elapsed"] = float(t.item())
@@ -785,6 +812,7 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args))
+    keep_stdout_for_the_line()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -799,13 +827,17 @@ def main():
     share = os.environ.get("LOGRAST_SHARE_GPU", "0") == "1"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if dist_on(world):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "MASTER_PORT" not in os.environ:     # (single-rank diagnostics without a launcher)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    n_ranks = dist.get_world_size() if world > 1 else 1     # what the process group really holds
+    n_ranks = dist.get_world_size() if dist_on(world) else 1     # what the process group really holds
 
     N, W, H = args.gaussians, args.width, args.height
     Px = W * H
@@ -836,14 +868,14 @@ def main():
             "parallelism": ("view-sharded dp%d, %s reduce-scatter of %d floats/step in %d groups of views (each under the "
                             "next group's rendering, side stream) + one all-gather" %
                             (n_ranks, r.get("exchange_mode", "dense"), r["bucket_floats"], r["exchange_parts"])
-                            if world > 1 else "single GPU") + ", %d view(s) in flight per GPU (HIP streams)" % S,
+                            if dist_on(world) else "single GPU") + ", %d view(s) in flight per GPU (HIP streams)" % S,
         },
         "ms_per_view": head["ms_per_view"], "host_enqueue_ms_per_view": head["host_enqueue_ms_per_view"],
         "modes": {"pipelined": dict(head, streams=S, sync_free=True, fused_gradient_accumulation=fused, hip_graphs=r["graphs"],
                                     note="value of this line: capacity from the warm-up, no host sync in forward(), "
                                          "gradients added by the backward kernels into the step's bucket")},
     }
-    if world > 1:
+    if dist_on(world):
         result["exchange"] = {
             "mode": r.get("exchange_mode"), "policy": args.exchange, "parts": r["exchange_parts"], "backend": backend,
             "streamed": r.get("exchange_streamed"), "parts_policy": "auto" if r.get("exchange_parts_auto") else "fixed",
@@ -995,7 +1027,7 @@ def main():
         result["parity"] = parity_summary()
         flatten_for_the_driver(result)
         emit(result, args)
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
         dist.destroy_process_group()
 
@@ -1107,10 +1139,35 @@ def emit(result, args=None):
         except OSError:
             pass
     if args is not None and getattr(args, "print_full", False):
-        print(full, flush=True)
+        _to_stdout(full)
     text = json.dumps(compact_line(result), separators=(",", ":"))
     assert len(text) < LINE_LIMIT and "\n" not in text, len(text)
-    print(text, flush=True)
+    _to_stdout(text)
+
+
+_STDOUT_FD = None
+
+
+def keep_stdout_for_the_line():
+    """Everything but the result line goes to stderr -- at the file-descriptor level, for every rank, before any library
+    is loaded.  Found in round 6 with a one-rank RCCL group on the MI355X: librccl prints a five-line banner ("RCCL version
+    ... Librccl path : ...") through C stdio to STDOUT, which reaches the pipe when the process exits, i.e. AFTER the JSON
+    line -- once per rank -- and a reader that takes the last stdout line as the result finds "Librccl path" there."""
+    global _STDOUT_FD
+    if _STDOUT_FD is None:
+        sys.stdout.flush()
+        _STDOUT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _to_stdout(text):
+    sys.stdout.flush()
+    if _STDOUT_FD is None:
+        print(text, flush=True)
+        return
+    data = (text + "\n").encode()
+    while data:
+        data = data[os.write(_STDOUT_FD, data):]
 
 
 def flatten_for_the_driver(result):

@@ -263,8 +263,19 @@ int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group,
  * (log_amd.dist.StepExchange, parts > 1, sparse) never zero-fills its buckets.  Rows dropped by an exceeded kmax stay. */
 int lograst_pack_rows_clear(float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
                             uint32_t* overflow, void* stream);
+/* The same with a HINT (added late in round 6, new entry point only): `hint` holds one 32-bit word per row of the whole array
+ * (row g * rows_per_group + r; rows from hint_rows on have none).  A row whose word is zero is, by the caller's contract, all
+ * zero: it is neither read nor packed (nor cleared).  The word is compared as bits: a view's point_weight [n] (float, zero
+ * exactly for the Gaussians that contributed to no pixel -- lograst_backward leaves their gradient rows untouched) is such a
+ * hint for a bucket that holds that ONE view's gradient rows: the scan then reads 4 bytes per row instead of 64.  clear != 0:
+ * as lograst_pack_rows_clear. */
+int lograst_pack_rows_hinted(float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                             uint32_t* overflow, int32_t clear, const uint32_t* hint, int64_t hint_rows, void* stream);
 int lograst_unpack_rows(float* dest, const float* packed, int32_t segments, int32_t kmax, int64_t rows_per_group,
                         int64_t dest_group_rows, int32_t atomic, void* stream);
+/* seen[i] += 1 where radii[i] > 0, i < n (the per-step "how many views saw this row" counts of log_amd.dist: what the
+ * reference's step calls flag_vis, /root/reference/LoG/model/counter.py:48,50, summed over a rank's views). */
+int lograst_add_visible(float* seen, const int32_t* radii, int64_t n, void* stream);
 
 /* ---- performance knobs -------------------------------------------------------------------------------------------
  * Launch-shape parameters that change no result (thresholds, grid caps, dispatch orders; the list is enumerated by

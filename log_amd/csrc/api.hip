@@ -29,7 +29,9 @@ void lr_launch_zero_words(uint32_t* p, size_t words, hipStream_t s);
 void lr_launch_zero_floats(float* p, size_t n, hipStream_t s);
 // exchange.hip
 void lx_launch_pack_rows(float* rows, int groups, long long rows_per_group, int kmax, float* packed,
-                         size_t seg_floats, uint32_t* overflow, int clear, hipStream_t s);
+                         size_t seg_floats, uint32_t* overflow, int clear, const uint32_t* hint, long long hint_rows,
+                         hipStream_t s);
+void lx_launch_add_visible(float* seen, const int32_t* radii, long long n, hipStream_t s);
 void lx_launch_unpack_rows(float* dest, const float* packed, int segments, int kmax, size_t seg_floats,
                            long long rows_per_group, long long dest_group_rows, int add, int zero, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
@@ -665,28 +667,38 @@ size_t lograst_sparse_segment_floats(int32_t kmax) {
   const size_t k = kmax > 0 ? (size_t)kmax : 0;
   return 16 + 16 * k + ((k + 15) / 16) * 16;
 }
-int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
-                      uint32_t* overflow, void* stream) {
-  if (groups < 0 || rows_per_group < 0 || kmax <= 0) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: negative size or kmax <= 0");
+static int lr_pack_rows_checked(const char* who, float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                                uint32_t* overflow, int clear, const uint32_t* hint, int64_t hint_rows, void* stream) {
+  if (groups < 0 || rows_per_group < 0 || kmax <= 0 || hint_rows < 0) return lr_fail(LOGRAST_ERR_ARG, std::string(who) + ": negative size or kmax <= 0");
   if (groups == 0 || rows_per_group == 0) return LOGRAST_OK;
-  if (!rows || !packed) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
+  if (!rows || !packed) return lr_fail(LOGRAST_ERR_ARG, std::string(who) + ": NULL pointer");
   if ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(packed)) & 15u)
-    return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: rows / packed must be 16-byte aligned");
-  if (rows_per_group > 0x7fffffffLL) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows: rows_per_group exceeds 31 bits (int32 row indices)");
-  lx_launch_pack_rows(const_cast<float*>(rows), groups, rows_per_group, kmax, packed, lograst_sparse_segment_floats(kmax), overflow, 0,
-                      (hipStream_t)stream);
+    return lr_fail(LOGRAST_ERR_ARG, std::string(who) + ": rows / packed must be 16-byte aligned");
+  if (rows_per_group > 0x7fffffffLL) return lr_fail(LOGRAST_ERR_ARG, std::string(who) + ": rows_per_group exceeds 31 bits (int32 row indices)");
+  lx_launch_pack_rows(rows, groups, rows_per_group, kmax, packed, lograst_sparse_segment_floats(kmax), overflow, clear, hint,
+                      hint_rows, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }
+int lograst_pack_rows(const float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                      uint32_t* overflow, void* stream) {
+  return lr_pack_rows_checked("lograst_pack_rows", const_cast<float*>(rows), groups, rows_per_group, kmax, packed, overflow, 0, nullptr, 0, stream);
+}
 int lograst_pack_rows_clear(float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
                             uint32_t* overflow, void* stream) {
-  if (groups < 0 || rows_per_group < 0 || kmax <= 0) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows_clear: negative size or kmax <= 0");
-  if (groups == 0 || rows_per_group == 0) return LOGRAST_OK;
-  if (!rows || !packed) return lr_fail(LOGRAST_ERR_ARG, "NULL pointer");
-  if ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(packed)) & 15u)
-    return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows_clear: rows / packed must be 16-byte aligned");
-  if (rows_per_group > 0x7fffffffLL) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows_clear: rows_per_group exceeds 31 bits (int32 row indices)");
-  lx_launch_pack_rows(rows, groups, rows_per_group, kmax, packed, lograst_sparse_segment_floats(kmax), overflow, 1, (hipStream_t)stream);
+  return lr_pack_rows_checked("lograst_pack_rows_clear", rows, groups, rows_per_group, kmax, packed, overflow, 1, nullptr, 0, stream);
+}
+int lograst_pack_rows_hinted(float* rows, int32_t groups, int64_t rows_per_group, int32_t kmax, float* packed,
+                             uint32_t* overflow, int32_t clear, const uint32_t* hint, int64_t hint_rows, void* stream) {
+  if (!hint) return lr_fail(LOGRAST_ERR_ARG, "lograst_pack_rows_hinted: NULL hint (use lograst_pack_rows / lograst_pack_rows_clear)");
+  return lr_pack_rows_checked("lograst_pack_rows_hinted", rows, groups, rows_per_group, kmax, packed, overflow, clear ? 1 : 0, hint,
+                              hint_rows, stream);
+}
+int lograst_add_visible(float* seen, const int32_t* radii, int64_t n, void* stream) {
+  if (n < 0) return lr_fail(LOGRAST_ERR_ARG, "lograst_add_visible: negative n");
+  if (n == 0) return LOGRAST_OK;
+  if (!seen || !radii) return lr_fail(LOGRAST_ERR_ARG, "lograst_add_visible: NULL pointer");
+  lx_launch_add_visible(seen, radii, n, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

@@ -26,10 +26,15 @@ lx_clear_headers_kernel(float* __restrict__ packed, int groups, size_t seg_float
 // CLEAR: a packed row is zeroed in the bucket behind the copy ("pack and clear": the bucket of a group of views is all zero
 // again once its rows are on their way, so a step that streams its exchange group by group never zero-fills a 1.9 GB
 // bucket; rows dropped by an exceeded kmax stay -- the caller repeats that step from zeroed buckets anyway).
-template <bool CLEAR>
+// HINT: `hint` holds one 32-bit word per row of the whole array (row g * rows_per_group + r; rows from `hint_rows` on have
+// none): a row whose word is zero is KNOWN to be all zero -- the caller's contract, e.g. the view's point_weight, whose bits
+// are zero exactly for the Gaussians that contributed to no pixel and therefore got no gradient -- and is not even read.  A
+// view touches 6 % of 30 M rows: the scan reads 4 bytes per row instead of 64 (0.49 -> 0.1 ms per view group).
+template <bool CLEAR, bool HINT>
 __global__ void __launch_bounds__(256)
 lx_pack_rows_kernel(float4* __restrict__ rows, int groups, long long rows_per_group, int kmax,
-                    float* __restrict__ packed, size_t seg_floats, uint32_t* __restrict__ overflow, int blocks_per_group) {
+                    float* __restrict__ packed, size_t seg_floats, uint32_t* __restrict__ overflow, int blocks_per_group,
+                    const uint32_t* __restrict__ hint, long long hint_rows) {
   __shared__ uint32_t wave_cnt[4][4];
   __shared__ uint32_t base_s;
   const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
@@ -42,7 +47,14 @@ lx_pack_rows_kernel(float4* __restrict__ rows, int groups, long long rows_per_gr
   for (int u = 0; u < 4; u++) {
     const long long r = r0 + u * 256 + tid;
     nz[u] = false;
-    if (r < rows_per_group) {
+    bool read = r < rows_per_group;
+    if (HINT && read) {
+      const long long gr = (long long)g * rows_per_group + r;
+      read = gr < hint_rows && hint[gr] != 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[u][q] = float4{0.f, 0.f, 0.f, 0.f};
+    if (read) {
       const float4* p = rows + 4 * ((size_t)g * (size_t)rows_per_group + (size_t)r);   // (read before any store of this thread: CLEAR touches its own rows only)
 #pragma unroll
       for (int q = 0; q < 4; q++) v[u][q] = p[q];
@@ -121,16 +133,30 @@ lx_unpack_rows_kernel(float* __restrict__ dest, const float* __restrict__ packed
 }
 
 void lx_launch_pack_rows(float* rows, int groups, long long rows_per_group, int kmax, float* packed,
-                         size_t seg_floats, uint32_t* overflow, int clear, hipStream_t s) {
+                         size_t seg_floats, uint32_t* overflow, int clear, const uint32_t* hint, long long hint_rows,
+                         hipStream_t s) {
   if (groups <= 0 || rows_per_group <= 0) return;
   const int bpg = (int)((rows_per_group + LX_ROWS_PER_BLOCK - 1) / LX_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(lx_clear_headers_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, packed, groups, seg_floats);
-  if (clear)
-    hipLaunchKernelGGL(lx_pack_rows_kernel<true>, dim3((uint32_t)groups * (uint32_t)bpg), dim3(256), 0, s,
-                       reinterpret_cast<float4*>(rows), groups, rows_per_group, kmax, packed, seg_floats, overflow, bpg);
-  else
-    hipLaunchKernelGGL(lx_pack_rows_kernel<false>, dim3((uint32_t)groups * (uint32_t)bpg), dim3(256), 0, s,
-                       reinterpret_cast<float4*>(rows), groups, rows_per_group, kmax, packed, seg_floats, overflow, bpg);
+  const dim3 grid((uint32_t)groups * (uint32_t)bpg);
+  float4* r4 = reinterpret_cast<float4*>(rows);
+#define LX_PACK(C, H) hipLaunchKernelGGL((lx_pack_rows_kernel<C, H>), grid, dim3(256), 0, s, r4, groups, rows_per_group, kmax, \
+                                         packed, seg_floats, overflow, bpg, hint, hint_rows)
+  if (hint) { if (clear) LX_PACK(true, true); else LX_PACK(false, true); }
+  else      { if (clear) LX_PACK(true, false); else LX_PACK(false, false); }
+#undef LX_PACK
+}
+
+// seen[i] += radii[i] > 0 (log_amd.dist.GradientBucket.mark_seen: one pass instead of torch's compare + convert + add)
+__global__ void __launch_bounds__(256)
+lx_add_visible_kernel(float* __restrict__ seen, const int32_t* __restrict__ radii, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && radii[i] > 0) seen[i] += 1.0f;
+}
+
+void lx_launch_add_visible(float* seen, const int32_t* radii, long long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(lx_add_visible_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, seen, radii, n);
 }
 
 void lx_launch_unpack_rows(float* dest, const float* packed, int segments, int kmax, size_t seg_floats,

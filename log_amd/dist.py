@@ -38,6 +38,7 @@ Two refinements of the exchange, both optional and both leaving the 
 With world_size == 1 nothing is communicated and results are bit-identical to the single-GPU path.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -84,8 +85,14 @@ def rows_per_rank(num_points, world, block_rows=0):
     return (per + unit - 1) // unit * unit
 
 
+def _single_rank_forced():
+    """LOGRAST_DIST_SINGLE_RANK=1 (diagnostics; bench.py, tests/test_gpu_dist.py): a world of ONE rank still goes through
+    every collective -- on a one-GPU box that runs the RCCL branches below for real (one-rank RCCL calls on the device)."""
+    return os.environ.get("LOGRAST_DIST_SINGLE_RANK", "0") == "1"
+
+
 def _active(world):
-    return world > 1 and dist.is_initialized()
+    return dist.is_initialized() and (world > 1 or _single_rank_forced())
 
 
 def _reduce_scatter(out, inp, group=None):
@@ -115,8 +122,9 @@ def _all_gather(out, inp, group=None):
 SPARSE_FLOATS = ROW_FLOATS + 1     # a packed row of the row-sparse exchange: 16 running sums | row index (int32 bits)
 
 
-def _pack_rows(rows, kmax, clear=False):
+def _pack_rows(rows, kmax, clear=False, hint=None):
     """clear: the packed rows are zeroed in `rows` afterwards (pack and clear; rows dropped by an exceeded kmax stay).
+    hint: see _pack_segments (rows whose hint word is zero are not looked at: here they are masked out).
     rows: float32 [G, R, 16] (G groups of R rows).  -> (packed float32 [G, kmax, 17], counts int64 [G], overflow bool):
     per group the rows with a non-zero entry, in ascending row order, as (16 values | row index inside the group, int32
     bits), padded with all-zero rows of index 0 (adding them is a no-op).  No host synchronisation: kmax is the caller's
@@ -124,6 +132,11 @@ def _pack_rows(rows, kmax, clear=False):
     G, R, C = rows.shape
     dev = rows.device
     nz = torch.count_nonzero(rows, dim=2) > 0                     # [G, R]
+    if hint is not None:
+        h = torch.zeros(G * R, dtype=torch.bool, device=dev)
+        n = min(int(hint.numel()), G * R)
+        h[:n] = hint.reshape(-1)[:n].view(torch.int32) != 0
+        nz &= h.view(G, R)
     csum = torch.cumsum(nz.view(-1).to(torch.int32), 0).view(G, R)
     before = torch.cat([csum.new_zeros(1), csum[:-1, -1]])        # non-zero rows in front of each group
     rank = csum - 1 - before[:, None]                             # position of a non-zero row inside its group's list
@@ -161,11 +174,13 @@ def _segment_floats(kmax, device):
     return int(_lib.lib().lograst_sparse_segment_floats(int(kmax)))
 
 
-def _pack_segments(rows, kmax, clear=False):
+def _pack_segments(rows, kmax, clear=False, hint=None):
     """rows [G, R, 16] -> (flat float32 buffer of G equal segments, overflow: device bool).  clear: every packed row is
-    zeroed in `rows` (which must then be the bucket's own contiguous storage: lograst_pack_rows_clear)."""
+    zeroed in `rows` (which must then be the bucket's own contiguous storage: lograst_pack_rows_clear).
+    hint: a 4-byte-per-row tensor over the rows of ALL groups in order (fewer entries: the rows behind them have none) whose
+    zero words mark rows the caller KNOWS to be zero -- they are not read (lograst_pack_rows_hinted)."""
     if rows.device.type != "cuda":
-        packed, _, over = _pack_rows(rows, kmax, clear=clear)
+        packed, _, over = _pack_rows(rows, kmax, clear=clear, hint=hint)
         return packed.reshape(-1), over
     import ctypes
     from . import _lib
@@ -177,9 +192,16 @@ def _pack_segments(rows, kmax, clear=False):
     packed = torch.empty(G * seg, dtype=torch.float32, device=rows.device)
     flag = torch.zeros(1, dtype=torch.int32, device=rows.device)
     with torch.cuda.device(rows.device):
-        fn = L.lograst_pack_rows_clear if clear else L.lograst_pack_rows
-        _lib.check(fn(ctypes.c_void_p(rows.data_ptr()), G, R, int(kmax), ctypes.c_void_p(packed.data_ptr()),
-                      ctypes.c_void_p(flag.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
+        if hint is not None:
+            assert hint.is_contiguous() and hint.element_size() == 4 and hint.device == rows.device
+            _lib.check(L.lograst_pack_rows_hinted(ctypes.c_void_p(rows.data_ptr()), G, R, int(kmax), ctypes.c_void_p(packed.data_ptr()),
+                                                  ctypes.c_void_p(flag.data_ptr()), 1 if clear else 0,
+                                                  ctypes.c_void_p(hint.data_ptr()), int(hint.numel()), stream))
+        else:
+            fn = L.lograst_pack_rows_clear if clear else L.lograst_pack_rows
+            _lib.check(fn(ctypes.c_void_p(rows.data_ptr()), G, R, int(kmax), ctypes.c_void_p(packed.data_ptr()),
+                          ctypes.c_void_p(flag.data_ptr()), stream))
     return packed, flag[0] != 0
 
 
@@ -348,7 +370,9 @@ class GradientBucket(_Flat):
         self.flat.zero_()
         self.seen.zero_()
         self._seen_reduced = False
+        self._seen_dirty = False
         self.touched = None
+        self._take_hint()
 
     def mark_seen(self, radii, index=None):
         """Record which rows one view touched: radii > 0 (what the reference's step calls flag_vis,
@@ -356,11 +380,39 @@ class GradientBucket(_Flat):
         handed to the rasterizer."""
         if not self.track_seen:
             raise RuntimeError("this bucket was built with track_seen=False")
+        self._seen_dirty = True
+        if index is None and radii.is_cuda and radii.dtype == torch.int32 and radii.is_contiguous() and self.seen.is_cuda:
+            import ctypes
+            from . import _lib
+            with torch.cuda.device(radii.device):
+                _lib.check(_lib.lib().lograst_add_visible(
+                    ctypes.c_void_p(self.seen.data_ptr()), ctypes.c_void_p(radii.data_ptr()), int(radii.numel()),
+                    ctypes.c_void_p(torch.cuda.current_stream(radii.device).cuda_stream)))
+            return
         vis = (radii > 0).to(torch.float32)
         if index is None:
             self.seen[:vis.numel()] += vis
         else:
             self.seen.index_add_(0, index, vis)
+
+    def mark_touched(self, point_weight):
+        """Hint for the row-sparse exchange of a bucket that holds ONE view's gradient rows (the streamed exchange, one
+        group per view): that view's `point_weight` [n] -- zero exactly for the Gaussians that contributed to no pixel,
+        whose gradient rows the backward left untouched.  The pack then reads 4 bytes per row instead of 64 for the rows
+        the view did not touch (94 % of them at the 30 M headline).  A second call before the bucket is exchanged (several
+        views in one group) withdraws the hint: the pack scans the rows themselves, as without it.  The tensor must stay
+        alive and unchanged until the exchange of this bucket has run."""
+        if getattr(self, "_hint_calls", 0) == 0 and point_weight is not None and point_weight.dim() == 1 \
+                and point_weight.element_size() == 4 and point_weight.is_contiguous():
+            self.touch_hint = point_weight
+        else:
+            self.touch_hint = None
+        self._hint_calls = getattr(self, "_hint_calls", 0) + 1
+
+    def _take_hint(self):
+        h = getattr(self, "touch_hint", None)
+        self.touch_hint, self._hint_calls = None, 0
+        return h
 
     def _sum_seen(self, group):
         if _active(self.world) and not self._seen_reduced and self.track_seen:
@@ -396,7 +448,7 @@ class GradientBucket(_Flat):
         """Share of this rank's rows with a non-zero gradient (row-major buckets; a device scalar)."""
         return (self.blocks["rows"].view(self.Ppad, ROW_FLOATS) != 0).any(dim=1).float().mean()
 
-    def reduce_scatter_rows_sparse(self, rank, group=None, kmax=None, into=None, clear=False):
+    def reduce_scatter_rows_sparse(self, rank, group=None, kmax=None, into=None, clear=False, seen_later=False):
         """Row-sparse form of ``reduce_scatter_rows`` (row-major buckets without SH columns): -> the same dict -- "rows"
         [Pr, 16] = the sum over ranks of this rank's rows, "seen" [Pr] -- but only the rows with a non-zero gradient
         travel: packed per owner as (16 sums | row index), padded to `kmax` rows per (sender, owner) pair, one all-to-all
@@ -413,12 +465,16 @@ class GradientBucket(_Flat):
         running sums that this group's received rows (and seen counts) are ADDED to instead of a fresh zeroed shard -- the
         step's shard then holds, row by row, (((0 + g0) + g1) + ...) with every g = ((r0 + r1) + ...) added segment by
         segment.  clear: the rows this call packs are zeroed in the bucket ("pack and clear"): the bucket is all zero again
-        and needs no zero-fill before the next step (unless a bound was outgrown: then zero() and repeat the step)."""
+        and needs no zero-fill before the next step (unless a bound was outgrown: then zero() and repeat the step).
+        seen_later: the seen counts are NOT exchanged here (StepExchange's streamed form sends them once per step, from
+        finish(): a dense 4-byte-per-row reduce-scatter per GROUP moved as many bytes as the packed rows themselves).
+        A hint left by ``mark_touched`` is consumed by this call."""
         assert self.row_major and [n for n, _ in self.layout] == ["rows"], "row-sparse exchange: row-major bucket without SH columns"
         self.touched = None
         dev, W, Pr = self.flat.device, self.world, self.Pr
         out = {}
         if not _active(self.world):
+            self._take_hint()
             self.sparse_overflow, self.sparse_kmax = None, 0
             if into is not None:           # world 1, streamed: the group's rows join the running sums, the bucket is cleared
                 into["rows"] += self.rows("rows", 0)
@@ -437,12 +493,15 @@ class GradientBucket(_Flat):
             dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=group)
             kmax = max(int(cnt.item()), 1)
         kmax = min(max(int(kmax), 1), Pr)
-        packed, over = _pack_segments(rows, kmax, clear=clear)
+        hint = self._take_hint()
+        if hint is not None and hint.is_cuda:
+            hint.record_stream(torch.cuda.current_stream(hint.device))      # (read here, possibly on a side stream)
+        packed, over = _pack_segments(rows, kmax, clear=clear, hint=hint)
         recv = torch.empty_like(packed)
         _all_to_all(recv, packed, group)
         shard = into["rows"] if into is not None else torch.zeros(Pr, ROW_FLOATS, dtype=torch.float32, device=dev)
         out["rows"] = _unpack_segments(shard, recv, W, kmax)
-        if self.track_seen:
+        if self.track_seen and not seen_later:
             mine = torch.empty(Pr, dtype=torch.float32, device=dev)
             _reduce_scatter(mine, self.seen, group)
             if into is not None:
@@ -595,7 +654,7 @@ class StepExchange:
         self.buckets = [GradientBucket(num_points, device, world, sh_coeffs, block_rows, track_seen, row_major)
                         for _ in range(self.parts)]
         self.device = self.buckets[0].flat.device
-        self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and self.world > 1) else None
+        self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and (self.world > 1 or _single_rank_forced())) else None
         self._shards = [None] * self.parts
         self.touched = None
         # device flag: a bounded touched-block / row-sparse exchange dropped rows (compact_overflowed).  ONE persistent
@@ -611,6 +670,12 @@ class StepExchange:
         """The bucket view `view` of the rank's `n_views` accumulates into (consecutive views share a group)."""
         return self.buckets[min(int(view) * self.parts // max(int(n_views), 1), self.parts - 1)]
 
+    def seen_bucket(self, part, streamed):
+        """The bucket whose ``mark_seen`` a caller should use for group `part`: the group's own -- or, when the step's sparse
+        exchange is streamed (launch(sparse=True), parts > 1), bucket 0 for every group: the counts then sit in ONE array
+        and finish() exchanges them once."""
+        return self.buckets[0 if (streamed and self.parts > 1) else part]
+
     def last_view_of(self, part, n_views):
         return max(v for v in range(n_views) if self.bucket_of(v, n_views) is self.buckets[part])
 
@@ -625,9 +690,11 @@ class StepExchange:
         """Between steps of the STREAMED sparse exchange: the buckets' rows were cleared by their own packs, so only the
         small per-step state is reset (seen counts, shard list) -- instead of zero()'s full zero-fill of every bucket."""
         for b in self.buckets:
-            if b.track_seen:
+            if b.track_seen and getattr(b, "_seen_dirty", True):       # (only the counts somebody marked since the last reset)
                 b.seen.zero_()
+            b._seen_dirty = False
             b.touched = None
+            b._take_hint()
         self._shards = [None] * self.parts
         self.touched = None
         self._stream_shard = None
@@ -681,7 +748,7 @@ class StepExchange:
                 if b.track_seen:
                     sh["seen"] = torch.zeros(b.Pr, dtype=torch.float32, device=self.device)
                 self._stream_shard = sh
-            b.reduce_scatter_rows_sparse(self.rank, self.group, kmax=kmax, into=self._stream_shard, clear=True)
+            b.reduce_scatter_rows_sparse(self.rank, self.group, kmax=kmax, into=self._stream_shard, clear=True, seen_later=True)
             return self._stream_shard
         run = (run_streamed if stream_it else
                (lambda: b.reduce_scatter_rows_sparse(self.rank, self.group, kmax=kmax)) if sparse else
@@ -732,7 +799,17 @@ class StepExchange:
                 for t in sh.values():
                     t.record_stream(main)
         if self._stream_shard is not None and all(sh is self._stream_shard for sh in self._shards):
-            return dict(self._stream_shard)            # streamed sparse exchange: the groups were added as they arrived
+            # streamed sparse exchange: the groups' rows were added as they arrived; the step's seen counts travel ONCE, now
+            # (the sum over the buckets somebody marked: callers that mark one bucket for the whole step -- seen_bucket() --
+            # pay one reduce-scatter of 4 bytes per row per step instead of one per group)
+            b0 = self.buckets[0]
+            if b0.track_seen and _active(self.world):
+                dirty = [b.seen for b in self.buckets if getattr(b, "_seen_dirty", False)]
+                if dirty:
+                    acc = dirty[0] if len(dirty) == 1 else torch.stack(dirty).sum(0)
+                    mine = torch.empty(b0.Pr, dtype=torch.float32, device=self.device)
+                    self._stream_shard["seen"] = _reduce_scatter(mine, acc, self.group)
+            return dict(self._stream_shard)
         total = dict(self._shards[0])
         if self.parts > 1:
             total = {k: v.clone() for k, v in total.items()} if not _active(self.world) else total
@@ -835,7 +912,7 @@ def gather_bands(image, rank, world, group=None):
     """image: [C, H, W] with this rank's band rendered (other rows: anything).  Returns the full image on every rank.
     Bands are padded to a common height for the collective (all_gather needs equal shapes)."""
     C, H, W = image.shape
-    if world <= 1 or not dist.is_initialized():
+    if not _active(world):
         return image
     rows = [band_pixels(r, world, H) for r in range(world)]
     hmax = max(e - b for b, e in rows)

@@ -464,7 +464,10 @@ def _sparse_worker(rank, world, port, out):
                              (torch.rand(P, generator=gen) < 0.3).to(torch.int32)))
         for mode, parts, kw_rs, kw_ag in (("one_group", 1, dict(sparse=True), dict(sparse_kmax="exact")),
                                           ("stream8", 8, dict(sparse=True), dict(sparse_kmax="exact")),
-                                          ("stream8_bound", 8, dict(sparse=True, kmax=64), dict(sparse_kmax=500))):
+                                          ("stream8_bound", 8, dict(sparse=True, kmax=64), dict(sparse_kmax=500)),
+                                          # each view's bucket packed from a HINT (the view's point_weight stand-in: non-zero
+                                          # exactly at the rows it touched) and the seen counts marked in ONE bucket for the step
+                                          ("stream8_hint", 8, dict(sparse=True), dict(sparse_kmax="exact"))):
             ex = StepExchange(P, "cpu", world, rank, parts=parts, row_major=True)
             result = torch.full((world * ex.buckets[0].Pr, 16), float("nan")) if parts > 1 else None   # (the first gather zero-fills it)
             for step in range(2):                                                # two steps: the second one starts from begin_step(), no zero()
@@ -473,7 +476,13 @@ def _sparse_worker(rank, world, port, out):
                 for v, (touched, vals, seen) in enumerate(per_view):
                     b = ex.bucket_of(v, 8)
                     b.views["rows"][touched, :14] += vals * (step + 1)
-                    b.mark_seen(seen)
+                    if mode == "stream8_hint":
+                        hint = torch.zeros(P)
+                        hint[touched] = 0.25
+                        b.mark_touched(hint)
+                        ex.seen_bucket(ex.buckets.index(b), True).mark_seen(seen)
+                    else:
+                        b.mark_seen(seen)
                     if v == ex.last_view_of(ex.buckets.index(b), 8):
                         ex.launch(ex.buckets.index(b), **kw_rs)
                 total = ex.finish()
@@ -535,7 +544,7 @@ def test_row_sparse_exchange_equals_the_dense_one(tmp_path, world):
         for step in range(2):
             one = got[r]["one_group_step%d" % step]
             assert not one["over"] and not one["streamed"] and float(one["full"].abs().sum()) > 0
-            for mode in ("stream8", "stream8_bound"):
+            for mode in ("stream8", "stream8_bound", "stream8_hint"):
                 m = got[r]["%s_step%d" % (mode, step)]
                 assert m["streamed"] and not m["over"], (r, mode, step)
                 assert m["left"] == [0.0] * 8 and m["after"] == [0.0] * 8, (mode, m["left"], m["after"])
@@ -553,6 +562,13 @@ def test_pack_rows_edge_cases():
     rows[0, 3, 15] = 2.0
     rows[0, 7, 0] = float("nan")
     rows[2, :, 5] = torch.arange(1, 11).float()
+    # a hint (4 bytes per row of all groups, in order; shorter: the rows behind it have none): rows whose word is zero are the
+    # caller's "known to be zero" -- not looked at, whatever they hold
+    hint = torch.zeros(25)
+    hint[[3, 20, 21]] = 1.0
+    ph, ch, _ = _pack_rows(rows, 12, hint=hint)
+    assert ch.tolist() == [1, 0, 2] and int(ph[0, 0, 16].view(torch.int32)) == 3
+    assert ph[2, :2, 16].view(torch.int32).tolist() == [0, 1] and ph[2, :2, 5].tolist() == [1.0, 2.0]
     packed, counts, over = _pack_rows(rows, 12)
     assert packed.shape == (3, 12, SPARSE_FLOATS) and counts.tolist() == [2, 0, 10] and not bool(over)
     assert float(packed[1].abs().sum()) == 0.0                                   # nothing but padding

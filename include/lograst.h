@@ -265,7 +265,8 @@ int lograst_pack_rows_clear(float* rows, int32_t groups, int64_t rows_per_group,
                             uint32_t* overflow, void* stream);
 /* The same with a HINT (added late in round 6, new entry point only): `hint` holds one 32-bit word per row of the whole array
  * (row g * rows_per_group + r; rows from hint_rows on have none).  A row whose word is zero is, by the caller's contract, all
- * zero: it is neither read nor packed (nor cleared).  The word is compared as bits: a view's point_weight [n] (float, zero
+ * zero: it is neither read nor packed (nor cleared); a row whose word is non-zero is packed whatever it holds (an all-zero
+ * row then travels as zeros).  The word is compared as bits: a view's point_weight [n] (float, zero
  * exactly for the Gaussians that contributed to no pixel -- lograst_backward leaves their gradient rows untouched) is such a
  * hint for a bucket that holds that ONE view's gradient rows: the scan then reads 4 bytes per row instead of 64.  clear != 0:
  * as lograst_pack_rows_clear. */

@@ -26,15 +26,10 @@ lx_clear_headers_kernel(float* __restrict__ packed, int groups, size_t seg_float
 // CLEAR: a packed row is zeroed in the bucket behind the copy ("pack and clear": the bucket of a group of views is all zero
 // again once its rows are on their way, so a step that streams its exchange group by group never zero-fills a 1.9 GB
 // bucket; rows dropped by an exceeded kmax stay -- the caller repeats that step from zeroed buckets anyway).
-// HINT: `hint` holds one 32-bit word per row of the whole array (row g * rows_per_group + r; rows from `hint_rows` on have
-// none): a row whose word is zero is KNOWN to be all zero -- the caller's contract, e.g. the view's point_weight, whose bits
-// are zero exactly for the Gaussians that contributed to no pixel and therefore got no gradient -- and is not even read.  A
-// view touches 6 % of 30 M rows: the scan reads 4 bytes per row instead of 64 (0.49 -> 0.1 ms per view group).
-template <bool CLEAR, bool HINT>
+template <bool CLEAR>
 __global__ void __launch_bounds__(256)
 lx_pack_rows_kernel(float4* __restrict__ rows, int groups, long long rows_per_group, int kmax,
-                    float* __restrict__ packed, size_t seg_floats, uint32_t* __restrict__ overflow, int blocks_per_group,
-                    const uint32_t* __restrict__ hint, long long hint_rows) {
+                    float* __restrict__ packed, size_t seg_floats, uint32_t* __restrict__ overflow, int blocks_per_group) {
   __shared__ uint32_t wave_cnt[4][4];
   __shared__ uint32_t base_s;
   const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
@@ -47,14 +42,7 @@ lx_pack_rows_kernel(float4* __restrict__ rows, int groups, long long rows_per_gr
   for (int u = 0; u < 4; u++) {
     const long long r = r0 + u * 256 + tid;
     nz[u] = false;
-    bool read = r < rows_per_group;
-    if (HINT && read) {
-      const long long gr = (long long)g * rows_per_group + r;
-      read = gr < hint_rows && hint[gr] != 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) v[u][q] = float4{0.f, 0.f, 0.f, 0.f};
-    if (read) {
+    if (r < rows_per_group) {
       const float4* p = rows + 4 * ((size_t)g * (size_t)rows_per_group + (size_t)r);   // (read before any store of this thread: CLEAR touches its own rows only)
 #pragma unroll
       for (int q = 0; q < 4; q++) v[u][q] = p[q];
@@ -107,6 +95,63 @@ lx_pack_rows_kernel(float4* __restrict__ rows, int groups, long long rows_per_gr
   }
 }
 
+// The HINTED pack (lograst_pack_rows_hinted): `hint` holds one 32-bit word per row of the whole array (row g * rows_per_group
+// + r; rows from `hint_rows` on have none).  A row whose word is zero is KNOWN to be all zero -- the caller's contract, e.g.
+// the view's point_weight, whose bits are zero exactly for the Gaussians that contributed to no pixel and therefore got no
+// gradient -- and is not read; a row whose word is non-zero is packed whatever it holds.  So the rows to pack are known from
+// the hints alone: a workgroup owns up to 16384 consecutive rows, lists the hinted ones in LDS (4 bytes read per row instead
+// of 64), reserves their slots with ONE atomic on the segment's counter -- the scanning kernel's one atomic per 1024 rows is
+// 29 000 returning atomics on one address at 30 M rows: 0.37 ms by themselves, measured -- and then moves them four lanes to
+// a row: every load, store and clear is a full 64-byte line.
+#define LX_HINT_ROWS_MAX 16384
+template <bool CLEAR>
+__global__ void __launch_bounds__(256)
+lx_pack_hinted_kernel(float4* __restrict__ rows, int groups, long long rows_per_group, int kmax, float* __restrict__ packed,
+                      size_t seg_floats, uint32_t* __restrict__ overflow, int blocks_per_group, int rows_per_block,
+                      const uint32_t* __restrict__ hint, long long hint_rows) {
+  __shared__ uint16_t list[LX_HINT_ROWS_MAX];
+  __shared__ uint32_t cnt_s, base_s;
+  const int g = blockIdx.x / blocks_per_group, b = blockIdx.x % blocks_per_group;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const long long r0 = (long long)b * rows_per_block;
+  const int span = (int)min((long long)rows_per_block, rows_per_group - r0);
+  if (tid == 0) cnt_s = 0u;
+  __syncthreads();
+  for (int o = 0; o < span; o += 256) {                          // (uniform trip count: the ballot needs the whole wave)
+    const int r = o + tid;
+    const long long gr = (long long)g * rows_per_group + r0 + r;
+    const bool set = r < span && gr < hint_rows && hint[gr] != 0u;
+    const uint64_t m = __ballot(set);
+    if (m) {
+      uint32_t p = 0u;
+      if (lane == 0) p = atomicAdd(&cnt_s, (uint32_t)__popcll(m));
+      p = __shfl(p, 0);
+      if (set) list[p + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)r;
+    }
+  }
+  __syncthreads();
+  const uint32_t total = cnt_s;
+  float* seg = packed + (size_t)g * seg_floats;
+  if (tid == 0) {
+    base_s = total ? atomicAdd(reinterpret_cast<uint32_t*>(seg), total) : 0u;
+    if (overflow && base_s + total > (uint32_t)kmax) atomicOr(overflow, 1u);
+  }
+  __syncthreads();
+  const uint32_t base = base_s;
+  float4* vals = reinterpret_cast<float4*>(seg + 16);
+  int32_t* idx = reinterpret_cast<int32_t*>(seg + 16 + 16 * (size_t)kmax);
+  const int q = tid & 3;
+  for (uint32_t i = (uint32_t)tid >> 2; i < total; i += 64u) {
+    const uint32_t pos = base + i;
+    if (pos >= (uint32_t)kmax) continue;                         // dropped (flagged above); the row stays in the bucket
+    const long long r = r0 + list[i];
+    float4* p = rows + 4 * ((size_t)g * (size_t)rows_per_group + (size_t)r) + q;
+    vals[4 * (size_t)pos + q] = *p;
+    if (q == 0) idx[pos] = (int32_t)r;
+    if (CLEAR) *p = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 // 16 lanes per packed row (lane = column): coalesced reads of the values, one 64-byte line per row on the destination side.
 // ADD: the segment's rows are added into dest with a plain read-modify-write -- rows inside ONE segment are unique, so a
 // launch that handles one segment needs no atomics; the launcher adds the segments one after the other, in segment (=
@@ -138,13 +183,29 @@ void lx_launch_pack_rows(float* rows, int groups, long long rows_per_group, int 
   if (groups <= 0 || rows_per_group <= 0) return;
   const int bpg = (int)((rows_per_group + LX_ROWS_PER_BLOCK - 1) / LX_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(lx_clear_headers_kernel, dim3((groups + 255) / 256), dim3(256), 0, s, packed, groups, seg_floats);
-  const dim3 grid((uint32_t)groups * (uint32_t)bpg);
   float4* r4 = reinterpret_cast<float4*>(rows);
-#define LX_PACK(C, H) hipLaunchKernelGGL((lx_pack_rows_kernel<C, H>), grid, dim3(256), 0, s, r4, groups, rows_per_group, kmax, \
-                                         packed, seg_floats, overflow, bpg, hint, hint_rows)
-  if (hint) { if (clear) LX_PACK(true, true); else LX_PACK(false, true); }
-  else      { if (clear) LX_PACK(true, false); else LX_PACK(false, false); }
-#undef LX_PACK
+  if (hint) {
+    // ~4096 workgroups in all, each owning 1024 ... 16384 consecutive rows of one group
+    long long rpb = (rows_per_group + (4096 / groups > 0 ? 4096 / groups : 1) - 1) / (4096 / groups > 0 ? 4096 / groups : 1);
+    rpb = (rpb + 255) / 256 * 256;
+    rpb = rpb < 1024 ? 1024 : (rpb > LX_HINT_ROWS_MAX ? LX_HINT_ROWS_MAX : rpb);
+    const int hb = (int)((rows_per_group + rpb - 1) / rpb);
+    const dim3 grid((uint32_t)groups * (uint32_t)hb);
+    if (clear)
+      hipLaunchKernelGGL(lx_pack_hinted_kernel<true>, grid, dim3(256), 0, s, r4, groups, rows_per_group, kmax, packed, seg_floats,
+                         overflow, hb, (int)rpb, hint, hint_rows);
+    else
+      hipLaunchKernelGGL(lx_pack_hinted_kernel<false>, grid, dim3(256), 0, s, r4, groups, rows_per_group, kmax, packed, seg_floats,
+                         overflow, hb, (int)rpb, hint, hint_rows);
+    return;
+  }
+  const dim3 grid((uint32_t)groups * (uint32_t)bpg);
+  if (clear)
+    hipLaunchKernelGGL(lx_pack_rows_kernel<true>, grid, dim3(256), 0, s, r4, groups, rows_per_group, kmax, packed, seg_floats,
+                       overflow, bpg);
+  else
+    hipLaunchKernelGGL(lx_pack_rows_kernel<false>, grid, dim3(256), 0, s, r4, groups, rows_per_group, kmax, packed, seg_floats,
+                       overflow, bpg);
 }
 
 // seen[i] += radii[i] > 0 (log_amd.dist.GradientBucket.mark_seen: one pass instead of torch's compare + convert + add)

@@ -124,7 +124,7 @@ SPARSE_FLOATS = ROW_FLOATS + 1     # a packed row of the row-sparse exchange: 16
 
 def _pack_rows(rows, kmax, clear=False, hint=None):
     """clear: the packed rows are zeroed in `rows` afterwards (pack and clear; rows dropped by an exceeded kmax stay).
-    hint: see _pack_segments (rows whose hint word is zero are not looked at: here they are masked out).
+    hint: see _pack_segments (the rows to pack are those with a non-zero hint word, whatever they hold).
     rows: float32 [G, R, 16] (G groups of R rows).  -> (packed float32 [G, kmax, 17], counts int64 [G], overflow bool):
     per group the rows with a non-zero entry, in ascending row order, as (16 values | row index inside the group, int32
     bits), padded with all-zero rows of index 0 (adding them is a no-op).  No host synchronisation: kmax is the caller's
@@ -136,7 +136,7 @@ def _pack_rows(rows, kmax, clear=False, hint=None):
         h = torch.zeros(G * R, dtype=torch.bool, device=dev)
         n = min(int(hint.numel()), G * R)
         h[:n] = hint.reshape(-1)[:n].view(torch.int32) != 0
-        nz &= h.view(G, R)
+        nz = h.view(G, R)             # (a hinted row is packed whatever it holds; the others are not looked at)
     csum = torch.cumsum(nz.view(-1).to(torch.int32), 0).view(G, R)
     before = torch.cat([csum.new_zeros(1), csum[:-1, -1]])        # non-zero rows in front of each group
     rank = csum - 1 - before[:, None]                             # position of a non-zero row inside its group's list
@@ -178,7 +178,8 @@ def _pack_segments(rows, kmax, clear=False, hint=None):
     """rows [G, R, 16] -> (flat float32 buffer of G equal segments, overflow: device bool).  clear: every packed row is
     zeroed in `rows` (which must then be the bucket's own contiguous storage: lograst_pack_rows_clear).
     hint: a 4-byte-per-row tensor over the rows of ALL groups in order (fewer entries: the rows behind them have none) whose
-    zero words mark rows the caller KNOWS to be zero -- they are not read (lograst_pack_rows_hinted)."""
+    zero words mark rows the caller KNOWS to be zero -- they are not read; rows with a non-zero word are packed whatever they
+    hold (lograst_pack_rows_hinted: the pack then knows its rows from the hints alone)."""
     if rows.device.type != "cuda":
         packed, _, over = _pack_rows(rows, kmax, clear=clear, hint=hint)
         return packed.reshape(-1), over

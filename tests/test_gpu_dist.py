@@ -395,7 +395,7 @@ def test_pack_rows_with_a_hint_and_the_visible_count_kernel():
         sel = torch.randperm(R, generator=gen)[: 3000 + 500 * g]
         rows[g, sel] = torch.randn(sel.numel(), 16, generator=gen)
     nz = (rows != 0).any(2).view(-1)
-    k = 6000
+    k = 9000
     for clear in (False, True):
         # truthful hint (with extra non-zero words on zero rows: a hint may say "look" too often, never too rarely)
         hint = torch.where(nz | (torch.rand(G * R, generator=gen) < 0.05), torch.rand(G * R, generator=gen) + 0.1, torch.zeros(G * R))

@@ -315,6 +315,8 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             with torch.cuda.stream(streams[li]):
                 if clean:
                     ex.begin_step()
+                elif li == 0:
+                    ex.zero()            # (lane 0's buckets ARE ex.buckets; also drops the previous step's shards / running sums)
                 else:
                     for bk in bks:
                         bk.zero()
@@ -525,6 +527,27 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         txe = torch.tensor([tsum], device=dev, dtype=torch.float64)
         dist.all_reduce(txe, op=dist.ReduceOp.MAX)
         res["exchange_only_ms_per_step"] = 1e3 * float(txe.item()) / xsteps
+        if sparse["on"] and n_parts() > 1 and S == 1 and not args.no_pack_hint and gathered["t"] is not None:
+            # self-check of the hinted pack (the views' point_weight tensors live in the graphs' pools): the step's gathered
+            # gradient sum with the hints against the same step with the scanning pack -- the same rows, the same sums up to
+            # the order of the reverse walk's float atomics between two renderings
+            step()
+            torch.cuda.synchronize()
+            with_hint = gathered["t"].clone()
+            args.no_pack_hint = True
+            try:
+                step()
+                torch.cuda.synchronize()
+            finally:
+                args.no_pack_hint = False
+            scan = gathered["t"]
+            rows_h, rows_s = (with_hint != 0).any(1), (scan != 0).any(1)
+            res["exchange_hint_check"] = {
+                "rel_l2": float((with_hint - scan).norm() / scan.norm().clamp_min(1e-30)),
+                "rows_with_hint": int(rows_h.sum()), "rows_scanning": int(rows_s.sum()),
+                "rows_differ": int((rows_h != rows_s).sum())}
+            assert res["exchange_hint_check"]["rel_l2"] < 1e-3 and res["exchange_hint_check"]["rows_with_hint"] > 0, res["exchange_hint_check"]
+            del with_hint, scan
         cols = sum(c for _, c in ex.buckets[0].layout) + 1
         frac = 1.0
         if compact["on"] and ex.touched is not None:
@@ -885,6 +908,7 @@ def main():
             "touched_4096_row_block_fraction": r.get("exchange_touched_block_fraction"),
             "bytes_moved_per_rank_per_step": r.get("exchange_bytes_per_step"), "timing_ms": r.get("exchange_timing"),
             "exchange_only_ms_per_step": r.get("exchange_only_ms_per_step"),
+            "hint_check": r.get("exchange_hint_check"),
             "exchange_only_busbw_GBs": (r["exchange_bytes_per_step"] / (r["exchange_only_ms_per_step"] * 1e-3) / 1e9
                                         if r.get("exchange_only_ms_per_step") and r.get("exchange_bytes_per_step") else None),
             "rccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO",

@@ -268,6 +268,15 @@ def test_bench_one_rank_over_rccl():
         assert full["n_gpus"] == 1 and full["exchange"]["backend"] == "nccl", full["exchange"]
         assert full["exchange"]["mode"] == mode and full["exchange"]["exchange_only_ms_per_step"] > 0
         assert full["value"] > 0
+    # one view in flight (as at the 30 M headline): every group holds one view and its pack reads the view's point_weight as
+    # its hint; bench.py then checks the hinted step's gradient sum against the scanning pack's
+    full = _bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--gaussians", "200000", "--streams", "1", "--no-cpu-baseline",
+                  "--no-dropin-mode", "--no-secondary", "--no-forward-only", "--no-rand-variant", "--no-trained-like",
+                  "--exchange", "sparse", env=dict(LOGRAST_DIST_SINGLE_RANK="1"))
+    chk = full["exchange"]["hint_check"]
+    assert full["exchange"]["streamed"] and full["exchange"]["parts"] == 8, full["exchange"]
+    assert chk is not None and chk["rel_l2"] < 1e-3 and chk["rows_with_hint"] > 1000, chk
+    assert chk["rows_differ"] <= 0.001 * chk["rows_scanning"], chk
 
 
 def test_pack_and_unpack_rows_kernels():

@@ -21,3 +21,15 @@ def test_random_cases_vs_oracle(oracle_mod, block):
         r = F.run_case(oracle_mod, seed)
         ran += "skipped" not in r
     assert ran >= 6
+
+
+def test_random_cases_bands_and_bucket_accumulation():
+    """The same draws through the packages' autograd drop-in: the image split into 2 / 3 / 5 / 8 bands of tile rows renders the
+    whole image bit for bit (radii / point_weight: maxima over the bands; reverse-walk gradients: sums), and views
+    accumulated by the backward kernels into a row-major / planar gradient bucket equal autograd's own accumulation."""
+    import fuzz_parity as F
+    banded = 0
+    for seed in [400000 + i for i in range(0, 40)]:
+        r = F.run_props(seed)
+        banded += bool(r.get("bands"))
+    assert banded >= 20

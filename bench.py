@@ -415,7 +415,13 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             res["exchange_touched_row_fraction"] = float(t.item())
             if args.exchange == "auto":
+                before = n_parts()
                 sparse["on"] = res["exchange_touched_row_fraction"] < 0.5
+                if sparse["on"] and n_parts() != before:
+                    # the decision changed the grouping (one group per view now): render into the per-view buckets before the
+                    # exact exchange below -- its list lengths become the bounds of every later all-to-all, and the union of a
+                    # rank's eight views in ONE bucket made them four times what a view needs (padded segments travel whole)
+                    step(do_exchange=False)
             if sparse["on"]:
                 # one exact row-sparse exchange (list lengths agreed by a max-reduce + read-back); from then on the
                 # all-to-all and the all-gather are sized from its longest lists + 10 % with no read-back.  (Every rank

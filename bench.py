@@ -1053,6 +1053,14 @@ def main():
             sec["error"] = "%s: %s" % (type(e).__name__, e)
         result["secondary"] = sec
 
+    # whatever the libraries left in C stdio buffers (librccl's banner) goes out NOW, on every rank, in front of the line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist_on(world):
+        dist.barrier()
     if rank == 0:
         result["parity"] = parity_summary()
         flatten_for_the_driver(result)

@@ -276,6 +276,12 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         blocks), ONE when --exchange-parts is automatic and the dense form runs (every dense group is full-size)."""
         return parts if (sparse["on"] or compact["on"] or not auto_parts) else 1
 
+    def sparse_bound(part):
+        """The all-to-all's rows per (sender, owner) pair for group `part`: its own list length of the exact exchange + 10 %
+        (padded segments travel whole: one bound for all groups -- the longest view's -- padded the others by ~20 %)."""
+        per = sparse.get("kmax_part")
+        return per[part] if per and part < len(per) else sparse["kmax"]
+
     def gather(total):
         if sparse["on"] and n_parts() > 1:
             if gathered["t"] is None:
@@ -286,7 +292,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
     def exchange():
         """The step's exchange: reduce-scatter (dense / touched blocks / touched rows) per group, then the all-gather."""
         for part in range(n_parts()):
-            ex.launch(part, compact=compact["on"], kmax=sparse["kmax"] if sparse["on"] else compact.get("kmax"), sparse=sparse["on"])
+            ex.launch(part, compact=compact["on"], kmax=sparse_bound(part) if sparse["on"] else compact.get("kmax"), sparse=sparse["on"])
         gather(ex.finish())
     lanes = []
     for li in range(S):   # every stream: leaf aliases of the (shared, read-only) attributes + its own flat gradient buckets
@@ -356,7 +362,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                         if w is not None:
                             ex.buckets[part].mark_touched(w)
                 if do_exchange:
-                    ex.launch(part, compact=compact["on"], kmax=sparse["kmax"] if sparse["on"] else compact.get("kmax"),
+                    ex.launch(part, compact=compact["on"], kmax=sparse_bound(part) if sparse["on"] else compact.get("kmax"),
                               sparse=sparse["on"])
         if dist_on(world) and do_exchange:                   # every rank ends the step with the whole gradient sum
             gather(ex.finish())
@@ -431,9 +437,12 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                     exchange()
                     torch.cuda.synchronize()
                     sparse["kmax"] = int(max(b.sparse_kmax for b in ex.buckets) * 1.1) + 16
+                    if n_parts() > 1:
+                        sparse["kmax_part"] = [int(b.sparse_kmax * 1.1) + 16 for b in ex.buckets[:n_parts()]]
                     sparse["gather"] = int(ex.gather_kmax * 1.1) + 16
                     assert not ex.compact_overflowed()
-                    res["exchange_row_bounds"] = {"per_pair": sparse["kmax"], "per_owner_gather": sparse["gather"],
+                    res["exchange_row_bounds"] = {"per_pair": sparse["kmax"], "per_pair_by_group": sparse.get("kmax_part"),
+                                                  "per_owner_gather": sparse["gather"],
                                                   "rows_per_rank": ex.buckets[0].Pr}
                 except Exception as e:
                     if args.exchange == "sparse":

@@ -97,6 +97,8 @@ def parse():
     ap.add_argument("--print-full", action="store_true",
                     help="also print the full result object (what bench_full.json holds) on an EARLIER stdout line")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-one-rank-leg", action="store_true",
+                    help="skip the leg that runs the N > 1 step through a one-rank RCCL group in a child process (N = 1 only)")
     ap.add_argument("--no-pack-hint", action="store_true",
                     help="streamed row-sparse exchange: scan the gradient rows themselves instead of the view's point_weight")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 / C3 legs (they run at N = 1 only)")
@@ -168,6 +170,44 @@ def effective_units(wl):
             acc["I_walked_fwd"] += float(fwd.sum())
             del saved
     return {k: v / len(wl.rasts) for k, v in acc.items()}
+
+
+def one_rank_rccl_leg(args, N):
+    """Rank 0's multi-GPU step on THIS box: the same workload through a process group of ONE rank over RCCL, forced through
+    every collective (LOGRAST_DIST_SINGLE_RANK=1: view groups, hinted pack, all-to-all, unpack-add on the side stream, the
+    closing all-gather -- everything an N > 1 step does except the links; profiles/r06_rccl_one_rank.md).  Run as a child
+    process with a time limit, after the headline is measured: whatever happens to it, the line above stands."""
+    import tempfile
+    out = {"what": "the N > 1 step with its whole gradient exchange, one rank over RCCL (no links): local cost of the exchange"}
+    fd, path = tempfile.mkstemp(suffix=".json")
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--gaussians", str(N), "--width", str(args.width),
+           "--height", str(args.height), "--views", str(args.views), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+           "--no-dropin-mode", "--no-secondary", "--no-forward-only", "--no-rand-variant", "--no-trained-like",
+           "--no-one-rank-leg", "--full-out", path]
+    try:
+        env = dict(os.environ, LOGRAST_DIST_SINGLE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+            env.pop(k, None)
+        p = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=300)
+        if p.returncode != 0:
+            out["error"] = "exit %d: %s" % (p.returncode, (p.stderr or "")[-300:])
+            return out
+        with open(path) as f:
+            r = json.load(f)
+        ex = r.get("exchange") or {}
+        out.update(ms_per_step=r.get("ms_per_step"), value=r.get("value"), exchange_mode=ex.get("mode"), parts=ex.get("parts"),
+                   backend=ex.get("backend"), streamed=ex.get("streamed"), timing_ms=ex.get("timing_ms"),
+                   exchange_only_ms_per_step=ex.get("exchange_only_ms_per_step"), hint_check=ex.get("hint_check"),
+                   row_bounds=ex.get("row_bounds"))
+    except Exception as e:                      # noqa: BLE001 -- a secondary leg: report, never raise
+        out["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return out
 
 
 def dist_on(world):
@@ -1062,6 +1102,9 @@ def main():
             sec["error"] = "%s: %s" % (type(e).__name__, e)
         result["secondary"] = sec
 
+    if world == 1 and not dist_on(world) and not args.no_one_rank_leg and not args.no_secondary and N >= 1_000_000:
+        result["multi_gpu_step_one_rank_rccl"] = one_rank_rccl_leg(args, N)
+
     # whatever the libraries left in C stdio buffers (librccl's banner) goes out NOW, on every rank, in front of the line
     try:
         import ctypes
@@ -1127,6 +1170,11 @@ def compact_line(result):
     c["forward_only_ms_per_view"] = _num(g(result, "forward_only", "headline", "capacity_hint", "ms_per_view"))
     for k in ("c2_ms_per_view", "c3_ms_per_view", "c3_fused_step_ms_per_view", "c5_band_ms_per_view_gradient_sink"):
         c[k] = _num(cfg.get(k))
+    one = result.get("multi_gpu_step_one_rank_rccl")
+    if isinstance(one, dict):
+        c["rccl_one_rank_step_ms"] = _num(one.get("ms_per_step"))
+        c["rccl_one_rank_exchange"] = ("%s x%s" % (one.get("exchange_mode"), one.get("parts"))) if one.get("exchange_mode") else \
+            str(one.get("error", ""))[:100]
     c["parallelism"] = str(cfg.get("parallelism", ""))[:120]
     ex = result.get("exchange")
     if isinstance(ex, dict):

@@ -139,3 +139,20 @@ def test_parity_summary_reaches_the_line():
     # check_gui's uniform draws -- both are REPORTED
     assert line["c2_upstream_pkg"] < 1e-4 < line["c2_wodilate_fork_clamp"]
     assert line["trained_like_30M"] < 1e-4
+
+
+def test_the_one_rank_rccl_leg_reaches_the_line():
+    """Round 6: the default N = 1 run also measures rank 0's N > 1 step through a one-rank RCCL group (a child process) and
+    the line carries its step time and exchange form -- or, had the leg failed, its error, without touching the headline."""
+    path = os.path.join(ROOT, "profiles", "r06_bench_full.json")
+    full = json.load(open(path))
+    leg = full.get("multi_gpu_step_one_rank_rccl")
+    assert isinstance(leg, dict) and leg.get("backend") == "nccl" and leg["ms_per_step"] > full["ms_per_step"]
+    assert leg["hint_check"]["rel_l2"] < 1e-3 and leg["hint_check"]["rows_differ"] == 0
+    line = bench.compact_line(full)
+    assert line["config"]["rccl_one_rank_step_ms"] == pytest.approx(leg["ms_per_step"], rel=1e-4)
+    assert line["config"]["rccl_one_rank_exchange"] == "sparse x8"
+    broken = dict(full, multi_gpu_step_one_rank_rccl={"error": "TimeoutExpired: x" * 40})
+    line = bench.compact_line(broken)
+    assert line["value"] == pytest.approx(full["value"], rel=1e-6) and len(line["config"]["rccl_one_rank_exchange"]) <= 100
+    assert "rccl_one_rank_step_ms" not in line["config"]

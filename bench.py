@@ -189,7 +189,7 @@ def one_rank_rccl_leg(args, N):
         env = dict(os.environ, LOGRAST_DIST_SINGLE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
             env.pop(k, None)
-        p = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=300)
+        p = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=150)
         if p.returncode != 0:
             out["error"] = "exit %d: %s" % (p.returncode, (p.stderr or "")[-300:])
             return out

@@ -348,7 +348,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         return min(j * np_ // max(len(lane_views[li]), 1), np_ - 1)
 
     lane_graphs = None
-    graph_weight = {}
+    graph_weight, graph_radii = {}, {}
     state = {"clean": False}   # did the previous step leave every bucket all zero (streamed exchange: pack and clear)?
 
     def step(do_exchange=True):
@@ -392,7 +392,11 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                 # common frustum), recorded once per group from the last forward's radii (kept by one_view)
                 streamed = bool(sparse["on"] and n_parts() > 1)
                 if wl.last_radii is not None:
-                    ex.seen_bucket(part, streamed).mark_seen(wl.last_radii)
+                    # (graphs: the radii of this group's last view, which its replay has just rewritten in place; streamed: all
+                    # of the step's views are counted in ONE pass when finish() reads the counts)
+                    last = [j for j in range(len(lane_views[0])) if part_of_view(0, j) == part][-1:]
+                    rad = graph_radii.get((0, last[0])) if (lane_graphs is not None and last) else None
+                    ex.seen_bucket(part, streamed).mark_seen(rad if rad is not None else wl.last_radii, defer=streamed)
                 if do_exchange and streamed and S == 1 and not args.no_pack_hint:
                     # one view in this group: its point_weight says which rows it touched -- the pack reads 4 bytes per row
                     # of the other 94 % instead of 64 (log_amd.dist.GradientBucket.mark_touched)
@@ -518,6 +522,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                     # (the view's point_weight lives in the graph's pool: held here so that no later capture reuses it --
                     # every replay rewrites it in place; the streamed exchange reads it as the pack's hint)
                     graph_weight[(li, j)] = wl.last_weight
+                    graph_radii[(li, j)] = wl.last_radii
                 built.append(gl)
             torch.cuda.synchronize()
             lane_graphs = built

@@ -277,6 +277,9 @@ int lograst_unpack_rows(float* dest, const float* packed, int32_t segments, int3
 /* seen[i] += 1 where radii[i] > 0, i < n (the per-step "how many views saw this row" counts of log_amd.dist: what the
  * reference's step calls flag_vis, /root/reference/LoG/model/counter.py:48,50, summed over a rank's views). */
 int lograst_add_visible(float* seen, const int32_t* radii, int64_t n, void* stream);
+/* The same for k <= 16 views in one pass: `radii` is a HOST array of k device pointers ([n] int32 each); seen[i] += the number
+ * of them with radii[j][i] > 0. */
+int lograst_add_visible_n(float* seen, const int32_t* const* radii, int32_t k, int64_t n, void* stream);
 
 /* ---- performance knobs -------------------------------------------------------------------------------------------
  * Launch-shape parameters that change no result (thresholds, grid caps, dispatch orders; the list is enumerated by

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "lograst_pack_rows_hinted": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p,
                                                 ctypes.c_int64, c_void_p]),
     "lograst_add_visible": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int64, c_void_p]),
+    "lograst_add_visible_n": (ctypes.c_int, [c_void_p, c_void_p, c_int32, ctypes.c_int64, c_void_p]),
     "lograst_unpack_rows": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64, c_int32,
                                            c_void_p]),
     "lograst_read_state": (ctypes.c_int, [c_void_p, ctypes.POINTER(c_uint32), ctypes.POINTER(c_uint32),

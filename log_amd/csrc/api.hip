@@ -32,6 +32,7 @@ void lx_launch_pack_rows(float* rows, int groups, long long rows_per_group, int 
                          size_t seg_floats, uint32_t* overflow, int clear, const uint32_t* hint, long long hint_rows,
                          hipStream_t s);
 void lx_launch_add_visible(float* seen, const int32_t* radii, long long n, hipStream_t s);
+void lx_launch_add_visible_n(float* seen, const int32_t* const* radii, int k, long long n, hipStream_t s);
 void lx_launch_unpack_rows(float* dest, const float* packed, int segments, int kmax, size_t seg_floats,
                            long long rows_per_group, long long dest_group_rows, int add, int zero, hipStream_t s);
 void lr_launch_fill(int N, int gx, const void* geom, uint32_t* state, uint32_t tiles, uint64_t* keys,
@@ -699,6 +700,16 @@ int lograst_add_visible(float* seen, const int32_t* radii, int64_t n, void* stre
   if (n == 0) return LOGRAST_OK;
   if (!seen || !radii) return lr_fail(LOGRAST_ERR_ARG, "lograst_add_visible: NULL pointer");
   lx_launch_add_visible(seen, radii, n, (hipStream_t)stream);
+  LR_HIP(hipGetLastError());
+  return LOGRAST_OK;
+}
+int lograst_add_visible_n(float* seen, const int32_t* const* radii, int32_t k, int64_t n, void* stream) {
+  if (n < 0 || k < 0 || k > 16) return lr_fail(LOGRAST_ERR_ARG, "lograst_add_visible_n: negative n, or k outside 0..16");
+  if (n == 0 || k == 0) return LOGRAST_OK;
+  if (!seen || !radii) return lr_fail(LOGRAST_ERR_ARG, "lograst_add_visible_n: NULL pointer");
+  for (int j = 0; j < k; j++)
+    if (!radii[j]) return lr_fail(LOGRAST_ERR_ARG, "lograst_add_visible_n: NULL radii pointer");
+  lx_launch_add_visible_n(seen, radii, k, n, (hipStream_t)stream);
   LR_HIP(hipGetLastError());
   return LOGRAST_OK;
 }

@@ -215,6 +215,27 @@ lx_add_visible_kernel(float* __restrict__ seen, const int32_t* __restrict__ radi
   if (i < n && radii[i] > 0) seen[i] += 1.0f;
 }
 
+// The same for up to 16 views at once (GradientBucket.mark_seen(defer=True)): the count array is read and written once per
+// STEP instead of once per view (8 views of 30 M rows: 1.1 GB instead of 2.9 GB).
+struct LxRadiiPtrs { const int32_t* p[16]; };
+__global__ void __launch_bounds__(256)
+lx_add_visible_n_kernel(float* __restrict__ seen, LxRadiiPtrs r, int k, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++)
+    if (j < k) c += r.p[j][i] > 0 ? 1 : 0;
+  if (c) seen[i] += (float)c;
+}
+
+void lx_launch_add_visible_n(float* seen, const int32_t* const* radii, int k, long long n, hipStream_t s) {
+  if (n <= 0 || k <= 0) return;
+  LxRadiiPtrs r;
+  for (int j = 0; j < 16; j++) r.p[j] = radii[j < k ? j : 0];
+  hipLaunchKernelGGL(lx_add_visible_n_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, seen, r, k, n);
+}
+
 void lx_launch_add_visible(float* seen, const int32_t* radii, long long n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(lx_add_visible_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, seen, radii, n);

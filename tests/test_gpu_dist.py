@@ -439,3 +439,17 @@ def test_pack_rows_with_a_hint_and_the_visible_count_kernel():
     for _ in range(3):
         b.mark_seen(radii.to(dev))
     assert torch.equal(b.seen[:100_003].cpu(), 3.0 * (radii > 0).float()) and float(b.seen[100_003:].abs().sum()) == 0.0
+    # deferred: the step's views are counted together when the counts are next read (lograst_add_visible_n, 16 per pass)
+    b.zero()
+    views = [torch.randint(-1, 3, (100_003,), generator=gen, dtype=torch.int32).to(dev) for _ in range(19)]
+    for v in views:
+        b.mark_seen(v, defer=True)
+    assert len(b._seen_pending) == 19 and float(b._seen.abs().sum()) == 0.0           # nothing counted yet
+    want = sum((v > 0).float() for v in views)
+    assert torch.equal(b.seen[:100_003], want) and not b._seen_pending
+    b.mark_seen(views[0], defer=True)
+    b.mark_seen(views[1])                                                                # an immediate mark counts the pending ones first
+    assert torch.equal(b.seen[:100_003], want + (views[0] > 0).float() + (views[1] > 0).float())
+    b.mark_seen(views[2], defer=True)
+    b.zero()                                                                             # ... and a reset drops them
+    assert float(b.seen.abs().sum()) == 0.0

@@ -316,6 +316,14 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         blocks), ONE when --exchange-parts is automatic and the dense form runs (every dense group is full-size)."""
         return parts if (sparse["on"] or compact["on"] or not auto_parts) else 1
 
+    def on_any_rank(flag):
+        """A per-rank condition as ONE decision of the job (a rank that raises alone leaves the others in their next collective)."""
+        if not dist_on(world):
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
     def sparse_bound(part):
         """The all-to-all's rows per (sender, owner) pair for group `part`: its own list length of the exact exchange + 10 %
         (padded segments travel whole: one bound for all groups -- the longest view's -- padded the others by ~20 %)."""
@@ -572,7 +580,7 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
         res["exchange_timing"] = ex.timing_summary(steps)
         # The same collectives with nothing to hide under: link time alone, so that a first run on real xGMI separates what
         # the links cost from what the overlap lost (exposed = ms_per_step - rendering; hidden = exchange_only - exposed).
-        assert not ex.compact_overflowed(), "touched-block / row-sparse exchange outgrew its bound inside the timed region: result invalid"
+        assert not on_any_rank(ex.compact_overflowed()), "touched-block / row-sparse exchange outgrew its bound inside the timed region: result invalid"
         xsteps, tsum = 3, 0.0
         for _ in range(xsteps):
             step(do_exchange=False)                     # (the rank's own sums again: the exchange leaves the total in bucket 0)
@@ -602,11 +610,22 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
                 args.no_pack_hint = False
             scan = gathered["t"]
             rows_h, rows_s = (with_hint != 0).any(1), (scan != 0).any(1)
+            # asserted on dL/dopacity and dL/dcolour (row slots 10-13: plain sums of the reverse walk); the slots behind the chain
+            # rule are reported only -- on check_gui's uniform scales one needle-shaped Gaussian can carry the tensor's norm and
+            # amplify the reverse walk's summation-order noise to 1e-3 between ANY two renderings (seen: 200 000 Gaussians,
+            # 1.3e-3 in three of five processes with every row present in both; tests/gpu_util.py quantifies that per row)
+            direct = float((with_hint[:, 10:14] - scan[:, 10:14]).norm() / scan[:, 10:14].norm().clamp_min(1e-30))
             res["exchange_hint_check"] = {
-                "rel_l2": float((with_hint - scan).norm() / scan.norm().clamp_min(1e-30)),
+                "rel_l2": direct, "rel_l2_all_slots": float((with_hint - scan).norm() / scan.norm().clamp_min(1e-30)),
                 "rows_with_hint": int(rows_h.sum()), "rows_scanning": int(rows_s.sum()),
                 "rows_differ": int((rows_h != rows_s).sum())}
-            assert res["exchange_hint_check"]["rel_l2"] < 1e-3 and res["exchange_hint_check"]["rows_with_hint"] > 0, res["exchange_hint_check"]
+            # (every rank must take the same decision, or the ones that go on hang in the next collective)
+            hc = res["exchange_hint_check"]
+            okf = torch.tensor([1.0 if (hc["rel_l2"] < 1e-4 and hc["rows_with_hint"] > 0
+                                        and hc["rows_differ"] <= 1e-3 * hc["rows_scanning"]) else 0.0], device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            res["exchange_hint_check"]["ok_on_every_rank"] = bool(okf.item() > 0)
+            assert res["exchange_hint_check"]["ok_on_every_rank"], res["exchange_hint_check"]
             del with_hint, scan
         cols = sum(c for _, c in ex.buckets[0].layout) + 1
         frac = 1.0
@@ -619,9 +638,9 @@ def measure(args, wl, S, fused, steps, warmup, world, timing, sync_free=True, gr
             res["exchange_bytes_per_step"] = int(4 * (world - 1) * (parts * SPARSE_FLOATS * max(b.sparse_kmax for b in ex.buckets)
                                                                     + b0.Pr + SPARSE_FLOATS * ex.gather_kmax))
     if dist_on(world):
-        assert not ex.compact_overflowed(), "touched-block exchange outgrew its bound inside the timed region: result invalid"
+        assert not on_any_rank(ex.compact_overflowed()), "touched-block exchange outgrew its bound inside the timed region: result invalid"
     chk = R.overflow_since_reset(dev)   # every forward since the capacity was set, on all streams
-    assert not chk["overflowed"] and chk["max_instances"] <= cap, \
+    assert not on_any_rank(chk["overflowed"] or chk["max_instances"] > cap), \
         "tile-instance capacity overflow inside the timed region: result invalid (%r)" % (chk,)
     R.set_instance_capacity(None)
     wl.zero_means2d = True

@@ -34,7 +34,8 @@ extern "C" {
  * until lograst_finish_lists, which now checks that `keys` is the buffer the forward filled and synchronises the stream;
  * (d) lograst_view gained hit_masks / hit_mask_words / hit_mask_form: an optional buffer in which the forward leaves its
  * per-chunk support ballots for the reverse walk (below); new entry points: lograst_hit_mask_bytes, lograst_forward_form,
- * lograst_pack_rows_clear, lograst_unpack_rows(atomic = 2), lograst_activate_backward_adam.
+ * lograst_pack_rows_clear, lograst_unpack_rows(atomic = 2), lograst_activate_backward_adam.  Added later in round 6 without a
+ * version change (new entry points only): lograst_pack_rows_hinted, lograst_add_visible, lograst_add_visible_n.
  * 2: lograst_view gained cov3d_precomp / dl_dcov3d; 3: the backward accumulates into 64-byte rows (bwd_rows); lograst_view gained walk_form.  Added since without a version change (new entry points only): lograst_sparse_segment_floats / lograst_pack_rows / lograst_unpack_rows / lograst_ordered_lengths / lograst_finish_lists */
 #define LOGRAST_TILE 16        /* pixels per tile side (tile rects are part of the integer contract) */
 #define LOGRAST_REC_FLOATS 16  /* floats per projected-Gaussian record (64 B): see log_amd/csrc/project.hip */
